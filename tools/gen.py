@@ -1,0 +1,222 @@
+"""Synthetic problem generators shared by tests/, bench.py and the golden-vector
+script. Pure numpy; no reference or oracle code is touched here.
+
+Two sources of randomness:
+  * xorshift64: s ^= s<<13; s ^= s>>7; s ^= s<<17,
+    seed 88172645463325252, u = (s >> 11) * 2**-53 -- the benchmark workloads.
+  * numpy Generator -- fuzz families for the differential tests.
+"""
+import numpy as np
+
+XS_SEED = 88172645463325252
+_M64 = (1 << 64) - 1
+
+
+class XorShift64:
+    def __init__(self, seed=XS_SEED):
+        self.s = seed & _M64
+
+    def next_u64(self):
+        s = self.s
+        s ^= (s << 13) & _M64
+        s ^= s >> 7
+        s ^= (s << 17) & _M64
+        self.s = s
+        return s
+
+    def uniform(self):
+        return (self.next_u64() >> 11) * 2.0 ** -53
+
+    def uniforms(self, n):
+        """n uniforms, vectorised in blocks (bit-identical to repeated uniform())."""
+        out = np.empty(n, dtype=np.float64)
+        s = self.s
+        for i in range(n):
+            s ^= (s << 13) & _M64
+            s ^= s >> 7
+            s ^= (s << 17) & _M64
+            out[i] = (s >> 11) * 2.0 ** -53
+        self.s = s
+        return out
+
+
+def xs_uniform_block(n, seed=XS_SEED):
+    """n xorshift64 uniforms from `seed`, computed with numpy uint64 lanes.
+
+    The stream is split into 4096 independent sub-streams seeded by the scalar
+    generator, so large tableaux (4096 x 8192) fill in well under a second; the
+    layout is deterministic and documented, not the single sequential stream.
+    """
+    lanes = 4096
+    g = XorShift64(seed)
+    s = np.array([g.next_u64() for _ in range(lanes)], dtype=np.uint64)
+    per = (n + lanes - 1) // lanes
+    out = np.empty((per, lanes), dtype=np.float64)
+    for i in range(per):
+        s ^= s << np.uint64(13)
+        s ^= s >> np.uint64(7)
+        s ^= s << np.uint64(17)
+        out[i] = (s >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
+    return out.reshape(-1)[:n]
+
+
+def vc_nonneg(nv, kind_float=True, free=()):
+    vc = np.zeros((nv, nv + 1), dtype=np.float64 if kind_float else np.int32)
+    for i in range(nv):
+        if i not in free:
+            vc[i, i] = -1
+    return vc
+
+
+# ---- benchmark workloads -----------------------------------
+def dense_lp_f64(m, n, seed=XS_SEED):
+    """cfg 2b / cfg 3(i): maximise c.x, A x <= b, x >= 0; A,c ~ U(0.1,1), b = n*U(0.5,1)."""
+    u = xs_uniform_block(m * n + m + n, seed)
+    A = 0.1 + 0.9 * u[: m * n].reshape(m, n)
+    b = n * (0.5 + 0.5 * u[m * n: m * n + m])
+    c = 0.1 + 0.9 * u[m * n + m:]
+    leq = np.concatenate([A, b[:, None]], axis=1)
+    tgtf = np.concatenate([c, [0.0]])
+    return leq, tgtf
+
+
+def tableau_f64(m, W, seed=XS_SEED):
+    """cfg 2a: T[m][W] ~ U(0.1,1) and an objective row of W entries."""
+    u = xs_uniform_block(m * W + W, seed)
+    return (0.1 + 0.9 * u[: m * W]).reshape(m, W).copy(), (0.1 + 0.9 * u[m * W:]).copy()
+
+
+def small_lp_batch_f64(nb, m=32, cols=64, family=0, seed=XS_SEED):
+    """cfg 3: nb independent LPs, leq m x cols (cols-1 variables + constant).
+
+    family 0: dense positive (as cfg 2b scaled); family 1: dependence-test-like,
+    entries in {-3..3} at density 0.25, rhs in {-2..17}, objective all ones.
+    Returns leq [nb,m,cols], tgtf [nb,cols] as float64.
+    """
+    n = cols - 1
+    per = m * n + m + n
+    u = xs_uniform_block(nb * per, seed).reshape(nb, per)
+    if family == 0:
+        A = 0.1 + 0.9 * u[:, : m * n].reshape(nb, m, n)
+        b = n * (0.5 + 0.5 * u[:, m * n: m * n + m])
+        c = 0.1 + 0.9 * u[:, m * n + m:]
+    else:
+        ua = u[:, : m * n].reshape(nb, m, n)
+        A = np.where(ua < 0.25, np.floor(ua * 28.0) - 3.0, 0.0)   # ua<0.25 -> ua*28 in [0,7) -> {-3..3}
+        b = np.floor(u[:, m * n: m * n + m] * 20.0) - 2.0
+        c = np.ones((nb, n))
+    leq = np.concatenate([A, b[:, :, None]], axis=2)
+    tgtf = np.concatenate([c, np.zeros((nb, 1))], axis=1)
+    return np.ascontiguousarray(leq), np.ascontiguousarray(tgtf)
+
+
+def int_lp_rat(m, n, seed=XS_SEED):
+    """cfg 4: integer data A in {1..9}, b = n*{3,4,5}, c in {1..9} as (num,den) int32."""
+    u = xs_uniform_block(m * n + m + n, seed)
+    A = np.floor(u[: m * n] * 9).astype(np.int32).reshape(m, n) + 1
+    b = (n * (3 + np.floor(u[m * n: m * n + m] * 3))).astype(np.int32)
+    c = np.floor(u[m * n + m:] * 9).astype(np.int32) + 1
+    leq = np.concatenate([A, b[:, None]], axis=1)
+    tgtf = np.concatenate([c, [0]]).astype(np.int32)
+    return to_rat(leq), to_rat(tgtf)
+
+
+def to_rat(a):
+    a = np.asarray(a, dtype=np.int32)
+    out = np.empty(a.shape + (2,), dtype=np.int32)
+    out[..., 0] = a
+    out[..., 1] = 1
+    return out
+
+
+# ---- fuzz families -----------------------------------------------------------------
+def random_problem(rng, kind, fam, m, nv, plain=False):
+    """A random (tgtf, vc, eq, leq) in the reference's calling convention.
+
+    fam 0: dense positive (origin feasible); 1: small signed integers (phase 1,
+    unbounded, infeasible all occur); 2: sparse signed integers with repeated
+    ratios (ties, degeneracy); 3: like 1 plus equalities and free variables.
+    plain=True keeps x >= 0 and no equalities (input to TwoStageMethod).
+    """
+    cols = nv + 1
+    if fam == 0:
+        A = rng.integers(1, 10, size=(m, nv)).astype(np.float64)
+        b = rng.integers(nv, 5 * nv + 1, size=m).astype(np.float64)
+        c = rng.integers(1, 10, size=nv).astype(np.float64)
+        if kind == 0 and rng.integers(0, 2):
+            A = A / 7.0 + rng.random((m, nv)) * 0.25
+            c = c / 3.0
+    elif fam == 1:
+        A = rng.integers(-4, 5, size=(m, nv)).astype(np.float64)
+        b = rng.integers(-6, 12, size=m).astype(np.float64)
+        c = rng.integers(-3, 4, size=nv).astype(np.float64)
+    else:
+        A = rng.integers(-2, 3, size=(m, nv)).astype(np.float64)
+        A *= rng.random((m, nv)) < 0.6
+        b = rng.integers(-2, 5, size=m).astype(np.float64)
+        c = rng.integers(-1, 3, size=nv).astype(np.float64)
+    leq = np.concatenate([A, b[:, None]], axis=1)
+    tgtf = np.concatenate([c, [float(rng.integers(0, 3)) if fam else 0.0]])
+    free = ()
+    eq = None
+    if fam == 3 and not plain:
+        free = tuple(i for i in range(nv) if rng.random() < 0.25)
+        if rng.random() < 0.6:
+            ne = int(rng.integers(1, 3))
+            Ae = rng.integers(-2, 3, size=(ne, nv)).astype(np.float64)
+            be = rng.integers(-3, 6, size=ne).astype(np.float64)
+            eq = np.concatenate([Ae, be[:, None]], axis=1)
+    vc = vc_nonneg(nv, True, free)
+    prob = dict(tgtf=tgtf, vc=vc, leq=leq)
+    if eq is not None:
+        prob["eq"] = eq
+    if kind == 1:
+        for k in list(prob):
+            prob[k] = to_rat(prob[k].astype(np.int32))
+    assert prob["tgtf"].shape[0] == cols
+    return prob
+
+
+def random_mip(rng, m, nv, is_bin):
+    A = rng.integers(0, 7, size=(m, nv))
+    if rng.random() < 0.3:
+        A = A - rng.integers(0, 3, size=(m, nv))
+    b = rng.integers(2, 4 * nv + 3, size=m)
+    c = rng.integers(1, 9, size=nv)
+    leq = np.concatenate([A, b[:, None]], axis=1).astype(np.int32)
+    if is_bin and rng.random() < 0.7:
+        ub = np.zeros((nv, nv + 1), dtype=np.int32)
+        ub[np.arange(nv), np.arange(nv)] = 1
+        ub[:, nv] = 1
+        leq = np.concatenate([leq, ub], axis=0)
+    tgtf = np.concatenate([c, [0]]).astype(np.int32)
+    prob = dict(tgtf=to_rat(tgtf), vc=to_rat(vc_nonneg(nv, False)), leq=to_rat(leq))
+    if rng.random() < 0.2:
+        prob["ind"] = (rng.random(nv + 1) < 0.3).astype(np.uint8)
+    return prob
+
+
+def random_system(rng, rows, nv):
+    A = rng.integers(-3, 4, size=(rows, nv))
+    A *= rng.random((rows, nv)) < 0.7
+    b = rng.integers(-5, 9, size=rows)
+    mat = np.concatenate([A, b[:, None]], axis=1).astype(np.int32)
+    if rows > 2 and rng.random() < 0.5:
+        mat[rng.integers(0, rows)] = mat[rng.integers(0, rows)]
+    out = to_rat(mat)
+    if rng.random() < 0.3:
+        i, j = rng.integers(0, rows), rng.integers(0, nv + 1)
+        out[i, j] = (int(rng.integers(-5, 6)), int(rng.integers(2, 5)))
+    return out
+
+
+def random_square(rng, n):
+    return to_rat(rng.integers(-4, 5, size=(n, n)).astype(np.int32))
+
+
+def random_feas(rng, rows, nv):
+    A = rng.integers(-3, 4, size=(rows, nv))
+    b = rng.integers(-4, 10, size=rows)
+    leq = to_rat(np.concatenate([A, b[:, None]], axis=1).astype(np.int32))
+    vc = to_rat(vc_nonneg(nv, False))
+    return leq, vc
