@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- simplex pivots/sec on a fp64 4096 x 8192 tableau (BASELINE.json's metric),
+plus batched small-LP throughput, on N MI355X GPUs of one node.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is ONE simplex pivot of the device-resident loop -- pricing scan, ratio
+test, pivot-pair upkeep, row/column staging and the rank-1 tableau update
+(src/com/lpsol.h:1039-1188) -- on a dense LP with m = 4096 constraints and
+n = 4095 variables, whose slack tableau is exactly 4096 x 8192 fp64 (268 MB,
+resident in HBM before the timed region). A single tableau does not shard
+("replicas only"): with N ranks every rank runs its own replica and
+`value` is the sum. The batched leg (config 3: independent 32 x 64 LPs, the
+dependence-test shape) shards its LPs across ranks with no data-path collective
+and one RCCL all_gather of the results at the end; it is reported in the same
+JSON line under "batched".
+
+One JSON line is printed by rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+M, NVARS = 4096, 4095                      # tableau 4096 x (4095 + 4096 + 1) = 4096 x 8192
+TAB_W = NVARS + M + 1
+ALG_BYTES_PER_PIVOT = 2 * M * TAB_W * 8    # every entry read once and written once
+HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s
+BATCH_PER_GPU = 8192                       # 65 536 LPs over 8 GPUs (BASELINE.json configs[2])
+BATCH_M, BATCH_COLS = 32, 64
+
+
+def cpu_baseline_pivots(budget_s=12.0):
+    """The oracle's K1 (oracle/oracle.cpp orc_pivot_f64) on the same 4096 x 8192 tableau, 1 core."""
+    from oracle.checker import Port
+    from tools import gen
+    port = Port()
+    tab, obj = gen.tableau_f64(M, TAB_W)
+    fn = port.lib.orc_pivot_f64
+    n, t0 = 0, time.perf_counter()
+    rng = np.random.default_rng(0)
+    while True:
+        r, c = int(rng.integers(0, M)), int(rng.integers(0, TAB_W - 1))
+        fn(tab.ctypes.data_as(C.c_void_p), C.c_int(M), C.c_int(TAB_W), obj.ctypes.data_as(C.c_void_p),
+           C.c_int(TAB_W - 1), C.c_int(r), C.c_int(c))
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s and n >= 3:
+            break
+    return dict(value=n / dt, unit="pivots/s", cores=1, kind="port",
+                sample="%d pivots of oracle orc_pivot_f64 on a 4096x8192 fp64 tableau, 1 thread, %.1f s" % (n, dt))
+
+
+def cpu_baseline_batch(leq, tgtf, budget_s=6.0):
+    from oracle.checker import Port
+    from tools import gen
+    port = Port()
+    vc = gen.vc_nonneg(BATCH_COLS - 1)
+    n, t0 = 0, time.perf_counter()
+    while n < len(leq):
+        port.six_solve(0, True, tgtf[n], vc, None, leq[n])
+        n += 1
+        if time.perf_counter() - t0 > budget_s and n >= 8:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=n / dt, unit="LPs/s", cores=1, kind="port",
+                sample="%d LPs (32x64, SIX::maxm) through the oracle, 1 thread, %.1f s" % (n, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batched", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local if world > 1 else 0)
+
+    import xpoly_amd
+    from tools import gen
+    ctx = xpoly_amd.Context(dev.index)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.sync()
+
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---- leg 1: pivots/s on the 4096 x 8192 tableau (replica per rank) -------------------
+    leq, tgtf = gen.dense_lp_f64(M, NVARS, seed=gen.XS_SEED + rank)
+    lp = xpoly_amd.DeviceLP(ctx, xpoly_amd.F64, leq, tgtf)
+    del leq
+    lp.begin()
+    st = lp.iterate(a.warmup) if a.warmup > 0 else xpoly_amd.six.XPG_RUNNING
+    assert st == xpoly_amd.six.XPG_RUNNING, "LP finished during warmup (status %d)" % st
+    barrier()
+    ctx.profile_begin(a.steps)
+    t0 = time.perf_counter()
+    st = lp.iterate(a.steps)
+    ctx.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    launches, sweep_ms = ctx.profile_end()
+    done = lp.pivots_done()
+    assert st == xpoly_amd.six.XPG_RUNNING, "LP finished inside the timed region (status %d)" % st
+    assert done == a.warmup + a.steps, "expected %d pivots, device did %d" % (a.warmup + a.steps, done)
+    rows, W, rhs = lp.shape()
+    assert (rows, W) == (M, TAB_W)
+    dt = max_over_ranks(dt)
+    value = world * a.steps / dt
+    sweep_avg_s = sweep_ms / 1e3 / max(launches, 1)
+    achieved = ALG_BYTES_PER_PIVOT / sweep_avg_s / 1e9
+    roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                    kernel="k_update_f64", launches=launches,
+                    avg_launch_us=round(sweep_avg_s * 1e6, 2),
+                    algorithmic_bytes_per_launch=ALG_BYTES_PER_PIVOT)
+    lp.close()
+
+    # ---- leg 2: batched 32 x 64 LPs, sharded across ranks, one all_gather at the end ----------
+    batched = None
+    b_leq = b_tg = None
+    if not a.no_batched:
+        fams = {}
+        for fam, name in ((0, "dense_positive"), (1, "dep_test_like")):
+            b_leq, b_tg = gen.small_lp_batch_f64(BATCH_PER_GPU, BATCH_M, BATCH_COLS, fam,
+                                                 seed=gen.XS_SEED + 1000 * (rank + 1) + fam)
+            d_leq = torch.from_numpy(b_leq).to(dev)
+            d_tg = torch.from_numpy(b_tg).to(dev)
+            d_st = torch.empty(BATCH_PER_GPU, dtype=torch.int32, device=dev)
+            d_v = torch.empty(BATCH_PER_GPU, dtype=torch.float64, device=dev)
+            d_sol = torch.zeros(BATCH_PER_GPU, BATCH_COLS, dtype=torch.float64, device=dev)
+            d_piv = torch.empty(BATCH_PER_GPU, dtype=torch.int32, device=dev)
+            rec = torch.empty(BATCH_PER_GPU, 2 + BATCH_COLS, dtype=torch.float64, device=dev)
+            gathered = torch.empty(world * BATCH_PER_GPU, 2 + BATCH_COLS, dtype=torch.float64, device=dev) \
+                if dist is not None else None
+
+            def one_pass():
+                ctx.six_batch_dev(xpoly_amd.F64, True, BATCH_PER_GPU, d_tg.data_ptr(), d_leq.data_ptr(),
+                                  BATCH_M, BATCH_COLS, d_st.data_ptr(), d_v.data_ptr(), d_sol.data_ptr(),
+                                  d_piv.data_ptr())
+                ctx.sync()
+                if dist is not None:      # the only collective of the path: fixed-size result records
+                    rec[:, 0] = d_st.to(torch.float64); rec[:, 1] = d_v; rec[:, 2:] = d_sol
+                    dist.all_gather_into_tensor(gathered, rec)
+                    torch.cuda.synchronize()
+
+            one_pass()
+            barrier()
+            reps = 5
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                one_pass()
+            barrier()
+            bdt = max_over_ranks(time.perf_counter() - t0)
+            piv = int(d_piv.sum().item())
+            hist = torch.bincount(d_st.clamp(min=0), minlength=5).tolist()
+            fams[name] = dict(lps_per_s=round(world * BATCH_PER_GPU * reps / bdt, 1),
+                              pivots_per_s=round(world * piv * reps / bdt, 1),
+                              status_hist_rank0=hist, ms_per_pass=round(bdt / reps * 1e3, 3))
+        tot = sum(f["lps_per_s"] for f in fams.values()) / len(fams)
+        batched = dict(metric="batched LPs/sec", value=round(tot, 1), unit="LPs/s",
+                       lps_per_gpu=BATCH_PER_GPU, shape="leq 32x64 (63 vars + rhs), SIX::maxm, x>=0",
+                       scaling="weak", collective="one all_gather of (status,v,sol) records" if dist else "none (1 GPU)",
+                       families=fams)
+
+    # ---- CPU baseline (rank 0, N = 1 only) -----------------------------------------------------------
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline_pivots()
+        if b_leq is not None:
+            cpu["batched"] = cpu_baseline_batch(b_leq, b_tg)
+
+    if rank == 0:
+        out = {
+            "metric": "simplex pivots/sec (float tableau 4kx8k)",
+            "value": round(value, 2), "unit": "pivots/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "dense LP m=4096 n=4095 (xorshift64 U(0.1,1)), slack tableau 4096x8192 fp64, "
+                                   "device-resident SIX::solveSlackForm loop, one pivot per step",
+                       "tableau": [M, TAB_W], "parallelism": "replicas only (1 tableau per GPU)"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "batched": batched,
+        }
+        print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

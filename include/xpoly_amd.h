@@ -1,0 +1,163 @@
+/* xpoly_amd -- MI355X (gfx950) simplex / row-elimination kernels behind xpoly's
+ * SIX<Mat,T>, MIP<Mat,T> and Lineq interfaces.  C ABI, no C++ or torch types.
+ *
+ * The reference (stevenknown/xpoly) has no FFI: its boundary is the C++ template
+ * contract of SIX<Mat,T> (src/com/lpsol.h:204-338) over Matrix<T>'s public
+ * row-major buffer (src/com/matt.h:152-156).  Each entry point below names the
+ * reference member it stands in for; INTEGRATION.md shows the adapter a
+ * maintainer would add on the xpoly side.
+ *
+ * Layouts (identical to the reference's in-memory layout):
+ *   f64   : double[rows*cols], row-major                  (FloatMat, xmat.h:140)
+ *   rat32 : struct {int32 num; int32 den;}[rows*cols]      (RMat, xmat.h:42; rational.h:66-67)
+ *   every matrix of one problem has `cols` columns; the last one is the constant
+ *   column (rhs_idx = cols-1, lpsol.h:1527-1552); `vc` is (cols-1) x cols with -1
+ *   on the diagonal for x_i >= 0 and an all-zero column for a free variable
+ *   (lpsol.h:1322); `eq`/`leq` may have 0 rows (pass NULL).
+ *
+ * Return values: the reference's own status integers (lpsol.h:198-202,
+ * :2082-2085) or a negative XPG_ERR_* code.  No exceptions cross this boundary.
+ * All buffers are caller-owned; the library never frees caller memory.
+ * Functions with a _dev suffix take DEVICE pointers; the others take HOST
+ * pointers and stage through HBM themselves.
+ */
+#ifndef XPOLY_AMD_H
+#define XPOLY_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* SIX status codes -- src/com/lpsol.h:198-202 */
+#define XPG_SIX_SUCC                  0
+#define XPG_SIX_UNBOUND               1
+#define XPG_SIX_NO_PRI_FEASIBLE_SOL   2
+#define XPG_SIX_OPTIMAL_IS_INFEASIBLE 3
+#define XPG_SIX_TIME_OUT              4
+/* MIP status codes -- src/com/lpsol.h:2082-2085 */
+#define XPG_IP_SUCC                    0
+#define XPG_IP_UNBOUND                 1
+#define XPG_IP_NO_PRI_FEASIBLE_SOL     2
+#define XPG_IP_NO_BETTER_THAN_BEST_SOL 3
+/* library errors (never overlap 0..4) */
+#define XPG_ERR_HIP          (-1)  /* a HIP runtime call failed; see xpg_last_error */
+#define XPG_ERR_ALLOC        (-2)
+#define XPG_ERR_SHAPE        (-3)  /* malformed sizes (reference: ASSERT only, lpsol.h:1517-1558) */
+#define XPG_ERR_UNSUPPORTED  (-4)
+#define XPG_ERR_NO_DEVICE    (-5)
+#define XPG_ERR_REF_UNDEFINED (-7) /* the reference's behaviour is undefined on this input */
+
+typedef struct xpg_ctx xpg_ctx;   /* one device + one HIP stream + scratch; re-entrant per handle */
+typedef struct xpg_lp  xpg_lp;    /* one device-resident slack-form LP (tableau, objective, basis) */
+
+typedef struct { int32_t num, den; } xpg_rat32;   /* src/com/rational.h:66-67 */
+
+/* ---- context ---------------------------------------------------------------- */
+int         xpg_device_count(void);
+int         xpg_create(xpg_ctx ** out, int device);
+void        xpg_destroy(xpg_ctx * ctx);
+const char *xpg_last_error(const xpg_ctx * ctx);
+const char *xpg_version(void);
+void *      xpg_stream(const xpg_ctx * ctx);            /* the hipStream_t all work is queued on */
+int         xpg_sync(xpg_ctx * ctx);
+/* device buffers for hosts without their own allocator (benchmarks, C callers) */
+int         xpg_malloc(xpg_ctx * ctx, void ** dptr, size_t bytes);
+int         xpg_free(xpg_ctx * ctx, void * dptr);
+int         xpg_upload(xpg_ctx * ctx, void * dst_dev, const void * src_host, size_t bytes);
+int         xpg_download(xpg_ctx * ctx, void * dst_host, const void * src_dev, size_t bytes);
+
+/* ---- in-library timing of the HBM-bound sweep (K1's update kernel) -------------------
+ * Between begin and end every launch of the sweep on this context is bracketed by
+ * a pair of HIP events recorded on the context's stream (at most `cap` launches are
+ * sampled).  end synchronises the stream and returns the number of sampled launches
+ * and the sum of their durations in milliseconds. */
+int         xpg_profile_begin(xpg_ctx * ctx, int cap);
+int         xpg_profile_end(xpg_ctx * ctx, int * launches, double * total_ms);
+
+/* ---- K1: one pivot -- SIX::pivot arithmetic, src/com/lpsol.h:1471-1501 ------------
+ * tab is m x W with leading dimension ld (elements); obj has W entries.  Row `row`
+ * is scaled by 1/tab[row][col], column `col` is eliminated from every other row and
+ * the scaled row is folded into obj.  Asynchronous on the context's stream. */
+int xpg_pivot_f64_dev(xpg_ctx * ctx, double * tab_dev, int m, int W, int ld,
+                      double * obj_dev, int rhs_idx, int row, int col);
+int xpg_pivot_rat32_dev(xpg_ctx * ctx, xpg_rat32 * tab_dev, int m, int W, int ld,
+                        xpg_rat32 * obj_dev, int rhs_idx, int row, int col);
+int xpg_pivot_f64(xpg_ctx * ctx, double * tab, int m, int W, double * obj,
+                  int rhs_idx, int row, int col);
+int xpg_pivot_rat32(xpg_ctx * ctx, xpg_rat32 * tab, int m, int W, xpg_rat32 * obj,
+                    int rhs_idx, int row, int col);
+
+/* ---- device-resident LP: SIX::TwoStageMethod, src/com/lpsol.h:1907-1930 ------------
+ * `leq` is m x cols (A | b), x >= 0 for every variable, `tgtf` has cols entries.
+ * vc_diag/vc_rhs hold vc(i,i) and vc(i,rhs) (the only cells SIX::is_feasible
+ * reads, lpsol.h:798-802); NULL means -1 / 0.  kind: 0 = f64, 1 = rat32.
+ * src_on_device != 0 when leq/tgtf are device pointers. */
+int  xpg_lp_create(xpg_ctx * ctx, int kind, const void * leq, int m, int cols,
+                   const void * tgtf, const void * vc_diag, const void * vc_rhs,
+                   int src_on_device, xpg_lp ** out);
+void xpg_lp_destroy(xpg_lp * lp);
+/* stage1 + solveSlackForm with SIX::set_param(.., max_iter) (lpsol.h:380-385). */
+int  xpg_lp_two_stage(xpg_lp * lp, unsigned max_iter);
+/* Only SIX::stage1's slack construction (lpsol.h:1820-1841); then xpg_lp_iterate
+ * runs at most `pivots` more iterations of solveSlackForm's loop (lpsol.h:1039-1188)
+ * without a host round trip per pivot.  Returns -1000 while still running. */
+int  xpg_lp_begin(xpg_lp * lp);
+int  xpg_lp_iterate(xpg_lp * lp, unsigned pivots);
+#define XPG_RUNNING (-1000)
+int  xpg_lp_pivots_done(xpg_lp * lp, unsigned * out);
+/* shape of the live tableau: rows, columns W (= rhs_idx + 1), rhs_idx */
+int  xpg_lp_shape(xpg_lp * lp, int * rows, int * W, int * rhs_idx);
+/* download the live state; any pointer may be NULL.  tab: rows*W, obj: W,
+ * nvset/bvset: rhs_idx bytes, bv2eq: rhs_idx, eq2bv: rows, maxv: 1, sol: W. */
+int  xpg_lp_read(xpg_lp * lp, void * tab, void * obj, uint8_t * nvset, uint8_t * bvset,
+                 int32_t * bv2eq, int32_t * eq2bv, void * maxv, void * sol);
+/* the (entering, leaving) pairs pivoted so far, for parity tests */
+int  xpg_lp_trace(xpg_lp * lp, int32_t * pairs, int cap_pairs, int * n_pairs);
+
+/* ---- SIX::maxm / SIX::minm, src/com/lpsol.h:1993-2033 / :1662-1732 -------------------
+ * Same argument meaning as the reference: out_v receives the optimum (0 on
+ * non-success, lpsol.h:2024), out_sol the cols entries of `res` with a trailing
+ * 1 in the constant slot (lpsol.h:1880-1887); out_sol is written only on success. */
+int xpg_six_maxm_f64(xpg_ctx * ctx, const double * tgtf, const double * vc, int vc_rows,
+                     const double * eq, int eq_rows, const double * leq, int leq_rows,
+                     int cols, unsigned max_iter, double * out_v, double * out_sol);
+int xpg_six_minm_f64(xpg_ctx * ctx, const double * tgtf, const double * vc, int vc_rows,
+                     const double * eq, int eq_rows, const double * leq, int leq_rows,
+                     int cols, unsigned max_iter, double * out_v, double * out_sol);
+int xpg_six_maxm_rat32(xpg_ctx * ctx, const xpg_rat32 * tgtf, const xpg_rat32 * vc,
+                       int vc_rows, const xpg_rat32 * eq, int eq_rows,
+                       const xpg_rat32 * leq, int leq_rows, int cols, unsigned max_iter,
+                       xpg_rat32 * out_v, xpg_rat32 * out_sol);
+int xpg_six_minm_rat32(xpg_ctx * ctx, const xpg_rat32 * tgtf, const xpg_rat32 * vc,
+                       int vc_rows, const xpg_rat32 * eq, int eq_rows,
+                       const xpg_rat32 * leq, int leq_rows, int cols, unsigned max_iter,
+                       xpg_rat32 * out_v, xpg_rat32 * out_sol);
+
+/* ---- batches of independent small LPs (the dependence-test workload) ------------------
+ * nb problems of identical shape: leq[nb][m][cols], tgtf[nb][cols], x >= 0, no
+ * equalities -- what Lineq::has_solution hands to SIX (src/com/linsys.cpp:852-904).
+ * Each LP is solved LDS-resident by one workgroup.  is_max selects maxm / minm.
+ * out_status[nb], out_v[nb], out_sol[nb][cols] (rows of failed LPs untouched).
+ * The _dev variants take device pointers for every array and are asynchronous. */
+int xpg_six_batch_f64(xpg_ctx * ctx, int is_max, int nb, const double * tgtf,
+                      const double * leq, int m, int cols, unsigned max_iter,
+                      int32_t * out_status, double * out_v, double * out_sol);
+int xpg_six_batch_rat32(xpg_ctx * ctx, int is_max, int nb, const xpg_rat32 * tgtf,
+                        const xpg_rat32 * leq, int m, int cols, unsigned max_iter,
+                        int32_t * out_status, xpg_rat32 * out_v, xpg_rat32 * out_sol);
+int xpg_six_batch_f64_dev(xpg_ctx * ctx, int is_max, int nb, const double * tgtf,
+                          const double * leq, int m, int cols, unsigned max_iter,
+                          int32_t * out_status, double * out_v, double * out_sol,
+                          uint32_t * out_pivots);
+int xpg_six_batch_rat32_dev(xpg_ctx * ctx, int is_max, int nb, const xpg_rat32 * tgtf,
+                            const xpg_rat32 * leq, int m, int cols, unsigned max_iter,
+                            int32_t * out_status, xpg_rat32 * out_v, xpg_rat32 * out_sol,
+                            uint32_t * out_pivots);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XPOLY_AMD_H */

@@ -1,0 +1,57 @@
+"""CPU suite, part 2: the C-ABI library builds, loads and exports every symbol
+include/xpoly_amd.h declares; without a GPU it must fail loudly, never fall back."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lib():
+    from xpoly_amd import build, _capi
+    build.build()
+    return _capi.lib()
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib()
+    hdr = open(os.path.join(ROOT, "include", "xpoly_amd.h")).read()
+    declared = sorted(set(re.findall(r"\b(xpg_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 30
+    from xpoly_amd._capi import SYMBOLS
+    assert sorted(SYMBOLS) == declared
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_no_gpu_means_loud_failure():
+    lib = _lib()
+    if lib.xpg_device_count() > 0:
+        pytest.skip("a GPU is present")
+    import xpoly_amd
+    with pytest.raises(xpoly_amd.XpgError):
+        xpoly_amd.Context(0)
+
+
+def test_product_never_touches_the_oracle():
+    """The shipped package must not import, link or read anything under oracle/."""
+    pkg = os.path.join(ROOT, "xpoly_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in text.replace("the CPU oracle", ""), os.path.join(dirpath, f)
+    hdr = open(os.path.join(ROOT, "include", "xpoly_amd.h")).read()
+    assert "oracle" not in hdr
+
+
+def test_status_codes_match_reference():
+    hdr = open(os.path.join(ROOT, "include", "xpoly_amd.h")).read()
+    want = {"XPG_SIX_SUCC": 0, "XPG_SIX_UNBOUND": 1, "XPG_SIX_NO_PRI_FEASIBLE_SOL": 2,
+            "XPG_SIX_OPTIMAL_IS_INFEASIBLE": 3, "XPG_SIX_TIME_OUT": 4, "XPG_IP_SUCC": 0,
+            "XPG_IP_UNBOUND": 1, "XPG_IP_NO_PRI_FEASIBLE_SOL": 2, "XPG_IP_NO_BETTER_THAN_BEST_SOL": 3}
+    for k, v in want.items():
+        m = re.search(r"#define\s+%s\s+(-?\d+)" % k, hdr)
+        assert m and int(m.group(1)) == v, k

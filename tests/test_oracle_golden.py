@@ -1,0 +1,183 @@
+"""CPU suite, part 1: pins the oracle (our CPU restatement, oracle/oracle.cpp) to the
+golden vectors generated from the real reference by tools/gen_golden.py. If the
+reference build is present (authoring container), also re-checks live against it.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tools import gen
+
+F64, RAT = 0, 1
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def dec(lst, kind, shape=None):
+    if kind == F64:
+        a = np.array([float.fromhex(x) for x in lst], dtype=np.float64)
+        return a.reshape(shape) if shape is not None else a
+    a = np.array(lst, dtype=np.int32)
+    if shape is not None:
+        return a.reshape(tuple(shape))
+    return a.reshape(-1, 2)
+
+
+def prob_dec(d, kind):
+    out = {}
+    for k, v in d.items():
+        out[k] = dec(v["data"], kind, v["shape"])
+    return out
+
+
+def same(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    if a.dtype == np.float64:
+        return a.shape == b.shape and np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    return a.shape == b.shape and np.array_equal(a, b)
+
+
+def fnv1a(arr):
+    h = 0xcbf29ce484222325
+    for b in np.ascontiguousarray(arr).tobytes():
+        h ^= b
+        h = (h * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    return "%016x" % h
+
+
+def test_g1_example(port):
+    g = json.load(open(os.path.join(GOLD, "g1_example.json")))
+    st, v, sol = port.six_solve(F64, True, [2.0, -1.0, 0.0], [[-1, 0, 0], [0, -1, 0]], None,
+                                [[2, -1, 2], [1, -5, -4]])
+    assert st == g["float_max"]["status"] == 0
+    assert same([v], dec(g["float_max"]["v"], F64)) and v == 2.0
+    assert same(sol, dec(g["float_max"]["sol"], F64))
+    assert sol.tolist() == [1.5555555555555556, 1.1111111111111112, 1.0]   # example.cpp:89-93
+    tg = [1, 1, 1, 1, 1, 0]
+    leq = [[-1, 0, 0, 0, 0, -10], [-1, -1, 0, 0, 0, -8], [-1, -1, -1, 0, 0, -9], [-1, -1, -1, -1, 0, -11],
+           [0, -1, -1, -1, -1, -13], [0, 0, -1, -1, -1, -8], [0, 0, 0, -1, -1, -5], [0, 0, 0, 0, -1, -3]]
+    vc = np.zeros((5, 6), dtype=np.int32); vc[range(5), range(5)] = -1
+    assert port.six_solve(RAT, True, tg, vc, None, leq)[0] == g["rat_max"]["status"] == 1
+    st, v, sol = port.six_solve(RAT, False, tg, vc, None, leq)
+    assert st == 0 and v.tolist() == [23, 1]                               # example.cpp:171-174
+    assert same(sol, dec(g["rat_min"]["sol"], RAT))
+
+
+def test_g2_two_stage_states(port):
+    g = json.load(open(os.path.join(GOLD, "g2_two_stage.json")))
+    n = 0
+    for case in g:
+        kind = case["kind"]
+        if case["fam"] == "xorshift_8x16":
+            leq, tgtf = gen.dense_lp_f64(8, 16)
+            for s in case["states"]:
+                r = port.two_stage(F64, leq, tgtf, s["K"])
+                assert r["status"] == s["status"] and r["rhs"] == s["rhs"]
+                assert fnv1a(r["tab"]) == s["tab_hash"]
+                assert same(r["tgtf"], dec(s["tgtf"], F64))
+                assert r["eq2bv"].tolist() == s["eq2bv"]
+                n += 1
+            continue
+        p = prob_dec(case["problem"], kind)
+        for s in case["states"]:
+            r = port.two_stage(kind, p["leq"], p["tgtf"], s["K"])
+            assert r["status"] == s["status"], (case["fam"], s["K"])
+            if s["status"] == 2:
+                continue
+            shape = s["tab_shape"] + ([2] if kind == RAT else [])
+            assert same(r["tab"], dec(s["tab"], kind, shape))
+            assert same(r["tgtf"], dec(s["tgtf"], kind, None if kind == F64 else (-1, 2)))
+            assert r["nvset"].tolist() == s["nvset"] and r["bvset"].tolist() == s["bvset"]
+            assert r["bv2eq"].tolist() == s["bv2eq"] and r["eq2bv"].tolist() == s["eq2bv"]
+            n += 1
+    assert n > 60
+
+
+def test_g3_six_status_objective_solution(port):
+    g = json.load(open(os.path.join(GOLD, "g3_six.json")))
+    statuses = set()
+    for case in g:
+        kind = case["kind"]
+        p = prob_dec(case["problem"], kind)
+        for key, is_max in (("max", True), ("min", False)):
+            if key not in case:
+                continue
+            st, v, sol = port.six_solve(kind, is_max, p["tgtf"], p["vc"], p.get("eq"), p.get("leq"))
+            w = case[key]
+            assert st == w["status"]
+            assert same(np.atleast_1d(v) if kind == F64 else v.reshape(-1, 2),
+                        dec(w["v"], kind))
+            if st == 0:
+                assert same(sol, dec(w["sol"], kind) if kind == F64 else dec(w["sol"], kind))
+            statuses.add(st)
+    assert {0, 1, 2, 3} <= statuses      # incl. the reference's "optimal is infeasible" answers
+
+
+def test_g4_rational_hashes_cross_appro(port):
+    g = json.load(open(os.path.join(GOLD, "g4_rational_hash.json")))
+    fired = 0
+    for rec in g:
+        leq, tgtf = gen.int_lp_rat(rec["m"], rec["n"])
+        c0 = port.appro_count()
+        r = port.two_stage(RAT, leq, tgtf, rec["K"])
+        assert r["status"] == rec["status"]
+        assert fnv1a(r["tab"]) == rec["tab_hash"], rec
+        assert fnv1a(r["tgtf"]) == rec["tgtf_hash"]
+        assert r["tgtf"][r["rhs"]].tolist() == rec["obj_const"]
+        assert port.appro_count() - c0 == rec["appro_calls"]
+        fired += rec["appro_calls"]
+    assert fired > 10000      # the float32 rescue (rational.cpp:189-226) really is exercised
+
+
+def test_g6_mip(port):
+    g = json.load(open(os.path.join(GOLD, "g6_mip.json")))
+    n = 0
+    for case in g:
+        p = prob_dec(case["problem"], RAT)
+        ind = np.array(case["ind"], dtype=np.uint8) if "ind" in case else None
+        for key, is_max in (("max", True), ("min", False)):
+            if key not in case:
+                continue
+            st, v, sol = port.mip_solve(RAT, is_max, case["is_bin"], p["tgtf"], p["vc"], None, p["leq"], ind)
+            w = case[key]
+            assert st == w["status"]
+            assert v.tolist() == w["v"]
+            if st == 0:
+                assert same(sol, dec(w["sol"], RAT))
+            n += 1
+    assert n > 40
+
+
+def test_scalar_semantics(port):
+    # Float '==' window of 1e-17 (flty.cpp:41-58)
+    assert port.flt_cmp(4, 0.0, 1e-17) == 1 and port.flt_cmp(4, 0.0, 1.1e-17) == 0
+    assert port.flt_cmp(4, 1e-18, -1e-18) == 0          # opposite signs never equal
+    assert port.flt_cmp(1, 1e-18, 0.0) == 1             # <= is < or ==
+    assert port.flt_cmp(2, 1e-18, 0.0) == 1             # > is raw
+    # Rational: '==' is field-wise, '<' cross-multiplies (rational.h:80-83, rational.cpp:229-237)
+    assert port.rat_cmp(4, (1, 2), (2, 4)) == 0 and port.rat_cmp(0, (1, 3), (1, 2)) == 1
+    assert port.rat_op(1, (5, 5), (-3, 7)) == (-7, 3)   # x/x divided by b: unreduced reciprocal
+    assert port.rat_op(0, (3, 4), (4, 3)) == (1, 1)
+    assert port.rat_op(2, (1, 2), (-1, 2)) == (0, 1)
+    # appro: 2^31/3 * 7/5 does not fit int32 -> float32 rescue
+    n, d = port.rat_op(0, (2147483647, 3), (7, 5))
+    assert d in (1, 10, 100, 1000, 10000, 100000, 1000000) or d > 0
+
+
+@pytest.mark.ref
+def test_live_reference_agrees_with_port(ref, port):
+    """Authoring container only: a short differential run against the real reference."""
+    rng = np.random.default_rng(99)
+    for it in range(60):
+        kind = int(rng.integers(0, 2)); fam = int(rng.integers(0, 3))
+        m, nv = int(rng.integers(1, 8)), int(rng.integers(1, 8))
+        p = gen.random_problem(rng, kind, fam, m, nv)
+        for is_max in (True, False):
+            o = port.six_solve(kind, is_max, p["tgtf"], p["vc"], p.get("eq"), p.get("leq"))
+            if o[0] == -7:
+                continue
+            r = ref.six_solve(kind, is_max, p["tgtf"], p["vc"], p.get("eq"), p.get("leq"))
+            assert r[0] == o[0] and same(r[1], o[1])
+            if r[0] == 0:
+                assert same(r[2], o[2])

@@ -1,0 +1,54 @@
+"""ctypes binding of include/xpoly_amd.h. Loads xpoly_amd/libxpoly_amd.so and
+fails loudly if it is missing: there is no CPU fallback anywhere in this package."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "libxpoly_amd.so")
+
+XPG_RUNNING = -1000
+ERRORS = {-1: "XPG_ERR_HIP", -2: "XPG_ERR_ALLOC", -3: "XPG_ERR_SHAPE", -4: "XPG_ERR_UNSUPPORTED",
+          -5: "XPG_ERR_NO_DEVICE", -7: "XPG_ERR_REF_UNDEFINED"}
+
+# every symbol include/xpoly_amd.h declares
+SYMBOLS = [
+    "xpg_device_count", "xpg_create", "xpg_destroy", "xpg_last_error", "xpg_version", "xpg_stream",
+    "xpg_sync", "xpg_profile_begin", "xpg_profile_end", "xpg_malloc", "xpg_free", "xpg_upload", "xpg_download",
+    "xpg_pivot_f64_dev", "xpg_pivot_rat32_dev", "xpg_pivot_f64", "xpg_pivot_rat32",
+    "xpg_lp_create", "xpg_lp_destroy", "xpg_lp_two_stage", "xpg_lp_begin", "xpg_lp_iterate",
+    "xpg_lp_pivots_done", "xpg_lp_shape", "xpg_lp_read", "xpg_lp_trace",
+    "xpg_six_maxm_f64", "xpg_six_minm_f64", "xpg_six_maxm_rat32", "xpg_six_minm_rat32",
+    "xpg_six_batch_f64", "xpg_six_batch_rat32", "xpg_six_batch_f64_dev", "xpg_six_batch_rat32_dev",
+]
+
+_lib = None
+
+
+class XpgError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise XpgError(
+                "%s is missing: build it with `python -m xpoly_amd.build` (hipcc, gfx950). "
+                "xpoly_amd has no CPU fallback." % SO_PATH)
+        _lib = C.CDLL(SO_PATH)
+        _lib.xpg_last_error.restype = C.c_char_p
+        _lib.xpg_version.restype = C.c_char_p
+        _lib.xpg_stream.restype = C.c_void_p
+        for name in SYMBOLS:
+            fn = getattr(_lib, name)
+            if fn.restype is C.c_int:
+                fn.restype = C.c_int
+    return _lib
+
+
+def vp(a):
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    return a.ctypes.data_as(C.c_void_p)

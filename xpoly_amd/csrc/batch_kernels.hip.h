@@ -1,0 +1,464 @@
+// Batches of independent small LPs -- the polyhedral dependence-test workload
+// (Lineq::has_solution -> SIX::maxm / minm, src/com/linsys.cpp:852-904; one call
+// per DepPoly::is_empty, src/eng/poly.cpp:530-573). One workgroup owns one LP
+// from input to answer: the whole slack tableau, objective row, basis maps and
+// pivot-pair table live in LDS (32x64 LP: ~29 KB of the CU's 160 KB), so HBM
+// sees only the 16 KB problem read and the ~0.5 KB result write. Every step of
+// SIX::maxm / minm for an x >= 0, inequality-only problem runs inside the
+// kernel: slack construction, the auxiliary-variable phase 1, solveSlackForm,
+// the feasibility check and the final objective.
+#pragma once
+#include "lp_kernels.hip.h"
+
+namespace xpg {
+
+template <class S> struct Small {
+    S * tab; int R, W, ld, rhs;     // R rows, W live columns, row stride ld
+    S * obj; S * e; S * k; S * x;
+    uint8_t * nv; uint8_t * bv; int * bv2eq; int * eq2bv;
+    uint32_t * ppt; int pw; int * rowcnt; int * colcnt;
+    Cand<S> * sh_c; int * sh_i;     // reduction scratch (16 entries each)
+    int * sh_w;                     // 8 words of broadcast scratch
+    unsigned pivots;
+};
+
+template <class S> __device__ __forceinline__ bool sm_seen(const Small<S> & P, int nv, int b)
+{ return (P.ppt[nv * P.pw + (b >> 5)] >> (b & 31)) & 1u; }
+
+// SIX::pivot (lpsol.h:1456-1511) on the LDS tableau; all threads participate.
+template <class S> __device__ void sm_pivot(Small<S> & P, int nv, int bv)
+{
+    const int r = P.bv2eq[bv], W = P.W, ld = P.ld;
+    const S piv = P.tab[r * ld + nv];
+    const S cnv = P.obj[nv];
+    __syncthreads();
+    const S s = div(one<S>(), piv);
+    const int smode = scale_mode(s), cmode = scale_mode(cnv);
+    for (int j = threadIdx.x; j < W; j += blockDim.x) {
+        const S ej = scaled(P.tab[r * ld + j], s, smode);
+        P.e[j] = ej;
+        P.tab[r * ld + j] = ej;
+        S t = mul(ej, minus_one<S>());
+        if (j >= P.rhs) t = neg(t);
+        t = scaled(t, cnv, cmode);
+        P.obj[j] = add(t, P.obj[j]);
+    }
+    for (int i = threadIdx.x; i < P.R; i += blockDim.x)
+        if (i != r) P.k[i] = neg(P.tab[i * ld + nv]);
+    __syncthreads();
+    // flat sweep over the R x W cells, consecutive lanes on consecutive cells
+    {
+        int i = 0, j = threadIdx.x;
+        while (j >= W) { j -= W; i++; }
+        while (i < P.R) {
+            if (i != r) {
+                S * p = P.tab + i * ld + j;
+                *p = add(*p, mul(P.k[i], P.e[j]));
+            }
+            j += blockDim.x;
+            while (j >= W) { j -= W; i++; }
+        }
+    }
+    if (threadIdx.x == 0) {
+        P.nv[nv] = 0; P.nv[bv] = 1; P.bv[nv] = 1; P.bv[bv] = 0;
+        P.eq2bv[r] = nv; P.bv2eq[nv] = r; P.bv2eq[bv] = -1;
+    }
+    P.pivots++;
+    __syncthreads();
+}
+
+// SIX::findPivotBV (lpsol.h:553-663)
+template <class S> __device__ int sm_ratio(const Small<S> & P, int nv)
+{
+    const int lim = P.rhs - 1;
+    for (int pass = 0; pass < 2; pass++) {
+        Cand<S> best; best.q = zero<S>(); best.idx = INT_MAX;
+        for (int i = threadIdx.x; i < P.R; i += blockDim.x) {
+            const S a = P.tab[i * P.ld + nv];
+            if (pass == 0 ? le(a, zero<S>()) : eq(a, zero<S>())) continue;
+            const int b = P.eq2bv[i];
+            if (sm_seen(P, nv, b) || P.colcnt[b] >= lim) continue;
+            Cand<S> c; c.q = div(P.tab[i * P.ld + P.rhs], a); c.idx = i;
+            best = better(best, c);
+        }
+        best = block_argmin(best, P.sh_c);
+        if (best.idx != INT_MAX) return P.eq2bv[best.idx];
+    }
+    return -1;
+}
+
+// SIX::solveSlackForm (lpsol.h:1008-1191) incl. is_feasible (lpsol.h:784-822,
+// vc = "-x_i <= 0" for every variable). Returns a SIX_* status; maxv on success.
+template <class S> __device__ int sm_solve(Small<S> & P, unsigned max_iter, S & maxv)
+{
+    const int rhs = P.rhs, lim = rhs - 1;
+    for (int i = threadIdx.x; i < rhs; i += blockDim.x) { P.rowcnt[i] = 0; P.colcnt[i] = 0; }
+    for (int t = threadIdx.x; t < rhs * P.pw; t += blockDim.x) P.ppt[t] = 0u;
+    maxv = zero<S>();
+    __syncthreads();
+    unsigned done = 0;
+    while (done < max_iter) {
+        int first = INT_MAX, anypos = 0;
+        for (int j = threadIdx.x; j < rhs; j += blockDim.x)
+            if (P.nv[j] && gt(P.obj[j], zero<S>())) {
+                anypos = 1;
+                if (P.rowcnt[j] < lim) first = min(first, j);
+            }
+        first = block_min_int(first, P.sh_i);
+        if (threadIdx.x == 0) P.sh_w[0] = 0;
+        __syncthreads();
+        if (anypos) P.sh_w[0] = 1;
+        const int stop = first == INT_MAX ? rhs : first;
+        for (int j = threadIdx.x; j < stop; j += blockDim.x)
+            if (!P.nv[j]) P.obj[j] = zero<S>();
+        __syncthreads();
+        int enter = -1, leave = -1;
+        if (first == INT_MAX) {
+            if (!P.sh_w[0]) {
+                // optimum: x_B = b, feasibility (lpsol.h:1104-1126)
+                if (threadIdx.x == 0) P.sh_w[1] = 0;
+                __syncthreads();
+                for (int j = threadIdx.x; j < P.W; j += blockDim.x) {
+                    S xv = zero<S>();
+                    if (j < rhs && P.bv[j]) xv = P.tab[P.bv2eq[j] * P.ld + rhs];
+                    P.x[j] = xv;
+                    if (j < rhs && gt(mul(minus_one<S>(), xv), zero<S>())) P.sh_w[1] = 1;
+                }
+                __syncthreads();
+                for (int i = threadIdx.x; i < P.R; i += blockDim.x) {
+                    S sum = zero<S>();
+                    const S * row = P.tab + i * P.ld;
+                    for (int j = 0; j < rhs; j++) sum = add(sum, mul(row[j], P.x[j]));
+                    reduce(sum);
+                    S b = row[rhs];
+                    reduce(b);
+                    P.tab[i * P.ld + rhs] = b;
+                    if (ne(sum, b)) P.sh_w[1] = 1;
+                }
+                __syncthreads();
+                if (P.sh_w[1]) return 3;
+                maxv = P.obj[rhs];
+                return 0;
+            }
+            for (int pass = 0; pass < 2 && enter < 0; pass++)           // lpsol.h:671-773
+                for (int i = 0; i < rhs; i++) {
+                    if (P.bv[i] || P.rowcnt[i] >= lim) continue;
+                    const S c = P.obj[i];
+                    const bool take = gt(c, zero<S>()) ? true : (eq(c, zero<S>()) ? pass == 1 : false);
+                    if (!take) continue;
+                    const int b = sm_ratio(P, i);
+                    if (b < 0) continue;
+                    enter = i; leave = b;
+                    break;
+                }
+            if (enter < 0) return 1;
+        } else {
+            leave = sm_ratio(P, first);
+            if (leave < 0) {                                            // lpsol.h:1146-1151
+                int add_n = 0;
+                for (int j = threadIdx.x; j < rhs; j += blockDim.x) {
+                    if (j == first || sm_seen(P, first, j)) continue;
+                    atomicOr(&P.ppt[first * P.pw + (j >> 5)], 1u << (j & 31));
+                    P.colcnt[j] += 1;
+                    add_n++;
+                }
+                if (add_n) atomicAdd(&P.rowcnt[first], add_n);
+                __syncthreads();
+                continue;
+            }
+            enter = first;
+        }
+        if (threadIdx.x == 0 && !sm_seen(P, enter, leave)) {
+            P.ppt[enter * P.pw + (leave >> 5)] |= 1u << (leave & 31);
+            P.rowcnt[enter] += 1; P.colcnt[leave] += 1;
+        }
+        __syncthreads();
+        sm_pivot(P, enter, leave);
+        done++;
+    }
+    return 4;
+}
+
+// Source of the slack form: the primal (is_max) or the dual built the way
+// SIX::calcDualMaxm does (lpsol.h:1602-1629) straight from the caller's arrays.
+template <class S> struct Source {
+    const S * leq; const S * tgtf; int m, cols, is_max;
+    __device__ int rows() const { return is_max ? m : cols - 1; }
+    __device__ int vars() const { return is_max ? cols - 1 : m; }
+    __device__ S A(int i, int j) const
+    { return is_max ? leq[i * cols + j] : mul(leq[j * cols + i], minus_one<S>()); }
+    __device__ S b(int i) const { return is_max ? leq[i * cols + cols - 1] : tgtf[i]; }
+    __device__ S c(int j) const
+    { return is_max ? tgtf[j] : mul(leq[j * cols + cols - 1], minus_one<S>()); }
+    __device__ S c0() const { return is_max ? tgtf[cols - 1] : mul(zero<S>(), minus_one<S>()); }
+};
+
+template <class S> __device__ void sm_build(Small<S> & P, const Source<S> & src, int with_xa)
+{
+    const int V = src.vars(), R = src.rows();
+    const int first_slack = V + (with_xa ? 1 : 0);
+    P.R = R; P.W = first_slack + R + 1; P.rhs = P.W - 1;
+    for (int i = 0; i < R; i++)
+        for (int j = threadIdx.x; j < P.W; j += blockDim.x) {
+            S val = zero<S>();
+            if (j < V) val = src.A(i, j);
+            else if (with_xa && j == V) val = minus_one<S>();
+            else if (j == P.rhs) val = src.b(i);
+            else if (j - first_slack == i) val = one<S>();
+            P.tab[i * P.ld + j] = val;
+        }
+    for (int j = threadIdx.x; j < P.W; j += blockDim.x) {
+        S val = zero<S>();
+        if (with_xa) { if (j == V) val = minus_one<S>(); }
+        else if (j < V) val = src.c(j);
+        else if (j == P.rhs) val = src.c0();
+        P.obj[j] = val;
+    }
+    for (int i = threadIdx.x; i < P.rhs; i += blockDim.x) {
+        const bool slack = i >= first_slack;
+        P.nv[i] = slack ? 0 : 1; P.bv[i] = slack ? 1 : 0;
+        P.bv2eq[i] = slack ? i - first_slack : -1;
+        if (slack) P.eq2bv[i - first_slack] = i;
+    }
+    __syncthreads();
+}
+
+// SIX::constructBasicFeasibleSolution (lpsol.h:839-988). Returns 1 when a
+// feasible slack form stands in P, 0 when there is none, -7 where the
+// reference's behaviour is undefined.
+template <class S> __device__ int sm_phase_one(Small<S> & P, const Source<S> & src, unsigned max_iter)
+{
+    const int V = src.vars(), xa = V;
+    sm_build(P, src, 1);
+    Cand<S> best; best.q = zero<S>(); best.idx = INT_MAX;
+    for (int i = threadIdx.x; i < P.R; i += blockDim.x) {
+        Cand<S> c; c.q = P.tab[i * P.ld + P.rhs]; c.idx = i;
+        best = better(best, c);
+    }
+    best = block_argmin(best, P.sh_c);
+    sm_pivot(P, xa, P.eq2bv[best.idx]);
+    S top;
+    if (sm_solve(P, max_iter, top) != 0) return 0;
+    reduce(top);
+    if (ne(top, zero<S>())) return 0;
+    if (P.bv[xa]) {
+        const int r = P.bv2eq[xa];
+        if (threadIdx.x == 0) {
+            int cand = 0;
+            for (; cand < P.rhs; cand++) {
+                if (!P.nv[cand]) continue;
+                S a = P.tab[r * P.ld + cand];
+                reduce(a);
+                P.tab[r * P.ld + cand] = a;
+                if (ne(a, zero<S>())) break;
+            }
+            P.sh_w[2] = cand;
+        }
+        __syncthreads();
+        const int cand = P.sh_w[2];
+        if (cand >= P.rhs) return -7;
+        sm_pivot(P, cand, xa);
+    }
+    // objective rebuild (lpsol.h:944-953; substit: xmat.cpp:571-599 / :1491-1519)
+    const int W = P.W, rhs = P.rhs;
+    for (int j = threadIdx.x; j < W; j += blockDim.x)
+        P.obj[j] = j < V ? src.c(j) : (j == rhs ? src.c0() : zero<S>());
+    __syncthreads();
+    for (int i = 0; i < rhs; i++) {
+        if (threadIdx.x == 0) { S f = P.obj[i]; reduce(f); P.obj[i] = f; }
+        __syncthreads();
+        const S f = P.obj[i];
+        const bool go = ne(f, zero<S>()) && P.bv[i];
+        __syncthreads();
+        if (go) {
+            const S * expr = P.tab + P.bv2eq[i] * P.ld;
+            const S ev = expr[i];
+            if (threadIdx.x == 0) P.obj[rhs] = mul(P.obj[rhs], minus_one<S>());
+            __syncthreads();
+            if (!eq(ev, zero<S>())) {
+                S kk; int mode;
+                if (ne(f, ev)) {
+                    kk = div(neg(f), ev);
+                    mode = eq(kk, zero<S>()) ? SCALE_ZERO : (eq(kk, one<S>()) ? SCALE_KEEP : SCALE_MUL);
+                } else { kk = minus_one<S>(); mode = SCALE_MUL; }
+                for (int j = threadIdx.x; j < W; j += blockDim.x)
+                    P.obj[j] = add(scaled(expr[j], kk, mode), P.obj[j]);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) P.obj[rhs] = mul(P.obj[rhs], minus_one<S>());
+            __syncthreads();
+        }
+    }
+    // drop column xa (lpsol.h:955-986)
+    for (int i = 0; i <= P.R; i++) {
+        S * row = i < P.R ? P.tab + i * P.ld : P.obj;
+        for (int c0 = xa; c0 < W - 1; c0 += blockDim.x) {
+            const int j = c0 + threadIdx.x;
+            S t = zero<S>();
+            if (j < W - 1) t = row[j + 1];
+            __syncthreads();
+            if (j < W - 1) row[j] = t;
+            __syncthreads();
+        }
+    }
+    for (int c0 = xa; c0 < rhs - 1; c0 += blockDim.x) {
+        const int j = c0 + threadIdx.x;
+        uint8_t a = 0, b = 0; int q = 0;
+        if (j < rhs - 1) { a = P.nv[j + 1]; b = P.bv[j + 1]; q = P.bv2eq[j + 1]; }
+        __syncthreads();
+        if (j < rhs - 1) { P.nv[j] = a; P.bv[j] = b; P.bv2eq[j] = q; }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < P.R; i += blockDim.x)
+        if (P.eq2bv[i] > xa) P.eq2bv[i] -= 1;
+    P.W -= 1; P.rhs -= 1;
+    __syncthreads();
+    return 1;
+}
+
+template <class S> __host__ __device__ inline size_t small_lds_bytes(int R, int V)
+{
+    const int Wmax = V + 1 + R + 1, nmax = Wmax - 1, pw = (nmax + 31) / 32;
+    size_t b = 0;
+    b += (size_t)R * Wmax * 8;            // tab
+    b += (size_t)Wmax * 8 * 3;            // obj, e, x
+    b += (size_t)((R + 1) & ~1) * 8;      // k
+    b += 16 * sizeof(Cand<S>);            // sh_c
+    b += (size_t)nmax * 4 * 3;            // bv2eq, rowcnt, colcnt
+    b += (size_t)R * 4;                   // eq2bv
+    b += (size_t)nmax * pw * 4;           // ppt
+    b += 16 * 4 + 8 * 4;                  // sh_i, sh_w
+    b += (size_t)((nmax + 3) & ~3) * 2;   // nv, bv
+    return (b + 15) & ~(size_t)15;
+}
+
+template <class S> __global__ void k_batch(int nb, const S * tgtf, const S * leq, int m, int cols,
+                                           int is_max, unsigned max_iter, int32_t * out_status,
+                                           S * out_v, S * out_sol, uint32_t * out_pivots)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int n = cols - 1;
+    const int R = is_max ? m : n, V = is_max ? n : m;
+    const int Wmax = V + 1 + R + 1, nmax = Wmax - 1;
+    Small<S> P;
+    unsigned char * p = lds;
+    P.tab = (S *)p; p += (size_t)R * Wmax * 8;
+    P.obj = (S *)p; p += (size_t)Wmax * 8;
+    P.e = (S *)p; p += (size_t)Wmax * 8;
+    P.x = (S *)p; p += (size_t)Wmax * 8;
+    P.k = (S *)p; p += (size_t)((R + 1) & ~1) * 8;
+    P.sh_c = (Cand<S> *)p; p += 16 * sizeof(Cand<S>);
+    P.bv2eq = (int *)p; p += (size_t)nmax * 4;
+    P.rowcnt = (int *)p; p += (size_t)nmax * 4;
+    P.colcnt = (int *)p; p += (size_t)nmax * 4;
+    P.eq2bv = (int *)p; p += (size_t)R * 4;
+    P.pw = (nmax + 31) / 32;
+    P.ppt = (uint32_t *)p; p += (size_t)nmax * P.pw * 4;
+    P.sh_i = (int *)p; p += 16 * 4;
+    P.sh_w = (int *)p; p += 8 * 4;
+    P.nv = (uint8_t *)p; p += (size_t)((nmax + 3) & ~3);
+    P.bv = (uint8_t *)p;
+    P.ld = Wmax;
+    for (int lp = blockIdx.x; lp < nb; lp += gridDim.x) {
+        Source<S> src;
+        src.leq = leq + (size_t)lp * m * cols; src.tgtf = tgtf + (size_t)lp * cols;
+        src.m = m; src.cols = cols; src.is_max = is_max;
+        P.pivots = 0;
+        __syncthreads();
+        // stage1 trigger (lpsol.h:1794-1803)
+        if (threadIdx.x == 0) { P.sh_w[3] = 0; P.sh_w[4] = 0; }
+        __syncthreads();
+        for (int j = threadIdx.x; j < V; j += blockDim.x) if (gt(src.c(j), zero<S>())) P.sh_w[3] = 1;
+        for (int i = threadIdx.x; i < R; i += blockDim.x) if (lt(src.b(i), zero<S>())) P.sh_w[4] = 1;
+        __syncthreads();
+        const bool phase1 = !P.sh_w[3] || P.sh_w[4];
+        __syncthreads();
+        int status = -1;
+        if (phase1) {
+            const int ok = sm_phase_one(P, src, max_iter);
+            if (ok == 0) status = 2;
+            else if (ok < 0) status = XPG_ERR_REF_UNDEFINED;
+        } else {
+            sm_build(P, src, 0);
+        }
+        S top = zero<S>();
+        if (status == -1) status = sm_solve(P, max_iter, top);
+        // SIX::calcFinalSolution (lpsol.h:1851-1899) / minm read-out (lpsol.h:1713-1716)
+        if (status == 0) {
+            S * sol = out_sol + (size_t)lp * cols;
+            for (int j = threadIdx.x; j < n; j += blockDim.x) {
+                S val = is_max ? P.x[j] : neg(P.obj[m + j]);
+                P.e[j] = val;
+                reduce(val);
+                sol[j] = val;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                sol[n] = one<S>();
+                S v = zero<S>();
+                for (int j = 0; j < n; j++) v = add(v, mul(P.e[j], src.tgtf[j]));
+                v = add(v, mul(one<S>(), src.tgtf[n]));
+                reduce(v);
+                out_v[lp] = v;
+            }
+        } else if (threadIdx.x == 0) {
+            out_v[lp] = zero<S>();
+        }
+        if (threadIdx.x == 0) {
+            out_status[lp] = status;
+            if (out_pivots) out_pivots[lp] = P.pivots;
+        }
+        __syncthreads();
+    }
+}
+
+template <class S>
+int batch_dev(xpg_ctx * ctx, int is_max, int nb, const S * tgtf, const S * leq, int m, int cols,
+              unsigned max_iter, int32_t * out_status, S * out_v, S * out_sol, uint32_t * out_pivots)
+{
+    if (!ctx || nb < 0 || !tgtf || !leq || m <= 0 || cols < 2 || !out_status || !out_v || !out_sol)
+        return XPG_ERR_SHAPE;
+    if (nb == 0) return 0;
+    const int n = cols - 1;
+    const int R = is_max ? m : n, V = is_max ? n : m;
+    const size_t lds = small_lds_bytes<S>(R, V);
+    if (lds > 160 * 1024) return XPG_ERR_UNSUPPORTED;     // one LP must fit one CU's LDS
+    XPG_HIP(ctx, hipFuncSetAttribute((const void *)k_batch<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int threads = (R * (V + R + 2) >= 4096) ? 128 : 64;
+    const int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
+    int grid = 256 * (per_cu > 16 ? 16 : per_cu) * 4;
+    if (grid > nb) grid = nb;
+    hipLaunchKernelGGL((k_batch<S>), dim3(grid), dim3(threads), lds, ctx->stream, nb, tgtf, leq, m,
+                       cols, is_max ? 1 : 0, max_iter, out_status, out_v, out_sol, out_pivots);
+    XPG_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+template <class S>
+int batch_host(xpg_ctx * ctx, int is_max, int nb, const S * tgtf, const S * leq, int m, int cols,
+               unsigned max_iter, int32_t * out_status, S * out_v, S * out_sol)
+{
+    if (!ctx || nb < 0 || m <= 0 || cols < 2) return XPG_ERR_SHAPE;
+    if (nb == 0) return 0;
+    const size_t bl = (size_t)nb * m * cols * 8, bt = (size_t)nb * cols * 8;
+    S * d_leq = 0; S * d_tgtf = 0; S * d_v = 0; S * d_sol = 0; int32_t * d_st = 0;
+    hipError_t e = hipMalloc((void **)&d_leq, bl);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_tgtf, bt);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_v, (size_t)nb * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_sol, bt);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_st, (size_t)nb * 4);
+    int rc = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(d_leq, leq, bl, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_tgtf, tgtf, bt, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_sol, out_sol, bt, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) rc = batch_dev<S>(ctx, is_max, nb, d_tgtf, d_leq, m, cols, max_iter, d_st, d_v, d_sol, 0);
+    if (e == hipSuccess && rc == 0) e = hipMemcpyAsync(out_status, d_st, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && rc == 0) e = hipMemcpyAsync(out_v, d_v, (size_t)nb * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && rc == 0) e = hipMemcpyAsync(out_sol, d_sol, bt, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_leq); (void)hipFree(d_tgtf); (void)hipFree(d_v); (void)hipFree(d_sol); (void)hipFree(d_st);
+    if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return XPG_ERR_HIP; }
+    return rc;
+}
+
+} // namespace xpg

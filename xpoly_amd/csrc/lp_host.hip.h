@@ -1,0 +1,315 @@
+// Host orchestration of the device-resident LP (xpg_lp): owns the HBM buffers,
+// queues the kernels of lp_kernels.hip.h on the context's stream and mirrors the
+// control flow of SIX::TwoStageMethod / stage1 / constructBasicFeasibleSolution
+// (src/com/lpsol.h:1907-1930, :1784-1844, :839-988). No arithmetic on tableau
+// data happens on the host.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include <stdio.h>
+#include "../../include/xpoly_amd.h"
+#include "lp_kernels.hip.h"
+
+struct xpg_ctx {
+    int device;
+    hipStream_t stream;
+    std::string err;
+    // scratch of the one-shot K1 entry points (xpg_pivot_*_dev)
+    void * rowbuf; void * colbuf; xpg::LoopState * st; size_t row_cap, col_cap;
+    int update_variant;     // tuning knob for the fp64 sweep (see launch_update_f64)
+    // xpg_profile_begin/end: event pairs around each sweep launch
+    std::vector<hipEvent_t> ev0, ev1;
+    int prof_cap, prof_n;
+};
+
+#define XPG_HIP(ctx, call)                                                         \
+    do {                                                                           \
+        hipError_t e_ = (call);                                                    \
+        if (e_ != hipSuccess) {                                                    \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);        \
+            return XPG_ERR_HIP;                                                    \
+        }                                                                          \
+    } while (0)
+
+namespace xpg {
+
+inline int round_up(int x, int a) { return (x + a - 1) / a * a; }
+
+// fp64 sweep launch. Variants are (rows per workgroup, rows in flight); the
+// default is what measured best on MI355X (profiles/), the others stay
+// reachable through XPG_UPDATE_VARIANT for A/B runs.
+inline void launch_update_f64(hipStream_t s, int variant, double * tab, int m, int W, int ld,
+                              const double * rowbuf, const double * colbuf,
+                              const LoopState * st, int guarded)
+{
+    const int strips = (W + 511) / 512;
+#define XPG_LAUNCH(R, U)                                                                    \
+    hipLaunchKernelGGL((k_update_f64<R, U>), dim3(strips, (m + R - 1) / R), dim3(256), 0, s, \
+                       tab, m, W, ld, rowbuf, colbuf, st, guarded)
+    switch (variant) {
+    case 1: XPG_LAUNCH(16, 4); break;
+    case 2: XPG_LAUNCH(32, 4); break;
+    case 3: XPG_LAUNCH(64, 8); break;
+    case 4: XPG_LAUNCH(16, 8); break;
+    case 5: XPG_LAUNCH(128, 8); break;
+    case 6: XPG_LAUNCH(8, 8); break;
+    case 7: XPG_LAUNCH(64, 16); break;
+    default: XPG_LAUNCH(32, 8); break;
+    }
+#undef XPG_LAUNCH
+}
+
+template <class S> inline void launch_update(xpg_ctx * ctx, const LpView<S> & v, int guarded);
+inline bool prof_open(xpg_ctx * ctx)
+{
+    if (ctx->prof_n >= ctx->prof_cap) return false;
+    (void)hipEventRecord(ctx->ev0[ctx->prof_n], ctx->stream);
+    return true;
+}
+inline void prof_close(xpg_ctx * ctx)
+{
+    (void)hipEventRecord(ctx->ev1[ctx->prof_n], ctx->stream);
+    ctx->prof_n++;
+}
+template <> inline void launch_update<F64>(xpg_ctx * ctx, const LpView<F64> & v, int guarded)
+{
+    const bool timed = prof_open(ctx);
+    launch_update_f64(ctx->stream, ctx->update_variant, (double *)v.tab, v.m, v.W, v.ld,
+                      (const double *)v.rowbuf, (const double *)v.colbuf, v.st, guarded);
+    if (timed) prof_close(ctx);
+}
+template <> inline void launch_update<R32>(xpg_ctx * ctx, const LpView<R32> & v, int guarded)
+{
+    const bool timed = prof_open(ctx);
+    hipLaunchKernelGGL((k_update<R32, 8>), dim3((v.W + 255) / 256, (v.m + 7) / 8), dim3(256), 0,
+                       ctx->stream, v, guarded);
+    if (timed) prof_close(ctx);
+}
+
+struct LpBase {
+    virtual ~LpBase() {}
+    xpg_ctx * ctx;
+    int kind;
+};
+
+template <class S> struct Lp : LpBase {
+    LpView<S> v;
+    int n0;                 // structural variables of the input problem
+    int m;
+    S * d_leq; S * d_tgtf;  // the input, kept for the phase-1 objective rebuild
+    S * d_maxv;
+    std::vector<void *> owned;
+    size_t tab_elems;
+    bool began;
+    int final_status;
+
+    int alloc(void ** p, size_t bytes)
+    {
+        hipError_t e = hipMalloc(p, bytes ? bytes : 8);
+        if (e != hipSuccess) { ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e); return XPG_ERR_ALLOC; }
+        owned.push_back(*p);
+        return 0;
+    }
+    ~Lp() { for (void * p : owned) (void)hipFree(p); }
+
+    int create(const void * leq, int m_, int cols, const void * tgtf, const void * vcd,
+               const void * vcr, int on_dev)
+    {
+        m = m_; n0 = cols - 1; began = false; final_status = XPG_RUNNING;
+        const int Wmax = n0 + 1 + m + 1;            // with the phase-1 column
+        const int ld = round_up(Wmax, 16);
+        const int nmax = Wmax - 1;
+        v.m = m; v.ld = ld; v.W = 0; v.rhs = 0;
+        v.pw = (nmax + 31) / 32;
+        v.trace_cap = 1 << 16;
+        tab_elems = (size_t)m * ld;
+        int rc;
+        if ((rc = alloc((void **)&v.tab, tab_elems * sizeof(S)))) return rc;
+        if ((rc = alloc((void **)&v.obj, (size_t)ld * sizeof(S)))) return rc;
+        if ((rc = alloc((void **)&v.rowbuf, (size_t)ld * sizeof(S)))) return rc;
+        if ((rc = alloc((void **)&v.colbuf, (size_t)round_up(m, 16) * sizeof(S)))) return rc;
+        if ((rc = alloc((void **)&v.x, (size_t)ld * sizeof(S)))) return rc;
+        if ((rc = alloc((void **)&v.vcd, (size_t)ld * sizeof(S)))) return rc;
+        if ((rc = alloc((void **)&v.vcr, (size_t)ld * sizeof(S)))) return rc;
+        if ((rc = alloc((void **)&v.nv, ld))) return rc;
+        if ((rc = alloc((void **)&v.bv, ld))) return rc;
+        if ((rc = alloc((void **)&v.bv2eq, (size_t)ld * 4))) return rc;
+        if ((rc = alloc((void **)&v.eq2bv, (size_t)round_up(m, 16) * 4))) return rc;
+        if ((rc = alloc((void **)&v.rowcnt, (size_t)ld * 4))) return rc;
+        if ((rc = alloc((void **)&v.colcnt, (size_t)ld * 4))) return rc;
+        if ((rc = alloc((void **)&v.ppt, (size_t)nmax * v.pw * 4))) return rc;
+        if ((rc = alloc((void **)&v.st, sizeof(LoopState)))) return rc;
+        if ((rc = alloc((void **)&v.trace, (size_t)v.trace_cap * 8))) return rc;
+        if ((rc = alloc((void **)&d_leq, (size_t)m * cols * sizeof(S)))) return rc;
+        if ((rc = alloc((void **)&d_tgtf, (size_t)cols * sizeof(S)))) return rc;
+        if ((rc = alloc((void **)&d_maxv, sizeof(S)))) return rc;
+        hipStream_t s = ctx->stream;
+        const hipMemcpyKind kd = on_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+        XPG_HIP(ctx, hipMemcpyAsync(d_leq, leq, (size_t)m * cols * sizeof(S), kd, s));
+        XPG_HIP(ctx, hipMemcpyAsync(d_tgtf, tgtf, (size_t)cols * sizeof(S), kd, s));
+        // vc(i,i) / vc(i,rhs): default -1 / 0; slack and xa entries are -1 / 0 (lpsol.h:1428, :867-868)
+        std::vector<S> hd(ld, minus_one<S>()), hr(ld, zero<S>());
+        if (vcd) for (int i = 0; i < n0; i++) hd[i] = ((const S *)vcd)[i];
+        if (vcr) for (int i = 0; i < n0; i++) hr[i] = ((const S *)vcr)[i];
+        XPG_HIP(ctx, hipMemcpyAsync(v.vcd, hd.data(), (size_t)ld * sizeof(S), hipMemcpyHostToDevice, s));
+        XPG_HIP(ctx, hipMemcpyAsync(v.vcr, hr.data(), (size_t)ld * sizeof(S), hipMemcpyHostToDevice, s));
+        XPG_HIP(ctx, hipMemsetAsync(v.st, 0, sizeof(LoopState), s));
+        XPG_HIP(ctx, hipStreamSynchronize(s));      // hd/hr are stack-owned
+        return 0;
+    }
+
+    int read_state(LoopState * out)
+    {
+        XPG_HIP(ctx, hipMemcpyAsync(out, v.st, sizeof(LoopState), hipMemcpyDeviceToHost, ctx->stream));
+        XPG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return 0;
+    }
+
+    void build(int with_xa)
+    {
+        v.W = n0 + (with_xa ? 1 : 0) + m + 1;
+        v.rhs = v.W - 1;
+        hipLaunchKernelGGL((k_build<S>), dim3(2048), dim3(256), 0, ctx->stream, v, d_leq, d_tgtf, n0, with_xa);
+        hipLaunchKernelGGL((k_init_basis<S>), dim3(64), dim3(256), 0, ctx->stream, v, n0 + (with_xa ? 1 : 0));
+    }
+    void reset_loop(unsigned max_iter)
+    {
+        hipLaunchKernelGGL((k_reset_loop<S>), dim3(1024), dim3(256), 0, ctx->stream, v, max_iter);
+    }
+    void queue_pivot(int guarded, int counted)
+    {
+        const int span = v.W > v.m ? v.W : v.m;
+        hipLaunchKernelGGL((k_prep<S>), dim3((span + 255) / 256), dim3(256), 0, ctx->stream, v,
+                           guarded, counted, 1);
+        launch_update<S>(ctx, v, guarded);
+    }
+    void queue_iterations(unsigned k)
+    {
+        for (unsigned t = 0; t < k; t++) {
+            hipLaunchKernelGGL((k_select<S>), dim3(1), dim3(1024), 0, ctx->stream, v);
+            queue_pivot(1, 1);
+        }
+    }
+
+    // Runs the queued loop until the device reports anything but ST_RUNNING,
+    // then performs the optimum check. Returns a SIX_* status.
+    int run_loop()
+    {
+        LoopState hs;
+        unsigned chunk = 32;
+        for (;;) {
+            queue_iterations(chunk);
+            int rc = read_state(&hs);
+            if (rc) return rc;
+            if (hs.status != ST_RUNNING) break;
+            if (chunk < 256) chunk *= 2;
+        }
+        return finish(hs.status);
+    }
+    int finish(int status)
+    {
+        if (status == ST_CHECK_OPT) {
+            hipLaunchKernelGGL((k_solution<S>), dim3(64), dim3(256), 0, ctx->stream, v);
+            hipLaunchKernelGGL((k_rowcheck<S>), dim3((v.m + 63) / 64), dim3(64), 0, ctx->stream, v);
+            hipLaunchKernelGGL((k_finish<S>), dim3(1), dim3(1), 0, ctx->stream, v, d_maxv);
+            LoopState hs;
+            int rc = read_state(&hs);
+            if (rc) return rc;
+            status = hs.status;
+        }
+        return status;
+    }
+
+    // SIX::stage1's slack branch only (lpsol.h:1820-1841) and a fresh loop.
+    int begin()
+    {
+        build(0);
+        reset_loop(0xFFFFFFFFu);
+        began = true; final_status = XPG_RUNNING;
+        XPG_HIP(ctx, hipGetLastError());
+        return 0;
+    }
+    // At most `pivots` further loop iterations, one host sync at the end.
+    int iterate(unsigned pivots)
+    {
+        if (!began) return XPG_ERR_SHAPE;
+        if (final_status != XPG_RUNNING) return final_status;
+        queue_iterations(pivots);
+        LoopState hs;
+        int rc = read_state(&hs);
+        if (rc) return rc;
+        if (hs.status == ST_RUNNING) return XPG_RUNNING;
+        final_status = finish(hs.status);
+        return final_status;
+    }
+
+    // SIX::TwoStageMethod (lpsol.h:1907-1930).
+    int two_stage(unsigned max_iter)
+    {
+        hipLaunchKernelGGL((k_need_phase1<S>), dim3(1), dim3(1024), 0, ctx->stream, d_leq, d_tgtf, m, n0, v.st);
+        LoopState hs;
+        int rc = read_state(&hs);
+        if (rc) return rc;
+        began = true;
+        if (hs.aux) {
+            rc = phase_one(max_iter);
+            if (rc != 0) { final_status = rc; return rc; }
+        } else {
+            build(0);
+        }
+        reset_loop(max_iter);
+        final_status = run_loop();
+        return final_status;
+    }
+
+    // SIX::constructBasicFeasibleSolution (lpsol.h:839-988). Returns 0 when a
+    // feasible slack form is in place, else SIX_NO_PRI_FEASIBLE_SOL (or an error).
+    int phase_one(unsigned max_iter)
+    {
+        const int xa = n0;
+        build(1);
+        hipLaunchKernelGGL((k_force_pivot<S>), dim3(1), dim3(1024), 0, ctx->stream, v, xa);
+        queue_pivot(0, 0);
+        reset_loop(max_iter);
+        int st = run_loop();
+        if (st < 0) return st;
+        if (st != XPG_SIX_SUCC) return XPG_SIX_NO_PRI_FEASIBLE_SOL;
+        hipLaunchKernelGGL((k_phase1_exit<S>), dim3(1), dim3(64), 0, ctx->stream, v, xa, d_maxv);
+        LoopState hs;
+        int rc = read_state(&hs);
+        if (rc) return rc;
+        if (hs.aux == -1) return XPG_SIX_NO_PRI_FEASIBLE_SOL;
+        if (hs.aux == -7) return XPG_ERR_REF_UNDEFINED;
+        if (hs.aux == 1) queue_pivot(0, 0);
+        hipLaunchKernelGGL((k_rebuild_obj<S>), dim3(1), dim3(1024), 0, ctx->stream, v, d_tgtf, n0);
+        hipLaunchKernelGGL((k_delete_col<S>), dim3(v.m + 1), dim3(256), 0, ctx->stream, v, xa);
+        v.W -= 1; v.rhs -= 1;
+        XPG_HIP(ctx, hipGetLastError());
+        return 0;
+    }
+
+    int read(void * tab, void * obj, uint8_t * nvset, uint8_t * bvset, int32_t * bv2eq,
+             int32_t * eq2bv, void * maxv, void * sol)
+    {
+        hipStream_t s = ctx->stream;
+        if (tab)
+            XPG_HIP(ctx, hipMemcpy2DAsync(tab, (size_t)v.W * sizeof(S), v.tab, (size_t)v.ld * sizeof(S),
+                                          (size_t)v.W * sizeof(S), v.m, hipMemcpyDeviceToHost, s));
+        if (obj) XPG_HIP(ctx, hipMemcpyAsync(obj, v.obj, (size_t)v.W * sizeof(S), hipMemcpyDeviceToHost, s));
+        if (nvset) XPG_HIP(ctx, hipMemcpyAsync(nvset, v.nv, v.rhs, hipMemcpyDeviceToHost, s));
+        if (bvset) XPG_HIP(ctx, hipMemcpyAsync(bvset, v.bv, v.rhs, hipMemcpyDeviceToHost, s));
+        if (bv2eq) XPG_HIP(ctx, hipMemcpyAsync(bv2eq, v.bv2eq, (size_t)v.rhs * 4, hipMemcpyDeviceToHost, s));
+        if (eq2bv) XPG_HIP(ctx, hipMemcpyAsync(eq2bv, v.eq2bv, (size_t)v.m * 4, hipMemcpyDeviceToHost, s));
+        if (maxv) {
+            if (final_status == XPG_SIX_SUCC)
+                XPG_HIP(ctx, hipMemcpyAsync(maxv, d_maxv, sizeof(S), hipMemcpyDeviceToHost, s));
+            else *(S *)maxv = zero<S>();
+        }
+        if (sol) XPG_HIP(ctx, hipMemcpyAsync(sol, v.x, (size_t)v.W * sizeof(S), hipMemcpyDeviceToHost, s));
+        XPG_HIP(ctx, hipStreamSynchronize(s));
+        return 0;
+    }
+};
+
+} // namespace xpg

@@ -1,0 +1,192 @@
+// Device-side scalar semantics of xpoly's Float and Rational for gfx950.
+//
+// The solver must replay the reference's arithmetic exactly:
+//   * Float   = one fp64 (src/com/flty.h:45-62); '*' then '+' are two roundings
+//               (flty.cpp:97-116), so this translation unit is compiled with
+//               -ffp-contract=off and carries the pragma below: v_fma_f64 must
+//               never appear in a kernel that includes this header.
+//   * Rational = int32/int32 with int64 intermediates, gcd reduction and the
+//               float32 "appro" rescue (src/com/rational.cpp:163-397).
+// Both are written as overloads on two POD types so that every kernel is a
+// single template over the scalar.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+#define XPG_HD __host__ __device__ __forceinline__
+
+namespace xpg {
+
+// ---- fp64 --------------------------------------------------------------------
+struct F64 {
+    double v;
+    XPG_HD F64() : v(0.0) {}
+    XPG_HD explicit F64(double d) : v(d) {}
+    static XPG_HD F64 from_int(int i) { return F64((double)i); }
+};
+
+// flty.cpp:41-58: not of opposite sign and |a|,|b| within 1e-17 of each other.
+XPG_HD bool eq(F64 a, F64 b)
+{
+    const double tiny = 0.00000000000000001;
+    double x = a.v, y = b.v;
+    if ((x > 0 && y < 0) || (x < 0 && y > 0)) return false;
+    x = x < 0 ? -x : x;
+    y = y < 0 ? -y : y;
+    if ((x == 0.0 && y <= tiny) || (y == 0.0 && x <= tiny)) return true;
+    return (x > y ? x - y : y - x) <= tiny;
+}
+XPG_HD bool ne(F64 a, F64 b) { return !eq(a, b); }
+XPG_HD bool lt(F64 a, F64 b) { return a.v < b.v; }
+XPG_HD bool gt(F64 a, F64 b) { return a.v > b.v; }
+XPG_HD bool le(F64 a, F64 b) { return a.v < b.v || eq(a, b); }
+XPG_HD bool ge(F64 a, F64 b) { return a.v > b.v || eq(a, b); }
+XPG_HD F64 mul(F64 a, F64 b) { return F64(a.v * b.v); }
+XPG_HD F64 div(F64 a, F64 b) { return F64(a.v / b.v); }
+XPG_HD F64 add(F64 a, F64 b) { return F64(a.v + b.v); }
+XPG_HD F64 neg(F64 a) { return F64(-a.v); }
+XPG_HD F64 sub(F64 a, F64 b) { return F64(a.v - b.v); }
+XPG_HD void reduce(F64 &) {}
+XPG_HD bool is_int(F64 a)   // flty.cpp:182-201
+{
+    const double tiny = 0.00000000000000001;
+    double x = a.v < 0 ? -a.v : a.v;
+    long long t = (long long)x;
+    if ((x - (double)t) < tiny) return true;
+    return ((double)(t + 1) - x) < tiny;
+}
+XPG_HD int to_int(F64 a) { return (int)a.v; }
+// strict weak order used by the parallel arg-min: value first, -0 == +0
+XPG_HD bool same_value(F64 a, F64 b) { return a.v == b.v; }
+
+// ---- int32 rational ------------------------------------------------------------
+struct R32 {
+    int32_t num, den;
+    XPG_HD R32() : num(0), den(1) {}
+    XPG_HD R32(int32_t n, int32_t d) : num(n), den(d) {}
+    static XPG_HD R32 from_int(int i) { return R32(i, 1); }
+};
+
+XPG_HD long long gcd64(long long x, long long y)   // rational.cpp:142-158
+{
+    if (x < 0) x = -x;
+    if (y < 0) y = -y;
+    if (x > y) { long long t = x; x = y; y = t; }
+    // Fast path: once both operands fit in 32 bits the 64-bit remainder
+    // (emulated on gfx950) is replaced by the 32-bit one; results are equal.
+    while (x != 0) {
+        if (y <= 0xFFFFFFFFLL) {
+            uint32_t a = (uint32_t)x, b = (uint32_t)y;
+            while (a != 0) { uint32_t t = a; a = b % a; b = t; }
+            return (long long)b;
+        }
+        long long t = x; x = y % x; y = t;
+    }
+    return y;
+}
+
+XPG_HD void reduce64(long long & n, long long & d)   // rational.cpp:163-185
+{
+    if (n == 0) { d = 1; return; }
+    long long g = gcd64(n, d);
+    if (g != 1) { n /= g; d /= g; }
+    if (d < 0) { d = -d; n = -n; }
+}
+
+// rational.cpp:189-226. float32 divide/multiply are IEEE (hipcc keeps
+// -fhip-fp32-correctly-rounded-divide-sqrt on), the cast truncates like C.
+XPG_HD void appro64(long long & n, long long & d)
+{
+    float q = (float)n / (float)d;
+    if (q < 100.0) { q = q * 1000000.0f; n = (int)q; d = 1000000; }
+    else if (q < 1000.0) { q = q * 100000.0f; n = (int)q; d = 100000; }
+    else if (q < 100000.0) { q = q * 10000.0f; n = (int)q; d = 10000; }
+    else if (q < 1000000.0) { q = q * 1000.0f; n = (int)q; d = 1000; }
+    else if (q < 10000000.0) { q = q * 100.0f; n = (int)q; d = 100; }
+    else if (q < 100000000.0) { q = q * 10.0f; n = (int)q; d = 10; }
+    else if (q < 2147483647.0) { n = (int)q; d = 1; }
+    else { n = 0; d = 1; }
+    reduce64(n, d);
+}
+
+XPG_HD R32 squeeze(long long n, long long d)   // rational.cpp:285-309, :336-360, :373-396
+{
+    const long long imax = 0x7fffFFFFLL;
+    if (n == d) return R32(1, 1);
+    if (n == -d) return R32(-1, 1);
+    if (d < 0) { n = -n; d = -d; }
+    reduce64(n, d);
+    long long mag = n >= 0 ? n : -n;
+    if (mag >= (imax >> 2) || d >= (imax >> 2)) {
+        // the reference reduces a second time here (a no-op on the value)
+        if (mag >= imax || d >= imax) appro64(mag, d);
+    }
+    return R32((int32_t)(n < 0 ? -mag : mag), (int32_t)d);
+}
+
+XPG_HD R32 mul(R32 a, R32 b)   // rational.cpp:273-310
+{
+    long long n = (long long)a.num * (long long)b.num;
+    if (n == 0) return R32(0, 1);
+    return squeeze(n, (long long)a.den * (long long)b.den);
+}
+XPG_HD R32 div(R32 a, R32 b)   // rational.cpp:312-361
+{
+    if (a.num == 0) return R32(0, 1);
+    if (a.num == a.den) return b.num < 0 ? R32(-b.den, -b.num) : R32(b.den, b.num);
+    return squeeze((long long)a.num * (long long)b.den, (long long)a.den * (long long)b.num);
+}
+XPG_HD R32 add(R32 a, R32 b)   // rational.cpp:363-397
+{
+    long long n = (long long)a.num * (long long)b.den + (long long)a.den * (long long)b.num;
+    if (n == 0) return R32(0, 1);
+    return squeeze(n, (long long)a.den * (long long)b.den);
+}
+XPG_HD R32 neg(R32 a) { return R32(-a.num, a.den); }
+XPG_HD R32 sub(R32 a, R32 b) { return add(a, neg(b)); }
+XPG_HD bool eq(R32 a, R32 b) { return a.num == b.num && a.den == b.den; }   // rational.h:80-83
+XPG_HD bool ne(R32 a, R32 b) { return a.num != b.num || a.den != b.den; }
+XPG_HD bool lt(R32 a, R32 b) { return (long long)a.num * b.den <  (long long)a.den * b.num; }
+XPG_HD bool le(R32 a, R32 b) { return (long long)a.num * b.den <= (long long)a.den * b.num; }
+XPG_HD bool gt(R32 a, R32 b) { return (long long)a.num * b.den >  (long long)a.den * b.num; }
+XPG_HD bool ge(R32 a, R32 b) { return (long long)a.num * b.den >= (long long)a.den * b.num; }
+XPG_HD void reduce(R32 & a)   // rational.cpp:76-98, :125-139
+{
+    if (a.num == 0) { a.den = 1; return; }
+    int32_t x = a.num < 0 ? -a.num : a.num;
+    int32_t y = a.den < 0 ? -a.den : a.den;
+    if (x > y) { int32_t t = x; x = y; y = t; }
+    while (x != 0) { int32_t t = x; x = y % x; y = t; }
+    if (y != 1) { a.num /= y; a.den /= y; }
+    if (a.den < 0) { a.den = -a.den; a.num = -a.num; }
+}
+XPG_HD bool is_int(R32 a) { return a.den == 1; }
+XPG_HD int to_int(R32 a) { return a.num / a.den; }
+// gt() is not a strict weak order on arbitrary (num,den) pairs but is on the
+// den > 0 values the solver produces; ties are "neither a>b nor b>a".
+XPG_HD bool same_value(R32 a, R32 b) { return !gt(a, b) && !gt(b, a); }
+
+template <class S> struct is_f64 { static const bool value = false; };
+template <> struct is_f64<F64> { static const bool value = true; };
+
+template <class S> XPG_HD S zero() { return S::from_int(0); }
+template <class S> XPG_HD S one() { return S::from_int(1); }
+template <class S> XPG_HD S minus_one() { return S::from_int(-1); }
+
+// Matrix::mul / mulOfRow / mulOfColumn scaling rule (matt.h:1331-1368):
+// multiplier "== 1" leaves the cell, "== 0" stores zero, else cell * x.
+enum ScaleMode { SCALE_KEEP = 0, SCALE_ZERO = 1, SCALE_MUL = 2 };
+template <class S> XPG_HD int scale_mode(S x)
+{
+    if (eq(x, one<S>())) return SCALE_KEEP;
+    if (eq(x, zero<S>())) return SCALE_ZERO;
+    return SCALE_MUL;
+}
+template <class S> XPG_HD S scaled(S cell, S x, int mode)
+{
+    return mode == SCALE_KEEP ? cell : (mode == SCALE_ZERO ? zero<S>() : mul(cell, x));
+}
+
+} // namespace xpg

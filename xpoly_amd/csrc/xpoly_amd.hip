@@ -1,0 +1,382 @@
+// C ABI of libxpoly_amd.so (declared in include/xpoly_amd.h). gfx950 only.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see
+// __graft_entry__.build()). fp-contract must stay off: the reference rounds
+// after the multiply and after the add (lpsol.h:1485-1489).
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+#include "../../include/xpoly_amd.h"
+#include "scalar.hip.h"
+#include "lp_kernels.hip.h"
+#include "lp_host.hip.h"
+#include "six_host.hip.h"
+#include "batch_kernels.hip.h"
+
+using namespace xpg;
+
+static_assert(sizeof(F64) == 8 && sizeof(R32) == 8, "both scalars are 8 bytes");
+static_assert(sizeof(xpg_rat32) == sizeof(R32), "ABI layout of a rational");
+
+struct xpg_lp { LpBase * impl; };
+
+extern "C" {
+
+const char * xpg_version(void) { return "xpoly_amd 0.1 (gfx950)"; }
+
+int xpg_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int xpg_create(xpg_ctx ** out, int device)
+{
+    if (!out) return XPG_ERR_SHAPE;
+    *out = 0;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n)
+        return XPG_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return XPG_ERR_HIP;
+    xpg_ctx * c = new (std::nothrow) xpg_ctx();
+    if (!c) return XPG_ERR_ALLOC;
+    c->device = device;
+    c->rowbuf = c->colbuf = 0; c->st = 0; c->row_cap = c->col_cap = 0;
+    const char * var = getenv("XPG_UPDATE_VARIANT");
+    c->update_variant = var ? atoi(var) : 0;
+    c->prof_cap = 0; c->prof_n = 0;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return XPG_ERR_HIP; }
+    if (hipMalloc((void **)&c->st, sizeof(LoopState)) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return XPG_ERR_ALLOC; }
+    *out = c;
+    return 0;
+}
+
+void xpg_destroy(xpg_ctx * ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (hipEvent_t e : ctx->ev0) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->ev1) (void)hipEventDestroy(e);
+    if (ctx->rowbuf) (void)hipFree(ctx->rowbuf);
+    if (ctx->colbuf) (void)hipFree(ctx->colbuf);
+    if (ctx->st) (void)hipFree(ctx->st);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int xpg_profile_begin(xpg_ctx * ctx, int cap)
+{
+    if (!ctx || cap < 0) return XPG_ERR_SHAPE;
+    XPG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    while ((int)ctx->ev0.size() < cap) {
+        hipEvent_t a, b;
+        XPG_HIP(ctx, hipEventCreate(&a));
+        XPG_HIP(ctx, hipEventCreate(&b));
+        ctx->ev0.push_back(a); ctx->ev1.push_back(b);
+    }
+    ctx->prof_cap = cap; ctx->prof_n = 0;
+    return 0;
+}
+
+int xpg_profile_end(xpg_ctx * ctx, int * launches, double * total_ms)
+{
+    if (!ctx) return XPG_ERR_SHAPE;
+    XPG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double sum = 0.0;
+    for (int i = 0; i < ctx->prof_n; i++) {
+        float ms = 0.f;
+        XPG_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0[i], ctx->ev1[i]));
+        sum += ms;
+    }
+    if (launches) *launches = ctx->prof_n;
+    if (total_ms) *total_ms = sum;
+    ctx->prof_cap = 0; ctx->prof_n = 0;
+    return 0;
+}
+
+const char * xpg_last_error(const xpg_ctx * ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+void * xpg_stream(const xpg_ctx * ctx) { return ctx ? (void *)ctx->stream : 0; }
+
+int xpg_sync(xpg_ctx * ctx)
+{
+    if (!ctx) return XPG_ERR_SHAPE;
+    XPG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int xpg_malloc(xpg_ctx * ctx, void ** dptr, size_t bytes)
+{
+    if (!ctx || !dptr) return XPG_ERR_SHAPE;
+    XPG_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 8);
+    if (e != hipSuccess) { ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e); return XPG_ERR_ALLOC; }
+    return 0;
+}
+int xpg_free(xpg_ctx * ctx, void * dptr)
+{
+    if (!ctx) return XPG_ERR_SHAPE;
+    XPG_HIP(ctx, hipFree(dptr));
+    return 0;
+}
+int xpg_upload(xpg_ctx * ctx, void * dst_dev, const void * src_host, size_t bytes)
+{
+    if (!ctx) return XPG_ERR_SHAPE;
+    XPG_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    XPG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int xpg_download(xpg_ctx * ctx, void * dst_host, const void * src_dev, size_t bytes)
+{
+    if (!ctx) return XPG_ERR_SHAPE;
+    XPG_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    XPG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+} // extern "C"
+
+// ---- K1 on caller-owned device tableaux --------------------------------------------
+namespace {
+
+int ensure_scratch(xpg_ctx * ctx, int m, int W)
+{
+    const size_t rb = (size_t)round_up(W, 16) * 8, cb = (size_t)round_up(m, 16) * 8;
+    if (rb > ctx->row_cap) {
+        if (ctx->rowbuf) XPG_HIP(ctx, hipFree(ctx->rowbuf));
+        ctx->rowbuf = 0; ctx->row_cap = 0;
+        if (hipMalloc(&ctx->rowbuf, rb) != hipSuccess) { ctx->err = "hipMalloc(rowbuf)"; return XPG_ERR_ALLOC; }
+        ctx->row_cap = rb;
+    }
+    if (cb > ctx->col_cap) {
+        if (ctx->colbuf) XPG_HIP(ctx, hipFree(ctx->colbuf));
+        ctx->colbuf = 0; ctx->col_cap = 0;
+        if (hipMalloc(&ctx->colbuf, cb) != hipSuccess) { ctx->err = "hipMalloc(colbuf)"; return XPG_ERR_ALLOC; }
+        ctx->col_cap = cb;
+    }
+    return 0;
+}
+
+template <class S> __global__ void k_stage_pivot(LpView<S> v, int row, int col)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    LoopState * st = v.st;
+    st->status = ST_RUNNING; st->row = row; st->col = col; st->leave = 0;
+    st->cnv_bits = to_bits(v.obj[col]);
+    st->piv_bits = to_bits(v.tab[(size_t)row * v.ld + col]);
+}
+
+template <class S>
+int pivot_dev(xpg_ctx * ctx, S * tab, int m, int W, int ld, S * obj, int rhs, int row, int col)
+{
+    if (!ctx || !tab || !obj || m <= 0 || W <= 1 || ld < W || row < 0 || row >= m || col < 0 ||
+        col >= W || rhs < 0 || rhs >= W)
+        return XPG_ERR_SHAPE;
+    // the fp64 sweep uses 16-byte accesses: rows must start 16-byte aligned
+    if (is_f64<S>::value && ((ld & 1) || ((uintptr_t)tab & 15))) return XPG_ERR_SHAPE;
+    int rc = ensure_scratch(ctx, m, W);
+    if (rc) return rc;
+    LpView<S> v;
+    memset(&v, 0, sizeof(v));
+    v.tab = tab; v.m = m; v.W = W; v.ld = ld; v.rhs = rhs; v.obj = obj;
+    v.rowbuf = (S *)ctx->rowbuf; v.colbuf = (S *)ctx->colbuf; v.st = ctx->st;
+    hipLaunchKernelGGL((k_stage_pivot<S>), dim3(1), dim3(64), 0, ctx->stream, v, row, col);
+    const int span = W > m ? W : m;
+    hipLaunchKernelGGL((k_prep<S>), dim3((span + 255) / 256), dim3(256), 0, ctx->stream, v, 0, 0, 0);
+    launch_update<S>(ctx, v, 0);
+    XPG_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+template <class S>
+int pivot_host(xpg_ctx * ctx, S * tab, int m, int W, S * obj, int rhs, int row, int col)
+{
+    if (!ctx || !tab || !obj || m <= 0 || W <= 1) return XPG_ERR_SHAPE;
+    const int ld = round_up(W, 16);
+    S * d_tab = 0; S * d_obj = 0;
+    XPG_HIP(ctx, hipMalloc((void **)&d_tab, (size_t)m * ld * sizeof(S)));
+    if (hipMalloc((void **)&d_obj, (size_t)ld * sizeof(S)) != hipSuccess) { (void)hipFree(d_tab); return XPG_ERR_ALLOC; }
+    int rc = 0;
+    hipError_t e = hipMemcpy2DAsync(d_tab, (size_t)ld * sizeof(S), tab, (size_t)W * sizeof(S),
+                                    (size_t)W * sizeof(S), m, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_obj, obj, (size_t)W * sizeof(S), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) rc = pivot_dev<S>(ctx, d_tab, m, W, ld, d_obj, rhs, row, col);
+    if (e == hipSuccess && rc == 0)
+        e = hipMemcpy2DAsync(tab, (size_t)W * sizeof(S), d_tab, (size_t)ld * sizeof(S),
+                             (size_t)W * sizeof(S), m, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && rc == 0) e = hipMemcpyAsync(obj, d_obj, (size_t)W * sizeof(S), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_tab); (void)hipFree(d_obj);
+    if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return XPG_ERR_HIP; }
+    return rc;
+}
+
+} // namespace
+
+extern "C" {
+
+int xpg_pivot_f64_dev(xpg_ctx * ctx, double * tab, int m, int W, int ld, double * obj,
+                      int rhs_idx, int row, int col)
+{ return pivot_dev<F64>(ctx, (F64 *)tab, m, W, ld, (F64 *)obj, rhs_idx, row, col); }
+int xpg_pivot_rat32_dev(xpg_ctx * ctx, xpg_rat32 * tab, int m, int W, int ld, xpg_rat32 * obj,
+                        int rhs_idx, int row, int col)
+{ return pivot_dev<R32>(ctx, (R32 *)tab, m, W, ld, (R32 *)obj, rhs_idx, row, col); }
+int xpg_pivot_f64(xpg_ctx * ctx, double * tab, int m, int W, double * obj, int rhs_idx, int row, int col)
+{ return pivot_host<F64>(ctx, (F64 *)tab, m, W, (F64 *)obj, rhs_idx, row, col); }
+int xpg_pivot_rat32(xpg_ctx * ctx, xpg_rat32 * tab, int m, int W, xpg_rat32 * obj, int rhs_idx, int row, int col)
+{ return pivot_host<R32>(ctx, (R32 *)tab, m, W, (R32 *)obj, rhs_idx, row, col); }
+
+// ---- device-resident LP ---------------------------------------------------------------
+int xpg_lp_create(xpg_ctx * ctx, int kind, const void * leq, int m, int cols, const void * tgtf,
+                  const void * vc_diag, const void * vc_rhs, int src_on_device, xpg_lp ** out)
+{
+    if (!ctx || !out || !leq || !tgtf || m <= 0 || cols < 2 || (kind != 0 && kind != 1))
+        return XPG_ERR_SHAPE;
+    *out = 0;
+    XPG_HIP(ctx, hipSetDevice(ctx->device));
+    xpg_lp * h = new (std::nothrow) xpg_lp();
+    if (!h) return XPG_ERR_ALLOC;
+    int rc;
+    if (kind == 0) {
+        Lp<F64> * p = new (std::nothrow) Lp<F64>();
+        if (!p) { delete h; return XPG_ERR_ALLOC; }
+        p->ctx = ctx; p->kind = 0; h->impl = p;
+        rc = p->create(leq, m, cols, tgtf, vc_diag, vc_rhs, src_on_device);
+    } else {
+        Lp<R32> * p = new (std::nothrow) Lp<R32>();
+        if (!p) { delete h; return XPG_ERR_ALLOC; }
+        p->ctx = ctx; p->kind = 1; h->impl = p;
+        rc = p->create(leq, m, cols, tgtf, vc_diag, vc_rhs, src_on_device);
+    }
+    if (rc) { delete h->impl; delete h; return rc; }
+    *out = h;
+    return 0;
+}
+
+void xpg_lp_destroy(xpg_lp * lp)
+{
+    if (!lp) return;
+    if (lp->impl) { (void)hipStreamSynchronize(lp->impl->ctx->stream); delete lp->impl; }
+    delete lp;
+}
+
+#define XPG_DISPATCH(lp, expr)                                                   \
+    do {                                                                         \
+        if (!(lp) || !(lp)->impl) return XPG_ERR_SHAPE;                          \
+        if ((lp)->impl->kind == 0) { Lp<F64> * p = (Lp<F64> *)(lp)->impl; return expr; } \
+        Lp<R32> * p = (Lp<R32> *)(lp)->impl; return expr;                        \
+    } while (0)
+
+int xpg_lp_two_stage(xpg_lp * lp, unsigned max_iter) { XPG_DISPATCH(lp, p->two_stage(max_iter)); }
+int xpg_lp_begin(xpg_lp * lp) { XPG_DISPATCH(lp, p->begin()); }
+int xpg_lp_iterate(xpg_lp * lp, unsigned pivots) { XPG_DISPATCH(lp, p->iterate(pivots)); }
+int xpg_lp_read(xpg_lp * lp, void * tab, void * obj, uint8_t * nvset, uint8_t * bvset,
+                int32_t * bv2eq, int32_t * eq2bv, void * maxv, void * sol)
+{ XPG_DISPATCH(lp, p->read(tab, obj, nvset, bvset, bv2eq, eq2bv, maxv, sol)); }
+
+int xpg_lp_shape(xpg_lp * lp, int * rows, int * W, int * rhs_idx)
+{
+    if (!lp || !lp->impl) return XPG_ERR_SHAPE;
+    int m, w, r;
+    if (lp->impl->kind == 0) { Lp<F64> * p = (Lp<F64> *)lp->impl; m = p->v.m; w = p->v.W; r = p->v.rhs; }
+    else { Lp<R32> * p = (Lp<R32> *)lp->impl; m = p->v.m; w = p->v.W; r = p->v.rhs; }
+    if (rows) *rows = m;
+    if (W) *W = w;
+    if (rhs_idx) *rhs_idx = r;
+    return 0;
+}
+
+int xpg_lp_pivots_done(xpg_lp * lp, unsigned * out)
+{
+    if (!lp || !lp->impl || !out) return XPG_ERR_SHAPE;
+    LoopState hs;
+    int rc;
+    if (lp->impl->kind == 0) rc = ((Lp<F64> *)lp->impl)->read_state(&hs);
+    else rc = ((Lp<R32> *)lp->impl)->read_state(&hs);
+    if (rc) return rc;
+    *out = hs.total_pivots;
+    return 0;
+}
+
+int xpg_lp_trace(xpg_lp * lp, int32_t * pairs, int cap_pairs, int * n_pairs)
+{
+    if (!lp || !lp->impl || !n_pairs) return XPG_ERR_SHAPE;
+    xpg_ctx * ctx = lp->impl->ctx;
+    LoopState hs;
+    int rc; int * d_trace; int cap;
+    if (lp->impl->kind == 0) { Lp<F64> * p = (Lp<F64> *)lp->impl; rc = p->read_state(&hs); d_trace = p->v.trace; cap = p->v.trace_cap; }
+    else { Lp<R32> * p = (Lp<R32> *)lp->impl; rc = p->read_state(&hs); d_trace = p->v.trace; cap = p->v.trace_cap; }
+    if (rc) return rc;
+    int n = (int)hs.total_pivots;
+    *n_pairs = n;
+    if (n > cap) n = cap;
+    if (n > cap_pairs) n = cap_pairs;
+    if (pairs && n > 0) {
+        XPG_HIP(ctx, hipMemcpyAsync(pairs, d_trace, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        XPG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return 0;
+}
+
+// ---- SIX::maxm / minm ---------------------------------------------------------------------
+int xpg_six_maxm_f64(xpg_ctx * ctx, const double * tgtf, const double * vc, int vc_rows,
+                     const double * eq, int eq_rows, const double * leq, int leq_rows, int cols,
+                     unsigned max_iter, double * out_v, double * out_sol)
+{
+    return six_solve<F64>(ctx, 0, true, (const F64 *)tgtf, (const F64 *)vc, vc_rows, (const F64 *)eq,
+                          eq_rows, (const F64 *)leq, leq_rows, cols, max_iter, (F64 *)out_v, (F64 *)out_sol);
+}
+int xpg_six_minm_f64(xpg_ctx * ctx, const double * tgtf, const double * vc, int vc_rows,
+                     const double * eq, int eq_rows, const double * leq, int leq_rows, int cols,
+                     unsigned max_iter, double * out_v, double * out_sol)
+{
+    return six_solve<F64>(ctx, 0, false, (const F64 *)tgtf, (const F64 *)vc, vc_rows, (const F64 *)eq,
+                          eq_rows, (const F64 *)leq, leq_rows, cols, max_iter, (F64 *)out_v, (F64 *)out_sol);
+}
+int xpg_six_maxm_rat32(xpg_ctx * ctx, const xpg_rat32 * tgtf, const xpg_rat32 * vc, int vc_rows,
+                       const xpg_rat32 * eq, int eq_rows, const xpg_rat32 * leq, int leq_rows,
+                       int cols, unsigned max_iter, xpg_rat32 * out_v, xpg_rat32 * out_sol)
+{
+    return six_solve<R32>(ctx, 1, true, (const R32 *)tgtf, (const R32 *)vc, vc_rows, (const R32 *)eq,
+                          eq_rows, (const R32 *)leq, leq_rows, cols, max_iter, (R32 *)out_v, (R32 *)out_sol);
+}
+int xpg_six_minm_rat32(xpg_ctx * ctx, const xpg_rat32 * tgtf, const xpg_rat32 * vc, int vc_rows,
+                       const xpg_rat32 * eq, int eq_rows, const xpg_rat32 * leq, int leq_rows,
+                       int cols, unsigned max_iter, xpg_rat32 * out_v, xpg_rat32 * out_sol)
+{
+    return six_solve<R32>(ctx, 1, false, (const R32 *)tgtf, (const R32 *)vc, vc_rows, (const R32 *)eq,
+                          eq_rows, (const R32 *)leq, leq_rows, cols, max_iter, (R32 *)out_v, (R32 *)out_sol);
+}
+
+// ---- batches ------------------------------------------------------------------------------
+int xpg_six_batch_f64_dev(xpg_ctx * ctx, int is_max, int nb, const double * tgtf, const double * leq,
+                          int m, int cols, unsigned max_iter, int32_t * out_status, double * out_v,
+                          double * out_sol, uint32_t * out_pivots)
+{
+    return batch_dev<F64>(ctx, is_max, nb, (const F64 *)tgtf, (const F64 *)leq, m, cols, max_iter,
+                          out_status, (F64 *)out_v, (F64 *)out_sol, out_pivots);
+}
+int xpg_six_batch_rat32_dev(xpg_ctx * ctx, int is_max, int nb, const xpg_rat32 * tgtf,
+                            const xpg_rat32 * leq, int m, int cols, unsigned max_iter,
+                            int32_t * out_status, xpg_rat32 * out_v, xpg_rat32 * out_sol,
+                            uint32_t * out_pivots)
+{
+    return batch_dev<R32>(ctx, is_max, nb, (const R32 *)tgtf, (const R32 *)leq, m, cols, max_iter,
+                          out_status, (R32 *)out_v, (R32 *)out_sol, out_pivots);
+}
+int xpg_six_batch_f64(xpg_ctx * ctx, int is_max, int nb, const double * tgtf, const double * leq,
+                      int m, int cols, unsigned max_iter, int32_t * out_status, double * out_v,
+                      double * out_sol)
+{
+    return batch_host<F64>(ctx, is_max, nb, (const F64 *)tgtf, (const F64 *)leq, m, cols, max_iter,
+                           out_status, (F64 *)out_v, (F64 *)out_sol);
+}
+int xpg_six_batch_rat32(xpg_ctx * ctx, int is_max, int nb, const xpg_rat32 * tgtf,
+                        const xpg_rat32 * leq, int m, int cols, unsigned max_iter,
+                        int32_t * out_status, xpg_rat32 * out_v, xpg_rat32 * out_sol)
+{
+    return batch_host<R32>(ctx, is_max, nb, (const R32 *)tgtf, (const R32 *)leq, m, cols, max_iter,
+                           out_status, (R32 *)out_v, (R32 *)out_sol);
+}
+
+} // extern "C"

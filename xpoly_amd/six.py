@@ -1,0 +1,245 @@
+"""Python face of the C ABI, shaped after the reference's solver classes so the
+parity tests read like calls into xpoly:
+
+    SIX<FloatMat,Float>  ->  SIX(ctx, F64)      maxm / minm / set_param / TwoStageMethod
+    SIX<RMat,Rational>   ->  SIX(ctx, RAT)      (src/com/lpsol.h:204-338)
+
+Arrays: fp64 problems are float64 numpy arrays; rational problems are int32
+arrays with a trailing axis of 2 = (num, den) -- the in-memory layout of RMat.
+Everything numeric happens in libxpoly_amd.so on the GPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import XPG_RUNNING, XpgError, lib, vp
+
+F64, RAT = 0, 1
+SIX_SUCC, SIX_UNBOUND, SIX_NO_PRI_FEASIBLE_SOL, SIX_OPTIMAL_IS_INFEASIBLE, SIX_TIME_OUT = range(5)
+
+
+def as_kind(a, kind):
+    if a is None:
+        return None
+    if kind == F64:
+        return np.ascontiguousarray(a, dtype=np.float64)
+    a = np.asarray(a)
+    if a.ndim >= 1 and a.shape[-1] == 2 and a.dtype == np.int32:
+        return np.ascontiguousarray(a)
+    out = np.empty(a.shape + (2,), dtype=np.int32)
+    out[..., 0] = a
+    out[..., 1] = 1
+    return out
+
+
+def empty_kind(shape, kind):
+    if kind == F64:
+        return np.zeros(shape, dtype=np.float64)
+    return np.zeros(tuple(shape) + (2,), dtype=np.int32)
+
+
+class Context:
+    """xpg_ctx: one GPU, one HIP stream."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        rc = lib().xpg_create(C.byref(self._h), C.c_int(device))
+        if rc != 0:
+            raise XpgError("xpg_create(device=%d) failed: %s" % (device, _capi.ERRORS.get(rc, rc)))
+        self.device = device
+
+    def check(self, rc, what):
+        if rc < 0 and rc != XPG_RUNNING:
+            raise XpgError("%s: %s (%s)" % (what, _capi.ERRORS.get(rc, rc),
+                                            lib().xpg_last_error(self._h).decode()))
+        return rc
+
+    @property
+    def stream(self):
+        return lib().xpg_stream(self._h)
+
+    def sync(self):
+        self.check(lib().xpg_sync(self._h), "xpg_sync")
+
+    def profile_begin(self, cap):
+        self.check(lib().xpg_profile_begin(self._h, C.c_int(cap)), "xpg_profile_begin")
+
+    def profile_end(self):
+        n, ms = C.c_int(), C.c_double()
+        self.check(lib().xpg_profile_end(self._h, C.byref(n), C.byref(ms)), "xpg_profile_end")
+        return n.value, ms.value
+
+    def malloc(self, nbytes):
+        p = C.c_void_p()
+        self.check(lib().xpg_malloc(self._h, C.byref(p), C.c_size_t(nbytes)), "xpg_malloc")
+        return p.value
+
+    def free(self, ptr):
+        self.check(lib().xpg_free(self._h, C.c_void_p(ptr)), "xpg_free")
+
+    def upload(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self.check(lib().xpg_upload(self._h, C.c_void_p(dptr), vp(arr), C.c_size_t(arr.nbytes)), "xpg_upload")
+
+    def download(self, arr, dptr):
+        self.check(lib().xpg_download(self._h, vp(arr), C.c_void_p(dptr), C.c_size_t(arr.nbytes)), "xpg_download")
+        return arr
+
+    def close(self):
+        if self._h:
+            lib().xpg_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- K1 ---------------------------------------------------------------------------
+    def pivot(self, kind, tab, obj, rhs_idx, row, col):
+        """SIX::pivot arithmetic (lpsol.h:1471-1501) on host arrays, in place."""
+        tab = as_kind(tab, kind); obj = as_kind(obj, kind)
+        m, W = tab.shape[0], tab.shape[1]
+        fn = lib().xpg_pivot_f64 if kind == F64 else lib().xpg_pivot_rat32
+        self.check(fn(self._h, vp(tab), C.c_int(m), C.c_int(W), vp(obj), C.c_int(rhs_idx),
+                      C.c_int(row), C.c_int(col)), "xpg_pivot")
+        return tab, obj
+
+    def pivot_dev(self, kind, tab_ptr, m, W, ld, obj_ptr, rhs_idx, row, col):
+        fn = lib().xpg_pivot_f64_dev if kind == F64 else lib().xpg_pivot_rat32_dev
+        self.check(fn(self._h, C.c_void_p(tab_ptr), C.c_int(m), C.c_int(W), C.c_int(ld),
+                      C.c_void_p(obj_ptr), C.c_int(rhs_idx), C.c_int(row), C.c_int(col)), "xpg_pivot_dev")
+
+    # ---- batches --------------------------------------------------------------------------
+    def six_batch(self, kind, is_max, tgtf, leq, max_iter=0xFFFFFFFF):
+        tgtf = as_kind(tgtf, kind); leq = as_kind(leq, kind)
+        nb, m, cols = leq.shape[0], leq.shape[1], leq.shape[2]
+        status = np.zeros(nb, dtype=np.int32)
+        v = empty_kind((nb,), kind)
+        sol = empty_kind((nb, cols), kind)
+        fn = lib().xpg_six_batch_f64 if kind == F64 else lib().xpg_six_batch_rat32
+        self.check(fn(self._h, C.c_int(int(is_max)), C.c_int(nb), vp(tgtf), vp(leq), C.c_int(m),
+                      C.c_int(cols), C.c_uint(max_iter), vp(status), vp(v), vp(sol)), "xpg_six_batch")
+        return status, v, sol
+
+    def six_batch_dev(self, kind, is_max, nb, tgtf_ptr, leq_ptr, m, cols, status_ptr, v_ptr, sol_ptr,
+                      pivots_ptr=None, max_iter=0xFFFFFFFF):
+        fn = lib().xpg_six_batch_f64_dev if kind == F64 else lib().xpg_six_batch_rat32_dev
+        self.check(fn(self._h, C.c_int(int(is_max)), C.c_int(nb), C.c_void_p(tgtf_ptr), C.c_void_p(leq_ptr),
+                      C.c_int(m), C.c_int(cols), C.c_uint(max_iter), C.c_void_p(status_ptr),
+                      C.c_void_p(v_ptr), C.c_void_p(sol_ptr),
+                      C.c_void_p(pivots_ptr) if pivots_ptr else None), "xpg_six_batch_dev")
+
+
+class DeviceLP:
+    """xpg_lp: a slack-form LP living in HBM (tableau, objective row, basis)."""
+
+    def __init__(self, ctx, kind, leq, tgtf, vc_diag=None, vc_rhs=None, on_device=False, m=None, cols=None):
+        self.ctx, self.kind = ctx, kind
+        if on_device:
+            leq_p, tg_p = C.c_void_p(leq), C.c_void_p(tgtf)
+        else:
+            leq = as_kind(leq, kind); tgtf = as_kind(tgtf, kind)
+            m, cols = leq.shape[0], leq.shape[1]
+            leq_p, tg_p = vp(leq), vp(tgtf)
+        self.m, self.cols = m, cols
+        vd = as_kind(vc_diag, kind); vr = as_kind(vc_rhs, kind)
+        self._h = C.c_void_p()
+        ctx.check(lib().xpg_lp_create(ctx._h, C.c_int(kind), leq_p, C.c_int(m), C.c_int(cols), tg_p,
+                                      vp(vd), vp(vr), C.c_int(int(on_device)), C.byref(self._h)),
+                  "xpg_lp_create")
+
+    def two_stage(self, max_iter=0xFFFFFFFF):
+        return self.ctx.check(lib().xpg_lp_two_stage(self._h, C.c_uint(max_iter)), "xpg_lp_two_stage")
+
+    def begin(self):
+        return self.ctx.check(lib().xpg_lp_begin(self._h), "xpg_lp_begin")
+
+    def iterate(self, pivots):
+        return self.ctx.check(lib().xpg_lp_iterate(self._h, C.c_uint(pivots)), "xpg_lp_iterate")
+
+    def pivots_done(self):
+        n = C.c_uint()
+        self.ctx.check(lib().xpg_lp_pivots_done(self._h, C.byref(n)), "xpg_lp_pivots_done")
+        return n.value
+
+    def shape(self):
+        r, w, rhs = C.c_int(), C.c_int(), C.c_int()
+        self.ctx.check(lib().xpg_lp_shape(self._h, C.byref(r), C.byref(w), C.byref(rhs)), "xpg_lp_shape")
+        return r.value, w.value, rhs.value
+
+    def read(self, want_tab=True):
+        r, W, rhs = self.shape()
+        k = self.kind
+        tab = empty_kind((r, W), k) if want_tab else None
+        obj = empty_kind((W,), k)
+        nv = np.zeros(rhs, dtype=np.uint8); bv = np.zeros(rhs, dtype=np.uint8)
+        bv2eq = np.zeros(rhs, dtype=np.int32); eq2bv = np.zeros(r, dtype=np.int32)
+        maxv = empty_kind((1,), k); sol = empty_kind((W,), k)
+        self.ctx.check(lib().xpg_lp_read(self._h, vp(tab), vp(obj), vp(nv), vp(bv), vp(bv2eq), vp(eq2bv),
+                                         vp(maxv), vp(sol)), "xpg_lp_read")
+        return dict(tab=tab, tgtf=obj, nvset=nv, bvset=bv, bv2eq=bv2eq, eq2bv=eq2bv, rhs=rhs,
+                    maxv=maxv[0], sol=sol)
+
+    def trace(self, cap=65536):
+        pairs = np.zeros((cap, 2), dtype=np.int32)
+        n = C.c_int()
+        self.ctx.check(lib().xpg_lp_trace(self._h, vp(pairs), C.c_int(cap), C.byref(n)), "xpg_lp_trace")
+        return pairs[: min(n.value, cap)].copy()
+
+    def close(self):
+        if self._h:
+            lib().xpg_lp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SIX:
+    """Mirror of SIX<Mat,T> (src/com/lpsol.h:204-338): same method names,
+    argument order and status codes; `kind` picks the FloatMat or RMat flavour."""
+
+    def __init__(self, ctx, kind):
+        self.ctx, self.kind = ctx, kind
+        self.max_iter = 0xFFFFFFFF
+
+    def set_param(self, indent, max_iter=0xFFFFFFFF):       # lpsol.h:380-385
+        self.max_iter = max_iter
+
+    def _solve(self, is_max, tgtf, vc, eq, leq):
+        k = self.kind
+        tgtf = as_kind(tgtf, k); vc = as_kind(vc, k)
+        cols = tgtf.shape[0]
+        eq_rows = 0 if eq is None else len(eq)
+        leq_rows = 0 if leq is None else len(leq)
+        eq_a = as_kind(eq, k) if eq_rows else None
+        leq_a = as_kind(leq, k) if leq_rows else None
+        v = empty_kind((1,), k); sol = empty_kind((cols,), k)
+        name = "xpg_six_%s_%s" % ("maxm" if is_max else "minm", "f64" if k == F64 else "rat32")
+        st = getattr(lib(), name)(self.ctx._h, vp(tgtf), vp(vc), C.c_int(vc.shape[0]), vp(eq_a),
+                                  C.c_int(eq_rows), vp(leq_a), C.c_int(leq_rows), C.c_int(cols),
+                                  C.c_uint(self.max_iter), vp(v), vp(sol))
+        if st < 0 and st != -7:
+            self.ctx.check(st, name)
+        return st, v[0], sol
+
+    def maxm(self, tgtf, vc, eq, leq):                      # lpsol.h:1993-2033
+        return self._solve(True, tgtf, vc, eq, leq)
+
+    def minm(self, tgtf, vc, eq, leq):                      # lpsol.h:1662-1732
+        return self._solve(False, tgtf, vc, eq, leq)
+
+    def TwoStageMethod(self, leq, tgtf, vc_diag=None, vc_rhs=None):   # lpsol.h:1907-1930
+        lp = DeviceLP(self.ctx, self.kind, leq, tgtf, vc_diag, vc_rhs)
+        st = lp.two_stage(self.max_iter)
+        out = lp.read()
+        out["status"] = st
+        out["trace"] = lp.trace()
+        lp.close()
+        return out
