@@ -116,7 +116,7 @@ def main():
         return float(t.item())
 
     # ---- leg 1: pivots/s on the 4096 x 8192 tableau (replica per rank) -------------------
-    leq, tgtf = gen.dense_lp_f64(M, NVARS, seed=gen.XS_SEED + rank)
+    leq, tgtf = gen.hard_lp_f64(M, NVARS, seed=gen.XS_SEED + rank)
     lp = xpoly_amd.DeviceLP(ctx, xpoly_amd.F64, leq, tgtf)
     del leq
     lp.begin()
@@ -208,7 +208,7 @@ def main():
             "ms_per_step": round(dt / a.steps * 1e3, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "dense LP m=4096 n=4095 (xorshift64 U(0.1,1)), slack tableau 4096x8192 fp64, "
+            "config": {"workload": "dense LP m=4096 n=4095 (gen.hard_lp_f64: A~U(0.1,1), b=A x*, c=A^T y*), slack tableau 4096x8192 fp64, "
                                    "device-resident SIX::solveSlackForm loop, one pivot per step",
                        "tableau": [M, TAB_W], "parallelism": "replicas only (1 tableau per GPU)"},
             "roofline": roofline,

@@ -220,3 +220,20 @@ def random_feas(rng, rows, nv):
     leq = to_rat(np.concatenate([A, b[:, None]], axis=1).astype(np.int32))
     vc = to_rat(vc_nonneg(nv, False))
     return leq, vc
+
+
+def hard_lp_f64(m, n, seed=XS_SEED):
+    """Dense LP whose optimum has every structural variable basic, so the simplex
+    needs >= n pivots from the origin (the cfg-2b recipe of SURVEY 8d converges in a
+    few dozen pivots, too few to time): A ~ U(0.1,1), b = A x*, c = A^T y* with
+    x*, y* ~ U(0.5,1.5) > 0 (x* primal feasible and tight, y* dual feasible =>
+    x* optimal by complementary slackness). Origin feasible: no phase 1."""
+    u = xs_uniform_block(m * n + m + n, seed)
+    A = 0.1 + 0.9 * u[: m * n].reshape(m, n)
+    xs = 0.5 + u[m * n + m:]
+    ys = 0.5 + u[m * n: m * n + m]
+    b = A @ xs
+    c = A.T @ ys
+    leq = np.concatenate([A, b[:, None]], axis=1)
+    tgtf = np.concatenate([c, [0.0]])
+    return np.ascontiguousarray(leq), np.ascontiguousarray(tgtf)
