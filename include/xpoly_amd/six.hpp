@@ -1,0 +1,100 @@
+// C++ adapter: classes with the names, signatures and status codes of xpoly's
+// SIX<Mat,T> (src/com/lpsol.h:204-338) on top of the C ABI in ../xpoly_amd.h, so
+// that an xpoly call site such as
+//
+//     SIX<RMat, Rational> six;                       // src/com/linsys.cpp:884
+//     six.set_param(0, 10000);
+//     UINT st = six.maxm(v, sol, tgtf, vc, eq, leq);  // src/com/lpsol.h:274-280
+//
+// compiles unchanged against `xpoly_amd::SIX` and runs on the GPU.  Header only;
+// it relies on nothing but the duck-typed Matrix<T> contract the reference's own
+// SIX relies on: get_row_size(), get_col_size(), get_matrix() (a row-major T*,
+// src/com/matt.h:152-156, :281-283), size(), reinit(rows, cols), and on T being
+// either an 8-byte fp64 wrapper (Float, flty.h:47-62) or an {int32 num; int32 den}
+// pair (Rational, rational.h:66-67).  Include it AFTER the xpoly headers, or with
+// any Matrix type that offers the same members.
+#ifndef XPOLY_AMD_SIX_HPP
+#define XPOLY_AMD_SIX_HPP
+
+#include <cstring>
+#include <vector>
+#include "../xpoly_amd.h"
+
+namespace xpoly_amd {
+
+// Which ABI flavour a scalar maps to. Specialise for your scalar type; the
+// primary template guesses from the size-8 layouts the reference uses.
+template <class T> struct scalar_kind { static const int value = -1; };
+
+namespace detail {
+
+inline xpg_ctx * shared_context()
+{
+    static xpg_ctx * ctx = 0;
+    if (!ctx && xpg_create(&ctx, 0) != 0) ctx = 0;
+    return ctx;
+}
+
+template <class Mat> inline const void * data_of(Mat const & m)
+{ return m.size() ? (const void *)m.get_matrix() : (const void *)0; }
+
+} // namespace detail
+
+template <class Mat, class T> class SIX {
+    unsigned m_max_iter;
+    unsigned m_indent;
+    xpg_ctx * m_ctx;
+    static_assert(sizeof(T) == 8, "xpoly_amd::SIX: T must be Float (fp64) or Rational (int32/int32)");
+public:
+    explicit SIX(xpg_ctx * ctx = 0) : m_max_iter(0xFFFFFFFFu), m_indent(0), m_ctx(ctx) {}
+    void init() {}
+    void destroy() {}
+    // SIX::set_param, lpsol.h:380-385
+    void set_param(unsigned indent, unsigned max_iter = 0xFFFFFFFFu) { m_indent = indent; m_max_iter = max_iter; }
+
+    // SIX::maxm, lpsol.h:1993-2033 -- same argument order and meaning.
+    unsigned maxm(T & maxv, Mat & res, Mat const & tgtf, Mat & vc, Mat const & eq, Mat const & leq, int rhs_idx = -1)
+    { return solve(true, maxv, res, tgtf, vc, eq, leq, rhs_idx); }
+    // SIX::minm, lpsol.h:1662-1732
+    unsigned minm(T & minv, Mat & res, Mat const & tgtf, Mat & vc, Mat const & eq, Mat const & leq, int rhs_idx = -1)
+    { return solve(false, minv, res, tgtf, vc, eq, leq, rhs_idx); }
+
+private:
+    unsigned solve(bool is_max, T & v, Mat & res, Mat const & tgtf, Mat & vc, Mat const & eq, Mat const & leq, int rhs_idx)
+    {
+        const int kind = scalar_kind<T>::value;
+        xpg_ctx * ctx = m_ctx ? m_ctx : detail::shared_context();
+        const int cols = (int)tgtf.get_col_size();
+        // the reference only ASSERTs these (lpsol.h:1527-1557); we refuse instead
+        if (!ctx) return (unsigned)XPG_ERR_NO_DEVICE;
+        if (kind < 0 || (rhs_idx != -1 && rhs_idx != cols - 1)) return (unsigned)XPG_ERR_SHAPE;
+        std::vector<T> out_sol((size_t)cols);
+        T out_v;
+        std::memset((void *)&out_v, 0, sizeof(T));
+        int st;
+        const int eq_rows = eq.size() ? (int)eq.get_row_size() : 0;
+        const int leq_rows = leq.size() ? (int)leq.get_row_size() : 0;
+        if (kind == 0) {
+            st = (is_max ? xpg_six_maxm_f64 : xpg_six_minm_f64)(
+                ctx, (const double *)detail::data_of(tgtf), (const double *)detail::data_of(vc),
+                (int)vc.get_row_size(), (const double *)detail::data_of(eq), eq_rows,
+                (const double *)detail::data_of(leq), leq_rows, cols, m_max_iter,
+                (double *)&out_v, (double *)out_sol.data());
+        } else {
+            st = (is_max ? xpg_six_maxm_rat32 : xpg_six_minm_rat32)(
+                ctx, (const xpg_rat32 *)detail::data_of(tgtf), (const xpg_rat32 *)detail::data_of(vc),
+                (int)vc.get_row_size(), (const xpg_rat32 *)detail::data_of(eq), eq_rows,
+                (const xpg_rat32 *)detail::data_of(leq), leq_rows, cols, m_max_iter,
+                (xpg_rat32 *)&out_v, (xpg_rat32 *)out_sol.data());
+        }
+        v = out_v;                                   // 0 on non-success, lpsol.h:2024
+        if (st == XPG_SIX_SUCC) {
+            res.reinit(1, cols);                     // calcFinalSolution, lpsol.h:1880
+            std::memcpy((void *)res.get_matrix(), (const void *)out_sol.data(), sizeof(T) * (size_t)cols);
+        }
+        return (unsigned)st;
+    }
+};
+
+} // namespace xpoly_amd
+#endif

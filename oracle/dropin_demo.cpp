@@ -1,0 +1,102 @@
+// TEST INFRASTRUCTURE -- drop-in check with the REAL xpoly types.
+// Compiled in the authoring container against /root/reference/src/com (headers
+// and objects where they lie) by `make -C oracle ref`; the binary lands in
+// oracle/_ref/dropin_demo and travels to the GPU box. It solves the same problems
+// once with the reference's own xcom::SIX<Mat,T> (CPU) and once with
+// xpoly_amd::SIX<Mat,T> (include/xpoly_amd/six.hpp -> C ABI -> GPU), on the
+// reference's FloatMat / RMat objects, and compares status, optimum and solution
+// bit for bit. Exit code 0 = all equal.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+
+#include "ltype.h"
+#include "comf.h"
+#include "smempool.h"
+#include "strbuf.h"
+#include "rational.h"
+#include "flty.h"
+#include "sstl.h"
+#include "matt.h"
+#include "xmat.h"
+#include "bs.h"
+#include "sbs.h"
+#include "sgraph.h"
+#include "lpsol.h"
+
+#include "xpoly_amd/six.hpp"
+
+namespace xpoly_amd {
+template <> struct scalar_kind<xcom::Float> { static const int value = 0; };
+template <> struct scalar_kind<xcom::Rational> { static const int value = 1; };
+}
+
+using namespace xcom;
+
+static unsigned long long rng_state = 88172645463325252ULL;
+static unsigned long long xs()
+{
+    rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17;
+    return rng_state;
+}
+static int irand(int lo, int hi) { return lo + (int)(xs() % (unsigned long long)(hi - lo + 1)); }
+
+template <class Mat, class T> static int compare_one(Mat & tgtf, Mat & vc, Mat & eq, Mat & leq, bool is_max, const char * tag)
+{
+    T v_ref, v_gpu;
+    Mat s_ref, s_gpu;
+    xcom::SIX<Mat, T> ref;
+    xpoly_amd::SIX<Mat, T> gpu;
+    UINT a = is_max ? ref.maxm(v_ref, s_ref, tgtf, vc, eq, leq) : ref.minm(v_ref, s_ref, tgtf, vc, eq, leq);
+    UINT b = is_max ? gpu.maxm(v_gpu, s_gpu, tgtf, vc, eq, leq) : gpu.minm(v_gpu, s_gpu, tgtf, vc, eq, leq);
+    int bad = (a != b) || memcmp(&v_ref, &v_gpu, sizeof(T)) != 0;
+    if (!bad && a == SIX_SUCC)
+        bad = s_ref.get_col_size() != s_gpu.get_col_size() ||
+              memcmp(s_ref.get_matrix(), s_gpu.get_matrix(), sizeof(T) * s_ref.get_col_size()) != 0;
+    if (bad) printf("MISMATCH %s %s: reference status %u, xpoly_amd status %u\n", tag, is_max ? "maxm" : "minm", a, b);
+    return bad;
+}
+
+int main()
+{
+    int bad = 0, n = 0;
+    {   // src/example/example.cpp:54-93
+        FloatMat leq(2, 3), tgtf(1, 3), vc(2, 3), eq;
+        double l[6] = {2, -1, 2, 1, -5, -4}, t[3] = {2, -1, 0};
+        for (int i = 0; i < 6; i++) leq.set(i / 3, i % 3, Float(l[i]));
+        for (int i = 0; i < 3; i++) tgtf.set(0, i, Float(t[i]));
+        vc.set(0, 0, Float(-1.0)); vc.set(1, 1, Float(-1.0));
+        bad += compare_one<FloatMat, Float>(tgtf, vc, eq, leq, true, "example-float"); n++;
+    }
+    {   // src/example/example.cpp:106-174
+        RMat leq(8, 6), tgtf(1, 6), vc(5, 6), eq;
+        int l[48] = {-1,0,0,0,0,-10, -1,-1,0,0,0,-8, -1,-1,-1,0,0,-9, -1,-1,-1,-1,0,-11,
+                     0,-1,-1,-1,-1,-13, 0,0,-1,-1,-1,-8, 0,0,0,-1,-1,-5, 0,0,0,0,-1,-3};
+        for (int i = 0; i < 48; i++) leq.setr(i / 6, i % 6, l[i], 1);
+        for (int i = 0; i < 5; i++) { tgtf.setr(0, i, 1, 1); vc.setr(i, i, -1, 1); }
+        bad += compare_one<RMat, Rational>(tgtf, vc, eq, leq, true, "example-rational"); n++;
+        bad += compare_one<RMat, Rational>(tgtf, vc, eq, leq, false, "example-rational"); n++;
+    }
+    for (int it = 0; it < 40; it++) {   // random small integer LPs, both scalars
+        int m = irand(1, 7), nv = irand(1, 7);
+        RMat rl(m, nv + 1), rt(1, nv + 1), rv(nv, nv + 1), req;
+        FloatMat fl(m, nv + 1), ft(1, nv + 1), fv(nv, nv + 1), feq;
+        for (int i = 0; i < m; i++)
+            for (int j = 0; j <= nv; j++) {
+                int x = j < nv ? irand(-3, 6) : irand(-2, 20);
+                rl.setr(i, j, x, 1); fl.set(i, j, Float((double)x));
+            }
+        for (int j = 0; j < nv; j++) {
+            int c = irand(-2, 6);
+            rt.setr(0, j, c, 1); ft.set(0, j, Float((double)c));
+            rv.setr(j, j, -1, 1); fv.set(j, j, Float(-1.0));
+        }
+        for (int mx = 0; mx < 2; mx++) {
+            bad += compare_one<RMat, Rational>(rt, rv, req, rl, mx == 0, "random-rational"); n++;
+            bad += compare_one<FloatMat, Float>(ft, fv, feq, fl, mx == 0, "random-float"); n++;
+        }
+    }
+    printf("dropin_demo: %d solves through xcom::SIX and xpoly_amd::SIX on the reference's own matrix types, %d mismatches\n", n, bad);
+    return bad ? 1 : 0;
+}
