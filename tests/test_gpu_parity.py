@@ -204,3 +204,16 @@ def test_batch_cfg3_shape_sample(ctx, port):
             assert same(v[b], want[1]), (fam, b)
             if want[0] == 0 and want[1] != 0:
                 assert abs(v[b] - want[1]) <= REL_TOL * abs(want[1])
+
+
+def test_dropin_demo_with_reference_types():
+    """oracle/_ref/dropin_demo (built in the authoring container against the real xpoly headers):
+    xcom::SIX on the CPU vs xpoly_amd::SIX -> C ABI -> GPU on the reference's own FloatMat / RMat."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "dropin_demo")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/dropin_demo not built")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 mismatches" in r.stdout
