@@ -70,11 +70,12 @@ int         xpg_upload(xpg_ctx * ctx, void * dst_dev, const void * src_host, siz
 int         xpg_download(xpg_ctx * ctx, void * dst_host, const void * src_dev, size_t bytes);
 
 /* ---- in-library timing of the HBM-bound sweep (K1's update kernel) -------------------
- * Between begin and end every launch of the sweep on this context is bracketed by
- * a pair of HIP events recorded on the context's stream (at most `cap` launches are
- * sampled).  end synchronises the stream and returns the number of sampled launches
- * and the sum of their durations in milliseconds. */
-int         xpg_profile_begin(xpg_ctx * ctx, int cap);
+ * Between begin and end every `stride`-th launch of the sweep on this context is
+ * bracketed by a pair of HIP events recorded on the context's stream (at most `cap`
+ * launches are sampled; an event pair costs ~6 us of stream time, hence the stride).
+ * end synchronises the stream and returns the number of sampled launches and the
+ * sum of their durations in milliseconds. */
+int         xpg_profile_begin(xpg_ctx * ctx, int cap, int stride);
 int         xpg_profile_end(xpg_ctx * ctx, int * launches, double * total_ms);
 
 /* ---- K1: one pivot -- SIX::pivot arithmetic, src/com/lpsol.h:1471-1501 ------------

@@ -20,7 +20,7 @@ struct xpg_ctx {
     int update_variant;     // tuning knob for the fp64 sweep (see launch_update_f64)
     // xpg_profile_begin/end: event pairs around each sweep launch
     std::vector<hipEvent_t> ev0, ev1;
-    int prof_cap, prof_n;
+    int prof_cap, prof_n, prof_stride, prof_seen;
 };
 
 #define XPG_HIP(ctx, call)                                                         \
@@ -41,12 +41,13 @@ inline int round_up(int x, int a) { return (x + a - 1) / a * a; }
 // reachable through XPG_UPDATE_VARIANT for A/B runs.
 inline void launch_update_f64(hipStream_t s, int variant, double * tab, int m, int W, int ld,
                               const double * rowbuf, const double * colbuf,
-                              const LoopState * st, int guarded)
+                              LoopState * st, int guarded, double * nextcol, double * bcol,
+                              int rhs)
 {
     const int strips = (W + 511) / 512;
 #define XPG_LAUNCH(R, U)                                                                    \
     hipLaunchKernelGGL((k_update_f64<R, U>), dim3(strips, (m + R - 1) / R), dim3(256), 0, s, \
-                       tab, m, W, ld, rowbuf, colbuf, st, guarded)
+                       tab, m, W, ld, rowbuf, colbuf, st, guarded, nextcol, bcol, rhs)
     switch (variant) {
     case 1: XPG_LAUNCH(16, 4); break;
     case 2: XPG_LAUNCH(32, 4); break;
@@ -64,6 +65,7 @@ template <class S> inline void launch_update(xpg_ctx * ctx, const LpView<S> & v,
 inline bool prof_open(xpg_ctx * ctx)
 {
     if (ctx->prof_n >= ctx->prof_cap) return false;
+    if ((ctx->prof_seen++ % ctx->prof_stride) != 0) return false;
     (void)hipEventRecord(ctx->ev0[ctx->prof_n], ctx->stream);
     return true;
 }
@@ -76,7 +78,8 @@ template <> inline void launch_update<F64>(xpg_ctx * ctx, const LpView<F64> & v,
 {
     const bool timed = prof_open(ctx);
     launch_update_f64(ctx->stream, ctx->update_variant, (double *)v.tab, v.m, v.W, v.ld,
-                      (const double *)v.rowbuf, (const double *)v.colbuf, v.st, guarded);
+                      (const double *)v.rowbuf, (const double *)v.colbuf, v.st, guarded,
+                      (double *)v.nextcol, (double *)v.bcol, v.rhs);
     if (timed) prof_close(ctx);
 }
 template <> inline void launch_update<R32>(xpg_ctx * ctx, const LpView<R32> & v, int guarded)
@@ -103,6 +106,7 @@ template <class S> struct Lp : LpBase {
     size_t tab_elems;
     bool began;
     int final_status;
+    hipEvent_t throttle[2] = {nullptr, nullptr};
 
     int alloc(void ** p, size_t bytes)
     {
@@ -111,7 +115,11 @@ template <class S> struct Lp : LpBase {
         owned.push_back(*p);
         return 0;
     }
-    ~Lp() { for (void * p : owned) (void)hipFree(p); }
+    ~Lp()
+    {
+        for (void * p : owned) (void)hipFree(p);
+        for (hipEvent_t e : throttle) if (e) (void)hipEventDestroy(e);
+    }
 
     int create(const void * leq, int m_, int cols, const void * tgtf, const void * vcd,
                const void * vcr, int on_dev)
@@ -130,6 +138,8 @@ template <class S> struct Lp : LpBase {
         if ((rc = alloc((void **)&v.rowbuf, (size_t)ld * sizeof(S)))) return rc;
         if ((rc = alloc((void **)&v.colbuf, (size_t)round_up(m, 16) * sizeof(S)))) return rc;
         if ((rc = alloc((void **)&v.x, (size_t)ld * sizeof(S)))) return rc;
+        if ((rc = alloc((void **)&v.nextcol, (size_t)round_up(m, 16) * sizeof(S)))) return rc;
+        if ((rc = alloc((void **)&v.bcol, (size_t)round_up(m, 16) * sizeof(S)))) return rc;
         if ((rc = alloc((void **)&v.vcd, (size_t)ld * sizeof(S)))) return rc;
         if ((rc = alloc((void **)&v.vcr, (size_t)ld * sizeof(S)))) return rc;
         if ((rc = alloc((void **)&v.nv, ld))) return rc;
@@ -155,6 +165,12 @@ template <class S> struct Lp : LpBase {
         XPG_HIP(ctx, hipMemcpyAsync(v.vcd, hd.data(), (size_t)ld * sizeof(S), hipMemcpyHostToDevice, s));
         XPG_HIP(ctx, hipMemcpyAsync(v.vcr, hr.data(), (size_t)ld * sizeof(S), hipMemcpyHostToDevice, s));
         XPG_HIP(ctx, hipMemsetAsync(v.st, 0, sizeof(LoopState), s));
+        // launch-throttle events, exercised once so their first use is not inside a solve
+        for (int i = 0; i < 2; i++) {
+            XPG_HIP(ctx, hipEventCreateWithFlags(&throttle[i], hipEventDisableTiming));
+            XPG_HIP(ctx, hipEventRecord(throttle[i], s));
+            XPG_HIP(ctx, hipEventSynchronize(throttle[i]));
+        }
         XPG_HIP(ctx, hipStreamSynchronize(s));      // hd/hr are stack-owned
         return 0;
     }
@@ -181,14 +197,26 @@ template <class S> struct Lp : LpBase {
     {
         const int span = v.W > v.m ? v.W : v.m;
         hipLaunchKernelGGL((k_prep<S>), dim3((span + 255) / 256), dim3(256), 0, ctx->stream, v,
-                           guarded, counted, 1);
+                           guarded, counted, 1, 0);
         launch_update<S>(ctx, v, guarded);
     }
+    // Queues k loop iterations. The host runs far ahead of the GPU (3 launches cost
+    // ~10 us, one iteration ~90 us), and an over-full HIP queue was measured to stall
+    // the stream for tens of ms, so at most 2 x 64 iterations are kept in flight:
+    // every 64 iterations an event is recorded and the one from two blocks back awaited.
     void queue_iterations(unsigned k)
     {
+        unsigned blk = 0;
         for (unsigned t = 0; t < k; t++) {
-            hipLaunchKernelGGL((k_select<S>), dim3(1), dim3(1024), 0, ctx->stream, v);
-            queue_pivot(1, 1);
+            hipLaunchKernelGGL((k_pick<S>), dim3(1), dim3(1024), 0, ctx->stream, v);
+            hipLaunchKernelGGL((k_prep<S>), dim3((v.W + 255) / 256), dim3(256), 0, ctx->stream, v, 1, 1, 0, 1);
+            launch_update<S>(ctx, v, 1);
+            if ((t & 63) == 63) {
+                hipEvent_t e = throttle[blk & 1];
+                if (blk >= 2) (void)hipEventSynchronize(e);
+                (void)hipEventRecord(e, ctx->stream);
+                blk++;
+            }
         }
     }
 

@@ -3,14 +3,18 @@
 // kernel template over the scalar S (xpg::F64 or xpg::R32); the host only
 // queues launches and polls a status word every few dozen pivots.
 //
-// Per loop iteration three launches, all reading their operands from LoopState:
-//   k_select : pricing scan (lpsol.h:1054-1069) + ratio test (lpsol.h:553-663)
-//              + pivot-pair table upkeep (lpsol.h:68-154)        -- 1 workgroup
-//   k_prep   : pivot row * 1/pivot -> rowbuf, -column -> colbuf, objective row
-//              update (lpsol.h:1471-1474, :1485, :1496-1501), basis swap
-//              (:1504-1510)                                       -- few workgroups
+// Per loop iteration two launches, communicating through LoopState:
+//   k_pick   : pricing scan (lpsol.h:1054-1069) + ratio test (lpsol.h:553-663)
+//              + pivot-pair table upkeep (lpsol.h:68-154) + staging of the pivot
+//              (row * 1/pivot -> rowbuf, -column -> colbuf, objective row update,
+//              basis swap: lpsol.h:1471-1474, :1485, :1496-1510) + look-ahead
+//              pricing                                           -- 1 workgroup
 //   k_update : a_ij += (-a_i,nv) * e_j for every i != r, all j   (lpsol.h:1481-1490)
-//              -- the HBM-bound sweep, >= 2048 workgroups
+//              -- the HBM-bound sweep, >= 2048 workgroups; it also exports the
+//              look-ahead column and the constant column contiguously so the
+//              next k_pick's ratio test reads 2 x 32 KB coalesced instead of
+//              2 x 4096 64-byte sectors
+// (k_prep is the multi-workgroup staging used by one-shot and phase-1 pivots.)
 //
 // HBM layout: tableau row-major, leading dimension ld (multiple of 16 elements
 // = 128 B so every row starts on a cache line and 16-byte vector accesses are
@@ -35,7 +39,14 @@ struct LoopState {
     int infeasible;        // set by the feasibility kernels
     unsigned total_pivots; // over the handle's lifetime (trace index)
     int aux;               // scratch result for phase-1 helper kernels
+    // look-ahead pricing, filled by k_prep's atomics after the objective update:
+    int next_first;        // lowest eligible entering column of the next iteration
+                           // (INT_MAX: none, NF_UNKNOWN: not computed)
+    int anypos;            // some nonbasic reduced cost is > 0
+    int cached_col;        // column currently held in nextcol[] (-1: none), set by the sweep
+    int bcol_valid;        // bcol[] holds the current constant column
 };
+enum { NF_UNKNOWN = -2 };
 
 template <class S> struct LpView {
     S * tab; int m, W, ld, rhs;
@@ -43,6 +54,7 @@ template <class S> struct LpView {
     uint8_t * nv; uint8_t * bv; int * bv2eq; int * eq2bv;
     uint32_t * ppt; int pw; int * rowcnt; int * colcnt;
     S * rowbuf; S * colbuf; S * x; S * vcd; S * vcr;
+    S * nextcol; S * bcol;   // contiguous copies of the predicted entering column / constant column
     LoopState * st;
     int * trace; int trace_cap;
 };
@@ -102,17 +114,21 @@ template <class S> __device__ __forceinline__ bool ppt_seen(const LpView<S> & v,
 
 // SIX::findPivotBV (lpsol.h:553-663) by one workgroup: rows strided over
 // threads, arg-min of b_i / a_i,nv with the lowest row winning ties.
-template <class S> __device__ int ratio_test(const LpView<S> & v, int nv, Cand<S> * sh)
+// The column and the constant column come from the contiguous copies the
+// previous sweep exported when they are current (col_cached / b_cached), else
+// from the tableau (one 64-byte sector per element).
+template <class S> __device__ int ratio_test(const LpView<S> & v, int nv, Cand<S> * sh,
+                                             bool col_cached = false, bool b_cached = false)
 {
     const int lim = v.rhs - 1;
     for (int pass = 0; pass < 2; pass++) {
         Cand<S> best; best.q = zero<S>(); best.idx = INT_MAX;
         for (int i = threadIdx.x; i < v.m; i += blockDim.x) {
-            S a = v.tab[(size_t)i * v.ld + nv];
+            S a = col_cached ? v.nextcol[i] : v.tab[(size_t)i * v.ld + nv];
             if (pass == 0 ? le(a, zero<S>()) : eq(a, zero<S>())) continue;
             int b = v.eq2bv[i];
             if (ppt_seen(v, nv, b) || v.colcnt[b] >= lim) continue;
-            Cand<S> c; c.q = div(v.tab[(size_t)i * v.ld + v.rhs], a); c.idx = i;
+            Cand<S> c; c.q = div(b_cached ? v.bcol[i] : v.tab[(size_t)i * v.ld + v.rhs], a); c.idx = i;
             best = better(best, c);
         }
         best = block_argmin(best, sh);
@@ -121,7 +137,35 @@ template <class S> __device__ int ratio_test(const LpView<S> & v, int nv, Cand<S
     return -1;
 }
 
-template <class S> __global__ __launch_bounds__(1024) void k_select(LpView<S> v)
+// In-workgroup pricing scan (lpsol.h:1054-1069 without the side effect): lowest
+// nonbasic j with c_j > 0 whose pair-table row is still open, and whether any
+// nonbasic c_j > 0 exists at all.
+template <class S> __device__ void price_scan(const LpView<S> & v, int * sh_i, int * sh_flag,
+                                              int & first, int & anypos)
+{
+    const int rhs = v.rhs, lim = rhs - 1;
+    int f = INT_MAX, any = 0;
+    for (int j = threadIdx.x; j < rhs; j += blockDim.x)
+        if (v.nv[j] && gt(v.obj[j], zero<S>())) {
+            any = 1;
+            if (v.rowcnt[j] < lim) f = min(f, j);
+        }
+    first = block_min_int(f, sh_i);
+    if (threadIdx.x == 0) *sh_flag = 0;
+    __syncthreads();
+    if (any) *sh_flag = 1;
+    __syncthreads();
+    anypos = *sh_flag;
+}
+
+// One workgroup per loop iteration, deliberately light on memory traffic (one CU
+// moves only ~30 GB/s): it consumes the look-ahead pricing result k_prep left in
+// LoopState, runs the ratio test (lpsol.h:553-663) on the contiguous column
+// copies the last sweep exported, keeps the pair table (lpsol.h:68-154), swaps
+// the basis (lpsol.h:1504-1510) and writes -column to colbuf (lpsol.h:1485).
+// Every rare branch of solveSlackForm (optimum, findPivotNVandBVPair, relaxed
+// ratio pass, disableNV) is handled here by the generic single-workgroup code.
+template <class S> __global__ __launch_bounds__(1024) void k_pick(LpView<S> v)
 {
     __shared__ __attribute__((aligned(8))) unsigned char sh_c_raw[16 * sizeof(Cand<S>)];
     Cand<S> * sh_c = (Cand<S> *)sh_c_raw;
@@ -135,25 +179,18 @@ template <class S> __global__ __launch_bounds__(1024) void k_select(LpView<S> v)
         return;
     }
     const int rhs = v.rhs, lim = rhs - 1;
-    // ---- pricing (lpsol.h:1054-1069)
-    int first = INT_MAX, anypos = 0;
-    for (int j = threadIdx.x; j < rhs; j += blockDim.x) {
-        if (v.nv[j] && gt(v.obj[j], zero<S>())) {
-            anypos = 1;
-            if (v.rowcnt[j] < lim) first = min(first, j);
-        }
-    }
-    first = block_min_int(first, sh_i);
-    if (threadIdx.x == 0) sh_flag = 0;
+    const int cached_col = st->cached_col;
+    const bool b_cached = st->bcol_valid != 0;
+    int first = st->next_first, anypos = st->anypos;
     __syncthreads();
-    if (anypos) sh_flag = 1;
+    if (first == NF_UNKNOWN) price_scan(v, sh_i, &sh_flag, first, anypos);
     const int stop = first == INT_MAX ? rhs : first;
     for (int j = threadIdx.x; j < stop; j += blockDim.x)
         if (!v.nv[j]) v.obj[j] = zero<S>();           // lpsol.h:1055-1060
     __syncthreads();
     int enter = -1, leave = -1;
     if (first == INT_MAX) {
-        if (!sh_flag) {                                // optimum reached: lpsol.h:1089
+        if (!anypos) {                                 // optimum reached: lpsol.h:1089
             if (threadIdx.x == 0) { st->status = ST_CHECK_OPT; st->row = -1; }
             return;
         }
@@ -164,7 +201,7 @@ template <class S> __global__ __launch_bounds__(1024) void k_select(LpView<S> v)
                 S c = v.obj[i];
                 bool take = gt(c, zero<S>()) ? true : (eq(c, zero<S>()) ? pass == 1 : false);
                 if (!take) continue;
-                int b = ratio_test(v, i, sh_c);
+                int b = ratio_test(v, i, sh_c, i == cached_col, b_cached);
                 if (b < 0) continue;
                 enter = i; leave = b;
                 break;
@@ -175,7 +212,7 @@ template <class S> __global__ __launch_bounds__(1024) void k_select(LpView<S> v)
             return;
         }
     } else {
-        leave = ratio_test(v, first, sh_c);
+        leave = ratio_test(v, first, sh_c, first == cached_col, b_cached);
         if (leave < 0) {                               // disableNV + continue, lpsol.h:1146-1151
             int add = 0;
             for (int j = threadIdx.x; j < rhs; j += blockDim.x) {
@@ -185,20 +222,36 @@ template <class S> __global__ __launch_bounds__(1024) void k_select(LpView<S> v)
                 add++;
             }
             if (add) atomicAdd(&v.rowcnt[first], add);
-            if (threadIdx.x == 0) st->row = -1;
+            __threadfence_block();
+            __syncthreads();
+            int nf, any;                               // no sweep follows: re-price here
+            price_scan(v, sh_i, &sh_flag, nf, any);
+            if (threadIdx.x == 0) { st->row = -1; st->next_first = nf; st->anypos = any; }
             return;
         }
         enter = first;
     }
+    // ---- pivot (enter, leave) chosen
+    const bool col_cached = enter == cached_col;
+    const int r = v.bv2eq[leave];
+    __syncthreads();                                   // everyone has read bv2eq[leave]
+    for (int i = threadIdx.x; i < v.m; i += blockDim.x)
+        v.colbuf[i] = neg(col_cached ? v.nextcol[i] : v.tab[(size_t)i * v.ld + enter]);   // :1485
     if (threadIdx.x == 0) {
         if (!ppt_seen(v, enter, leave)) {              // genPair, lpsol.h:100-104
             v.ppt[(size_t)enter * v.pw + (leave >> 5)] |= 1u << (leave & 31);
             v.rowcnt[enter] += 1; v.colcnt[leave] += 1;
         }
-        const int r = v.bv2eq[leave];
         st->row = r; st->col = enter; st->leave = leave;
         st->cnv_bits = to_bits(v.obj[enter]);
-        st->piv_bits = to_bits(v.tab[(size_t)r * v.ld + enter]);
+        st->piv_bits = to_bits(col_cached ? v.nextcol[r] : v.tab[(size_t)r * v.ld + enter]);
+        v.nv[enter] = 0; v.nv[leave] = 1; v.bv[enter] = 1; v.bv[leave] = 0;   // :1504-1510
+        v.eq2bv[r] = enter; v.bv2eq[enter] = r; v.bv2eq[leave] = -1;
+        const unsigned t = st->total_pivots;
+        if ((int)t < v.trace_cap) { v.trace[2 * t] = enter; v.trace[2 * t + 1] = leave; }
+        st->total_pivots = t + 1;
+        st->done += 1;
+        st->next_first = INT_MAX; st->anypos = 0;      // k_prep's look-ahead fills these
     }
 }
 
@@ -207,7 +260,7 @@ template <class S> __global__ __launch_bounds__(1024) void k_select(LpView<S> v)
 // guarded: only while the loop is running; counted: the pivot counts towards 'cnt'
 // (the forced pivots of phase 1 are neither, lpsol.h:906-908, :939).
 template <class S> __global__ __launch_bounds__(256)
-void k_prep(LpView<S> v, int guarded, int counted, int bookkeeping)
+void k_prep(LpView<S> v, int guarded, int counted, int bookkeeping, int lookahead)
 {
     LoopState * st = v.st;
     if ((guarded && st->status != ST_RUNNING) || st->row < 0) return;
@@ -217,13 +270,29 @@ void k_prep(LpView<S> v, int guarded, int counted, int bookkeeping)
     const S cnv = from_bits<S>(st->cnv_bits);
     const int cmode = scale_mode(cnv);
     const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+    const int lim = v.rhs - 1;
+    int nf = INT_MAX, any = 0;
     for (int j = gid; j < v.W; j += gsz) {
         S e = scaled(v.tab[(size_t)r * v.ld + j], s, smode);
         v.rowbuf[j] = e;
         S t = mul(e, minus_one<S>());                          // nvexp.mul(-1), :1496
         if (j >= v.rhs) t = neg(t);                            // :1497-1499
         t = scaled(t, cnv, cmode);                             // nvexp.mul(tgtf(nv)), :1500
-        v.obj[j] = add(t, v.obj[j]);                           // addRowToRow, :1501
+        const S o = add(t, v.obj[j]);                          // addRowToRow, :1501
+        v.obj[j] = o;
+        // look-ahead pricing of the next iteration (basis already swapped by k_pick)
+        if (lookahead && j < v.rhs && v.nv[j] && gt(o, zero<S>())) {
+            any = 1;
+            if (v.rowcnt[j] < lim) nf = min(nf, j);
+        }
+    }
+    if (lookahead) {
+        for (int o = 32; o > 0; o >>= 1) { nf = min(nf, __shfl_xor(nf, o)); any |= __shfl_xor(any, o); }
+        if ((threadIdx.x & 63) == 0) {
+            if (nf != INT_MAX) atomicMin(&st->next_first, nf);
+            if (any) atomicOr(&st->anypos, 1);
+        }
+        return;                                                // colbuf / basis were done by k_pick
     }
     for (int i = gid; i < v.m; i += gsz)
         v.colbuf[i] = neg(v.tab[(size_t)i * v.ld + c]);        // coeff_of_nv, :1485
@@ -236,9 +305,12 @@ void k_prep(LpView<S> v, int guarded, int counted, int bookkeeping)
         st->total_pivots = t + 1;
         if (counted) st->done += 1;
     }
+    if (gid == 0) { st->next_first = NF_UNKNOWN; st->cached_col = -1; st->bcol_valid = 0; }
 }
 
 // K1, generic scalar: one element per thread per row, rows looped per block.
+// In loop mode (guarded) the sweep also writes the post-update values of the
+// look-ahead column and of the constant column to contiguous arrays.
 template <class S, int ROWS> __global__ __launch_bounds__(256)
 void k_update(LpView<S> v, int guarded)
 {
@@ -247,13 +319,21 @@ void k_update(LpView<S> v, int guarded)
     const int r = st->row;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= v.W) return;
+    const int xcol = guarded ? st->next_first : -1;
+    const bool ex_col = guarded && j == xcol, ex_b = guarded && j == v.rhs;
+    if (guarded && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        v.st->cached_col = (xcol >= 0 && xcol < v.W) ? xcol : -1; v.st->bcol_valid = 1;
+    }
     const S e = v.rowbuf[j];
     const int i0 = blockIdx.y * ROWS;
     for (int ii = 0; ii < ROWS; ii++) {
         const int i = i0 + ii;
         if (i >= v.m) break;
         S * p = v.tab + (size_t)i * v.ld + j;
-        *p = (i == r) ? e : add(*p, mul(v.colbuf[i], e));
+        const S o = (i == r) ? e : add(*p, mul(v.colbuf[i], e));
+        *p = o;
+        if (ex_col) v.nextcol[i] = o;
+        if (ex_b) v.bcol[i] = o;
     }
 }
 
@@ -265,12 +345,21 @@ void k_update(LpView<S> v, int guarded)
 template <int ROWS, int UNROLL> __global__ __launch_bounds__(256)
 void k_update_f64(double * __restrict__ tab, int m, int W, int ld,
                   const double * __restrict__ rowbuf, const double * __restrict__ colbuf,
-                  const LoopState * __restrict__ st, int guarded)
+                  LoopState * __restrict__ st, int guarded,
+                  double * __restrict__ nextcol, double * __restrict__ bcol, int rhs)
 {
     if ((guarded && st->status != ST_RUNNING) || st->row < 0) return;
     const int r = st->row;
     const int j = blockIdx.x * 512 + threadIdx.x * 2;
     if (j >= W) return;
+    // contiguous export of the look-ahead column and the constant column (loop mode)
+    int xc = guarded ? st->next_first : -1;
+    if (xc >= W) xc = -1;                                     // INT_MAX: nothing to price next
+    const int xb = guarded ? rhs : -1;
+    if (guarded && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        st->cached_col = xc >= 0 ? xc : -1; st->bcol_valid = 1;
+    }
+    const bool ex_col = xc >= 0 && (xc >> 1) == (j >> 1), ex_b = xb >= 0 && (xb >> 1) == (j >> 1);
     const int i0 = blockIdx.y * ROWS;
     const int iend = min(i0 + ROWS, m);
     if (j + 1 < W) {
@@ -292,6 +381,8 @@ void k_update_f64(double * __restrict__ tab, int m, int W, int ld,
                 o.x = a[u].x + p0; o.y = a[u].y + p1;
                 if (i + u == r) o = e;
                 *reinterpret_cast<double2 *>(base + (size_t)u * ld) = o;
+                if (ex_col) nextcol[i + u] = (xc & 1) ? o.y : o.x;
+                if (ex_b) bcol[i + u] = (xb & 1) ? o.y : o.x;
             }
             base += (size_t)UNROLL * ld;
         }
@@ -303,6 +394,8 @@ void k_update_f64(double * __restrict__ tab, int m, int W, int ld,
             o.x = a.x + p0; o.y = a.y + p1;
             if (i == r) o = e;
             *reinterpret_cast<double2 *>(base) = o;
+            if (ex_col) nextcol[i] = (xc & 1) ? o.y : o.x;
+            if (ex_b) bcol[i] = (xb & 1) ? o.y : o.x;
             base += ld;
         }
     } else {                                                  // odd last column
@@ -310,7 +403,10 @@ void k_update_f64(double * __restrict__ tab, int m, int W, int ld,
         for (int i = i0; i < iend; i++) {
             double * p = tab + (size_t)i * ld + j;
             const double q = colbuf[i] * e;
-            *p = (i == r) ? e : (*p + q);
+            const double o = (i == r) ? e : (*p + q);
+            *p = o;
+            if (ex_col) nextcol[i] = o;
+            if (ex_b) bcol[i] = o;
         }
     }
 }
@@ -398,6 +494,7 @@ template <class S> __global__ void k_reset_loop(LpView<S> v, unsigned max_iter)
         LoopState * st = v.st;
         st->status = ST_RUNNING; st->done = 0; st->max_iter = max_iter;
         st->row = -1; st->infeasible = 0;
+        st->next_first = NF_UNKNOWN; st->anypos = 0; st->cached_col = -1; st->bcol_valid = 0;
     }
 }
 

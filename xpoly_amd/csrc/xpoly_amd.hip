@@ -45,7 +45,7 @@ int xpg_create(xpg_ctx ** out, int device)
     c->rowbuf = c->colbuf = 0; c->st = 0; c->row_cap = c->col_cap = 0;
     const char * var = getenv("XPG_UPDATE_VARIANT");
     c->update_variant = var ? atoi(var) : 0;
-    c->prof_cap = 0; c->prof_n = 0;
+    c->prof_cap = 0; c->prof_n = 0; c->prof_stride = 1; c->prof_seen = 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return XPG_ERR_HIP; }
     if (hipMalloc((void **)&c->st, sizeof(LoopState)) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return XPG_ERR_ALLOC; }
     *out = c;
@@ -66,9 +66,9 @@ void xpg_destroy(xpg_ctx * ctx)
     delete ctx;
 }
 
-int xpg_profile_begin(xpg_ctx * ctx, int cap)
+int xpg_profile_begin(xpg_ctx * ctx, int cap, int stride)
 {
-    if (!ctx || cap < 0) return XPG_ERR_SHAPE;
+    if (!ctx || cap < 0 || stride < 1) return XPG_ERR_SHAPE;
     XPG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     while ((int)ctx->ev0.size() < cap) {
         hipEvent_t a, b;
@@ -76,7 +76,7 @@ int xpg_profile_begin(xpg_ctx * ctx, int cap)
         XPG_HIP(ctx, hipEventCreate(&b));
         ctx->ev0.push_back(a); ctx->ev1.push_back(b);
     }
-    ctx->prof_cap = cap; ctx->prof_n = 0;
+    ctx->prof_cap = cap; ctx->prof_n = 0; ctx->prof_stride = stride; ctx->prof_seen = 0;
     return 0;
 }
 
@@ -182,7 +182,7 @@ int pivot_dev(xpg_ctx * ctx, S * tab, int m, int W, int ld, S * obj, int rhs, in
     v.rowbuf = (S *)ctx->rowbuf; v.colbuf = (S *)ctx->colbuf; v.st = ctx->st;
     hipLaunchKernelGGL((k_stage_pivot<S>), dim3(1), dim3(64), 0, ctx->stream, v, row, col);
     const int span = W > m ? W : m;
-    hipLaunchKernelGGL((k_prep<S>), dim3((span + 255) / 256), dim3(256), 0, ctx->stream, v, 0, 0, 0);
+    hipLaunchKernelGGL((k_prep<S>), dim3((span + 255) / 256), dim3(256), 0, ctx->stream, v, 0, 0, 0, 0);
     launch_update<S>(ctx, v, 0);
     XPG_HIP(ctx, hipGetLastError());
     return 0;

@@ -62,8 +62,8 @@ class Context:
     def sync(self):
         self.check(lib().xpg_sync(self._h), "xpg_sync")
 
-    def profile_begin(self, cap):
-        self.check(lib().xpg_profile_begin(self._h, C.c_int(cap)), "xpg_profile_begin")
+    def profile_begin(self, cap, stride=1):
+        self.check(lib().xpg_profile_begin(self._h, C.c_int(cap), C.c_int(stride)), "xpg_profile_begin")
 
     def profile_end(self):
         n, ms = C.c_int(), C.c_double()
