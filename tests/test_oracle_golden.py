@@ -149,6 +149,46 @@ def test_g6_mip(port):
     assert n > 40
 
 
+def test_g5_lineq_and_gauss(port):
+    g = json.load(open(os.path.join(GOLD, "g5_lineq.json")))
+    for c in g["fme"]:
+        mat = dec(c["mat"]["data"], RAT, c["mat"]["shape"])
+        ok, res = port.fme(mat, c["rhs"], c["u"], c.get("dark", False))
+        assert ok == c["ok"], c.get("tag")
+        assert same(res, dec(c["out"], RAT, c["out_shape"])), c.get("tag")
+    # the author's worked example (linsys.cpp:1035-1040): 1<=i1<=4, 5-i1<=i2<=12-i1  =>  1<=i2<=11
+    c = [x for x in g["fme"] if x.get("tag") == "linsys.cpp:1035-1040"][0]
+    out = dec(c["out"], RAT, c["out_shape"])
+    bounds = sorted((int(r[1][0]), int(r[2][0])) for r in out if r[0][0] == 0)
+    assert (-1, -1) in bounds and (1, 11) in bounds
+    for c in g["reduce"]:
+        mat = dec(c["mat"]["data"], RAT, c["mat"]["shape"])
+        ok, res = port.reduce(mat, c["rhs"], c["inter"])
+        assert ok == c["ok"] and same(res, dec(c["out"], RAT, c["out_shape"]))
+    for c in g["iden"]:
+        mat = dec(c["mat"]["data"], RAT, c["mat"]["shape"])
+        assert same(port.remove_iden_row(mat), dec(c["out"], RAT, c["out_shape"]))
+    seen = set()
+    for c in g["has_solution"]:
+        leq = dec(c["leq"]["data"], RAT, c["leq"]["shape"])
+        nv = leq.shape[1] - 1
+        vc = gen.to_rat(gen.vc_nonneg(nv, False))
+        r = port.has_solution(leq, None, vc, nv, c["is_int"], c["is_unique"])
+        assert r == c["result"]
+        seen.add(r)
+    assert seen == {0, 1}
+    for c in g["gauss"]:
+        sq = dec(c["sq"]["data"], RAT, c["sq"]["shape"])
+        assert port.rat_rank(sq) == c["rank"]
+        assert list(port.rat_det(sq)) == c["det"]
+        ok, inv = port.rat_inv(sq)
+        assert ok == c["inv_ok"]
+        if ok:
+            assert same(inv, dec(c["inv"], RAT, sq.shape))
+        rect = dec(c["rect"]["data"], RAT, c["rect"]["shape"])
+        assert port.rat_rank(rect) == c["rect_rank"]
+
+
 def test_scalar_semantics(port):
     # Float '==' window of 1e-17 (flty.cpp:41-58)
     assert port.flt_cmp(4, 0.0, 1e-17) == 1 and port.flt_cmp(4, 0.0, 1.1e-17) == 0

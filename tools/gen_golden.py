@@ -150,6 +150,48 @@ def main():
             rec["max" if is_max else "min"] = r
         g6.append(rec)
     json.dump(g6, open(os.path.join(OUT, "g6_mip.json"), "w"))
+
+    # ---- G5: Lineq::reduce / fme / removeIdenRow / has_solution, Matrix<Rational> rank/det/inv ----
+    g5 = dict(fme=[], reduce=[], iden=[], has_solution=[], gauss=[])
+    # the worked FME example of src/com/linsys.cpp:645-655: eliminate x from
+    #   -3x-4y<=-16, 4x-7y<=20, 4x+7y<=56, -2x+3y<=9
+    ex = gen.to_rat(np.array([[-3, -4, -16], [4, -7, 20], [4, 7, 56], [-2, 3, 9]], dtype=np.int32))
+    ok, res = ref.fme(ex, 2, 0)
+    g5["fme"].append(dict(tag="linsys.cpp:645-655", mat=dict(shape=list(ex.shape), data=enc(ex, RAT)), rhs=2, u=0,
+                          ok=ok, out_shape=list(res.shape), out=enc(res, RAT)))
+    # calcBound's example (linsys.cpp:1035-1040): 1<=i1<=4, 5-i1<=i2<=12-i1; eliminate i1 -> 1<=i2<=11
+    ex = gen.to_rat(np.array([[-1, 0, -1], [1, 0, 4], [-1, -1, -5], [1, 1, 12]], dtype=np.int32))
+    ok, res = ref.fme(ex, 2, 0)
+    g5["fme"].append(dict(tag="linsys.cpp:1035-1040", mat=dict(shape=list(ex.shape), data=enc(ex, RAT)), rhs=2, u=0,
+                          ok=ok, out_shape=list(res.shape), out=enc(res, RAT)))
+    for rep in range(48):
+        rows, nv = int(rng.integers(1, 12)), int(rng.integers(1, 7))
+        mat = gen.random_system(rng, rows, nv)
+        u = int(rng.integers(0, nv)); dark = bool(rng.integers(0, 2))
+        ok, res = ref.fme(mat, nv, u, dark)
+        g5["fme"].append(dict(mat=dict(shape=list(mat.shape), data=enc(mat, RAT)), rhs=nv, u=u, dark=dark,
+                              ok=ok, out_shape=list(res.shape), out=enc(res, RAT)))
+        for inter in (True, False):
+            ok, res = ref.reduce(mat, nv, inter)
+            g5["reduce"].append(dict(mat=dict(shape=list(mat.shape), data=enc(mat, RAT)), rhs=nv, inter=inter,
+                                     ok=ok, out_shape=list(res.shape), out=enc(res, RAT)))
+        res = ref.remove_iden_row(mat)
+        g5["iden"].append(dict(mat=dict(shape=list(mat.shape), data=enc(mat, RAT)), out_shape=list(res.shape), out=enc(res, RAT)))
+        sysm, vc = gen.random_feas(rng, int(rng.integers(1, 7)), int(rng.integers(1, 5)))
+        for ii in (True, False):
+            for uu in (True, False):
+                if port.has_solution(sysm, None, vc, sysm.shape[1] - 1, ii, uu) == -7:
+                    continue
+                r = ref.has_solution(sysm, None, vc, sysm.shape[1] - 1, ii, uu)
+                g5["has_solution"].append(dict(leq=dict(shape=list(sysm.shape), data=enc(sysm, RAT)),
+                                               is_int=ii, is_unique=uu, result=r))
+        sq = gen.random_square(rng, int(rng.integers(1, 7)))
+        okinv, inv = ref.rat_inv(sq)
+        rk = gen.random_system(rng, int(rng.integers(1, 7)), int(rng.integers(1, 7)))
+        g5["gauss"].append(dict(sq=dict(shape=list(sq.shape), data=enc(sq, RAT)), rank=ref.rat_rank(sq),
+                                det=list(ref.rat_det(sq)), inv_ok=okinv, inv=enc(inv, RAT) if okinv else None,
+                                rect=dict(shape=list(rk.shape), data=enc(rk, RAT)), rect_rank=ref.rat_rank(rk)))
+    json.dump(g5, open(os.path.join(OUT, "g5_lineq.json"), "w"))
     print("golden vectors written to", OUT)
 
 
