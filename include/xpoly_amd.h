@@ -158,6 +158,31 @@ int xpg_six_batch_rat32_dev(xpg_ctx * ctx, int is_max, int nb, const xpg_rat32 *
                             int32_t * out_status, xpg_rat32 * out_v, xpg_rat32 * out_sol,
                             uint32_t * out_pivots);
 
+/* ---- rational row elimination, batches of small systems (one wavefront each) -------------
+ * mats is [nb][rows][cols] of xpg_rat32 on the host; rhs_idx is the constant column,
+ * columns after it are constant symbols (src/com/linsys.h:64-70).
+ *   reduce      : Lineq::reduce(m, rhs_idx, is_intersect), src/com/linsys.cpp:359-626, in
+ *                 place; out_rows[b] = surviving rows (packed at the front of system b),
+ *                 out_ok[b] = its bool (consistent).
+ *   remove_iden : Lineq::removeIdenRow, src/com/linsys.cpp:1209-1268, in place.
+ *   fme         : Lineq::fme(u, res, darkshadow), src/com/linsys.cpp:656-774; outs is
+ *                 [nb][cap_rows][cols]; out_rows[b] < 0 means the result needs -out_rows[b]
+ *                 rows (> cap_rows) and was not written.
+ *   rank/det/inv: Matrix<Rational>::rank / det / inv, src/com/matt.h:2614-2726, :1621-1736,
+ *                 :1743-1845 (Gauss-Jordan with the reference's pivot preference). */
+int xpg_lineq_reduce_batch_rat32(xpg_ctx * ctx, int nb, xpg_rat32 * mats, int rows, int cols,
+                                 int rhs_idx, int is_intersect, int32_t * out_rows, int32_t * out_ok);
+int xpg_lineq_remove_iden_batch_rat32(xpg_ctx * ctx, int nb, xpg_rat32 * mats, int rows, int cols,
+                                      int32_t * out_rows);
+int xpg_lineq_fme_batch_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols,
+                              int rhs_idx, int u, int darkshadow, xpg_rat32 * outs, int cap_rows,
+                              int32_t * out_rows, int32_t * out_ok);
+int xpg_rat_rank_batch(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols,
+                       int32_t * out_rank);
+int xpg_rat_det_batch(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int n, xpg_rat32 * out_det);
+int xpg_rat_inv_batch(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int n, xpg_rat32 * out_inv,
+                      int32_t * out_ok);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,110 @@
+"""GPU parity of the rational row-elimination kernels (one wavefront per system)
+against the CPU oracle and the golden vectors of the real reference: bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tools import gen
+
+pytestmark = pytest.mark.gpu
+RAT = 1
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rows_equal(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    if a.shape[0] == 0 and b.shape[0] == 0:
+        return True
+    return a.shape == b.shape and np.array_equal(a, b)
+
+
+@pytest.fixture(scope="module")
+def lq(ctx):
+    from xpoly_amd.lineq import Lineq
+    return Lineq(ctx)
+
+
+def dec(lst, shape):
+    return np.array(lst, dtype=np.int32).reshape(tuple(shape))
+
+
+def test_golden_fme_reduce_iden(lq):
+    g = json.load(open(os.path.join(GOLD, "g5_lineq.json")))
+    for c in g["fme"]:
+        mat = dec(c["mat"]["data"], c["mat"]["shape"])
+        ok, res = lq.fme(mat, c["rhs"], c["u"], c.get("dark", False))
+        assert ok[0] == c["ok"], c.get("tag")
+        assert rows_equal(res[0], dec(c["out"], c["out_shape"])), c.get("tag")
+    for c in g["reduce"]:
+        mat = dec(c["mat"]["data"], c["mat"]["shape"])
+        ok, res = lq.reduce(mat, c["rhs"], c["inter"])
+        assert ok[0] == c["ok"]
+        if c["ok"]:
+            assert rows_equal(res[0], dec(c["out"], c["out_shape"]))
+    for c in g["iden"]:
+        mat = dec(c["mat"]["data"], c["mat"]["shape"])
+        assert rows_equal(lq.removeIdenRow(mat)[0], dec(c["out"], c["out_shape"]))
+
+
+def test_golden_gauss(lq):
+    g = json.load(open(os.path.join(GOLD, "g5_lineq.json")))
+    for c in g["gauss"]:
+        sq = dec(c["sq"]["data"], c["sq"]["shape"])
+        assert lq.rank(sq)[0] == c["rank"]
+        assert lq.det(sq)[0].tolist() == c["det"]
+        ok, inv = lq.inv(sq)
+        assert ok[0] == c["inv_ok"]
+        if c["inv_ok"]:
+            assert np.array_equal(inv[0], dec(c["inv"], sq.shape))
+        rect = dec(c["rect"]["data"], c["rect"]["shape"])
+        assert lq.rank(rect)[0] == c["rect_rank"]
+
+
+@pytest.mark.parametrize("rows,nv", [(1, 1), (4, 2), (9, 4), (16, 6), (30, 9), (60, 19)])
+def test_batched_systems_match_oracle(lq, port, rows, nv):
+    """Whole batches (one launch) at dependence-test sizes up to R=60, W=20."""
+    rng = np.random.default_rng(rows * 100 + nv)
+    nb = 48
+    mats = np.stack([gen.random_system(rng, rows, nv) for _ in range(nb)])
+    for inter in (True, False):
+        ok, res = lq.reduce(mats, nv, inter)
+        for b in range(nb):
+            wok, wres = port.reduce(mats[b], nv, inter)
+            assert ok[b] == wok, (b, inter)
+            if wok:
+                assert rows_equal(res[b], wres), (b, inter)
+    res = lq.removeIdenRow(mats)
+    for b in range(nb):
+        assert rows_equal(res[b], port.remove_iden_row(mats[b]))
+    u = int(rng.integers(0, nv))
+    for dark in (False, True):
+        ok, res = lq.fme(mats, nv, u, dark)
+        for b in range(nb):
+            wok, wres = port.fme(mats[b], nv, u, dark)
+            assert ok[b] == wok, (b, dark)
+            assert rows_equal(res[b], wres), (b, dark)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 6, 9])
+def test_batched_gauss_match_oracle(lq, port, n):
+    rng = np.random.default_rng(n)
+    nb = 64
+    sq = np.stack([gen.random_square(rng, n) for _ in range(nb)])
+    if n >= 3:       # some structured ones: triangular, singular, unit pivots
+        sq[0, :, :, 0] = np.triu(sq[0, :, :, 0]); sq[1, :, :, 0] = np.tril(sq[1, :, :, 0])
+        sq[2, 1] = sq[2, 0]; sq[3, :, :, 0] = np.fliplr(np.triu(sq[3, :, :, 0]))
+    rk, dt = lq.rank(sq), lq.det(sq)
+    ok, inv = lq.inv(sq)
+    for b in range(nb):
+        assert rk[b] == port.rat_rank(sq[b]), b
+        assert tuple(dt[b]) == port.rat_det(sq[b]), b
+        wok, winv = port.rat_inv(sq[b])
+        assert ok[b] == wok, b
+        if wok:
+            assert np.array_equal(inv[b], winv), b
+    rect = np.stack([gen.random_system(rng, n + 2, n) for _ in range(nb)])
+    rk = lq.rank(rect)
+    for b in range(nb):
+        assert rk[b] == port.rat_rank(rect[b])

@@ -1,0 +1,100 @@
+// Host launch wrappers of lineq_kernels.hip.h: stage the caller's host arrays
+// through HBM, one wavefront per system, results back. No arithmetic here.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "lp_host.hip.h"
+#include "lineq_kernels.hip.h"
+
+namespace xpg {
+
+struct DevBuf {
+    void * p;
+    DevBuf() : p(0) {}
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+};
+
+inline int lineq_grid(int nb) { return nb < 256 * 16 ? nb : 256 * 16; }
+
+#define XPG_TRY(e_) do { hipError_t err_ = (e_); if (err_ != hipSuccess) { ctx->err = std::string(#e_) + ": " + hipGetErrorString(err_); return XPG_ERR_HIP; } } while (0)
+
+// mode 0: removeIdenRow, 1: reduce -- in place on mats[nb][rows][cols]
+inline int lineq_reduce_batch(xpg_ctx * ctx, int nb, R32 * mats, int rows, int cols, int rhs, int mode,
+                              int is_intersect, int32_t * out_rows, int32_t * out_ok)
+{
+    if (!ctx || nb < 0 || !mats || rows <= 0 || cols <= 0 || !out_rows || (mode == 1 && (rhs < 0 || rhs >= cols)))
+        return XPG_ERR_SHAPE;
+    if (nb == 0) return 0;
+    const size_t lds = lineq_lds_bytes(rows, cols);
+    if (lds > 160 * 1024 || rows > 32767) return XPG_ERR_UNSUPPORTED;
+    const size_t bytes = (size_t)nb * rows * cols * 8;
+    DevBuf dm, dr, dk;
+    XPG_TRY(dm.alloc(bytes)); XPG_TRY(dr.alloc((size_t)nb * 4)); XPG_TRY(dk.alloc((size_t)nb * 4));
+    XPG_TRY(hipMemcpyAsync(dm.p, mats, bytes, hipMemcpyHostToDevice, ctx->stream));
+    XPG_TRY(hipFuncSetAttribute((const void *)k_reduce_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_reduce_batch, dim3(lineq_grid(nb)), dim3(64), lds, ctx->stream, nb, (R32 *)dm.p, rows,
+                       cols, rhs, mode, is_intersect, (int *)dr.p, (int *)dk.p);
+    XPG_TRY(hipGetLastError());
+    XPG_TRY(hipMemcpyAsync(mats, dm.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    XPG_TRY(hipMemcpyAsync(out_rows, dr.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_ok) XPG_TRY(hipMemcpyAsync(out_ok, dk.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+    XPG_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+inline int lineq_fme_batch(xpg_ctx * ctx, int nb, const R32 * mats, int rows, int cols, int rhs, int u,
+                           int darkshadow, R32 * outs, int cap, int32_t * out_rows, int32_t * out_ok)
+{
+    if (!ctx || nb < 0 || !mats || !outs || rows <= 0 || cols <= 1 || rhs < 1 || rhs >= cols || u < 0 || u >= rhs ||
+        cap < rows || !out_rows || !out_ok)
+        return XPG_ERR_SHAPE;
+    if (nb == 0) return 0;
+    size_t lds = lineq_lds_bytes(cap, cols) + (size_t)rows * cols * 8;
+    int res_global = 0;
+    if (lds > 64 * 1024) {                       // keep >= 2 systems per CU; else build the result in HBM
+        res_global = 1;
+        lds = lineq_lds_bytes(cap, cols) - (size_t)cap * cols * 8 + (size_t)rows * cols * 8 + 16;
+    }
+    if (lds > 160 * 1024 || cap > 32767) return XPG_ERR_UNSUPPORTED;
+    const size_t bi = (size_t)nb * rows * cols * 8, bo = (size_t)nb * cap * cols * 8;
+    DevBuf di, dout, dr, dk;
+    XPG_TRY(di.alloc(bi)); XPG_TRY(dout.alloc(bo)); XPG_TRY(dr.alloc((size_t)nb * 4)); XPG_TRY(dk.alloc((size_t)nb * 4));
+    XPG_TRY(hipMemcpyAsync(di.p, mats, bi, hipMemcpyHostToDevice, ctx->stream));
+    XPG_TRY(hipMemsetAsync(dout.p, 0, bo, ctx->stream));
+    XPG_TRY(hipFuncSetAttribute((const void *)k_fme_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_fme_batch, dim3(lineq_grid(nb)), dim3(64), lds, ctx->stream, nb, (const R32 *)di.p, rows,
+                       cols, rhs, u, darkshadow, (R32 *)dout.p, cap, (int *)dr.p, (int *)dk.p, res_global);
+    XPG_TRY(hipGetLastError());
+    XPG_TRY(hipMemcpyAsync(outs, dout.p, bo, hipMemcpyDeviceToHost, ctx->stream));
+    XPG_TRY(hipMemcpyAsync(out_rows, dr.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+    XPG_TRY(hipMemcpyAsync(out_ok, dk.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+    XPG_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// op 0: rank, 1: det, 2: inv
+inline int gauss_batch(xpg_ctx * ctx, int nb, const R32 * mats, int rows, int cols, int op, int32_t * out_int,
+                       R32 * out_val, R32 * out_mat)
+{
+    if (!ctx || nb < 0 || !mats || rows <= 0 || cols <= 0 || (op != 0 && rows != cols)) return XPG_ERR_SHAPE;
+    if (nb == 0) return 0;
+    const size_t lds = ((size_t)rows * cols * 8 * (op == 2 ? 2 : 1) + 15) & ~(size_t)15;
+    if (lds > 160 * 1024) return XPG_ERR_UNSUPPORTED;
+    const size_t bi = (size_t)nb * rows * cols * 8;
+    DevBuf di, dint, dval, dmat;
+    XPG_TRY(di.alloc(bi)); XPG_TRY(dint.alloc((size_t)nb * 4)); XPG_TRY(dval.alloc((size_t)nb * 8));
+    XPG_TRY(dmat.alloc(op == 2 ? bi : 8));
+    XPG_TRY(hipMemcpyAsync(di.p, mats, bi, hipMemcpyHostToDevice, ctx->stream));
+    if (op == 2) XPG_TRY(hipMemsetAsync(dmat.p, 0, bi, ctx->stream));
+    XPG_TRY(hipFuncSetAttribute((const void *)k_gauss_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_gauss_batch, dim3(lineq_grid(nb)), dim3(64), lds, ctx->stream, nb, (const R32 *)di.p, rows,
+                       cols, op, (int *)dint.p, (R32 *)dval.p, (R32 *)dmat.p);
+    XPG_TRY(hipGetLastError());
+    if (out_int) XPG_TRY(hipMemcpyAsync(out_int, dint.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_val) XPG_TRY(hipMemcpyAsync(out_val, dval.p, (size_t)nb * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_mat && op == 2) XPG_TRY(hipMemcpyAsync(out_mat, dmat.p, bi, hipMemcpyDeviceToHost, ctx->stream));
+    XPG_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+} // namespace xpg

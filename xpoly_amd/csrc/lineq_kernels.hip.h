@@ -1,0 +1,548 @@
+// Rational row elimination for batches of small systems -- the work behind the
+// polyhedral dependence tests and loop-bound generation:
+//   Lineq::removeIdenRow / reduce / fme     (src/com/linsys.cpp:1209-1268, :359-626, :656-774)
+//   Matrix<Rational>::rank / det / inv      (src/com/matt.h:2614-2726, :1621-1736, :1743-1845)
+//   row primitives mulOfRow / addRowToRow / mul_and_add_row / interch_row / is_rowequ
+//                                            (src/com/matt.h:1353, :1437-1460, :1493, :1097, :2344)
+// Systems are tiny (W ~ 9-20 columns, R ~ 10-60 rows) and
+// thousands are independent, so ONE WAVEFRONT owns one system: the matrix is
+// staged in LDS, the reference's data-dependent control flow is executed
+// wave-uniformly, and every row operation runs one lane per column. The
+// arithmetic is integer (gcd loops), so the bound is ALU/divergence, not HBM.
+#pragma once
+#include "scalar.hip.h"
+#include <limits.h>
+
+namespace xpg {
+
+enum { CST_UNK = 1, CST_LT = 2, CST_GT = 3, CST_EQ = 4 };       // linsys.h:55-58
+
+// A small row-major rational matrix in LDS (or global scratch), one wave's property.
+struct WMat { R32 * a; int r, c, ld; };
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ void wave_sync() { __syncthreads(); }   // blockDim == 64: one wave
+
+// mulOfRow (matt.h:1353-1368): every lane evaluates the same shortcut tests.
+__device__ inline void w_scale_row(WMat & m, int row, R32 x)
+{
+    const int mode = scale_mode(x);
+    if (mode != SCALE_KEEP)
+        for (int j = lane_id(); j < m.c; j += 64) {
+            R32 * p = m.a + row * m.ld + j;
+            *p = scaled(*p, x, mode);
+        }
+    wave_sync();
+}
+
+// Lineq::compareConstIterm (linsys.cpp:204-231, :235-274); constant symbols are
+// the columns after rhs.
+__device__ inline int w_cmp_value(const WMat & m, int rhs, int row, R32 v)
+{
+    for (int j = rhs + 1; j < m.c; j++) if (ne(m.a[row * m.ld + j], R32(0, 1))) return CST_UNK;
+    const R32 c = m.a[row * m.ld + rhs];
+    if (eq(c, v)) return CST_EQ;
+    return lt(c, v) ? CST_LT : CST_GT;
+}
+__device__ inline int w_cmp_rows(const WMat & m, int rhs, int r1, int r2)
+{
+    bool s1 = false, s2 = false, same = true;
+    for (int j = rhs + 1; j < m.c; j++) {
+        const R32 a = m.a[r1 * m.ld + j], b = m.a[r2 * m.ld + j];
+        if (ne(a, R32(0, 1))) s1 = true;
+        if (ne(b, R32(0, 1))) s2 = true;
+        if (ne(a, b)) { same = false; break; }
+    }
+    if ((!s1 && !s2) || same) {
+        const R32 a = m.a[r1 * m.ld + rhs], b = m.a[r2 * m.ld + rhs];
+        if (eq(a, b)) return CST_EQ;
+        return lt(a, b) ? CST_LT : CST_GT;
+    }
+    return CST_UNK;
+}
+
+// Compacts the rows whose flag is 0, keeping their order. flags/scratch in LDS.
+__device__ inline void w_compact(WMat & m, const unsigned char * drop, int * map)
+{
+    if (lane_id() == 0) {
+        int k = 0;
+        for (int i = 0; i < m.r; i++) map[i] = drop[i] ? -1 : k++;
+        map[m.r] = k;
+    }
+    wave_sync();
+    const int keep = map[m.r];
+    // rows only move up, so ascending order is safe row by row
+    for (int i = 0; i < m.r; i++) {
+        const int to = map[i];
+        if (to >= 0 && to != i)
+            for (int j = lane_id(); j < m.c; j += 64) m.a[to * m.ld + j] = m.a[i * m.ld + j];
+        wave_sync();
+    }
+    m.r = keep;
+}
+
+// Lineq::removeIdenRow (linsys.cpp:1209-1268): a row goes iff an earlier row is
+// field-wise identical (the row-sum test there is only a prefilter).
+__device__ inline void w_remove_iden(WMat & m, unsigned char * drop, int * map)
+{
+    for (int k = lane_id(); k < m.r; k += 64) {
+        unsigned char gone = 0;
+        for (int i = 0; i < k && !gone; i++) {
+            bool same = true;
+            for (int j = 0; j < m.c && same; j++) same = eq(m.a[i * m.ld + j], m.a[k * m.ld + j]);
+            gone = same ? 1 : 0;
+        }
+        drop[k] = gone;
+    }
+    wave_sync();
+    w_compact(m, drop, map);
+}
+
+// One side of Lineq::reduce's pairwise tightening (linsys.cpp:433-497, :505-573).
+// rows[] lists, in row order, the single-variable rows of `var` with the wanted sign.
+__device__ inline void w_tighten(WMat & m, int rhs, int var, const short * rows, int n, bool negative,
+                                 bool is_intersect, unsigned char * removed, int * any_removed)
+{
+    const int last = n - 1;
+    for (int k1 = 0; k1 < last; k1++) {
+        const int r1 = rows[k1];
+        if (removed[r1]) continue;
+        R32 c = m.a[r1 * m.ld + var];
+        if (negative) c = neg(c);
+        if (ne(c, R32(1, 1))) w_scale_row(m, r1, div(R32(1, 1), c));
+        bool r1_gone = false;
+        for (int k2 = k1 + 1; k2 <= last; k2++) {
+            const int r2 = rows[k2];
+            if (removed[r2]) continue;
+            c = m.a[r2 * m.ld + var];
+            if (negative) c = neg(c);
+            if (ne(c, R32(1, 1))) w_scale_row(m, r2, div(R32(1, 1), c));
+            const int cres = w_cmp_rows(m, rhs, r1, r2);
+            wave_sync();
+            if (is_intersect) {
+                if (cres == CST_LT || cres == CST_EQ) { if (lane_id() == 0) { removed[r2] = 1; *any_removed = 1; } }
+                else if (cres == CST_GT) { if (lane_id() == 0) { removed[r1] = 1; *any_removed = 1; } r1_gone = true; }
+            } else {
+                if (cres == CST_LT || cres == CST_EQ) { if (lane_id() == 0) { removed[r1] = 1; *any_removed = 1; } r1_gone = true; }
+                else if (cres == CST_GT) { if (lane_id() == 0) { removed[r2] = 1; *any_removed = 1; } }
+            }
+            wave_sync();
+            if (r1_gone) break;
+        }
+    }
+}
+
+// Per-wave scratch that lives next to the matrix in LDS.
+struct WScratch {
+    unsigned char * drop;     // cap_rows
+    int * map;                // cap_rows + 1
+    short * pos; short * negs;   // cap_rows each: row lists of the current variable
+    int * flags;              // 4 ints
+};
+
+// Lineq::reduce (linsys.cpp:359-626). Returns consistency; m rewritten in place.
+__device__ inline bool w_reduce(WMat & m, int rhs, bool is_intersect, WScratch & s)
+{
+    w_remove_iden(m, s.drop, s.map);
+    unsigned char * removed = s.drop;
+    int * any_removed = &s.flags[0];
+    int * bad = &s.flags[1];
+    // single-variable classification: kind[i] = var (+1) with sign, 0 = other
+    int * kind = s.map;
+    if (lane_id() == 0) { *any_removed = 0; *bad = 0; }
+    for (int i = lane_id(); i < m.r; i += 64) { removed[i] = 0; kind[i] = 0; }
+    wave_sync();
+    for (int i = lane_id(); i < m.r; i += 64) {                       // linsys.cpp:378-421
+        int vars = 0, single = -1;
+        for (int j = 0; j < rhs; j++) if (ne(m.a[i * m.ld + j], R32(0, 1))) { vars++; single = j; }
+        if (vars == 0) {
+            const int c = w_cmp_value(m, rhs, i, R32(0, 1));
+            if (c == CST_LT) *bad = 1;
+            else if (c == CST_EQ || c == CST_GT) { removed[i] = 1; *any_removed = 1; }
+        } else if (vars == 1) {
+            const R32 c = m.a[i * m.ld + single];
+            if (gt(c, R32(0, 1))) kind[i] = single + 1;
+            else if (lt(c, R32(0, 1))) kind[i] = -(single + 1);
+        }
+    }
+    wave_sync();
+    if (*bad) {
+        // The reference stops at the FIRST inconsistent row, having marked the constant-true
+        // rows before it as removed -- but it returns without compacting, so only the flag matters.
+        return false;
+    }
+    for (int var = 0; var < rhs; var++) {
+        if (lane_id() == 0) {
+            int np = 0, nn = 0;
+            for (int i = 0; i < m.r; i++) {
+                if (kind[i] == var + 1) s.pos[np++] = (short)i;
+                else if (kind[i] == -(var + 1)) s.negs[nn++] = (short)i;
+            }
+            s.flags[2] = np; s.flags[3] = nn;
+        }
+        wave_sync();
+        const int np = s.flags[2], nn = s.flags[3];
+        wave_sync();
+        if (np) w_tighten(m, rhs, var, s.pos, np, false, is_intersect, removed, any_removed);
+        if (nn) w_tighten(m, rhs, var, s.negs, nn, true, is_intersect, removed, any_removed);
+        if (is_intersect && np && nn) {                                // linsys.cpp:577-602
+            for (int a = 0; a < np; a++) {
+                const int pi = s.pos[a];
+                R32 c = m.a[pi * m.ld + var];
+                if (ne(c, R32(1, 1))) w_scale_row(m, pi, div(R32(1, 1), c));
+                for (int b = 0; b < nn; b++) {
+                    const int ni = s.negs[b];
+                    c = neg(m.a[ni * m.ld + var]);
+                    wave_sync();
+                    if (ne(c, R32(1, 1))) w_scale_row(m, ni, div(R32(-1, 1), c));
+                    else w_scale_row(m, ni, R32(-1, 1));
+                    const int cres = w_cmp_rows(m, rhs, pi, ni);
+                    wave_sync();
+                    w_scale_row(m, ni, R32(-1, 1));
+                    if (cres == CST_LT) return false;
+                }
+            }
+        }
+    }
+    if (*any_removed) w_compact(m, removed, s.map);
+    return true;
+}
+
+// ---- batched entry kernels --------------------------------------------------------------------
+__device__ inline void w_load(WMat & m, const R32 * src, int rows, int cols)
+{
+    m.r = rows; m.c = cols;
+    for (int t = lane_id(); t < rows * cols; t += 64) m.a[(t / cols) * m.ld + (t % cols)] = src[t];
+    wave_sync();
+}
+__device__ inline void w_store(const WMat & m, R32 * dst)
+{
+    for (int t = lane_id(); t < m.r * m.c; t += 64) dst[t] = m.a[(t / m.c) * m.ld + (t % m.c)];
+}
+
+__device__ inline WScratch carve_scratch(unsigned char * p, int cap)
+{
+    WScratch s;
+    s.map = (int *)p; p += (size_t)(cap + 1) * 4;
+    s.flags = (int *)p; p += 16;
+    s.pos = (short *)p; p += (size_t)((cap + 1) & ~1) * 2;
+    s.negs = (short *)p; p += (size_t)((cap + 1) & ~1) * 2;
+    s.drop = p;
+    return s;
+}
+__host__ __device__ inline size_t lineq_lds_bytes(int cap, int cols)
+{
+    size_t b = (size_t)cap * cols * 8;
+    b += (size_t)(cap + 1) * 4 + 16 + (size_t)((cap + 1) & ~1) * 4 + (size_t)((cap + 3) & ~3);
+    return (b + 15) & ~(size_t)15;
+}
+
+// mode 0: removeIdenRow, 1: reduce. One wave per system; in/out [nb][rows][cols] in place.
+__global__ __launch_bounds__(64) void k_reduce_batch(int nb, R32 * mats, int rows, int cols, int rhs,
+                                                     int mode, int is_intersect, int * out_rows, int * out_ok)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    WMat m; m.a = (R32 *)lds; m.ld = cols;
+    WScratch s = carve_scratch(lds + (size_t)rows * cols * 8, rows);
+    for (int b = blockIdx.x; b < nb; b += gridDim.x) {
+        R32 * g = mats + (size_t)b * rows * cols;
+        w_load(m, g, rows, cols);
+        bool ok = true;
+        if (mode == 0) w_remove_iden(m, s.drop, s.map);
+        else ok = w_reduce(m, rhs, is_intersect != 0, s);
+        wave_sync();
+        w_store(m, g);
+        if (lane_id() == 0) { out_rows[b] = m.r; out_ok[b] = ok ? 1 : 0; }
+        wave_sync();
+    }
+}
+
+// Lineq::fme (linsys.cpp:656-774) for one system per wave. out has cap rows.
+// res_global != 0: the P*N result does not fit LDS next to the input, so it is built and
+// reduced directly in its HBM output slot (flat pointers; L2-resident at these sizes).
+__global__ __launch_bounds__(64) void k_fme_batch(int nb, const R32 * mats, int rows, int cols, int rhs, int u,
+                                                  int darkshadow, R32 * outs, int cap, int * out_rows, int * out_ok,
+                                                  int res_global)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    // LDS layout: [result matrix (cap x cols) unless res_global] [normalised input (rows x cols)] [scratch]
+    WMat res; res.a = (R32 *)lds; res.ld = cols; res.c = cols;
+    WMat tmp; tmp.a = res_global ? (R32 *)lds : res.a + (size_t)cap * cols; tmp.ld = cols;
+    WScratch s = carve_scratch((unsigned char *)(tmp.a + (size_t)rows * cols), cap);
+    for (int b = blockIdx.x; b < nb; b += gridDim.x) {
+        const R32 * g = mats + (size_t)b * rows * cols;
+        if (res_global) res.a = outs + (size_t)b * cap * cols;
+        w_load(tmp, g, rows, cols);
+        res.r = 0;
+        // classify rows: 0 = no u (copy), 1 = positive, 2 = negative; 3 = inconsistent constant row
+        int * kind = s.map;
+        int * bad_at = &s.flags[1];
+        if (lane_id() == 0) *bad_at = INT_MAX;
+        wave_sync();
+        for (int i = lane_id(); i < rows; i += 64) {
+            bool have = false;
+            for (int j = 0; j < rhs && !have; j++) have = ne(tmp.a[i * cols + j], R32(0, 1));
+            if (!have && w_cmp_value(tmp, rhs, i, R32(0, 1)) == CST_LT) atomicMin(bad_at, i);
+            const R32 c = tmp.a[i * cols + u];
+            kind[i] = ne(c, R32(0, 1)) ? (gt(c, R32(0, 1)) ? 1 : 2) : 0;
+        }
+        wave_sync();
+        const int stop = *bad_at == INT_MAX ? rows : *bad_at;      // rows before the first bad one are processed
+        // normalise the rows that contain u (linsys.cpp:711-723); one lane per column
+        for (int i = 0; i < stop; i++) {
+            if (kind[i] == 0) continue;
+            R32 c = tmp.a[i * cols + u];
+            wave_sync();
+            if (kind[i] == 1) { if (ne(c, R32(1, 1))) w_scale_row(tmp, i, div(R32(1, 1), c)); }
+            else {
+                if (ne(c, R32(-1, 1))) w_scale_row(tmp, i, div(R32(1, 1), neg(c)));
+                if (darkshadow && lane_id() == 0) tmp.a[i * cols + rhs] = sub(tmp.a[i * cols + rhs], R32(1, 1));
+                wave_sync();
+            }
+        }
+        // rows without u go first, in order (linsys.cpp:724-730)
+        if (lane_id() == 0) {
+            int k = 0, np = 0, nn = 0;
+            for (int i = 0; i < stop; i++) {
+                if (kind[i] == 0) kind[i] = -(k++) - 1;               // destination row, encoded negative
+                else if (kind[i] == 1) s.pos[np++] = (short)i;
+                else s.negs[nn++] = (short)i;
+            }
+            s.flags[0] = k; s.flags[2] = np; s.flags[3] = nn;
+        }
+        wave_sync();
+        const int nfree = s.flags[0], np = s.flags[2], nn = s.flags[3];
+        for (int i = 0; i < stop; i++) {
+            if (kind[i] >= 0) continue;
+            const int to = -kind[i] - 1;
+            for (int j = lane_id(); j < cols; j += 64) res.a[to * cols + j] = tmp.a[i * cols + j];
+        }
+        res.r = nfree;
+        bool ok = true;
+        int status_rows = -1;
+        if (stop < rows) {                                              // inconsistent constant row
+            ok = false;
+        } else {
+            int extra = 0;
+            if (np + nn == 1) extra = 1;
+            else if (np + nn > 1) extra = np * nn;
+            if (res.r + extra > cap) { status_rows = res.r + extra; ok = false; }
+            else if (np + nn == 1) {
+                const int pi = np == 1 ? s.pos[0] : s.negs[0];
+                for (int j = lane_id(); j < cols; j += 64) res.a[res.r * cols + j] = tmp.a[pi * cols + j];
+                res.r += 1;
+            } else if (np + nn > 1) {                                   // every (pos, neg) pair summed
+                const int base = res.r * cols, total = np * nn * cols;
+                for (int t = lane_id(); t < total; t += 64) {
+                    const int pair = t / cols, j = t % cols;
+                    const int pi = s.pos[pair / nn], ni = s.negs[pair % nn];
+                    res.a[base + t] = add(tmp.a[pi * cols + j], tmp.a[ni * cols + j]);
+                }
+                res.r += np * nn;
+            }
+            wave_sync();
+            if (status_rows < 0 && res.r > 0) ok = w_reduce(res, rhs, true, s);
+        }
+        wave_sync();
+        R32 * go = outs + (size_t)b * cap * cols;
+        if (status_rows < 0 && !res_global) w_store(res, go);
+        (void)go;
+        if (lane_id() == 0) {
+            out_rows[b] = status_rows < 0 ? res.r : -status_rows;       // negative: did not fit, needs that many rows
+            out_ok[b] = ok ? 1 : 0;
+        }
+        wave_sync();
+    }
+}
+
+// ---- Gauss-Jordan family: rank / det / inv, one wave per matrix -----------------------------------
+__device__ inline R32 abs_r(R32 v) { return lt(v, R32(0, 1)) ? neg(v) : v; }          // matt.h:206-212
+
+__device__ inline void w_swap_rows(WMat & m, int a, int b)
+{
+    if (a != b)
+        for (int j = lane_id(); j < m.c; j += 64) {
+            const R32 t = m.a[a * m.ld + j]; m.a[a * m.ld + j] = m.a[b * m.ld + j]; m.a[b * m.ld + j] = t;
+        }
+    wave_sync();
+}
+// mul_and_add_row (matt.h:1493-1501): to += from * v
+__device__ inline void w_axpy_row(WMat & m, int from, R32 v, int to)
+{
+    for (int j = lane_id(); j < m.c; j += 64)
+        m.a[to * m.ld + j] = add(mul(m.a[from * m.ld + j], v), m.a[to * m.ld + j]);
+    wave_sync();
+}
+// pivot choice shared by rank/det/inv: first nonzero, a later exact 1 wins at once,
+// otherwise the largest magnitude (matt.h:2644-2668, :1675-1695, :1796-1813).
+__device__ inline int w_find_pivot(const WMat & m, int col, int from, bool & unit_break)
+{
+    int swap_row = -1;
+    R32 entry(0, 1);
+    unit_break = false;
+    for (int k = from; k < m.r; k++) {
+        const R32 t = m.a[k * m.ld + col];
+        if (eq(t, R32(0, 1))) continue;
+        if (swap_row == -1) { swap_row = k; entry = t; if (eq(entry, R32(1, 1))) break; }
+        else if (eq(t, R32(1, 1))) { swap_row = k; entry = t; break; }
+        else if (lt(abs_r(entry), abs_r(t))) { swap_row = k; entry = t; }
+    }
+    return swap_row;
+}
+
+// Matrix<Rational>::rank with basis == NULL (matt.h:2614-2726).
+__device__ inline int w_rank(WMat & p)
+{
+    int rankv = 0;
+    for (int row = 0, col = 0; row < p.r && col < p.c; row++, col++) {
+        int swap_row = -1; bool ub;
+        for (int w = col; w < p.c; w++) {
+            swap_row = w_find_pivot(p, w, row, ub);
+            if (swap_row == -1) continue;
+            w_swap_rows(p, swap_row, row);
+            col = w;
+            break;
+        }
+        if (swap_row == -1) break;
+        const R32 d = p.a[row * p.ld + col];
+        wave_sync();
+        if (ne(d, R32(1, 1))) w_scale_row(p, row, div(R32(1, 1), d));
+        for (int i = 0; i < p.r; i++) {
+            if (i == row) continue;
+            const R32 e = p.a[i * p.ld + col];
+            if (eq(e, R32(0, 1))) continue;
+            const R32 t = div(neg(e), p.a[row * p.ld + col]);
+            wave_sync();
+            w_axpy_row(p, row, t, i);
+        }
+        rankv++;
+    }
+    return rankv;
+}
+
+__device__ inline bool w_tri(const WMat & m, int which)
+{
+    const int n = m.r;
+    bool ok = true;
+    if (which == 0) { for (int j = 0; j < n && ok; j++) for (int i = j + 1; i < n && ok; i++) ok = eq(m.a[i * m.ld + j], R32(0, 1)); }
+    else if (which == 1) { for (int i = 0; i < n && ok; i++) for (int j = i + 1; j < n && ok; j++) ok = eq(m.a[i * m.ld + j], R32(0, 1)); }
+    else if (which == 2) { for (int i = 0; i < n && ok; i++) for (int j = 0; j < n - 1 - i && ok; j++) ok = eq(m.a[i * m.ld + j], R32(0, 1)); }
+    else { for (int j = 0; j < n && ok; j++) for (int i = n - 1; i > n - 1 - j && ok; i--) ok = eq(m.a[i * m.ld + j], R32(0, 1)); }
+    return ok;
+}
+
+// Matrix<Rational>::det (matt.h:1621-1736).
+__device__ inline R32 w_det(WMat & a)
+{
+    const int n = a.r;
+#define M_(i, j) a.a[(i) * a.ld + (j)]
+    if (n == 1) return M_(0, 0);
+    if (n == 2) return sub(mul(M_(0, 0), M_(1, 1)), mul(M_(0, 1), M_(1, 0)));
+    if (n == 3) {
+        if (w_tri(a, 0) || w_tri(a, 1)) return mul(mul(M_(0, 0), M_(1, 1)), M_(2, 2));
+        if (w_tri(a, 2) || w_tri(a, 3)) return mul(mul(mul(M_(2, 0), M_(1, 1)), M_(0, 2)), R32(-1, 1));
+        R32 d = mul(mul(M_(0, 0), M_(1, 1)), M_(2, 2));
+        d = add(d, mul(mul(M_(1, 0), M_(2, 1)), M_(0, 2)));
+        d = add(d, mul(mul(M_(0, 1), M_(1, 2)), M_(2, 0)));
+        d = sub(d, mul(mul(M_(0, 2), M_(1, 1)), M_(2, 0)));
+        d = sub(d, mul(mul(M_(0, 1), M_(1, 0)), M_(2, 2)));
+        d = sub(d, mul(mul(M_(2, 1), M_(1, 2)), M_(0, 0)));
+        return d;
+    }
+    R32 d(1, 1);
+    if (w_tri(a, 0) || w_tri(a, 1)) { for (int i = 0; i < n; i++) d = mul(d, M_(i, i)); return d; }
+    if (w_tri(a, 2) || w_tri(a, 3)) { for (int i = 0; i < n; i++) d = mul(d, M_(i, n - 1 - i)); return d; }
+    int swaps = 0;
+    for (int j = 0; j < n; j++) {
+        bool ub;
+        const int swap_row = w_find_pivot(a, j, j, ub);
+        if (swap_row == -1) return R32(0, 1);
+        if (swap_row != j) { w_swap_rows(a, swap_row, j); swaps++; }
+        for (int i = j + 1; i < n; i++) {
+            const R32 e = M_(i, j);
+            if (eq(e, R32(0, 1))) continue;
+            const R32 t = neg(div(e, M_(j, j)));
+            wave_sync();
+            w_axpy_row(a, j, t, i);
+        }
+    }
+    for (int j = 0; j < n; j++) d = mul(d, M_(j, j));
+    if (swaps & 1) d = neg(d);
+    return d;
+#undef M_
+}
+
+// Matrix<Rational>::inv (matt.h:1743-1845) on the augmented matrix [p | e] (n x 2n) so
+// that the row operations hit both halves in one lane-parallel pass.
+__device__ inline bool w_inv(WMat & pe, int n)
+{
+#define P_(i, j) pe.a[(i) * pe.ld + (j)]
+#define E_(i, j) pe.a[(i) * pe.ld + n + (j)]
+    if (n == 1) { if (lane_id() == 0) E_(0, 0) = div(R32(1, 1), P_(0, 0)); wave_sync(); return true; }
+    if (n == 2) {
+        R32 k = sub(mul(P_(0, 0), P_(1, 1)), mul(P_(0, 1), P_(1, 0)));
+        if (eq(k, R32(0, 1))) return false;
+        k = div(R32(1, 1), k);
+        wave_sync();
+        if (lane_id() == 0) {
+            R32 v[4] = { P_(1, 1), mul(R32(-1, 1), P_(0, 1)), mul(R32(-1, 1), P_(1, 0)), P_(0, 0) };
+            const int mode = eq(k, R32(0, 1)) ? SCALE_ZERO : (eq(k, R32(1, 1)) ? SCALE_KEEP : SCALE_MUL);
+            for (int t = 0; t < 4; t++) E_(t / 2, t % 2) = scaled(v[t], k, mode);
+        }
+        wave_sync();
+        return true;
+    }
+    for (int j = 0; j < n; j++) {
+        bool ub;
+        WMat pv = pe; pv.c = n;                       // pivot search looks at the left half only
+        const int swap_row = w_find_pivot(pv, j, j, ub);
+        if (swap_row == -1) return false;
+        w_swap_rows(pe, swap_row, j);
+        const R32 d = P_(j, j);
+        wave_sync();
+        if (ne(d, R32(1, 1))) w_scale_row(pe, j, div(R32(1, 1), d));
+        for (int i = 0; i < n; i++) {
+            if (i == j) continue;
+            const R32 e = P_(i, j);
+            if (eq(e, R32(0, 1))) continue;
+            const R32 t = mul(R32(-1, 1), e);
+            wave_sync();
+            w_axpy_row(pe, j, t, i);
+        }
+    }
+    return true;
+#undef P_
+#undef E_
+}
+
+// op 0: rank (rows x cols), 1: det (n x n), 2: inv (n x n -> out n x n). One wave per matrix.
+__global__ __launch_bounds__(64) void k_gauss_batch(int nb, const R32 * mats, int rows, int cols, int op,
+                                                    int * out_int, R32 * out_val, R32 * out_mat)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    WMat m; m.a = (R32 *)lds;
+    for (int b = blockIdx.x; b < nb; b += gridDim.x) {
+        const R32 * g = mats + (size_t)b * rows * cols;
+        if (op == 2) {
+            const int n = rows;
+            m.r = n; m.c = 2 * n; m.ld = 2 * n;
+            for (int t = lane_id(); t < n * n; t += 64) {
+                m.a[(t / n) * m.ld + (t % n)] = g[t];
+                m.a[(t / n) * m.ld + n + (t % n)] = (t / n == t % n && n > 2) ? R32(1, 1) : R32(0, 1);
+            }
+            wave_sync();
+            const bool ok = w_inv(m, n);
+            wave_sync();
+            if (ok) for (int t = lane_id(); t < n * n; t += 64) out_mat[(size_t)b * n * n + t] = m.a[(t / n) * m.ld + n + (t % n)];
+            if (lane_id() == 0) out_int[b] = ok ? 1 : 0;
+        } else {
+            m.ld = cols;
+            w_load(m, g, rows, cols);
+            if (op == 0) { const int r = w_rank(m); if (lane_id() == 0) out_int[b] = r; }
+            else { const R32 d = (rows == cols) ? w_det(m) : R32(0, 1); if (lane_id() == 0) out_val[b] = d; }
+        }
+        wave_sync();
+    }
+}
+
+} // namespace xpg

@@ -12,6 +12,7 @@
 #include "lp_host.hip.h"
 #include "six_host.hip.h"
 #include "batch_kernels.hip.h"
+#include "lineq_host.hip.h"
 
 using namespace xpg;
 
@@ -378,5 +379,26 @@ int xpg_six_batch_rat32(xpg_ctx * ctx, int is_max, int nb, const xpg_rat32 * tgt
     return batch_host<R32>(ctx, is_max, nb, (const R32 *)tgtf, (const R32 *)leq, m, cols, max_iter,
                            out_status, (R32 *)out_v, (R32 *)out_sol);
 }
+
+// ---- rational row elimination ---------------------------------------------------------------
+int xpg_lineq_reduce_batch_rat32(xpg_ctx * ctx, int nb, xpg_rat32 * mats, int rows, int cols, int rhs_idx,
+                                 int is_intersect, int32_t * out_rows, int32_t * out_ok)
+{ return lineq_reduce_batch(ctx, nb, (R32 *)mats, rows, cols, rhs_idx, 1, is_intersect, out_rows, out_ok); }
+int xpg_lineq_remove_iden_batch_rat32(xpg_ctx * ctx, int nb, xpg_rat32 * mats, int rows, int cols,
+                                      int32_t * out_rows)
+{ return lineq_reduce_batch(ctx, nb, (R32 *)mats, rows, cols, 0, 0, 1, out_rows, 0); }
+int xpg_lineq_fme_batch_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols, int rhs_idx,
+                              int u, int darkshadow, xpg_rat32 * outs, int cap_rows, int32_t * out_rows,
+                              int32_t * out_ok)
+{
+    return lineq_fme_batch(ctx, nb, (const R32 *)mats, rows, cols, rhs_idx, u, darkshadow, (R32 *)outs, cap_rows,
+                           out_rows, out_ok);
+}
+int xpg_rat_rank_batch(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols, int32_t * out_rank)
+{ return out_rank ? gauss_batch(ctx, nb, (const R32 *)mats, rows, cols, 0, out_rank, 0, 0) : XPG_ERR_SHAPE; }
+int xpg_rat_det_batch(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int n, xpg_rat32 * out_det)
+{ return out_det ? gauss_batch(ctx, nb, (const R32 *)mats, n, n, 1, 0, (R32 *)out_det, 0) : XPG_ERR_SHAPE; }
+int xpg_rat_inv_batch(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int n, xpg_rat32 * out_inv, int32_t * out_ok)
+{ return (out_inv && out_ok) ? gauss_batch(ctx, nb, (const R32 *)mats, n, n, 2, out_ok, 0, (R32 *)out_inv) : XPG_ERR_SHAPE; }
 
 } // extern "C"

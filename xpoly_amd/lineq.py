@@ -1,0 +1,81 @@
+"""Python face of the row-elimination entry points, shaped after xpoly's Lineq
+(src/com/linsys.h:61-186) and Matrix<Rational> (src/com/matt.h). Batched: every
+call takes a stack of equally shaped systems [nb, rows, cols, 2] (int32 num/den)
+and runs one wavefront per system on the GPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._capi import lib, vp
+from .six import RAT, as_kind
+
+
+def _stack(mats):
+    a = as_kind(mats, RAT)
+    if a.ndim == 3:
+        a = a[None]
+    return np.ascontiguousarray(a)
+
+
+class Lineq:
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def reduce(self, mats, rhs_idx, is_intersect=True):
+        """Lineq::reduce (linsys.cpp:359-626). Returns (ok[nb], [system b's surviving rows])."""
+        a = _stack(mats).copy()
+        nb, rows, cols = a.shape[:3]
+        out_rows = np.zeros(nb, dtype=np.int32); ok = np.zeros(nb, dtype=np.int32)
+        self.ctx.check(lib().xpg_lineq_reduce_batch_rat32(self.ctx._h, C.c_int(nb), vp(a), C.c_int(rows), C.c_int(cols),
+                                                          C.c_int(rhs_idx), C.c_int(int(is_intersect)), vp(out_rows), vp(ok)),
+                       "xpg_lineq_reduce_batch_rat32")
+        return ok, [a[b, : out_rows[b]].copy() for b in range(nb)]
+
+    def removeIdenRow(self, mats):
+        """Lineq::removeIdenRow (linsys.cpp:1209-1268)."""
+        a = _stack(mats).copy()
+        nb, rows, cols = a.shape[:3]
+        out_rows = np.zeros(nb, dtype=np.int32)
+        self.ctx.check(lib().xpg_lineq_remove_iden_batch_rat32(self.ctx._h, C.c_int(nb), vp(a), C.c_int(rows),
+                                                               C.c_int(cols), vp(out_rows)),
+                       "xpg_lineq_remove_iden_batch_rat32")
+        return [a[b, : out_rows[b]].copy() for b in range(nb)]
+
+    def fme(self, mats, rhs_idx, u, darkshadow=False, cap_rows=None):
+        """Lineq::fme (linsys.cpp:656-774). Returns (ok[nb], [result of system b])."""
+        a = _stack(mats)
+        nb, rows, cols = a.shape[:3]
+        cap = cap_rows or max(rows, rows * rows // 4 + rows + 1)
+        outs = np.zeros((nb, cap, cols, 2), dtype=np.int32)
+        out_rows = np.zeros(nb, dtype=np.int32); ok = np.zeros(nb, dtype=np.int32)
+        self.ctx.check(lib().xpg_lineq_fme_batch_rat32(self.ctx._h, C.c_int(nb), vp(a), C.c_int(rows), C.c_int(cols),
+                                                       C.c_int(rhs_idx), C.c_int(u), C.c_int(int(darkshadow)), vp(outs),
+                                                       C.c_int(cap), vp(out_rows), vp(ok)),
+                       "xpg_lineq_fme_batch_rat32")
+        if (out_rows < 0).any():
+            raise ValueError("fme result needs %d rows, cap_rows is %d" % (-out_rows.min(), cap))
+        return ok, [outs[b, : out_rows[b]].copy() for b in range(nb)]
+
+    def rank(self, mats):
+        a = _stack(mats)
+        nb, rows, cols = a.shape[:3]
+        out = np.zeros(nb, dtype=np.int32)
+        self.ctx.check(lib().xpg_rat_rank_batch(self.ctx._h, C.c_int(nb), vp(a), C.c_int(rows), C.c_int(cols), vp(out)),
+                       "xpg_rat_rank_batch")
+        return out
+
+    def det(self, mats):
+        a = _stack(mats)
+        nb, n = a.shape[0], a.shape[1]
+        out = np.zeros((nb, 2), dtype=np.int32)
+        self.ctx.check(lib().xpg_rat_det_batch(self.ctx._h, C.c_int(nb), vp(a), C.c_int(n), vp(out)), "xpg_rat_det_batch")
+        return out
+
+    def inv(self, mats):
+        a = _stack(mats)
+        nb, n = a.shape[0], a.shape[1]
+        out = np.zeros((nb, n, n, 2), dtype=np.int32); ok = np.zeros(nb, dtype=np.int32)
+        self.ctx.check(lib().xpg_rat_inv_batch(self.ctx._h, C.c_int(nb), vp(a), C.c_int(n), vp(out), vp(ok)),
+                       "xpg_rat_inv_batch")
+        return ok, out
