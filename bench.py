@@ -5,16 +5,16 @@ plus batched small-LP throughput, on N MI355X GPUs of one node.
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is ONE simplex pivot of the device-resident loop -- pricing scan, ratio
-test, pivot-pair upkeep, row/column staging and the rank-1 tableau update
+A "step" is ONE simplex pivot of the device-resident loop -- pricing, ratio test,
+pivot-pair upkeep, row/column staging and the rank-1 tableau update
 (src/com/lpsol.h:1039-1188) -- on a dense LP with m = 4096 constraints and
 n = 4095 variables, whose slack tableau is exactly 4096 x 8192 fp64 (268 MB,
 resident in HBM before the timed region). A single tableau does not shard
-("replicas only", DESIGN.md): with N ranks every rank runs its own replica and
-`value` is the sum. The batched leg (config 3: independent 32 x 64 LPs, the
-dependence-test shape) shards its LPs across ranks with no data-path collective
-and one RCCL all_gather of the results at the end; it is reported in the same
-JSON line under "batched".
+("replicas only", DESIGN.md section 6): with N ranks every rank runs its own replica and
+`value` is the sum. The batched leg (BASELINE.json configs[2]: independent 32 x 64
+LPs, the dependence-test shape, 8192 per GPU = 65 536 on 8 GPUs) shards contiguously
+(xpoly_amd/shard.py) with no data-path collective and ONE all_gather of the result
+records at the end, inside its timed region; it is reported under "batched".
 
 One JSON line is printed by rank 0.
 """
@@ -37,10 +37,11 @@ HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 BATCH_PER_GPU = 8192                       # 65 536 LPs over 8 GPUs (BASELINE.json configs[2])
 BATCH_M, BATCH_COLS = 32, 64
 PREWARM = 256                              # untimed set-up iterations before the warmup
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "round1_pmc_hbm_traffic.json")
 
 
 def cpu_baseline_pivots(budget_s=12.0):
-    """The oracle's K1 (oracle/oracle.cpp orc_pivot_f64) on the same 4096 x 8192 tableau, 1 core."""
+    """The oracle's K1 (oracle/oracle.cpp orc_pivot_f64) on a 4096 x 8192 tableau, 1 core."""
     from oracle.checker import Port
     from tools import gen
     port = Port()
@@ -56,8 +57,27 @@ def cpu_baseline_pivots(budget_s=12.0):
         dt = time.perf_counter() - t0
         if dt > budget_s and n >= 3:
             break
-    return dict(value=n / dt, unit="pivots/s", cores=1, kind="port",
-                sample="%d pivots of oracle orc_pivot_f64 on a 4096x8192 fp64 tableau, 1 thread, %.1f s" % (n, dt))
+    return dict(value=round(n / dt, 3), unit="pivots/s", cores=1, kind="port",
+                sample="%d pivots of the oracle's SIX::pivot restatement (orc_pivot_f64) on a 4096x8192 fp64 "
+                       "tableau, 1 thread, %.1f s" % (n, dt))
+
+
+def cpu_reference_pivots(leq, tgtf):
+    """The REAL reference (oracle/_ref/libxpoly_ref.so, if it travelled): SIX::TwoStageMethod with
+    set_param(0, K) for K = 1 and K = 3 on the same LP; per-pivot time by differencing."""
+    from oracle.checker import F64, Ref
+    if not Ref.available():
+        return None
+    ref = Ref()
+    ts = {}
+    for K in (1, 3):
+        t0 = time.perf_counter()
+        ref.two_stage(F64, leq, tgtf, K)
+        ts[K] = time.perf_counter() - t0
+    per = (ts[3] - ts[1]) / 2.0
+    return dict(value=round(1.0 / per, 4) if per > 0 else None, unit="pivots/s", cores=1, kind="reference",
+                sample="xcom::SIX<FloatMat,Float>::TwoStageMethod on the bench LP (m=4096,n=4095), "
+                       "(t[K=3]-t[K=1])/2 = %.3f s/pivot; set-up %.1f s per call" % (per, ts[1] - per))
 
 
 def cpu_baseline_batch(leq, tgtf, budget_s=6.0):
@@ -72,18 +92,19 @@ def cpu_baseline_batch(leq, tgtf, budget_s=6.0):
         if time.perf_counter() - t0 > budget_s and n >= 8:
             break
     dt = time.perf_counter() - t0
-    return dict(value=n / dt, unit="LPs/s", cores=1, kind="port",
+    return dict(value=round(n / dt, 2), unit="LPs/s", cores=1, kind="port",
                 sample="%d LPs (32x64, SIX::maxm) through the oracle, 1 thread, %.1f s" % (n, dt))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ref-baseline", action="store_true", help="also time the real reference build (~35 s)")
     ap.add_argument("--no-batched", action="store_true")
-    ap.add_argument("--no-events", action="store_true", help="do not bracket the sweep launches with HIP events")
+    ap.add_argument("--no-events", action="store_true", help="do not bracket sweep launches with HIP events")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -102,6 +123,8 @@ def main():
 
     import xpoly_amd
     from tools import gen
+    from xpoly_amd.shard import gather_records, pack_records, shard_range
+    RUNNING = xpoly_amd.six.XPG_RUNNING
     ctx = xpoly_amd.Context(dev.index)
 
     def barrier():
@@ -117,19 +140,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    # ---- leg 1: pivots/s on the 4096 x 8192 tableau (replica per rank) -------------------
+    # ---- leg 1: pivots/s on the 4096 x 8192 tableau (one replica per rank) -------------------
     leq, tgtf = gen.hard_lp_f64(M, NVARS, seed=gen.XS_SEED + rank)
     lp = xpoly_amd.DeviceLP(ctx, xpoly_amd.F64, leq, tgtf)
-    del leq
     lp.begin()
     # set-up, not measured: one pass through every code path of the timed region (launch
     # throttling, event pairs) so lazy runtime initialisation does not land inside it
     ctx.profile_begin(8, 32)
     st = lp.iterate(PREWARM)
     ctx.profile_end()
-    assert st == xpoly_amd.six.XPG_RUNNING, "LP finished during set-up (status %d)" % st
-    st = lp.iterate(a.warmup) if a.warmup > 0 else xpoly_amd.six.XPG_RUNNING
-    assert st == xpoly_amd.six.XPG_RUNNING, "LP finished during warmup (status %d)" % st
+    assert st == RUNNING, "LP finished during set-up (status %d)" % st
+    st = lp.iterate(a.warmup) if a.warmup > 0 else RUNNING
+    assert st == RUNNING, "LP finished during warmup (status %d)" % st
     barrier()
     stride = max(1, a.steps // 128)           # ~128 sampled sweep launches spread over the region
     ctx.profile_begin(0 if a.no_events else a.steps, stride)
@@ -140,72 +162,91 @@ def main():
     dt = time.perf_counter() - t0
     launches, sweep_ms = ctx.profile_end()
     done = lp.pivots_done()
-    assert st == xpoly_amd.six.XPG_RUNNING, "LP finished inside the timed region (status %d)" % st
+    assert st == RUNNING, "LP finished inside the timed region (status %d)" % st
     assert done == PREWARM + a.warmup + a.steps, "expected %d pivots, device did %d" % (PREWARM + a.warmup + a.steps, done)
     rows, W, rhs = lp.shape()
     assert (rows, W) == (M, TAB_W)
     dt = max_over_ranks(dt)
     value = world * a.steps / dt
-    sweep_avg_s = sweep_ms / 1e3 / max(launches, 1)
-    achieved = ALG_BYTES_PER_PIVOT / sweep_avg_s / 1e9
-    roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
-                    kernel="k_update_f64", launches=launches,
-                    avg_launch_us=round(sweep_avg_s * 1e6, 2),
-                    algorithmic_bytes_per_launch=ALG_BYTES_PER_PIVOT)
+    roofline = None
+    if launches:
+        sweep_avg_s = sweep_ms / 1e3 / launches
+        achieved = ALG_BYTES_PER_PIVOT / sweep_avg_s / 1e9
+        traffic, traffic_src = None, None
+        if os.path.exists(PMC_SUMMARY):      # measured with rocprofv3 --pmc (separate passes), not live
+            pm = json.load(open(PMC_SUMMARY))
+            traffic = round(pm["traffic_bytes_per_launch"])
+            traffic_src = "profiles/round1_pmc_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, KiB->B)"
+        roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src,
+                        kernel="k_update_f64<32,8>", launches_sampled=launches,
+                        avg_launch_us=round(sweep_avg_s * 1e6, 2),
+                        algorithmic_bytes_per_launch=ALG_BYTES_PER_PIVOT)
     lp.close()
 
     # ---- leg 2: batched 32 x 64 LPs, sharded across ranks, one all_gather at the end ----------
     batched = None
     b_leq = b_tg = None
     if not a.no_batched:
+        total = BATCH_PER_GPU * world
+        lo, hi = shard_range(total, rank, world)
+        nloc = hi - lo
         fams = {}
         for fam, name in ((0, "dense_positive"), (1, "dep_test_like")):
-            b_leq, b_tg = gen.small_lp_batch_f64(BATCH_PER_GPU, BATCH_M, BATCH_COLS, fam,
+            b_leq, b_tg = gen.small_lp_batch_f64(nloc, BATCH_M, BATCH_COLS, fam,
                                                  seed=gen.XS_SEED + 1000 * (rank + 1) + fam)
             d_leq = torch.from_numpy(b_leq).to(dev)
             d_tg = torch.from_numpy(b_tg).to(dev)
-            d_st = torch.empty(BATCH_PER_GPU, dtype=torch.int32, device=dev)
-            d_v = torch.empty(BATCH_PER_GPU, dtype=torch.float64, device=dev)
-            d_sol = torch.zeros(BATCH_PER_GPU, BATCH_COLS, dtype=torch.float64, device=dev)
-            d_piv = torch.empty(BATCH_PER_GPU, dtype=torch.int32, device=dev)
-            rec = torch.empty(BATCH_PER_GPU, 2 + BATCH_COLS, dtype=torch.float64, device=dev)
-            gathered = torch.empty(world * BATCH_PER_GPU, 2 + BATCH_COLS, dtype=torch.float64, device=dev) \
-                if dist is not None else None
+            d_st = torch.empty(nloc, dtype=torch.int32, device=dev)
+            d_v = torch.empty(nloc, dtype=torch.float64, device=dev)
+            d_sol = torch.zeros(nloc, BATCH_COLS, dtype=torch.float64, device=dev)
+            d_piv = torch.empty(nloc, dtype=torch.int32, device=dev)
+            full = None
 
             def one_pass():
-                ctx.six_batch_dev(xpoly_amd.F64, True, BATCH_PER_GPU, d_tg.data_ptr(), d_leq.data_ptr(),
+                ctx.six_batch_dev(xpoly_amd.F64, True, nloc, d_tg.data_ptr(), d_leq.data_ptr(),
                                   BATCH_M, BATCH_COLS, d_st.data_ptr(), d_v.data_ptr(), d_sol.data_ptr(),
                                   d_piv.data_ptr())
                 ctx.sync()
-                if dist is not None:      # the only collective of the path: fixed-size result records
-                    rec[:, 0] = d_st.to(torch.float64); rec[:, 1] = d_v; rec[:, 2:] = d_sol
-                    dist.all_gather_into_tensor(gathered, rec)
-                    torch.cuda.synchronize()
+                if dist is None:
+                    return None
+                # the only collective of the path: fixed-size (status, v, sol) records
+                out = gather_records(pack_records(d_st, d_v, d_sol), total, rank, world, dist)
+                torch.cuda.synchronize()
+                return out
 
-            one_pass()
+            full = one_pass()
             barrier()
             reps = 5
             t0 = time.perf_counter()
             for _ in range(reps):
-                one_pass()
+                full = one_pass()
             barrier()
             bdt = max_over_ranks(time.perf_counter() - t0)
-            piv = int(d_piv.sum().item())
+            if full is not None:
+                assert full.shape[0] == total
+            piv = float(d_piv.sum().item())
+            if dist is not None:
+                pt = torch.tensor([piv], dtype=torch.float64, device=dev)
+                dist.all_reduce(pt)
+                piv = float(pt.item())
             hist = torch.bincount(d_st.clamp(min=0), minlength=5).tolist()
-            fams[name] = dict(lps_per_s=round(world * BATCH_PER_GPU * reps / bdt, 1),
-                              pivots_per_s=round(world * piv * reps / bdt, 1),
+            fams[name] = dict(lps_per_s=round(total * reps / bdt, 1), pivots_per_s=round(piv * reps / bdt, 1),
                               status_hist_rank0=hist, ms_per_pass=round(bdt / reps * 1e3, 3))
         tot = sum(f["lps_per_s"] for f in fams.values()) / len(fams)
-        batched = dict(metric="batched LPs/sec", value=round(tot, 1), unit="LPs/s",
-                       lps_per_gpu=BATCH_PER_GPU, shape="leq 32x64 (63 vars + rhs), SIX::maxm, x>=0",
-                       scaling="weak", collective="one all_gather of (status,v,sol) records" if dist else "none (1 GPU)",
+        batched = dict(metric="batched LPs/sec", value=round(tot, 1), unit="LPs/s", n_gpus=world,
+                       total_lps=total, lps_per_gpu=BATCH_PER_GPU,
+                       shape="leq 32x64 (63 vars + rhs), SIX::maxm, x>=0, whole solve per LP in LDS",
+                       scaling="weak",
+                       collective="one all_gather_into_tensor of (status,v,sol) records" if dist else "none (1 GPU)",
                        families=fams)
 
     # ---- CPU baseline (rank 0, N = 1 only) -----------------------------------------------------------
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline_pivots()
+        if a.ref_baseline:
+            cpu["reference"] = cpu_reference_pivots(leq, tgtf)
         if b_leq is not None:
             cpu["batched"] = cpu_baseline_batch(b_leq, b_tg)
 
@@ -217,8 +258,9 @@ def main():
             "ms_per_step": round(dt / a.steps * 1e3, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "dense LP m=4096 n=4095 (gen.hard_lp_f64: A~U(0.1,1), b=A x*, c=A^T y*), slack tableau 4096x8192 fp64, "
-                                   "device-resident SIX::solveSlackForm loop, one pivot per step",
+            "config": {"workload": "dense LP m=4096 n=4095 (gen.hard_lp_f64: A~U(0.1,1), b=A x*, c=A^T y*), "
+                                   "slack tableau 4096x8192 fp64 resident in HBM, device-resident "
+                                   "SIX::solveSlackForm loop, one pivot per step",
                        "tableau": [M, TAB_W], "parallelism": "replicas only (1 tableau per GPU)"},
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -158,6 +158,33 @@ int xpg_six_batch_rat32_dev(xpg_ctx * ctx, int is_max, int nb, const xpg_rat32 *
                             int32_t * out_status, xpg_rat32 * out_v, xpg_rat32 * out_sol,
                             uint32_t * out_pivots);
 
+/* ---- MIP<Mat,T>::maxm / minm, src/com/lpsol.h:2636-2657 / :2681-2702 ---------------------
+ * Depth-first branch and bound exactly as MIP::RecusivePart (lpsol.h:2427-2612): every
+ * node is a from-scratch SIX solve (max_iter 10000, lpsol.h:2441) on the GPU; is_bin
+ * selects 0-1 programming; rational_indicator (cols bytes, may be NULL) marks entries
+ * allowed to stay fractional (lpsol.h:2369-2393).  Returns XPG_IP_* or XPG_ERR_*.
+ * (The reference cannot instantiate MIP<FloatMat,Float>, lpsol.h:2242-2254; the f64
+ * flavour follows the same template text.) */
+int xpg_mip_maxm_rat32(xpg_ctx * ctx, const xpg_rat32 * tgtf, const xpg_rat32 * vc, int vc_rows,
+                       const xpg_rat32 * eq, int eq_rows, const xpg_rat32 * leq, int leq_rows,
+                       int cols, int is_bin, const uint8_t * rational_indicator,
+                       xpg_rat32 * out_v, xpg_rat32 * out_sol);
+int xpg_mip_minm_rat32(xpg_ctx * ctx, const xpg_rat32 * tgtf, const xpg_rat32 * vc, int vc_rows,
+                       const xpg_rat32 * eq, int eq_rows, const xpg_rat32 * leq, int leq_rows,
+                       int cols, int is_bin, const uint8_t * rational_indicator,
+                       xpg_rat32 * out_v, xpg_rat32 * out_sol);
+int xpg_mip_maxm_f64(xpg_ctx * ctx, const double * tgtf, const double * vc, int vc_rows,
+                     const double * eq, int eq_rows, const double * leq, int leq_rows, int cols,
+                     int is_bin, const uint8_t * rational_indicator, double * out_v, double * out_sol);
+int xpg_mip_minm_f64(xpg_ctx * ctx, const double * tgtf, const double * vc, int vc_rows,
+                     const double * eq, int eq_rows, const double * leq, int leq_rows, int cols,
+                     int is_bin, const uint8_t * rational_indicator, double * out_v, double * out_sol);
+/* Lineq::has_solution(leq, eq, vc, rhs_idx, is_int_sol, is_unique_sol),
+ * src/com/linsys.cpp:830-906.  Returns 1 / 0, or XPG_ERR_*. */
+int xpg_has_solution_rat32(xpg_ctx * ctx, const xpg_rat32 * leq, int leq_rows, const xpg_rat32 * eq,
+                           int eq_rows, const xpg_rat32 * vc, int vc_rows, int cols, int rhs_idx,
+                           int is_int_sol, int is_unique_sol);
+
 /* ---- rational row elimination, batches of small systems (one wavefront each) -------------
  * mats is [nb][rows][cols] of xpg_rat32 on the host; rhs_idx is the constant column,
  * columns after it are constant symbols (src/com/linsys.h:64-70).

@@ -1,0 +1,110 @@
+"""GPU parity of the branch-and-bound controller (MIP<Mat,T>) and of
+Lineq::has_solution: host DFS in the library, every node LP on the GPU; compared
+with the golden vectors of the real reference and with the CPU oracle, bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tools import gen
+
+pytestmark = pytest.mark.gpu
+F64, RAT = 0, 1
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def dec(d):
+    return np.array(d["data"], dtype=np.int32).reshape(tuple(d["shape"]))
+
+
+def test_mip_golden(ctx):
+    import xpoly_amd
+    from xpoly_amd.six import MIP
+    g = json.load(open(os.path.join(GOLD, "g6_mip.json")))
+    mip = MIP(ctx, RAT)
+    n = 0
+    for case in g:
+        p = {k: dec(v) for k, v in case["problem"].items()}
+        ind = np.array(case["ind"], dtype=np.uint8) if "ind" in case else None
+        for key, is_max in (("max", True), ("min", False)):
+            if key not in case:
+                continue
+            st, v, sol = (mip.maxm if is_max else mip.minm)(p["tgtf"], p["vc"], None, p["leq"], case["is_bin"], ind)
+            w = case[key]
+            assert st == w["status"], (n, key)
+            assert v.tolist() == w["v"], (n, key)
+            if st == 0:
+                assert sol.reshape(-1).tolist() == w["sol"], (n, key)
+            n += 1
+    assert n > 40
+
+
+@pytest.mark.parametrize("kind", [RAT, F64])
+def test_mip_matches_oracle(ctx, port, kind):
+    from xpoly_amd.six import MIP
+    rng = np.random.default_rng(17 + kind)
+    mip = MIP(ctx, kind)
+    seen = set()
+    for it in range(30):
+        m, nv = int(rng.integers(1, 6)), int(rng.integers(1, 7))
+        is_bin = bool(rng.integers(0, 2))
+        p = gen.random_mip(rng, m, nv, is_bin)
+        if kind == F64:
+            p = {k: (v[..., 0].astype(np.float64) if k != "ind" else v) for k, v in p.items()}
+        for is_max in (True, False):
+            want = port.mip_solve(kind, is_max, is_bin, p["tgtf"], p["vc"], None, p["leq"], p.get("ind"))
+            if want[0] == -7:
+                continue
+            got = (mip.maxm if is_max else mip.minm)(p["tgtf"], p["vc"], None, p["leq"], is_bin, p.get("ind"))
+            assert got[0] == want[0], (it, is_max)
+            assert np.array_equal(np.asarray(got[1]), np.asarray(want[1])), (it, is_max)
+            if want[0] == 0:
+                assert np.array_equal(got[2], want[2]), (it, is_max)
+            seen.add(want[0])
+    assert 0 in seen
+
+
+def test_has_solution_golden_and_oracle(ctx, port):
+    from xpoly_amd.six import has_solution
+    g = json.load(open(os.path.join(GOLD, "g5_lineq.json")))
+    seen = set()
+    for c in g["has_solution"]:
+        leq = dec(c["leq"])
+        nv = leq.shape[1] - 1
+        vc = gen.to_rat(gen.vc_nonneg(nv, False))
+        r = has_solution(ctx, leq, None, vc, nv, c["is_int"], c["is_unique"])
+        assert r == c["result"]
+        seen.add(r)
+    assert seen == {0, 1}
+    rng = np.random.default_rng(3)
+    for it in range(25):
+        sysm, vc = gen.random_feas(rng, int(rng.integers(1, 9)), int(rng.integers(1, 6)))
+        for ii in (True, False):
+            for uu in (True, False):
+                want = port.has_solution(sysm, None, vc, sysm.shape[1] - 1, ii, uu)
+                if want == -7:
+                    continue
+                assert has_solution(ctx, sysm, None, vc, sysm.shape[1] - 1, ii, uu) == want, (it, ii, uu)
+
+
+@pytest.mark.parametrize("kind", [F64, RAT])
+def test_six_through_the_hbm_resident_path(ctx, port, kind, monkeypatch):
+    """six.maxm/minm normally use the LDS kernel for small problems; force the HBM-resident
+    loop (device LP + host dual construction) and check it against the oracle as well."""
+    import xpoly_amd
+    monkeypatch.setenv("XPG_FORCE_DEVICE_LP", "1")
+    rng = np.random.default_rng(70 + kind)
+    six = xpoly_amd.SIX(ctx, kind)
+    for it in range(25):
+        fam = int(rng.integers(0, 4))
+        prob = gen.random_problem(rng, kind, fam, int(rng.integers(1, 8)), int(rng.integers(1, 8)))
+        for is_max in (True, False):
+            want = port.six_solve(kind, is_max, prob["tgtf"], prob["vc"], prob.get("eq"), prob.get("leq"))
+            if want[0] == -7:
+                continue
+            got = (six.maxm if is_max else six.minm)(prob["tgtf"], prob["vc"], prob.get("eq"), prob.get("leq"))
+            assert got[0] == want[0], (it, is_max)
+            assert np.array_equal(np.asarray(got[1]), np.asarray(want[1]))
+            if want[0] == 0:
+                assert np.array_equal(got[2], want[2])

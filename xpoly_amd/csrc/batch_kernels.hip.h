@@ -334,7 +334,7 @@ template <class S> __host__ __device__ inline size_t small_lds_bytes(int R, int 
 
 template <class S> __global__ void k_batch(int nb, const S * tgtf, const S * leq, int m, int cols,
                                            int is_max, unsigned max_iter, int32_t * out_status,
-                                           S * out_v, S * out_sol, uint32_t * out_pivots)
+                                           S * out_v, S * out_sol, uint32_t * out_pivots, int raw_sol)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int n = cols - 1;
@@ -389,7 +389,7 @@ template <class S> __global__ void k_batch(int nb, const S * tgtf, const S * leq
             for (int j = threadIdx.x; j < n; j += blockDim.x) {
                 S val = is_max ? P.x[j] : neg(P.obj[m + j]);
                 P.e[j] = val;
-                reduce(val);
+                if (!raw_sol) reduce(val);          // raw_sol: the host finishes calcFinalSolution itself
                 sol[j] = val;
             }
             __syncthreads();
@@ -414,7 +414,8 @@ template <class S> __global__ void k_batch(int nb, const S * tgtf, const S * leq
 
 template <class S>
 int batch_dev(xpg_ctx * ctx, int is_max, int nb, const S * tgtf, const S * leq, int m, int cols,
-              unsigned max_iter, int32_t * out_status, S * out_v, S * out_sol, uint32_t * out_pivots)
+              unsigned max_iter, int32_t * out_status, S * out_v, S * out_sol, uint32_t * out_pivots,
+              int raw_sol = 0)
 {
     if (!ctx || nb < 0 || !tgtf || !leq || m <= 0 || cols < 2 || !out_status || !out_v || !out_sol)
         return XPG_ERR_SHAPE;
@@ -429,14 +430,14 @@ int batch_dev(xpg_ctx * ctx, int is_max, int nb, const S * tgtf, const S * leq, 
     int grid = 256 * (per_cu > 16 ? 16 : per_cu) * 4;
     if (grid > nb) grid = nb;
     hipLaunchKernelGGL((k_batch<S>), dim3(grid), dim3(threads), lds, ctx->stream, nb, tgtf, leq, m,
-                       cols, is_max ? 1 : 0, max_iter, out_status, out_v, out_sol, out_pivots);
+                       cols, is_max ? 1 : 0, max_iter, out_status, out_v, out_sol, out_pivots, raw_sol);
     XPG_HIP(ctx, hipGetLastError());
     return 0;
 }
 
 template <class S>
 int batch_host(xpg_ctx * ctx, int is_max, int nb, const S * tgtf, const S * leq, int m, int cols,
-               unsigned max_iter, int32_t * out_status, S * out_v, S * out_sol)
+               unsigned max_iter, int32_t * out_status, S * out_v, S * out_sol, int raw_sol = 0)
 {
     if (!ctx || nb < 0 || m <= 0 || cols < 2) return XPG_ERR_SHAPE;
     if (nb == 0) return 0;
@@ -451,7 +452,7 @@ int batch_host(xpg_ctx * ctx, int is_max, int nb, const S * tgtf, const S * leq,
     if (e == hipSuccess) e = hipMemcpyAsync(d_leq, leq, bl, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_tgtf, tgtf, bt, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_sol, out_sol, bt, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) rc = batch_dev<S>(ctx, is_max, nb, d_tgtf, d_leq, m, cols, max_iter, d_st, d_v, d_sol, 0);
+    if (e == hipSuccess) rc = batch_dev<S>(ctx, is_max, nb, d_tgtf, d_leq, m, cols, max_iter, d_st, d_v, d_sol, 0, raw_sol);
     if (e == hipSuccess && rc == 0) e = hipMemcpyAsync(out_status, d_st, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && rc == 0) e = hipMemcpyAsync(out_v, d_v, (size_t)nb * 8, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && rc == 0) e = hipMemcpyAsync(out_sol, d_sol, bt, hipMemcpyDeviceToHost, ctx->stream);

@@ -5,7 +5,9 @@
 // ratio test and pricing scan of the solve itself runs on the GPU through Lp<S>.
 #pragma once
 #include <vector>
+#include <stdlib.h>
 #include "lp_host.hip.h"
+#include "batch_kernels.hip.h"
 
 namespace xpg {
 
@@ -114,6 +116,35 @@ int six_solve(xpg_ctx * ctx, int kind, bool is_max, const S * tgtf, const S * vc
         scale_run(&N(0, twin), L.r, N.c, minus_one<S>());
         obj[twin] = tgtf[j];
         scale_run(&obj[twin], 1, 1, minus_one<S>());
+    }
+
+    // ---- small problems (the dependence-test and branch-and-bound node sizes): one launch of
+    // the LDS-resident batch kernel with nb = 1, which builds the dual itself for minm
+    bool plain_vc = true;
+    for (int j = 0; j < n && plain_vc; j++) plain_vc = eq(vcd[j], minus_one<S>()) && eq(vcr[j], zero<S>());
+    {
+        const int R = is_max ? N.r : n, V = is_max ? n : N.r;
+        const char * force = getenv("XPG_FORCE_DEVICE_LP");     // test hook: always take the HBM-resident path
+        if (plain_vc && !(force && force[0] == '1') && small_lds_bytes<S>(R, V) <= 64 * 1024) {
+            int32_t st1 = 0; S v1 = zero<S>();
+            std::vector<S> raw(n + 1, zero<S>());
+            rc = batch_host<S>(ctx, is_max ? 1 : 0, 1, obj.data(), N.a.data(), N.r, n + 1, max_iter, &st1, &v1,
+                               raw.data(), /*raw_sol=*/1);
+            if (rc) return rc;
+            if (st1 != XPG_SIX_SUCC) return st1;
+            std::vector<S> y(raw.begin(), raw.begin() + n);
+            y.push_back(zero<S>());
+            for (int k = 0; k < extra; k++) y[free_var[k]] = sub(y[free_var[k]], y[n0 + k]);
+            S v = zero<S>();
+            std::vector<S> sol(cols);
+            for (int j = 0; j < n0; j++) sol[j] = y[j];
+            sol[n0] = one<S>();
+            for (int j = 0; j < cols; j++) v = add(v, mul(sol[j], tgtf[j]));
+            reduce(v);
+            *out_v = v;
+            if (out_sol) for (int j = 0; j < cols; j++) { reduce(sol[j]); out_sol[j] = sol[j]; }
+            return XPG_SIX_SUCC;
+        }
     }
 
     // ---- the slack form handed to the GPU: primal for maxm, dual for minm

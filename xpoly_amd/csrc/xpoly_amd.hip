@@ -13,6 +13,7 @@
 #include "six_host.hip.h"
 #include "batch_kernels.hip.h"
 #include "lineq_host.hip.h"
+#include "mip_host.hip.h"
 
 using namespace xpg;
 
@@ -378,6 +379,43 @@ int xpg_six_batch_rat32(xpg_ctx * ctx, int is_max, int nb, const xpg_rat32 * tgt
 {
     return batch_host<R32>(ctx, is_max, nb, (const R32 *)tgtf, (const R32 *)leq, m, cols, max_iter,
                            out_status, (R32 *)out_v, (R32 *)out_sol);
+}
+
+// ---- MIP / has_solution -------------------------------------------------------------------------
+int xpg_mip_maxm_rat32(xpg_ctx * ctx, const xpg_rat32 * tgtf, const xpg_rat32 * vc, int vc_rows,
+                       const xpg_rat32 * eq, int eq_rows, const xpg_rat32 * leq, int leq_rows, int cols,
+                       int is_bin, const uint8_t * ind, xpg_rat32 * out_v, xpg_rat32 * out_sol)
+{
+    return mip_solve<R32>(ctx, 1, true, is_bin != 0, (const R32 *)tgtf, (const R32 *)vc, vc_rows, (const R32 *)eq,
+                          eq_rows, (const R32 *)leq, leq_rows, cols, ind, (R32 *)out_v, (R32 *)out_sol, 0);
+}
+int xpg_mip_minm_rat32(xpg_ctx * ctx, const xpg_rat32 * tgtf, const xpg_rat32 * vc, int vc_rows,
+                       const xpg_rat32 * eq, int eq_rows, const xpg_rat32 * leq, int leq_rows, int cols,
+                       int is_bin, const uint8_t * ind, xpg_rat32 * out_v, xpg_rat32 * out_sol)
+{
+    return mip_solve<R32>(ctx, 1, false, is_bin != 0, (const R32 *)tgtf, (const R32 *)vc, vc_rows, (const R32 *)eq,
+                          eq_rows, (const R32 *)leq, leq_rows, cols, ind, (R32 *)out_v, (R32 *)out_sol, 0);
+}
+int xpg_mip_maxm_f64(xpg_ctx * ctx, const double * tgtf, const double * vc, int vc_rows, const double * eq,
+                     int eq_rows, const double * leq, int leq_rows, int cols, int is_bin, const uint8_t * ind,
+                     double * out_v, double * out_sol)
+{
+    return mip_solve<F64>(ctx, 0, true, is_bin != 0, (const F64 *)tgtf, (const F64 *)vc, vc_rows, (const F64 *)eq,
+                          eq_rows, (const F64 *)leq, leq_rows, cols, ind, (F64 *)out_v, (F64 *)out_sol, 0);
+}
+int xpg_mip_minm_f64(xpg_ctx * ctx, const double * tgtf, const double * vc, int vc_rows, const double * eq,
+                     int eq_rows, const double * leq, int leq_rows, int cols, int is_bin, const uint8_t * ind,
+                     double * out_v, double * out_sol)
+{
+    return mip_solve<F64>(ctx, 0, false, is_bin != 0, (const F64 *)tgtf, (const F64 *)vc, vc_rows, (const F64 *)eq,
+                          eq_rows, (const F64 *)leq, leq_rows, cols, ind, (F64 *)out_v, (F64 *)out_sol, 0);
+}
+int xpg_has_solution_rat32(xpg_ctx * ctx, const xpg_rat32 * leq, int leq_rows, const xpg_rat32 * eq, int eq_rows,
+                           const xpg_rat32 * vc, int vc_rows, int cols, int rhs_idx, int is_int_sol,
+                           int is_unique_sol)
+{
+    return has_solution(ctx, (const R32 *)leq, leq_rows, (const R32 *)eq, eq_rows, (const R32 *)vc, vc_rows, cols,
+                        rhs_idx, is_int_sol != 0, is_unique_sol != 0);
 }
 
 // ---- rational row elimination ---------------------------------------------------------------

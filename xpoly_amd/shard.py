@@ -1,0 +1,51 @@
+"""Sharding of independent LPs / systems across the GPUs of one node.
+
+The polyhedral workload is thousands of independent feasibility problems per SCoP
+(src/eng/poly.cpp:530-573 -> src/com/linsys.cpp:830-906); nothing is shared between
+them, so each rank takes a contiguous slice, solves it with no data-path
+communication, and the fixed-size result records are gathered ONCE at the end
+(torch.distributed all_gather: RCCL over xGMI on GPUs, gloo in the CPU tests).
+"""
+import numpy as np
+
+
+def shard_range(total, rank, world):
+    """Contiguous slice [lo, hi) of `total` items owned by `rank`; sizes differ by at most one."""
+    base, extra = divmod(total, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def pack_records(status, v, sol):
+    """(status, v, sol[cols]) -> one float64 record per LP: [status, v, sol...]. Works for torch
+    tensors and numpy arrays; rational results are packed by the caller as two float64 columns."""
+    import torch
+    status = torch.as_tensor(status)
+    v = torch.as_tensor(v)
+    sol = torch.as_tensor(sol)
+    rec = torch.empty(status.shape[0], 2 + sol.shape[1], dtype=torch.float64, device=sol.device)
+    rec[:, 0] = status.to(torch.float64)
+    rec[:, 1] = v
+    rec[:, 2:] = sol
+    return rec
+
+
+def gather_records(rec, total, rank, world, dist=None):
+    """All-gathers per-rank record blocks (ragged by at most one row) into the global order.
+
+    rec: [n_local, width] float64 tensor of this rank (n_local = shard size). Returns a
+    [total, width] tensor on every rank. With world == 1 (or dist None) it is a no-op."""
+    import torch
+    if world == 1 or dist is None:
+        return rec
+    base, extra = divmod(total, world)
+    cap = base + (1 if extra else 0)
+    pad = torch.zeros(cap, rec.shape[1], dtype=rec.dtype, device=rec.device)
+    pad[: rec.shape[0]] = rec
+    out = torch.empty(world * cap, rec.shape[1], dtype=rec.dtype, device=rec.device)
+    dist.all_gather_into_tensor(out, pad)
+    parts = []
+    for r in range(world):
+        lo, hi = shard_range(total, r, world)
+        parts.append(out[r * cap: r * cap + (hi - lo)])
+    return torch.cat(parts, dim=0)

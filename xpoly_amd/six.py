@@ -201,6 +201,54 @@ class DeviceLP:
             pass
 
 
+class MIP:
+    """Mirror of MIP<Mat,T> (src/com/lpsol.h:2087-2157): maxm / minm with is_bin and
+    rational_indicator; IP_* status codes."""
+
+    def __init__(self, ctx, kind):
+        self.ctx, self.kind = ctx, kind
+
+    def _solve(self, is_max, tgtf, vc, eq, leq, is_bin, rational_indicator):
+        k = self.kind
+        tgtf = as_kind(tgtf, k); vc = as_kind(vc, k)
+        cols = tgtf.shape[0]
+        eq_rows = 0 if eq is None else len(eq)
+        leq_rows = 0 if leq is None else len(leq)
+        eq_a = as_kind(eq, k) if eq_rows else None
+        leq_a = as_kind(leq, k) if leq_rows else None
+        ind = None if rational_indicator is None else np.ascontiguousarray(rational_indicator, dtype=np.uint8)
+        v = empty_kind((1,), k); sol = empty_kind((cols,), k)
+        name = "xpg_mip_%s_%s" % ("maxm" if is_max else "minm", "f64" if k == F64 else "rat32")
+        st = getattr(lib(), name)(self.ctx._h, vp(tgtf), vp(vc), C.c_int(vc.shape[0]), vp(eq_a), C.c_int(eq_rows),
+                                  vp(leq_a), C.c_int(leq_rows), C.c_int(cols), C.c_int(int(is_bin)), vp(ind),
+                                  vp(v), vp(sol))
+        if st < 0 and st != -7:
+            self.ctx.check(st, name)
+        return st, v[0], sol
+
+    def maxm(self, tgtf, vc, eq, leq, is_bin=False, rational_indicator=None):     # lpsol.h:2636-2657
+        return self._solve(True, tgtf, vc, eq, leq, is_bin, rational_indicator)
+
+    def minm(self, tgtf, vc, eq, leq, is_bin=False, rational_indicator=None):     # lpsol.h:2681-2702
+        return self._solve(False, tgtf, vc, eq, leq, is_bin, rational_indicator)
+
+
+def has_solution(ctx, leq, eq, vc, rhs_idx, is_int_sol, is_unique_sol):
+    """Lineq::has_solution (src/com/linsys.cpp:830-906) on rational systems."""
+    vc = as_kind(vc, RAT)
+    cols = vc.shape[1]
+    leq_rows = 0 if leq is None else len(leq)
+    eq_rows = 0 if eq is None else len(eq)
+    leq_a = as_kind(leq, RAT) if leq_rows else None
+    eq_a = as_kind(eq, RAT) if eq_rows else None
+    r = lib().xpg_has_solution_rat32(ctx._h, vp(leq_a), C.c_int(leq_rows), vp(eq_a), C.c_int(eq_rows), vp(vc),
+                                     C.c_int(vc.shape[0]), C.c_int(cols), C.c_int(rhs_idx),
+                                     C.c_int(int(is_int_sol)), C.c_int(int(is_unique_sol)))
+    if r < 0 and r != -7:
+        ctx.check(r, "xpg_has_solution_rat32")
+    return r
+
+
 class SIX:
     """Mirror of SIX<Mat,T> (src/com/lpsol.h:204-338): same method names,
     argument order and status codes; `kind` picks the FloatMat or RMat flavour."""
