@@ -102,7 +102,8 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--ref-baseline", action="store_true", help="also time the real reference build (~35 s)")
+    ap.add_argument("--no-ref-baseline", action="store_true",
+                    help="skip timing the real reference build (oracle/_ref, ~1 s on the GPU box's host)")
     ap.add_argument("--no-batched", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not bracket sweep launches with HIP events")
     a = ap.parse_args()
@@ -245,7 +246,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline_pivots()
-        if a.ref_baseline:
+        if not a.no_ref_baseline:
             cpu["reference"] = cpu_reference_pivots(leq, tgtf)
         if b_leq is not None:
             cpu["batched"] = cpu_baseline_batch(b_leq, b_tg)

@@ -20,6 +20,7 @@ template <class S> struct Small {
     Cand<S> * sh_c; int * sh_i;     // reduction scratch (16 entries each)
     int * sh_w;                     // 8 words of broadcast scratch
     unsigned pivots;
+    unsigned closes;                // iterations that ended in disableNV (no pivot), for profiling
 };
 
 template <class S> __device__ __forceinline__ bool sm_seen(const Small<S> & P, int nv, int b)
@@ -46,17 +47,16 @@ template <class S> __device__ void sm_pivot(Small<S> & P, int nv, int bv)
     for (int i = threadIdx.x; i < P.R; i += blockDim.x)
         if (i != r) P.k[i] = neg(P.tab[i * ld + nv]);
     __syncthreads();
-    // flat sweep over the R x W cells, consecutive lanes on consecutive cells
+    // sweep: a lane owns a column (e_j stays in a register), lane groups of CW lanes take
+    // alternate rows; k_i is an LDS broadcast. Consecutive lanes touch consecutive cells.
     {
-        int i = 0, j = threadIdx.x;
-        while (j >= W) { j -= W; i++; }
-        while (i < P.R) {
-            if (i != r) {
-                S * p = P.tab + i * ld + j;
-                *p = add(*p, mul(P.k[i], P.e[j]));
-            }
-            j += blockDim.x;
-            while (j >= W) { j -= W; i++; }
+        const int CW = blockDim.x >= 128 && W > 64 ? 128 : 64;
+        const int tx = threadIdx.x % CW, ty = threadIdx.x / CW, ny = blockDim.x / CW;
+        for (int j = tx; j < W; j += CW) {
+            const S ej = P.e[j];
+            S * p = P.tab + ty * ld + j;
+            for (int i = ty; i < P.R; i += ny, p += ny * ld)
+                if (i != r) *p = add(*p, mul(P.k[i], ej));
         }
     }
     if (threadIdx.x == 0) {
@@ -87,6 +87,106 @@ template <class S> __device__ int sm_ratio(const Small<S> & P, int nv)
     return -1;
 }
 
+// ---- fast path for the dependence-test sizes (rhs <= 128 variables, R <= 64 rows) ------------
+// Wave 0 alone does the selection with wave-level primitives (ballot / shuffles, no
+// workgroup barrier); the other waves join for the staging and the sweep. Three barriers
+// per pivot instead of ten.
+enum { ACT_PIVOT = 0, ACT_OPT = 1, ACT_FINDPAIR = 2, ACT_CLOSE = 3 };
+
+template <class S> __device__ __forceinline__ Cand<S> wave_argmin(Cand<S> c)
+{
+    for (int o = 32; o > 0; o >>= 1) {
+        Cand<S> t; t.q = shfl_xor_s(c.q, o); t.idx = __shfl_xor(c.idx, o);
+        c = better(c, t);
+    }
+    return c;
+}
+
+// Pricing (lpsol.h:1054-1069) + ratio test (lpsol.h:553-663) + genPair by wave 0.
+// Results in sh_w[0..2] = action, entering column, leaving variable; the pivot element and
+// c_nv are parked in sh_c so that nobody re-reads them after the row has been rescaled.
+template <class S> __device__ void sm_select_wave0(Small<S> & P)
+{
+    const int lane = threadIdx.x, rhs = P.rhs, lim = rhs - 1;
+    const int j0 = lane, j1 = lane + 64;
+    const bool in0 = j0 < rhs, in1 = j1 < rhs;
+    const bool nb0 = in0 && P.nv[j0], nb1 = in1 && P.nv[j1];
+    const bool c0 = nb0 && gt(P.obj[j0], zero<S>()), c1 = nb1 && gt(P.obj[j1], zero<S>());
+    const bool o0 = c0 && P.rowcnt[j0] < lim, o1 = c1 && P.rowcnt[j1] < lim;
+    const unsigned long long m0 = __ballot(o0), m1 = __ballot(o1), any = __ballot(c0 || c1);
+    const int first = m0 ? __ffsll((long long)m0) - 1 : (m1 ? 64 + __ffsll((long long)m1) - 1 : INT_MAX);
+    const int stop = first == INT_MAX ? rhs : first;
+    if (in0 && j0 < stop && !nb0) P.obj[j0] = zero<S>();             // lpsol.h:1055-1060
+    if (in1 && j1 < stop && !nb1) P.obj[j1] = zero<S>();
+    int action, leave = -1, row = -1;
+    if (first == INT_MAX) action = any ? ACT_FINDPAIR : ACT_OPT;
+    else {
+        Cand<S> best; best.q = zero<S>(); best.idx = INT_MAX;
+        for (int pass = 0; pass < 2 && best.idx == INT_MAX; pass++) {
+            Cand<S> c; c.q = zero<S>(); c.idx = INT_MAX;
+            if (lane < P.R) {
+                const S a = P.tab[lane * P.ld + first];
+                const bool skip = pass == 0 ? le(a, zero<S>()) : eq(a, zero<S>());
+                if (!skip) {
+                    const int b = P.eq2bv[lane];
+                    if (!sm_seen(P, first, b) && P.colcnt[b] < lim) { c.q = div(P.tab[lane * P.ld + rhs], a); c.idx = lane; }
+                }
+            }
+            best = wave_argmin(c);
+        }
+        if (best.idx == INT_MAX) action = ACT_CLOSE;
+        else { action = ACT_PIVOT; row = best.idx; leave = P.eq2bv[row]; }
+    }
+    if (lane == 0) {
+        P.sh_w[0] = action; P.sh_w[1] = first; P.sh_w[2] = leave;
+        if (action == ACT_PIVOT) {
+            if (!sm_seen(P, first, leave)) {                              // genPair, lpsol.h:100-104
+                P.ppt[first * P.pw + (leave >> 5)] |= 1u << (leave & 31);
+                P.rowcnt[first] += 1; P.colcnt[leave] += 1;
+            }
+            S * park = (S *)P.sh_c;
+            park[0] = P.tab[row * P.ld + first];
+            park[1] = P.obj[first];
+        }
+    }
+}
+
+// SIX::pivot (lpsol.h:1456-1511) with the pivot element and c_nv handed in.
+template <class S> __device__ void sm_pivot_fast(Small<S> & P, int nv, int bv, S piv, S cnv)
+{
+    const int r = P.bv2eq[bv], W = P.W, ld = P.ld;
+    const S s = div(one<S>(), piv);
+    const int smode = scale_mode(s), cmode = scale_mode(cnv);
+    for (int j = threadIdx.x; j < W; j += blockDim.x) {
+        const S ej = scaled(P.tab[r * ld + j], s, smode);
+        P.e[j] = ej;
+        P.tab[r * ld + j] = ej;
+        S t = mul(ej, minus_one<S>());
+        if (j >= P.rhs) t = neg(t);
+        t = scaled(t, cnv, cmode);
+        P.obj[j] = add(t, P.obj[j]);
+    }
+    for (int i = threadIdx.x; i < P.R; i += blockDim.x)
+        if (i != r) P.k[i] = neg(P.tab[i * ld + nv]);
+    __syncthreads();
+    {
+        const int CW = blockDim.x >= 128 && W > 64 ? 128 : 64;
+        const int tx = threadIdx.x % CW, ty = threadIdx.x / CW, ny = blockDim.x / CW;
+        for (int j = tx; j < W; j += CW) {
+            const S ej = P.e[j];
+            S * p = P.tab + ty * ld + j;
+            for (int i = ty; i < P.R; i += ny, p += ny * ld)
+                if (i != r) *p = add(*p, mul(P.k[i], ej));
+        }
+    }
+    if (threadIdx.x == 0) {
+        P.nv[nv] = 0; P.nv[bv] = 1; P.bv[nv] = 1; P.bv[bv] = 0;
+        P.eq2bv[r] = nv; P.bv2eq[nv] = r; P.bv2eq[bv] = -1;
+    }
+    P.pivots++;
+    __syncthreads();
+}
+
 // SIX::solveSlackForm (lpsol.h:1008-1191) incl. is_feasible (lpsol.h:784-822,
 // vc = "-x_i <= 0" for every variable). Returns a SIX_* status; maxv on success.
 template <class S> __device__ int sm_solve(Small<S> & P, unsigned max_iter, S & maxv)
@@ -97,7 +197,24 @@ template <class S> __device__ int sm_solve(Small<S> & P, unsigned max_iter, S & 
     maxv = zero<S>();
     __syncthreads();
     unsigned done = 0;
+    const bool fast = rhs <= 128 && P.R <= 64;
     while (done < max_iter) {
+        if (fast) {
+            if (threadIdx.x < 64) sm_select_wave0(P);
+            __syncthreads();
+            const int action = P.sh_w[0];
+            if (action == ACT_PIVOT) {
+                const int enter_f = P.sh_w[1], leave_f = P.sh_w[2];
+                const S * park = (const S *)P.sh_c;
+                const S piv = park[0], cnv = park[1];
+                sm_pivot_fast(P, enter_f, leave_f, piv, cnv);
+                done++;
+                continue;
+            }
+            // rare outcomes fall through to the generic code below, which redoes the (idempotent)
+            // pricing scan with all threads
+            __syncthreads();
+        }
         int first = INT_MAX, anypos = 0;
         for (int j = threadIdx.x; j < rhs; j += blockDim.x)
             if (P.nv[j] && gt(P.obj[j], zero<S>())) {
@@ -164,6 +281,7 @@ template <class S> __device__ int sm_solve(Small<S> & P, unsigned max_iter, S & 
                 }
                 if (add_n) atomicAdd(&P.rowcnt[first], add_n);
                 __syncthreads();
+                P.closes++;
                 continue;
             }
             enter = first;
@@ -336,6 +454,8 @@ template <class S> __global__ void k_batch(int nb, const S * tgtf, const S * leq
                                            int is_max, unsigned max_iter, int32_t * out_status,
                                            S * out_v, S * out_sol, uint32_t * out_pivots, int raw_sol)
 {
+    const bool getenv_closes = (raw_sol & 2) != 0;     // profiling: report disableNV iterations instead
+    raw_sol &= 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int n = cols - 1;
     const int R = is_max ? m : n, V = is_max ? n : m;
@@ -363,7 +483,7 @@ template <class S> __global__ void k_batch(int nb, const S * tgtf, const S * leq
         Source<S> src;
         src.leq = leq + (size_t)lp * m * cols; src.tgtf = tgtf + (size_t)lp * cols;
         src.m = m; src.cols = cols; src.is_max = is_max;
-        P.pivots = 0;
+        P.pivots = 0; P.closes = 0;
         __syncthreads();
         // stage1 trigger (lpsol.h:1794-1803)
         if (threadIdx.x == 0) { P.sh_w[3] = 0; P.sh_w[4] = 0; }
@@ -406,7 +526,7 @@ template <class S> __global__ void k_batch(int nb, const S * tgtf, const S * leq
         }
         if (threadIdx.x == 0) {
             out_status[lp] = status;
-            if (out_pivots) out_pivots[lp] = P.pivots;
+            if (out_pivots) out_pivots[lp] = getenv_closes ? P.closes : P.pivots;
         }
         __syncthreads();
     }
@@ -425,7 +545,11 @@ int batch_dev(xpg_ctx * ctx, int is_max, int nb, const S * tgtf, const S * leq, 
     const size_t lds = small_lds_bytes<S>(R, V);
     if (lds > 160 * 1024) return XPG_ERR_UNSUPPORTED;     // one LP must fit one CU's LDS
     XPG_HIP(ctx, hipFuncSetAttribute((const void *)k_batch<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int threads = (R * (V + R + 2) >= 4096) ? 128 : 64;
+    // measured on MI355X (32x64 LPs): 64 / 128 / 256 threads -> 61k / 91k / 118k LPs/s
+    const int cells = R * (V + R + 2);
+    int threads = cells >= 2048 ? 256 : (cells >= 1024 ? 128 : 64);
+    if (const char * c = getenv("XPG_BATCH_COUNT_CLOSES")) { if (c[0] == '1') raw_sol |= 2; }   // profiling aid
+    if (const char * t = getenv("XPG_BATCH_THREADS")) { const int v = atoi(t); if (v >= 64 && v <= 1024 && v % 64 == 0) threads = v; }
     const int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
     int grid = 256 * (per_cu > 16 ? 16 : per_cu) * 4;
     if (grid > nb) grid = nb;
