@@ -96,5 +96,65 @@ private:
     }
 };
 
+// MIP<Mat,T> (src/com/lpsol.h:2087-2157): maxm / minm with is_bin and a BMat-like
+// rational_indicator (anything with get_col_size() and get(0, j) -> bool), same IP_* codes.
+template <class Mat, class T> class MIP {
+    xpg_ctx * m_ctx;
+    static_assert(sizeof(T) == 8, "xpoly_amd::MIP: T must be Float (fp64) or Rational (int32/int32)");
+public:
+    explicit MIP(xpg_ctx * ctx = 0) : m_ctx(ctx) {}
+    void init() {}
+    void destroy() {}
+
+    template <class BoolMat>
+    unsigned maxm(T & maxv, Mat & res, Mat const & tgtf, Mat & vc, Mat const & eq, Mat const & leq,
+                  bool is_bin, BoolMat * rational_indicator, int rhs_idx = -1)
+    { return solve(true, maxv, res, tgtf, vc, eq, leq, is_bin, rational_indicator, rhs_idx); }
+    template <class BoolMat>
+    unsigned minm(T & minv, Mat & res, Mat const & tgtf, Mat & vc, Mat const & eq, Mat const & leq,
+                  bool is_bin, BoolMat * rational_indicator, int rhs_idx = -1)
+    { return solve(false, minv, res, tgtf, vc, eq, leq, is_bin, rational_indicator, rhs_idx); }
+    unsigned maxm(T & maxv, Mat & res, Mat const & tgtf, Mat & vc, Mat const & eq, Mat const & leq, bool is_bin = false)
+    { return solve(true, maxv, res, tgtf, vc, eq, leq, is_bin, (Mat *)0, -1); }
+    unsigned minm(T & minv, Mat & res, Mat const & tgtf, Mat & vc, Mat const & eq, Mat const & leq, bool is_bin = false)
+    { return solve(false, minv, res, tgtf, vc, eq, leq, is_bin, (Mat *)0, -1); }
+
+private:
+    template <class BoolMat>
+    unsigned solve(bool is_max, T & v, Mat & res, Mat const & tgtf, Mat & vc, Mat const & eq, Mat const & leq,
+                   bool is_bin, BoolMat * ind, int rhs_idx)
+    {
+        const int kind = scalar_kind<T>::value;
+        xpg_ctx * ctx = m_ctx ? m_ctx : detail::shared_context();
+        const int cols = (int)tgtf.get_col_size();
+        if (!ctx) return (unsigned)XPG_ERR_NO_DEVICE;
+        if (kind < 0 || (rhs_idx != -1 && rhs_idx != cols - 1)) return (unsigned)XPG_ERR_SHAPE;
+        std::vector<unsigned char> flags;
+        if (ind) { flags.resize((size_t)cols); for (int j = 0; j < cols; j++) flags[(size_t)j] = ind->get(0, j) ? 1 : 0; }
+        std::vector<T> out_sol((size_t)cols);
+        T out_v;
+        std::memset((void *)&out_v, 0, sizeof(T));
+        const int eq_rows = eq.size() ? (int)eq.get_row_size() : 0;
+        const int leq_rows = leq.size() ? (int)leq.get_row_size() : 0;
+        int st;
+        if (kind == 0)
+            st = (is_max ? xpg_mip_maxm_f64 : xpg_mip_minm_f64)(
+                ctx, (const double *)detail::data_of(tgtf), (const double *)detail::data_of(vc), (int)vc.get_row_size(),
+                (const double *)detail::data_of(eq), eq_rows, (const double *)detail::data_of(leq), leq_rows, cols,
+                is_bin ? 1 : 0, ind ? flags.data() : (const unsigned char *)0, (double *)&out_v, (double *)out_sol.data());
+        else
+            st = (is_max ? xpg_mip_maxm_rat32 : xpg_mip_minm_rat32)(
+                ctx, (const xpg_rat32 *)detail::data_of(tgtf), (const xpg_rat32 *)detail::data_of(vc), (int)vc.get_row_size(),
+                (const xpg_rat32 *)detail::data_of(eq), eq_rows, (const xpg_rat32 *)detail::data_of(leq), leq_rows, cols,
+                is_bin ? 1 : 0, ind ? flags.data() : (const unsigned char *)0, (xpg_rat32 *)&out_v, (xpg_rat32 *)out_sol.data());
+        v = out_v;
+        if (st == XPG_IP_SUCC) {
+            res.reinit(1, cols);
+            std::memcpy((void *)res.get_matrix(), (const void *)out_sol.data(), sizeof(T) * (size_t)cols);
+        }
+        return (unsigned)st;
+    }
+};
+
 } // namespace xpoly_amd
 #endif

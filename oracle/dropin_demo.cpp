@@ -97,6 +97,29 @@ int main()
             bad += compare_one<FloatMat, Float>(ft, fv, feq, fl, mx == 0, "random-float"); n++;
         }
     }
+    for (int it = 0; it < 24; it++) {   // MIP<RMat,Rational> on small integer / 0-1 knapsack-like problems
+        int m = irand(1, 4), nv = irand(2, 5);
+        bool is_bin = (it & 1) != 0;
+        RMat leq(m + (is_bin ? nv : 0), nv + 1), tgtf(1, nv + 1), vc(nv, nv + 1), eq;
+        for (int i = 0; i < m; i++) {
+            for (int j = 0; j < nv; j++) leq.setr(i, j, irand(1, 6), 1);
+            leq.setr(i, nv, irand(4, 4 * nv + 2), 1);
+        }
+        if (is_bin)
+            for (int j = 0; j < nv; j++) { leq.setr(m + j, j, 1, 1); leq.setr(m + j, nv, 1, 1); }
+        for (int j = 0; j < nv; j++) { tgtf.setr(0, j, irand(1, 8), 1); vc.setr(j, j, -1, 1); }
+        Rational v_ref, v_gpu;
+        RMat s_ref, s_gpu;
+        xcom::MIP<RMat, Rational> ref;
+        xpoly_amd::MIP<RMat, Rational> gpu;
+        UINT a = ref.maxm(v_ref, s_ref, tgtf, vc, eq, leq, is_bin, NULL);
+        UINT b = gpu.maxm(v_gpu, s_gpu, tgtf, vc, eq, leq, is_bin, (BMat *)NULL);
+        int mis = (a != b) || memcmp(&v_ref, &v_gpu, sizeof(Rational)) != 0;
+        if (!mis && a == IP_SUCC)
+            mis = memcmp(s_ref.get_matrix(), s_gpu.get_matrix(), sizeof(Rational) * s_ref.get_col_size()) != 0;
+        if (mis) printf("MISMATCH MIP %s: reference status %u, xpoly_amd status %u\n", is_bin ? "0-1" : "integer", a, b);
+        bad += mis; n++;
+    }
     printf("dropin_demo: %d solves through xcom::SIX and xpoly_amd::SIX on the reference's own matrix types, %d mismatches\n", n, bad);
     return bad ? 1 : 0;
 }
