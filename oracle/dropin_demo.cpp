@@ -60,7 +60,7 @@ template <class Mat, class T> static int compare_one(Mat & tgtf, Mat & vc, Mat &
 
 int main()
 {
-    int bad = 0, n = 0;
+    int bad = 0, n = 0, undefined = 0;
     {   // src/example/example.cpp:54-93
         FloatMat leq(2, 3), tgtf(1, 3), vc(2, 3), eq;
         double l[6] = {2, -1, 2, 1, -5, -4}, t[3] = {2, -1, 0};
@@ -98,8 +98,8 @@ int main()
         }
     }
     for (int it = 0; it < 24; it++) {   // MIP<RMat,Rational> on small integer / 0-1 knapsack-like problems
-        int m = irand(1, 4), nv = irand(2, 5);
         bool is_bin = (it & 1) != 0;
+        int m = is_bin && (it & 2) ? 1 : irand(1, 4), nv = irand(2, 5);
         RMat leq(m + (is_bin ? nv : 0), nv + 1), tgtf(1, nv + 1), vc(nv, nv + 1), eq;
         for (int i = 0; i < m; i++) {
             for (int j = 0; j < nv; j++) leq.setr(i, j, irand(1, 6), 1);
@@ -114,12 +114,20 @@ int main()
         xpoly_amd::MIP<RMat, Rational> gpu;
         UINT a = ref.maxm(v_ref, s_ref, tgtf, vc, eq, leq, is_bin, NULL);
         UINT b = gpu.maxm(v_gpu, s_gpu, tgtf, vc, eq, leq, is_bin, (BMat *)NULL);
+        if (b == (UINT)XPG_ERR_REF_UNDEFINED) {
+            // convertEq2Ineq reads the equality row at the inequality's row index (lpsol.h:1232);
+            // with more inequality rows than columns that is a read past the buffer in the
+            // reference, so there is nothing to compare with -- xpoly_amd refuses the input.
+            undefined++;
+            continue;
+        }
         int mis = (a != b) || memcmp(&v_ref, &v_gpu, sizeof(Rational)) != 0;
         if (!mis && a == IP_SUCC)
             mis = memcmp(s_ref.get_matrix(), s_gpu.get_matrix(), sizeof(Rational) * s_ref.get_col_size()) != 0;
         if (mis) printf("MISMATCH MIP %s: reference status %u, xpoly_amd status %u\n", is_bin ? "0-1" : "integer", a, b);
         bad += mis; n++;
     }
-    printf("dropin_demo: %d solves through xcom::SIX and xpoly_amd::SIX on the reference's own matrix types, %d mismatches\n", n, bad);
+    printf("dropin_demo: %d solves through xcom::SIX / MIP and xpoly_amd::SIX / MIP on the reference's own matrix types, "
+           "%d refused as undefined in the reference, %d mismatches\n", n, undefined, bad);
     return bad ? 1 : 0;
 }

@@ -1,0 +1,136 @@
+"""GPU edge cases: malformed shapes, empty / ragged inputs, size limits, the inputs on which the
+x86-64 reference is undefined, iteration caps (SIX::set_param) and size-independent properties
+at BASELINE.json's full sizes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tools import gen
+
+pytestmark = pytest.mark.gpu
+F64, RAT = 0, 1
+
+
+def test_shape_errors_are_negative_codes_not_crashes(ctx):
+    from xpoly_amd._capi import lib, vp
+    L = lib()
+    t = np.zeros(4); vc = np.zeros((3, 4)); leq = np.zeros((2, 4)); v = np.zeros(1); sol = np.zeros(4)
+    # no constraints at all (reference: ASSERT "no constraints", lpsol.h:1538)
+    assert L.xpg_six_maxm_f64(ctx._h, vp(t), vp(vc), 3, None, 0, None, 0, 4, 10, vp(v), vp(sol)) == -3
+    # vc with the wrong number of rows (lpsol.h:1555-1557)
+    assert L.xpg_six_maxm_f64(ctx._h, vp(t), vp(vc), 2, None, 0, vp(leq), 2, 4, 10, vp(v), vp(sol)) == -3
+    # pivot outside the tableau
+    tab = np.ones((4, 8)); obj = np.ones(8)
+    assert L.xpg_pivot_f64(ctx._h, vp(tab), 4, 8, vp(obj), 7, 9, 0) == -3
+    assert L.xpg_pivot_f64(ctx._h, vp(tab), 4, 8, vp(obj), 7, 0, 8) == -3
+    # null context
+    assert L.xpg_sync(None) == -3
+    # empty batches are fine
+    st = np.zeros(1, dtype=np.int32)
+    assert L.xpg_six_batch_f64(ctx._h, 1, 0, vp(t), vp(leq), 2, 4, 10, vp(st), vp(v), vp(sol)) == 0
+
+
+def test_lds_limit_reports_unsupported(ctx):
+    from xpoly_amd._capi import lib, vp
+    m, cols = 200, 201          # 200 x 402 slack tableau does not fit one CU's LDS
+    leq = np.ones((1, m, cols)); tg = np.ones((1, cols))
+    st = np.zeros(1, dtype=np.int32); v = np.zeros(1); sol = np.zeros((1, cols))
+    rc = lib().xpg_six_batch_f64(ctx._h, 1, 1, vp(tg), vp(leq), m, cols, 10, vp(st), vp(v), vp(sol))
+    assert rc == -4
+    # ... but SIX::maxm on the same problem falls back to the HBM-resident loop and works
+    import xpoly_amd
+    six = xpoly_amd.SIX(ctx, F64)
+    leq2, tg2 = gen.dense_lp_f64(200, 200)
+    six.set_param(0, 5)
+    st, _, _ = six.maxm(tg2, gen.vc_nonneg(200), None, leq2)
+    assert st in (0, 1, 3, 4)
+
+
+def test_reference_undefined_inputs_are_refused_or_defined(ctx, port):
+    import xpoly_amd
+    six = xpoly_amd.SIX(ctx, RAT)
+    # equality substitution whose row index leaves the equality row (lpsol.h:1232): refused
+    nv = 2
+    leq = gen.to_rat(np.array([[1, 1, 4], [1, 0, 3], [0, 1, 3], [1, 2, 9]], dtype=np.int32))
+    eq = gen.to_rat(np.array([[1, -1, 0]], dtype=np.int32))
+    st, _, _ = six.maxm(gen.to_rat(np.array([1, 1, 0], dtype=np.int32)), gen.to_rat(gen.vc_nonneg(nv, False)), eq, leq)
+    want = port.six_solve(RAT, True, gen.to_rat(np.array([1, 1, 0], dtype=np.int32)), gen.to_rat(gen.vc_nonneg(nv, False)), eq, leq)
+    assert st == want[0]
+    # a free variable: the reference's vcmap is garbage (sete), we implement v = v' - v''
+    vc = gen.vc_nonneg(2, True, free=(1,))
+    six = xpoly_amd.SIX(ctx, F64)
+    # max x0 - x1  s.t. x0 <= 3, x1 >= -2 (free), x0 - x1 <= 4  ->  optimum 4
+    leq = np.array([[1, 0, 3], [0, -1, 2], [1, -1, 4]], dtype=np.float64)
+    st, v, sol = six.maxm([1.0, -1.0, 0.0], vc, None, leq)
+    assert st == 0 and v == 4.0
+    assert abs((sol[0] - sol[1]) - 4.0) < 1e-12 and sol[2] == 1.0
+
+
+@pytest.mark.parametrize("kind", [F64, RAT])
+def test_max_iter_gives_time_out_and_exact_pivot_count(ctx, kind):
+    """SIX::set_param(indent, max_iter): K pivots then SIX_TIME_OUT (lpsol.h:1039, :1190)."""
+    import xpoly_amd
+    leq, tg = (gen.hard_lp_f64(24, 23) if kind == F64 else gen.int_lp_rat(24, 23))
+    for K in (0, 1, 7):
+        lp = xpoly_amd.DeviceLP(ctx, kind, leq, tg)
+        assert lp.two_stage(K) == 4
+        assert lp.pivots_done() == K
+        lp.close()
+
+
+def test_iterate_in_chunks_equals_one_shot(ctx):
+    """Idempotence of the device loop: 5+7+11 pivots == 23 pivots, bit for bit."""
+    import xpoly_amd
+    leq, tg = gen.hard_lp_f64(40, 39)
+    a = xpoly_amd.DeviceLP(ctx, F64, leq, tg); a.begin()
+    for k in (5, 7, 11):
+        a.iterate(k)
+    b = xpoly_amd.DeviceLP(ctx, F64, leq, tg); b.begin(); b.iterate(23)
+    ra, rb = a.read(), b.read()
+    assert np.array_equal(ra["tab"].view(np.uint64), rb["tab"].view(np.uint64))
+    assert np.array_equal(a.trace(), b.trace()) and len(a.trace()) == 23
+    a.close(); b.close()
+
+
+def test_full_size_tableau_properties(ctx, port):
+    """4096 x 8192 fp64 (BASELINE.json configs[1]): after K pivots of the device loop
+    (a) every basic column is a unit vector up to the reference's own rounding,
+    (b) the objective constant only grows (maximisation, nonnegative ratios),
+    (c) a 64-row random sample of the tableau equals the oracle's rows bit for bit."""
+    import xpoly_amd
+    m, n = 4096, 4095
+    leq, tg = gen.hard_lp_f64(m, n)
+    lp = xpoly_amd.DeviceLP(ctx, F64, leq, tg)
+    lp.begin()
+    consts = []
+    for _ in range(3):
+        assert lp.iterate(4) == xpoly_amd.six.XPG_RUNNING
+        consts.append(lp.read(want_tab=False)["tgtf"][-1])
+    st = lp.read()
+    lp.close()
+    assert consts[0] <= consts[1] <= consts[2] and consts[2] > 0
+    tab, eq2bv = st["tab"], st["eq2bv"]
+    assert st["bvset"].sum() == m and st["nvset"].sum() == n
+    for r in (0, 17, 4095):
+        col = tab[:, eq2bv[r]]
+        assert abs(col[r] - 1.0) < 1e-9 and np.abs(np.delete(col, r)).max() < 1e-9
+    # oracle replay of the same 12 pivots on the CPU, compared on a row sample
+    want = port.two_stage(F64, leq, tg, 12)
+    rows = np.random.default_rng(0).integers(0, m, 64)
+    assert np.array_equal(tab[rows].view(np.uint64), want["tab"][rows].view(np.uint64))
+    assert np.array_equal(st["tgtf"].view(np.uint64), want["tgtf"].view(np.uint64))
+    assert np.array_equal(eq2bv, want["eq2bv"])
+
+
+def test_batch_sizes_ragged_and_single(ctx, port):
+    """nb = 1, nb not a multiple of anything, 1 x 1 LPs."""
+    rng = np.random.default_rng(4)
+    for nb, m, nv in ((1, 1, 1), (3, 2, 5), (130, 4, 3)):
+        probs = [gen.random_problem(rng, RAT, 1, m, nv, plain=True) for _ in range(nb)]
+        leq = np.stack([p["leq"] for p in probs]); tg = np.stack([p["tgtf"] for p in probs])
+        for is_max in (True, False):
+            status, v, sol = ctx.six_batch(RAT, is_max, tg, leq)
+            for b in range(nb):
+                want = port.six_solve(RAT, is_max, probs[b]["tgtf"], probs[b]["vc"], None, probs[b]["leq"])
+                assert status[b] == want[0] and np.array_equal(v[b], want[1])
