@@ -185,6 +185,20 @@ int xpg_has_solution_rat32(xpg_ctx * ctx, const xpg_rat32 * leq, int leq_rows, c
                            int eq_rows, const xpg_rat32 * vc, int vc_rows, int cols, int rhs_idx,
                            int is_int_sol, int is_unique_sol);
 
+/* Batches: nb independent problems of one shape, x >= 0, inequalities only
+ * (tgtf[nb][cols], leq[nb][leq_rows][cols]).  All trees advance in lock step; in each
+ * round the node LPs of equal shape share one launch of the LDS-resident kernel.
+ * out_nodes (may be NULL) receives the total number of node LPs solved. */
+int xpg_mip_batch_rat32(xpg_ctx * ctx, int nb, int is_max, int is_bin, const xpg_rat32 * tgtf,
+                        const xpg_rat32 * leq, int leq_rows, int cols, int32_t * out_status,
+                        xpg_rat32 * out_v, xpg_rat32 * out_sol, long long * out_nodes);
+/* DepPoly::is_empty(keepit, vc = NULL), src/eng/poly.cpp:530-573, for nb dependence polyhedra
+ * mats[nb][rows][cols] without constant symbols (constant in the last column):
+ * Lineq::reduce pre-filter, then Lineq::has_solution(is_int_sol, is_unique_sol) = MIP::maxm
+ * and, failing that, MIP::minm.  out_empty[b] = 1 / 0, or XPG_ERR_REF_UNDEFINED. */
+int xpg_dep_is_empty_batch_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols,
+                                 int32_t * out_empty, long long * out_nodes);
+
 /* ---- rational row elimination, batches of small systems (one wavefront each) -------------
  * mats is [nb][rows][cols] of xpg_rat32 on the host; rhs_idx is the constant column,
  * columns after it are constant symbols (src/com/linsys.h:64-70).

@@ -88,6 +88,57 @@ def test_has_solution_golden_and_oracle(ctx, port):
                 assert has_solution(ctx, sysm, None, vc, sysm.shape[1] - 1, ii, uu) == want, (it, ii, uu)
 
 
+def test_mip_batch_lockstep_matches_oracle(ctx, port):
+    """Many trees advanced together (node LPs of equal shape share a launch) give, per problem,
+    exactly what the one-at-a-time recursion gives."""
+    from xpoly_amd.six import mip_batch
+    rng = np.random.default_rng(11)
+    for is_bin in (False, True):
+        for (m, nv) in ((3, 4), (2, 6)):
+            nb = 40
+            probs = [gen.random_mip(rng, m, nv, False) for _ in range(nb)]
+            if is_bin:      # x <= 1 rows make it a 0-1 knapsack; keep rows <= cols so the reference is defined
+                probs = [gen.random_mip(rng, 1, nv, False) for _ in range(nb)]
+                for p in probs:
+                    ub = np.zeros((nv, nv + 1), dtype=np.int32); ub[np.arange(nv), np.arange(nv)] = 1; ub[:, nv] = 1
+                    p["leq"] = np.concatenate([p["leq"], gen.to_rat(ub)], axis=0)
+            leq = np.stack([p["leq"] for p in probs]); tg = np.stack([p["tgtf"] for p in probs])
+            for is_max in (True, False):
+                st, v, sol, nodes = mip_batch(ctx, is_max, is_bin, tg, leq)
+                assert nodes >= nb
+                for b in range(nb):
+                    want = port.mip_solve(RAT, is_max, is_bin, probs[b]["tgtf"], probs[b]["vc"], None, probs[b]["leq"])
+                    assert st[b] == want[0], (is_bin, m, nv, is_max, b)
+                    assert np.array_equal(v[b], want[1]), (is_bin, m, nv, is_max, b)
+                    if want[0] == 0:
+                        assert np.array_equal(sol[b], want[2]), (is_bin, m, nv, is_max, b)
+
+
+def test_dep_is_empty_batch_matches_oracle(ctx, port):
+    """DepPoly::is_empty composed from the oracle's reduce + has_solution(int, unique)."""
+    from xpoly_amd.six import dep_is_empty_batch
+    rng = np.random.default_rng(21)
+    seen = set()
+    for (rows, nv) in ((4, 2), (8, 3), (12, 4)):
+        nb = 64
+        mats = np.stack([gen.random_system(rng, rows, nv) for _ in range(nb)])
+        mats[..., 1] = 1                                   # dependence polyhedra are integer systems
+        empty, nodes = dep_is_empty_batch(ctx, mats)
+        vc = gen.to_rat(gen.vc_nonneg(nv, False))
+        for b in range(nb):
+            ok, res = port.reduce(mats[b], nv, True)
+            if not ok:
+                want = 1
+            elif res.shape[0] == 0:
+                want = 0
+            else:
+                h = port.has_solution(res, None, vc, nv, True, True)
+                want = h if h < 0 else int(not h)
+            assert empty[b] == want, (rows, nv, b, empty[b], want)
+            seen.add(want)
+    assert {0, 1} <= seen
+
+
 @pytest.mark.parametrize("kind", [F64, RAT])
 def test_six_through_the_hbm_resident_path(ctx, port, kind, monkeypatch):
     """six.maxm/minm normally use the LDS kernel for small problems; force the HBM-resident

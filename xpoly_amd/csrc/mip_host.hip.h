@@ -1,12 +1,19 @@
-// Host controller of xpoly's branch-and-bound MIP<Mat,T> (src/com/lpsol.h:2087-2702)
-// and of Lineq::has_solution (src/com/linsys.cpp:830-906). The tree walk is the
-// reference's depth-first recursion -- its results depend on DFS order through the
-// shared fork_count row and the incumbent (lpsol.h:2474-2497) -- and every node's
-// LP relaxation is a from-scratch SIX solve with max_iter = 10000 (lpsol.h:2441)
-// executed on the GPU (six_solve: one LDS-resident launch at these sizes).
+// Host controller of xpoly's branch-and-bound MIP<Mat,T> (src/com/lpsol.h:2087-2702),
+// of Lineq::has_solution (src/com/linsys.cpp:830-906) and of the DepPoly::is_empty front
+// end (src/eng/poly.cpp:530-573).
+//
+// The tree walk is the reference's depth-first recursion -- its results depend on DFS order
+// through the shared fork_count row and the incumbent (lpsol.h:2474-2497) -- written as an
+// explicit stack machine per problem so that MANY problems advance in lock step: in every
+// round each unfinished problem contributes the LP relaxation of its current node, nodes of
+// equal shape are solved by ONE launch of the LDS-resident batch kernel, and the host feeds
+// the answers back into the stack machines. A node is a from-scratch SIX solve with
+// max_iter = 10000 (lpsol.h:2441), exactly as in the reference.
 #pragma once
+#include <map>
 #include <vector>
 #include "six_host.hip.h"
+#include "lineq_host.hip.h"
 
 namespace xpg {
 
@@ -14,102 +21,6 @@ template <class S> struct MipProblem {
     int cols;
     std::vector<S> tgtf, vc, eq, leq;      // flat row-major; vc has cols-1 rows
     int eq_rows, leq_rows;
-};
-
-template <class S> struct MipHost {
-    xpg_ctx * ctx;
-    int kind;
-    bool have_best;
-    std::vector<S> best_sol;
-    S best_v;
-    const uint8_t * allow_rational;         // 1 x cols, or null (lpsol.h:2369-2393)
-    int rhs0;
-    long nodes;
-
-    MipHost(xpg_ctx * c, int k, const uint8_t * allow, int rhs)
-        : ctx(c), kind(k), have_best(false), best_v(zero<S>()), allow_rational(allow), rhs0(rhs), nodes(0) {}
-
-    // MIP::is_satisfying (lpsol.h:2364-2408); `col` is the first offending entry.
-    bool satisfied(std::vector<S> & s, bool is_bin, int & col) const
-    {
-        for (size_t j = 0; j < s.size(); j++) {
-            if (allow_rational || is_bin) reduce(s[j]);
-            if (allow_rational) {
-                if (allow_rational[j]) continue;
-                if (!is_int(s[j])) { col = (int)j; return false; }
-                if (is_bin && ne(s[j], zero<S>()) && ne(s[j], one<S>())) { col = (int)j; return false; }
-            } else if (is_bin) {
-                if (ne(s[j], zero<S>()) && ne(s[j], one<S>())) { col = (int)j; return false; }
-            } else if (!is_int(s[j])) { col = (int)j; return false; }     // {R,Float}Mat::is_imat
-        }
-        return true;
-    }
-
-    void remember(const std::vector<S> & s, S v, bool is_max)
-    {
-        if (!have_best || (is_max ? lt(best_v, v) : gt(best_v, v))) { best_sol = s; best_v = v; have_best = true; }
-    }
-
-    static void add_row(std::vector<S> & rows, int & nrows, int cols, int col, S coef, int rhs, S b)
-    {
-        rows.resize((size_t)(nrows + 1) * cols, zero<S>());
-        for (int j = 0; j < cols; j++) rows[(size_t)nrows * cols + j] = zero<S>();
-        rows[(size_t)nrows * cols + col] = coef;
-        rows[(size_t)nrows * cols + rhs] = b;
-        nrows++;
-    }
-
-    // MIP::RecusivePart (lpsol.h:2427-2612).
-    int node(const MipProblem<S> & Q, bool is_max, bool is_bin, std::vector<int> & forks, S & v, std::vector<S> & sol)
-    {
-        nodes++;
-        std::vector<S> out_sol(Q.cols);
-        S out_v = zero<S>();
-        int st = six_solve<S>(ctx, kind, is_max, Q.tgtf.data(), Q.vc.data(), Q.cols - 1,
-                              Q.eq_rows ? Q.eq.data() : (const S *)0, Q.eq_rows,
-                              Q.leq_rows ? Q.leq.data() : (const S *)0, Q.leq_rows, Q.cols, 10000u, &out_v,
-                              out_sol.data());
-        v = out_v;
-        if (st < 0) return st;
-        if (st != XPG_SIX_SUCC) {
-            if (st == XPG_SIX_UNBOUND) return XPG_IP_UNBOUND;
-            if (st == XPG_SIX_TIME_OUT) return XPG_ERR_REF_UNDEFINED;         // UNREACH() in the reference
-            return XPG_IP_NO_PRI_FEASIBLE_SOL;
-        }
-        sol = out_sol;
-        int col = 0;
-        if (satisfied(sol, is_bin, col)) return XPG_IP_SUCC;
-        if (have_best && (is_max ? le(v, best_v) : ge(v, best_v))) return XPG_IP_NO_BETTER_THAN_BEST_SOL;
-        if (forks[col] >= 1) return XPG_IP_NO_PRI_FEASIBLE_SOL;              // lpsol.h:2486-2496
-        forks[col]++;
-        int lo = 0, hi = 1;
-        MipProblem<S> L = Q;                                                  // floor branch, lpsol.h:2503-2521
-        if (is_bin) add_row(L.eq, L.eq_rows, Q.cols, col, one<S>(), rhs0, S::from_int(lo));
-        else {
-            if (!int_cast_ok(sol[col])) return XPG_ERR_REF_UNDEFINED;
-            lo = to_int(sol[col]); hi = lo + 1;
-            add_row(L.leq, L.leq_rows, Q.cols, col, one<S>(), rhs0, S::from_int(lo));
-        }
-        std::vector<S> kept_sol; S kept_v = zero<S>(); bool kept = false;
-        st = node(L, is_max, is_bin, forks, v, sol);
-        if (st < 0) return st;
-        if (st == XPG_IP_SUCC) { kept_sol = sol; kept_v = v; kept = true; remember(sol, v, is_max); }
-        MipProblem<S> H = Q;                                                  // ceiling branch, lpsol.h:2545-2560
-        if (is_bin) add_row(H.eq, H.eq_rows, Q.cols, col, one<S>(), rhs0, S::from_int(hi));
-        else add_row(H.leq, H.leq_rows, Q.cols, col, minus_one<S>(), rhs0, S::from_int(-hi));
-        st = node(H, is_max, is_bin, forks, v, sol);
-        if (st < 0) return st;
-        if (st == XPG_IP_SUCC) {                                              // lpsol.h:2563-2592
-            if (kept && (is_max ? gt(kept_v, v) : lt(kept_v, v))) { v = kept_v; sol = kept_sol; }
-            remember(sol, v, is_max);
-            return XPG_IP_SUCC;
-        }
-        if (kept) { v = kept_v; sol = kept_sol; remember(sol, v, is_max); return XPG_IP_SUCC; }
-        return st;
-    }
-
-    static bool int_cast_ok(F64) { return true; }
-    static bool int_cast_ok(R32 a) { return a.den != 0; }
 };
 
 template <class S>
@@ -125,6 +36,191 @@ MipProblem<S> make_problem(const S * tgtf, const S * vc, int vc_rows, const S * 
     return Q;
 }
 
+inline bool int_cast_ok(F64) { return true; }
+inline bool int_cast_ok(R32 a) { return a.den != 0; }
+
+// One problem's MIP::RecusivePart (lpsol.h:2427-2612) as a resumable stack machine.
+template <class S> struct MipTask {
+    struct Frame {
+        MipProblem<S> Q;
+        int stage;                          // 0: LP pending, 1: floor child running, 2: ceiling child running
+        int col, lo, hi;
+        bool kept; S kept_v; std::vector<S> kept_sol;
+    };
+    bool is_max, is_bin;
+    const uint8_t * allow_rational;         // 1 x cols or null (lpsol.h:2369-2393)
+    int rhs0;
+    // the by-reference state the reference threads through its recursion
+    S v; std::vector<S> sol;
+    bool have_best; S best_v; std::vector<S> best_sol;
+    std::vector<int> forks;
+    std::vector<Frame> stack;
+    NormalForm<S> F;                        // normal form of the pending node LP
+    bool done; int final_status; long nodes;
+
+    void start(const MipProblem<S> & root, bool mx, bool bin, const uint8_t * allow)
+    {
+        is_max = mx; is_bin = bin; allow_rational = allow; rhs0 = root.cols - 1;
+        v = zero<S>(); sol.clear(); have_best = false; best_v = zero<S>(); best_sol.clear();
+        forks.assign(root.cols, 0);
+        stack.clear(); done = false; final_status = 0; nodes = 0;
+        push(root);
+    }
+    void push(const MipProblem<S> & Q)
+    {
+        Frame f; f.Q = Q; f.stage = 0; f.col = 0; f.lo = 0; f.hi = 1; f.kept = false; f.kept_v = zero<S>();
+        stack.push_back(f);
+    }
+    // Normalises the pending node; a negative return is the LP's "status" (shape / undefined).
+    int prepare()
+    {
+        const MipProblem<S> & Q = stack.back().Q;
+        nodes++;
+        return normalize_host(Q.tgtf.data(), Q.vc.data(), Q.cols - 1, Q.eq_rows ? Q.eq.data() : (const S *)0, Q.eq_rows,
+                              Q.leq_rows ? Q.leq.data() : (const S *)0, Q.leq_rows, Q.cols, F);
+    }
+
+    // MIP::is_satisfying (lpsol.h:2364-2408); `col` is the first offending entry.
+    bool satisfied(std::vector<S> & s, int & col) const
+    {
+        for (size_t j = 0; j < s.size(); j++) {
+            if (allow_rational || is_bin) reduce(s[j]);
+            if (allow_rational) {
+                if (allow_rational[j]) continue;
+                if (!is_int(s[j])) { col = (int)j; return false; }
+                if (is_bin && ne(s[j], zero<S>()) && ne(s[j], one<S>())) { col = (int)j; return false; }
+            } else if (is_bin) {
+                if (ne(s[j], zero<S>()) && ne(s[j], one<S>())) { col = (int)j; return false; }
+            } else if (!is_int(s[j])) { col = (int)j; return false; }     // {R,Float}Mat::is_imat
+        }
+        return true;
+    }
+    void remember()
+    {
+        if (!have_best || (is_max ? lt(best_v, v) : gt(best_v, v))) { best_sol = sol; best_v = v; have_best = true; }
+    }
+    static void add_row(std::vector<S> & rows, int & nrows, int cols, int col, S coef, int rhs, S b)
+    {
+        rows.resize((size_t)(nrows + 1) * cols, zero<S>());
+        for (int j = 0; j < cols; j++) rows[(size_t)nrows * cols + j] = zero<S>();
+        rows[(size_t)nrows * cols + col] = coef;
+        rows[(size_t)nrows * cols + rhs] = b;
+        nrows++;
+    }
+    void push_branch(const Frame & p, bool ceiling)
+    {
+        MipProblem<S> B = p.Q;
+        if (is_bin) add_row(B.eq, B.eq_rows, B.cols, p.col, one<S>(), rhs0, S::from_int(ceiling ? p.hi : p.lo));   // lpsol.h:2506-2512, :2548-2553
+        else if (!ceiling) add_row(B.leq, B.leq_rows, B.cols, p.col, one<S>(), rhs0, S::from_int(p.lo));          // :2514-2520
+        else add_row(B.leq, B.leq_rows, B.cols, p.col, minus_one<S>(), rhs0, S::from_int(-p.hi));                  // :2555-2559
+        push(B);
+    }
+
+    // Feeds the answer of the pending LP (st: SIX status or a negative error; y: raw values of
+    // the normalised variables on success) and runs until the next LP is needed or the tree ends.
+    void on_lp(int st, const std::vector<S> & y)
+    {
+        int ret;
+        {
+            Frame & f = stack.back();
+            v = zero<S>();
+            if (st == XPG_SIX_SUCC) {
+                std::vector<S> s(f.Q.cols);
+                finish_host(F, f.Q.tgtf.data(), y, &v, s.data());
+                sol = s;
+            }
+            if (st < 0) ret = st;
+            else if (st == XPG_SIX_UNBOUND) ret = XPG_IP_UNBOUND;
+            else if (st == XPG_SIX_TIME_OUT) ret = XPG_ERR_REF_UNDEFINED;     // UNREACH() in the reference
+            else if (st != XPG_SIX_SUCC) ret = XPG_IP_NO_PRI_FEASIBLE_SOL;
+            else {
+                int col = 0;
+                if (satisfied(sol, col)) ret = XPG_IP_SUCC;
+                else if (have_best && (is_max ? le(v, best_v) : ge(v, best_v))) ret = XPG_IP_NO_BETTER_THAN_BEST_SOL;
+                else if (forks[col] >= 1) ret = XPG_IP_NO_PRI_FEASIBLE_SOL;                  // lpsol.h:2486-2496
+                else if (!is_bin && !int_cast_ok(sol[col])) ret = XPG_ERR_REF_UNDEFINED;
+                else {
+                    forks[col]++;
+                    f.col = col; f.lo = 0; f.hi = 1;
+                    if (!is_bin) { f.lo = to_int(sol[col]); f.hi = f.lo + 1; }
+                    f.stage = 1;
+                    const Frame snapshot = f;          // push() may reallocate the stack
+                    push_branch(snapshot, false);
+                    return;
+                }
+            }
+        }
+        for (;;) {                                      // hand `ret` to the callers up the stack
+            stack.pop_back();
+            if (stack.empty()) { final_status = ret; done = true; return; }
+            Frame & p = stack.back();
+            if (ret < 0) continue;
+            if (p.stage == 1) {                         // floor branch came back, lpsol.h:2527-2543
+                if (ret == XPG_IP_SUCC) { p.kept_sol = sol; p.kept_v = v; p.kept = true; remember(); }
+                p.stage = 2;
+                const Frame snapshot = p;
+                push_branch(snapshot, true);
+                return;
+            }
+            if (ret == XPG_IP_SUCC) {                   // ceiling branch came back, lpsol.h:2563-2611
+                if (p.kept && (is_max ? gt(p.kept_v, v) : lt(p.kept_v, v))) { v = p.kept_v; sol = p.kept_sol; }
+                remember();
+            } else if (p.kept) { v = p.kept_v; sol = p.kept_sol; remember(); ret = XPG_IP_SUCC; }
+        }
+    }
+};
+
+// Advances every task to completion; node LPs of equal shape share one kernel launch.
+template <class S> int run_mip_tasks(xpg_ctx * ctx, int kind, std::vector<MipTask<S> > & tasks)
+{
+    struct Key { int is_max, rows, cols; bool operator<(const Key & o) const
+        { return is_max != o.is_max ? is_max < o.is_max : (rows != o.rows ? rows < o.rows : cols < o.cols); } };
+    const std::vector<S> none;
+    for (;;) {
+        std::map<Key, std::vector<int> > groups;
+        std::vector<int> large;
+        bool any = false;
+        for (size_t t = 0; t < tasks.size(); t++) {
+            MipTask<S> & T = tasks[t];
+            while (!T.done) {
+                const int rc = T.prepare();
+                if (rc == 0) break;
+                T.on_lp(rc, none);                      // malformed / reference-undefined node: no GPU work
+            }
+            if (T.done) continue;
+            any = true;
+            if (T.F.fits_lds(T.is_max)) { Key k = { T.is_max ? 1 : 0, T.F.N.r, T.F.n + 1 }; groups[k].push_back((int)t); }
+            else large.push_back((int)t);
+        }
+        if (!any) return 0;
+        for (typename std::map<Key, std::vector<int> >::iterator g = groups.begin(); g != groups.end(); ++g) {
+            const Key & k = g->first;
+            const std::vector<int> & ids = g->second;
+            const int nb = (int)ids.size();
+            std::vector<S> tg((size_t)nb * k.cols), lq((size_t)nb * k.rows * k.cols), vv(nb), raw((size_t)nb * k.cols);
+            std::vector<int32_t> st(nb);
+            for (int b = 0; b < nb; b++) {
+                const NormalForm<S> & F = tasks[ids[b]].F;
+                for (int j = 0; j < k.cols; j++) tg[(size_t)b * k.cols + j] = F.obj[j];
+                for (size_t e = 0; e < F.N.a.size(); e++) lq[(size_t)b * k.rows * k.cols + e] = F.N.a[e];
+            }
+            int rc = batch_host<S>(ctx, k.is_max, nb, tg.data(), lq.data(), k.rows, k.cols, 10000u, st.data(), vv.data(),
+                                   raw.data(), /*raw_sol=*/1);
+            if (rc) return rc;
+            for (int b = 0; b < nb; b++) {
+                std::vector<S> y(raw.begin() + (size_t)b * k.cols, raw.begin() + (size_t)b * k.cols + (k.cols - 1));
+                tasks[ids[b]].on_lp(st[b], y);
+            }
+        }
+        for (size_t q = 0; q < large.size(); q++) {
+            MipTask<S> & T = tasks[large[q]];
+            std::vector<S> y;
+            const int st = solve_large(ctx, kind, T.is_max, T.F, 10000u, y);
+            T.on_lp(st, y);
+        }
+    }
+}
+
 // MIP::maxm / minm (lpsol.h:2636-2657, :2681-2702).
 template <class S>
 int mip_solve(xpg_ctx * ctx, int kind, bool is_max, bool is_bin, const S * tgtf, const S * vc, int vc_rows,
@@ -134,28 +230,50 @@ int mip_solve(xpg_ctx * ctx, int kind, bool is_max, bool is_bin, const S * tgtf,
     if (!ctx || !tgtf || !vc || !out_v || cols < 2 || vc_rows != cols - 1 || eq_rows < 0 || leq_rows < 0 ||
         (eq_rows == 0 && leq_rows == 0) || (eq_rows > 0 && !eqs) || (leq_rows > 0 && !leq))
         return XPG_ERR_SHAPE;
-    MipProblem<S> Q = make_problem(tgtf, vc, vc_rows, eqs, eq_rows, leq, leq_rows, cols);
-    MipHost<S> M(ctx, kind, allow_rational, cols - 1);
-    std::vector<int> forks(cols, 0);
-    S v = zero<S>();
-    std::vector<S> sol;
-    int st = M.node(Q, is_max, is_bin, forks, v, sol);
-    *out_v = v;
-    if (st == XPG_IP_SUCC && out_sol && (int)sol.size() == cols)
-        for (int j = 0; j < cols; j++) out_sol[j] = sol[j];
-    if (out_nodes) *out_nodes = M.nodes;
-    return st;
+    std::vector<MipTask<S> > tasks(1);
+    tasks[0].start(make_problem(tgtf, vc, vc_rows, eqs, eq_rows, leq, leq_rows, cols), is_max, is_bin, allow_rational);
+    int rc = run_mip_tasks(ctx, kind, tasks);
+    if (rc) return rc;
+    const MipTask<S> & T = tasks[0];
+    *out_v = T.v;
+    if (T.final_status == XPG_IP_SUCC && out_sol && (int)T.sol.size() == cols)
+        for (int j = 0; j < cols; j++) out_sol[j] = T.sol[j];
+    if (out_nodes) *out_nodes = T.nodes;
+    return T.final_status;
 }
 
-// Lineq::has_solution (linsys.cpp:830-906): objective sum(x) with unconstrained columns
-// zeroed (SIX::reviseTargetFunc, lpsol.h:2053-2074), maxm then minm; success, or an
-// unbounded answer when a unique solution is not demanded, means "has a solution".
-inline int has_solution(xpg_ctx * ctx, const R32 * leq, int leq_rows, const R32 * eqs, int eq_rows, const R32 * vc,
-                        int vc_rows, int cols, int rhs, bool is_int, bool is_unique)
+// nb independent MIPs of one shape (x >= 0, inequalities only), advanced together.
+template <class S>
+int mip_batch(xpg_ctx * ctx, int kind, int nb, bool is_max, bool is_bin, const S * tgtf, const S * leq, int leq_rows,
+              int cols, int32_t * out_status, S * out_v, S * out_sol, long long * out_nodes)
 {
-    if (!ctx || !vc || cols < 2 || rhs != cols - 1 || vc_rows != rhs) return XPG_ERR_SHAPE;
-    if (leq_rows == 0 && eq_rows == 0) return 0;
-    if (leq_rows == 0) return XPG_ERR_REF_UNDEFINED;      // the reference sizes tgtf from leq (linsys.cpp:851)
+    if (!ctx || nb < 0 || !tgtf || !leq || leq_rows <= 0 || cols < 2 || !out_status || !out_v) return XPG_ERR_SHAPE;
+    if (nb == 0) return 0;
+    const int rhs = cols - 1;
+    std::vector<S> vc((size_t)rhs * cols, zero<S>());
+    for (int i = 0; i < rhs; i++) vc[(size_t)i * cols + i] = minus_one<S>();
+    std::vector<MipTask<S> > tasks(nb);
+    for (int b = 0; b < nb; b++)
+        tasks[b].start(make_problem<S>(tgtf + (size_t)b * cols, vc.data(), rhs, (const S *)0, 0,
+                                       leq + (size_t)b * leq_rows * cols, leq_rows, cols), is_max, is_bin, (const uint8_t *)0);
+    int rc = run_mip_tasks<S>(ctx, kind, tasks);
+    if (rc) return rc;
+    long long nodes = 0;
+    for (int b = 0; b < nb; b++) {
+        const MipTask<S> & T = tasks[b];
+        out_status[b] = T.final_status;
+        out_v[b] = T.v;
+        nodes += T.nodes;
+        if (T.final_status == XPG_IP_SUCC && out_sol && (int)T.sol.size() == cols)
+            for (int j = 0; j < cols; j++) out_sol[(size_t)b * cols + j] = T.sol[j];
+    }
+    if (out_nodes) *out_nodes = nodes;
+    return 0;
+}
+
+// SIX::reviseTargetFunc on the all-ones objective (lpsol.h:2053-2074, linsys.cpp:851-862).
+inline std::vector<R32> feasibility_objective(const R32 * leq, int leq_rows, const R32 * eqs, int eq_rows, int cols, int rhs)
+{
     std::vector<R32> tgtf(cols, R32(0, 1));
     for (int j = 0; j < rhs; j++) {
         bool nz = false;
@@ -163,6 +281,18 @@ inline int has_solution(xpg_ctx * ctx, const R32 * leq, int leq_rows, const R32 
         for (int i = 0; i < eq_rows && !nz; i++) nz = !eq(eqs[(size_t)i * cols + j], R32(0, 1));
         tgtf[j] = nz ? R32(1, 1) : R32(0, 1);
     }
+    return tgtf;
+}
+
+// Lineq::has_solution (linsys.cpp:830-906): maxm then minm; success, or an unbounded answer
+// when a unique solution is not demanded, means "has a solution".
+inline int has_solution(xpg_ctx * ctx, const R32 * leq, int leq_rows, const R32 * eqs, int eq_rows, const R32 * vc,
+                        int vc_rows, int cols, int rhs, bool is_int, bool is_unique)
+{
+    if (!ctx || !vc || cols < 2 || rhs != cols - 1 || vc_rows != rhs) return XPG_ERR_SHAPE;
+    if (leq_rows == 0 && eq_rows == 0) return 0;
+    if (leq_rows == 0) return XPG_ERR_REF_UNDEFINED;      // the reference sizes tgtf from leq (linsys.cpp:851)
+    const std::vector<R32> tgtf = feasibility_objective(leq, leq_rows, eqs, eq_rows, cols, rhs);
     R32 v; std::vector<R32> sol(cols);
     for (int pass = 0; pass < 2; pass++) {
         int st = is_int
@@ -174,6 +304,55 @@ inline int has_solution(xpg_ctx * ctx, const R32 * leq, int leq_rows, const R32 
         if (st == 0) return 1;
         if (!is_unique && st == 1) return 1;
     }
+    return 0;
+}
+
+// DepPoly::is_empty(keepit, vc = NULL) (src/eng/poly.cpp:530-573) for a batch of dependence
+// polyhedra without constant symbols (rhs_idx == cols - 1): Lineq::reduce as the cheap
+// pre-filter, then Lineq::has_solution(is_int_sol = true, is_unique_sol = true) with x >= 0,
+// i.e. MIP::maxm and, failing that, MIP::minm. All systems advance together: one
+// wave-per-system reduce launch, then rounds of batched node LPs.
+inline int dep_is_empty_batch(xpg_ctx * ctx, int nb, const R32 * mats, int rows, int cols, int32_t * out_empty,
+                              long * out_nodes)
+{
+    if (!ctx || nb < 0 || !mats || rows <= 0 || cols < 2 || !out_empty) return XPG_ERR_SHAPE;
+    if (nb == 0) return 0;
+    const int rhs = cols - 1;
+    std::vector<R32> work(mats, mats + (size_t)nb * rows * cols);
+    std::vector<int32_t> kept(nb), ok(nb);
+    int rc = lineq_reduce_batch(ctx, nb, work.data(), rows, cols, rhs, 1, 1, kept.data(), ok.data());
+    if (rc) return rc;
+    std::vector<R32> vc((size_t)rhs * cols, R32(0, 1));
+    for (int i = 0; i < rhs; i++) vc[(size_t)i * cols + i] = R32(-1, 1);
+    std::vector<int> open;                       // systems still undecided
+    for (int b = 0; b < nb; b++) {
+        if (!ok[b]) out_empty[b] = 1;            // inconsistent bounds: empty (poly.cpp:550-552)
+        else if (kept[b] == 0) out_empty[b] = 0; // only redundant constraints: conservatively non-empty (:553-557)
+        else { out_empty[b] = 1; open.push_back(b); }
+    }
+    long nodes = 0;
+    for (int pass = 0; pass < 2 && !open.empty(); pass++) {          // maxm, then minm (linsys.cpp:864-876)
+        std::vector<MipTask<R32> > tasks(open.size());
+        for (size_t t = 0; t < open.size(); t++) {
+            const int b = open[t];
+            const R32 * leq = work.data() + (size_t)b * rows * cols;
+            const std::vector<R32> tgtf = feasibility_objective(leq, kept[b], (const R32 *)0, 0, cols, rhs);
+            tasks[t].start(make_problem<R32>(tgtf.data(), vc.data(), rhs, (const R32 *)0, 0, leq, kept[b], cols),
+                           pass == 0, false, (const uint8_t *)0);
+        }
+        rc = run_mip_tasks<R32>(ctx, 1, tasks);
+        if (rc) return rc;
+        std::vector<int> still;
+        for (size_t t = 0; t < open.size(); t++) {
+            nodes += tasks[t].nodes;
+            const int st = tasks[t].final_status;
+            if (st < 0) out_empty[open[t]] = st;             // reference undefined on this system
+            else if (st == XPG_IP_SUCC) out_empty[open[t]] = 0;
+            else still.push_back(open[t]);
+        }
+        open.swap(still);
+    }
+    if (out_nodes) *out_nodes = nodes;
     return 0;
 }
 

@@ -2,7 +2,8 @@
 // SIX::normalize / convertEq2Ineq / calcDualMaxm / calcFinalSolution
 // (src/com/lpsol.h:1290-1394, :1197-1278, :1586-1655, :1851-1899). These are
 // O(rows x cols) one-shot copies on the caller's host buffers; every pivot,
-// ratio test and pricing scan of the solve itself runs on the GPU through Lp<S>.
+// ratio test and pricing scan of the solve itself runs on the GPU: small
+// problems through the LDS-resident batch kernel, large ones through Lp<S>.
 #pragma once
 #include <vector>
 #include <stdlib.h>
@@ -76,94 +77,101 @@ template <class S> int fold_eq(HostMat<S> & L, const HostMat<S> & E, int rhs)
     return 0;
 }
 
+// The result of SIX::normalize (lpsol.h:1290-1394): inequalities only, every variable
+// non-negative, free variables split v = v' - v''.
+template <class S> struct NormalForm {
+    int n0, n, cols;                      // original / normalised variable counts
+    HostMat<S> N;                         // rows x (n + 1)
+    std::vector<S> obj, vcd, vcr;         // objective (n + 1), vc(i,i), vc(i,rhs)
+    std::vector<int> free_var;
+    bool plain_vc;                        // every variable constraint is exactly -x_i <= 0
+    bool fits_lds(bool is_max) const
+    {
+        const int R = is_max ? N.r : n, V = is_max ? n : N.r;
+        return plain_vc && small_lds_bytes<S>(R, V) <= 64 * 1024;
+    }
+};
+
 template <class S>
-int six_solve(xpg_ctx * ctx, int kind, bool is_max, const S * tgtf, const S * vc, int vc_rows,
-              const S * eqs, int eq_rows, const S * leq, int leq_rows, int cols, unsigned max_iter,
-              S * out_v, S * out_sol)
+int normalize_host(const S * tgtf, const S * vc, int vc_rows, const S * eqs, int eq_rows, const S * leq,
+                   int leq_rows, int cols, NormalForm<S> & F)
 {
-    if (!ctx || !tgtf || !vc || !out_v || cols < 2 || vc_rows != cols - 1 || eq_rows < 0 ||
-        leq_rows < 0 || (eq_rows == 0 && leq_rows == 0) || (eq_rows > 0 && !eqs) ||
-        (leq_rows > 0 && !leq))
+    if (!tgtf || !vc || cols < 2 || vc_rows != cols - 1 || eq_rows < 0 || leq_rows < 0 ||
+        (eq_rows == 0 && leq_rows == 0) || (eq_rows > 0 && !eqs) || (leq_rows > 0 && !leq))
         return XPG_ERR_SHAPE;
-    *out_v = zero<S>();
     const int n0 = cols - 1;
     HostMat<S> L = leq_rows ? HostMat<S>(leq, leq_rows, cols) : HostMat<S>();
     const HostMat<S> E = eq_rows ? HostMat<S>(eqs, eq_rows, cols) : HostMat<S>();
     int rc = fold_eq(L, E, n0);
     if (rc) return rc;
     if (L.r == 0) return XPG_ERR_SHAPE;
-
-    // ---- free variables: v = v' - v'' (lpsol.h:1321-1392)
-    std::vector<int> free_var;
-    for (int j = 0; j < n0; j++) {
+    F.free_var.clear();
+    for (int j = 0; j < n0; j++) {                               // lpsol.h:1321-1339
         bool all_zero = true;
         for (int i = 0; i < vc_rows && all_zero; i++) all_zero = eq(vc[(size_t)i * cols + j], zero<S>());
-        if (all_zero) free_var.push_back(j);
+        if (all_zero) F.free_var.push_back(j);
     }
-    const int extra = (int)free_var.size(), n = n0 + extra;
-    HostMat<S> N(L.r, n + 1);
-    std::vector<S> obj(n + 1, zero<S>()), vcd(n, zero<S>()), vcr(n, zero<S>());
+    const int extra = (int)F.free_var.size(), n = n0 + extra;
+    F.n0 = n0; F.n = n; F.cols = cols;
+    F.N = HostMat<S>(L.r, n + 1);
+    F.obj.assign(n + 1, zero<S>()); F.vcd.assign(n, zero<S>()); F.vcr.assign(n, zero<S>());
     for (int i = 0; i < L.r; i++) {
-        for (int j = 0; j < n0; j++) N(i, j) = L(i, j);
-        N(i, n) = L(i, n0);
+        for (int j = 0; j < n0; j++) F.N(i, j) = L(i, j);
+        F.N(i, n) = L(i, n0);
     }
-    for (int j = 0; j < n0; j++) { obj[j] = tgtf[j]; vcd[j] = vc[(size_t)j * cols + j]; vcr[j] = vc[(size_t)j * cols + n0]; }
-    obj[n] = tgtf[n0];
-    for (int k = 0; k < extra; k++) {
-        const int j = free_var[k], twin = n0 + k;
-        vcd[j] = minus_one<S>(); vcd[twin] = minus_one<S>();
-        for (int i = 0; i < L.r; i++) N(i, twin) = L(i, j);
-        scale_run(&N(0, twin), L.r, N.c, minus_one<S>());
-        obj[twin] = tgtf[j];
-        scale_run(&obj[twin], 1, 1, minus_one<S>());
+    for (int j = 0; j < n0; j++) { F.obj[j] = tgtf[j]; F.vcd[j] = vc[(size_t)j * cols + j]; F.vcr[j] = vc[(size_t)j * cols + n0]; }
+    F.obj[n] = tgtf[n0];
+    for (int k = 0; k < extra; k++) {                            // lpsol.h:1365-1392
+        const int j = F.free_var[k], twin = n0 + k;
+        F.vcd[j] = minus_one<S>(); F.vcd[twin] = minus_one<S>();
+        for (int i = 0; i < L.r; i++) F.N(i, twin) = L(i, j);
+        scale_run(&F.N(0, twin), L.r, F.N.c, minus_one<S>());
+        F.obj[twin] = tgtf[j];
+        scale_run(&F.obj[twin], 1, 1, minus_one<S>());
     }
+    F.plain_vc = true;
+    for (int j = 0; j < n && F.plain_vc; j++) F.plain_vc = eq(F.vcd[j], minus_one<S>()) && eq(F.vcr[j], zero<S>());
+    return 0;
+}
 
-    // ---- small problems (the dependence-test and branch-and-bound node sizes): one launch of
-    // the LDS-resident batch kernel with nb = 1, which builds the dual itself for minm
-    bool plain_vc = true;
-    for (int j = 0; j < n && plain_vc; j++) plain_vc = eq(vcd[j], minus_one<S>()) && eq(vcr[j], zero<S>());
-    {
-        const int R = is_max ? N.r : n, V = is_max ? n : N.r;
-        const char * force = getenv("XPG_FORCE_DEVICE_LP");     // test hook: always take the HBM-resident path
-        if (plain_vc && !(force && force[0] == '1') && small_lds_bytes<S>(R, V) <= 64 * 1024) {
-            int32_t st1 = 0; S v1 = zero<S>();
-            std::vector<S> raw(n + 1, zero<S>());
-            rc = batch_host<S>(ctx, is_max ? 1 : 0, 1, obj.data(), N.a.data(), N.r, n + 1, max_iter, &st1, &v1,
-                               raw.data(), /*raw_sol=*/1);
-            if (rc) return rc;
-            if (st1 != XPG_SIX_SUCC) return st1;
-            std::vector<S> y(raw.begin(), raw.begin() + n);
-            y.push_back(zero<S>());
-            for (int k = 0; k < extra; k++) y[free_var[k]] = sub(y[free_var[k]], y[n0 + k]);
-            S v = zero<S>();
-            std::vector<S> sol(cols);
-            for (int j = 0; j < n0; j++) sol[j] = y[j];
-            sol[n0] = one<S>();
-            for (int j = 0; j < cols; j++) v = add(v, mul(sol[j], tgtf[j]));
-            reduce(v);
-            *out_v = v;
-            if (out_sol) for (int j = 0; j < cols; j++) { reduce(sol[j]); out_sol[j] = sol[j]; }
-            return XPG_SIX_SUCC;
-        }
-    }
+// SIX::calcFinalSolution (lpsol.h:1851-1899) from the raw values y[0..n) of the normalised
+// variables: undo the free-variable split, recompute the objective on the ORIGINAL tgtf.
+template <class S>
+void finish_host(const NormalForm<S> & F, const S * tgtf, std::vector<S> y, S * out_v, S * out_sol)
+{
+    y.resize(F.n + 1, zero<S>());
+    for (size_t k = 0; k < F.free_var.size(); k++) y[F.free_var[k]] = sub(y[F.free_var[k]], y[F.n0 + (int)k]);
+    S v = zero<S>();
+    std::vector<S> sol(F.cols);
+    for (int j = 0; j < F.n0; j++) sol[j] = y[j];
+    sol[F.n0] = one<S>();
+    for (int j = 0; j < F.cols; j++) v = add(v, mul(sol[j], tgtf[j]));
+    reduce(v);
+    *out_v = v;
+    if (out_sol) for (int j = 0; j < F.cols; j++) { reduce(sol[j]); out_sol[j] = sol[j]; }
+}
 
-    // ---- the slack form handed to the GPU: primal for maxm, dual for minm
+// The HBM-resident route for problems that do not fit one CU's LDS.
+template <class S>
+int solve_large(xpg_ctx * ctx, int kind, bool is_max, const NormalForm<S> & F, unsigned max_iter, std::vector<S> & y)
+{
+    const int n = F.n;
     HostMat<S> P; std::vector<S> pobj, pd, pr;
-    if (is_max) { P = N; pobj = obj; pd = vcd; pr = vcr; }
-    else {                                                       // lpsol.h:1602-1629
-        const int mm = N.r;
+    if (is_max) { P = F.N; pobj = F.obj; pd = F.vcd; pr = F.vcr; }
+    else {                                                       // SIX::calcDualMaxm, lpsol.h:1602-1629
+        const int mm = F.N.r;
         P = HostMat<S>(n, mm + 1);
         for (int i = 0; i < n; i++)
-            for (int j = 0; j < mm; j++) P(i, j) = N(j, i);
+            for (int j = 0; j < mm; j++) P(i, j) = F.N(j, i);
         scale_run(P.a.data(), (int)P.a.size(), 1, minus_one<S>());
-        for (int i = 0; i < n; i++) P(i, mm) = obj[i];
+        for (int i = 0; i < n; i++) P(i, mm) = F.obj[i];
         pobj.assign(mm + 1, zero<S>());
-        for (int j = 0; j < mm; j++) pobj[j] = N(j, n);
+        for (int j = 0; j < mm; j++) pobj[j] = F.N(j, n);
         scale_run(pobj.data(), mm + 1, 1, minus_one<S>());
         pd.assign(mm, minus_one<S>()); pr.assign(mm, zero<S>());
     }
     xpg_lp * lp = 0;
-    rc = xpg_lp_create(ctx, kind, P.a.data(), P.r, P.c, pobj.data(), pd.data(), pr.data(), 0, &lp);
+    int rc = xpg_lp_create(ctx, kind, P.a.data(), P.r, P.c, pobj.data(), pd.data(), pr.data(), 0, &lp);
     if (rc) return rc;
     int st = xpg_lp_two_stage(lp, max_iter);
     if (st != XPG_SIX_SUCC) { xpg_lp_destroy(lp); return st; }
@@ -173,23 +181,43 @@ int six_solve(xpg_ctx * ctx, int kind, bool is_max, const S * tgtf, const S * vc
     rc = xpg_lp_read(lp, 0, fobj.data(), 0, 0, 0, 0, 0, x.data());
     xpg_lp_destroy(lp);
     if (rc) return rc;
-    std::vector<S> y;
-    if (is_max) y = x;
+    if (is_max) y.assign(x.begin(), x.begin() + n);
     else {                                                       // lpsol.h:1713-1716
-        const int nd = N.r;
-        y.assign(n + 1, zero<S>());
+        const int nd = F.N.r;
+        y.assign(n, zero<S>());
         for (int k = 0; k < n; k++) y[k] = neg(fobj[nd + k]);
     }
-    // ---- SIX::calcFinalSolution (lpsol.h:1851-1899)
-    for (int k = 0; k < extra; k++) y[free_var[k]] = sub(y[free_var[k]], y[n0 + k]);
-    S v = zero<S>();
-    std::vector<S> sol(cols);
-    for (int j = 0; j < n0; j++) sol[j] = y[j];
-    sol[n0] = one<S>();
-    for (int j = 0; j < cols; j++) v = add(v, mul(sol[j], tgtf[j]));
-    reduce(v);
-    *out_v = v;
-    if (out_sol) for (int j = 0; j < cols; j++) { reduce(sol[j]); out_sol[j] = sol[j]; }
+    return XPG_SIX_SUCC;
+}
+
+// SIX::maxm / minm (lpsol.h:1993-2033, :1662-1732).
+template <class S>
+int six_solve(xpg_ctx * ctx, int kind, bool is_max, const S * tgtf, const S * vc, int vc_rows,
+              const S * eqs, int eq_rows, const S * leq, int leq_rows, int cols, unsigned max_iter,
+              S * out_v, S * out_sol)
+{
+    if (!ctx || !out_v) return XPG_ERR_SHAPE;
+    *out_v = zero<S>();
+    NormalForm<S> F;
+    int rc = normalize_host(tgtf, vc, vc_rows, eqs, eq_rows, leq, leq_rows, cols, F);
+    if (rc) return rc;
+    std::vector<S> y;
+    const char * force = getenv("XPG_FORCE_DEVICE_LP");          // test hook: always take the HBM-resident path
+    if (!(force && force[0] == '1') && F.fits_lds(is_max)) {
+        // dependence-test / branch-and-bound node sizes: one launch of the LDS-resident batch
+        // kernel with nb = 1 (it builds the dual itself for minm)
+        int32_t st1 = 0; S v1 = zero<S>();
+        std::vector<S> raw(F.n + 1, zero<S>());
+        rc = batch_host<S>(ctx, is_max ? 1 : 0, 1, F.obj.data(), F.N.a.data(), F.N.r, F.n + 1, max_iter, &st1, &v1,
+                           raw.data(), /*raw_sol=*/1);
+        if (rc) return rc;
+        if (st1 != XPG_SIX_SUCC) return st1;
+        y.assign(raw.begin(), raw.begin() + F.n);
+    } else {
+        int st = solve_large(ctx, kind, is_max, F, max_iter, y);
+        if (st != XPG_SIX_SUCC) return st;
+    }
+    finish_host(F, tgtf, y, out_v, out_sol);
     return XPG_SIX_SUCC;
 }
 

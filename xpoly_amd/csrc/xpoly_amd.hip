@@ -418,6 +418,22 @@ int xpg_has_solution_rat32(xpg_ctx * ctx, const xpg_rat32 * leq, int leq_rows, c
                         rhs_idx, is_int_sol != 0, is_unique_sol != 0);
 }
 
+int xpg_mip_batch_rat32(xpg_ctx * ctx, int nb, int is_max, int is_bin, const xpg_rat32 * tgtf, const xpg_rat32 * leq,
+                        int leq_rows, int cols, int32_t * out_status, xpg_rat32 * out_v, xpg_rat32 * out_sol,
+                        long long * out_nodes)
+{
+    return mip_batch<R32>(ctx, 1, nb, is_max != 0, is_bin != 0, (const R32 *)tgtf, (const R32 *)leq, leq_rows, cols,
+                          out_status, (R32 *)out_v, (R32 *)out_sol, out_nodes);
+}
+int xpg_dep_is_empty_batch_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols,
+                                 int32_t * out_empty, long long * out_nodes)
+{
+    long n = 0;
+    int rc = dep_is_empty_batch(ctx, nb, (const R32 *)mats, rows, cols, out_empty, &n);
+    if (out_nodes) *out_nodes = n;
+    return rc;
+}
+
 // ---- rational row elimination ---------------------------------------------------------------
 int xpg_lineq_reduce_batch_rat32(xpg_ctx * ctx, int nb, xpg_rat32 * mats, int rows, int cols, int rhs_idx,
                                  int is_intersect, int32_t * out_rows, int32_t * out_ok)

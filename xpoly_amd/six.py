@@ -233,6 +233,31 @@ class MIP:
         return self._solve(False, tgtf, vc, eq, leq, is_bin, rational_indicator)
 
 
+def mip_batch(ctx, is_max, is_bin, tgtf, leq):
+    """nb independent rational MIPs (x >= 0, inequalities only) advanced in lock step.
+    tgtf [nb, cols(,2)], leq [nb, rows, cols(,2)]. Returns (status[nb], v[nb,2], sol[nb,cols,2], nodes)."""
+    tgtf = as_kind(tgtf, RAT); leq = as_kind(leq, RAT)
+    nb, rows, cols = leq.shape[0], leq.shape[1], leq.shape[2]
+    st = np.zeros(nb, dtype=np.int32); v = empty_kind((nb,), RAT); sol = empty_kind((nb, cols), RAT)
+    nodes = C.c_longlong()
+    ctx.check(lib().xpg_mip_batch_rat32(ctx._h, C.c_int(nb), C.c_int(int(is_max)), C.c_int(int(is_bin)), vp(tgtf),
+                                        vp(leq), C.c_int(rows), C.c_int(cols), vp(st), vp(v), vp(sol),
+                                        C.byref(nodes)), "xpg_mip_batch_rat32")
+    return st, v, sol, nodes.value
+
+
+def dep_is_empty_batch(ctx, mats):
+    """DepPoly::is_empty (src/eng/poly.cpp:530-573) for a stack of dependence polyhedra
+    [nb, rows, cols(,2)] with the constant in the last column. Returns (empty[nb], nodes)."""
+    mats = as_kind(mats, RAT)
+    nb, rows, cols = mats.shape[0], mats.shape[1], mats.shape[2]
+    out = np.zeros(nb, dtype=np.int32)
+    nodes = C.c_longlong()
+    ctx.check(lib().xpg_dep_is_empty_batch_rat32(ctx._h, C.c_int(nb), vp(mats), C.c_int(rows), C.c_int(cols),
+                                                 vp(out), C.byref(nodes)), "xpg_dep_is_empty_batch_rat32")
+    return out, nodes.value
+
+
 def has_solution(ctx, leq, eq, vc, rhs_idx, is_int_sol, is_unique_sol):
     """Lineq::has_solution (src/com/linsys.cpp:830-906) on rational systems."""
     vc = as_kind(vc, RAT)
