@@ -55,3 +55,17 @@ def test_status_codes_match_reference():
     for k, v in want.items():
         m = re.search(r"#define\s+%s\s+(-?\d+)" % k, hdr)
         assert m and int(m.group(1)) == v, k
+
+
+def test_header_is_plain_c99_and_links():
+    """The drop-in boundary is a C ABI: a C99 translation unit includes the header, links the
+    library and (without a GPU) gets XPG_ERR_NO_DEVICE back instead of a crash."""
+    import subprocess
+    _lib()
+    exe = os.path.join(ROOT, "tests", "cxx", "abi_c99")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cxx", "abi_c99.c"), "-o", exe,
+                           "-L", os.path.join(ROOT, "xpoly_amd"), "-lxpoly_amd",
+                           "-Wl,-rpath," + os.path.join(ROOT, "xpoly_amd")])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "libxpoly_amd.so")
+SO_PATH = os.environ.get("XPG_SO_PATH") or os.path.join(HERE, "libxpoly_amd.so")   # override: A/B builds
 
 XPG_RUNNING = -1000
 ERRORS = {-1: "XPG_ERR_HIP", -2: "XPG_ERR_ALLOC", -3: "XPG_ERR_SHAPE", -4: "XPG_ERR_UNSUPPORTED",

@@ -167,17 +167,32 @@ template <class S> __device__ void sm_pivot_fast(Small<S> & P, int nv, int bv, S
         P.obj[j] = add(t, P.obj[j]);
     }
     for (int i = threadIdx.x; i < P.R; i += blockDim.x)
-        if (i != r) P.k[i] = neg(P.tab[i * ld + nv]);
+        P.k[i] = i != r ? neg(P.tab[i * ld + nv]) : zero<S>();
     __syncthreads();
     {
         const int CW = blockDim.x >= 128 && W > 64 ? 128 : 64;
         const int tx = threadIdx.x % CW, ty = threadIdx.x / CW, ny = blockDim.x / CW;
+        // Four rows of LDS reads are issued before the first use: the loop is latency-bound
+        // (one dependent ds_read -> mul -> add -> ds_write chain per cell otherwise).
+        const int last = P.R - 1;
+#ifndef XPG_EXP_NOSWEEP      /* timing experiment only: results are wrong without the sweep */
         for (int j = tx; j < W; j += CW) {
             const S ej = P.e[j];
-            S * p = P.tab + ty * ld + j;
-            for (int i = ty; i < P.R; i += ny, p += ny * ld)
-                if (i != r) *p = add(*p, mul(P.k[i], ej));
+            for (int i0 = ty; i0 < P.R; i0 += ny * 4) {
+                const int i1 = i0 + ny, i2 = i0 + 2 * ny, i3 = i0 + 3 * ny;
+                // loads are unconditional (row index clamped), stores are guarded
+                const S a0 = P.tab[min(i0, last) * ld + j], a1 = P.tab[min(i1, last) * ld + j];
+                const S a2 = P.tab[min(i2, last) * ld + j], a3 = P.tab[min(i3, last) * ld + j];
+                const S k0 = P.k[min(i0, last)], k1 = P.k[min(i1, last)], k2 = P.k[min(i2, last)], k3 = P.k[min(i3, last)];
+                if (i0 != r) P.tab[i0 * ld + j] = add(a0, mul(k0, ej));
+                if (i1 <= last && i1 != r) P.tab[i1 * ld + j] = add(a1, mul(k1, ej));
+                if (i2 <= last && i2 != r) P.tab[i2 * ld + j] = add(a2, mul(k2, ej));
+                if (i3 <= last && i3 != r) P.tab[i3 * ld + j] = add(a3, mul(k3, ej));
+            }
         }
+#else
+        (void)last; (void)tx; (void)ty; (void)ny;
+#endif
     }
     if (threadIdx.x == 0) {
         P.nv[nv] = 0; P.nv[bv] = 1; P.bv[nv] = 1; P.bv[bv] = 0;
@@ -450,7 +465,7 @@ template <class S> __host__ __device__ inline size_t small_lds_bytes(int R, int 
     return (b + 15) & ~(size_t)15;
 }
 
-template <class S> __global__ void k_batch(int nb, const S * tgtf, const S * leq, int m, int cols,
+template <class S> __global__ __launch_bounds__(256) void k_batch(int nb, const S * tgtf, const S * leq, int m, int cols,
                                            int is_max, unsigned max_iter, int32_t * out_status,
                                            S * out_v, S * out_sol, uint32_t * out_pivots, int raw_sol)
 {
@@ -549,7 +564,7 @@ int batch_dev(xpg_ctx * ctx, int is_max, int nb, const S * tgtf, const S * leq, 
     const int cells = R * (V + R + 2);
     int threads = cells >= 2048 ? 256 : (cells >= 1024 ? 128 : 64);
     if (const char * c = getenv("XPG_BATCH_COUNT_CLOSES")) { if (c[0] == '1') raw_sol |= 2; }   // profiling aid
-    if (const char * t = getenv("XPG_BATCH_THREADS")) { const int v = atoi(t); if (v >= 64 && v <= 1024 && v % 64 == 0) threads = v; }
+    if (const char * t = getenv("XPG_BATCH_THREADS")) { const int v = atoi(t); if (v >= 64 && v <= 256 && v % 64 == 0) threads = v; }
     const int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
     int grid = 256 * (per_cu > 16 ? 16 : per_cu) * 4;
     if (grid > nb) grid = nb;
