@@ -21,6 +21,9 @@ template <class S> struct Small {
     int * sh_w;                     // 8 words of broadcast scratch
     unsigned pivots;
     unsigned closes;                // iterations that ended in disableNV (no pivot), for profiling
+#ifdef XPG_EXP_STAMPS
+    long long t_sel, t_b1, t_piv, t_stage;
+#endif
 };
 
 template <class S> __device__ __forceinline__ bool sm_seen(const Small<S> & P, int nv, int b)
@@ -93,13 +96,39 @@ template <class S> __device__ int sm_ratio(const Small<S> & P, int nv)
 // per pivot instead of ten.
 enum { ACT_PIVOT = 0, ACT_OPT = 1, ACT_FINDPAIR = 2, ACT_CLOSE = 3 };
 
+// Wave-wide arg-min on the VALU: four DPP row_shr steps reduce each 16-lane row into its last
+// lane, four v_readlane pairs fetch the row results, the final combine is scalar. This
+// replaces six dependent ds_bpermute stages (LDS-latency each) in the selection chain.
+template <int CTRL> __device__ __forceinline__ int dpp_row_shr(int own)
+{ return __builtin_amdgcn_update_dpp(own, own, CTRL, 0xf, 0xf, false); }   // lanes without a source keep `own`
+
+template <class S, int CTRL> __device__ __forceinline__ Cand<S> dpp_step(Cand<S> c)
+{
+    int w[2];
+    __builtin_memcpy(w, &c.q, 8);
+    w[0] = dpp_row_shr<CTRL>(w[0]); w[1] = dpp_row_shr<CTRL>(w[1]);
+    Cand<S> t;
+    __builtin_memcpy(&t.q, w, 8);
+    t.idx = dpp_row_shr<CTRL>(c.idx);
+    return better(c, t);
+}
+template <class S> __device__ __forceinline__ Cand<S> read_lane(Cand<S> c, int lane)
+{
+    int w[2];
+    __builtin_memcpy(w, &c.q, 8);
+    w[0] = __builtin_amdgcn_readlane(w[0], lane); w[1] = __builtin_amdgcn_readlane(w[1], lane);
+    Cand<S> t;
+    __builtin_memcpy(&t.q, w, 8);
+    t.idx = __builtin_amdgcn_readlane(c.idx, lane);
+    return t;
+}
 template <class S> __device__ __forceinline__ Cand<S> wave_argmin(Cand<S> c)
 {
-    for (int o = 32; o > 0; o >>= 1) {
-        Cand<S> t; t.q = shfl_xor_s(c.q, o); t.idx = __shfl_xor(c.idx, o);
-        c = better(c, t);
-    }
-    return c;
+    c = dpp_step<S, 0x111>(c);      // row_shr:1
+    c = dpp_step<S, 0x112>(c);      // row_shr:2
+    c = dpp_step<S, 0x114>(c);      // row_shr:4
+    c = dpp_step<S, 0x118>(c);      // row_shr:8 -> lanes 15, 31, 47, 63 hold their row's winner
+    return better(better(read_lane(c, 15), read_lane(c, 31)), better(read_lane(c, 47), read_lane(c, 63)));
 }
 
 // Pricing (lpsol.h:1054-1069) + ratio test (lpsol.h:553-663) + genPair by wave 0.
@@ -138,7 +167,7 @@ template <class S> __device__ void sm_select_wave0(Small<S> & P)
         else { action = ACT_PIVOT; row = best.idx; leave = P.eq2bv[row]; }
     }
     if (lane == 0) {
-        P.sh_w[0] = action; P.sh_w[1] = first; P.sh_w[2] = leave;
+        P.sh_w[0] = action; P.sh_w[1] = first; P.sh_w[2] = leave; P.sh_w[3] = row;
         if (action == ACT_PIVOT) {
             if (!sm_seen(P, first, leave)) {                              // genPair, lpsol.h:100-104
                 P.ppt[first * P.pw + (leave >> 5)] |= 1u << (leave & 31);
@@ -152,9 +181,12 @@ template <class S> __device__ void sm_select_wave0(Small<S> & P)
 }
 
 // SIX::pivot (lpsol.h:1456-1511) with the pivot element and c_nv handed in.
-template <class S> __device__ void sm_pivot_fast(Small<S> & P, int nv, int bv, S piv, S cnv)
+template <class S> __device__ void sm_pivot_fast(Small<S> & P, int nv, int bv, int r, S piv, S cnv)
 {
-    const int r = P.bv2eq[bv], W = P.W, ld = P.ld;
+#ifdef XPG_EXP_STAMPS
+    const long long t_in = clock64();
+#endif
+    const int W = P.W, ld = P.ld;
     const S s = div(one<S>(), piv);
     const int smode = scale_mode(s), cmode = scale_mode(cnv);
     for (int j = threadIdx.x; j < W; j += blockDim.x) {
@@ -169,6 +201,9 @@ template <class S> __device__ void sm_pivot_fast(Small<S> & P, int nv, int bv, S
     for (int i = threadIdx.x; i < P.R; i += blockDim.x)
         P.k[i] = i != r ? neg(P.tab[i * ld + nv]) : zero<S>();
     __syncthreads();
+#ifdef XPG_EXP_STAMPS
+    P.t_stage += clock64() - t_in;
+#endif
     {
         const int CW = blockDim.x >= 128 && W > 64 ? 128 : 64;
         const int tx = threadIdx.x % CW, ty = threadIdx.x / CW, ny = blockDim.x / CW;
@@ -215,14 +250,26 @@ template <class S> __device__ int sm_solve(Small<S> & P, unsigned max_iter, S & 
     const bool fast = rhs <= 128 && P.R <= 64;
     while (done < max_iter) {
         if (fast) {
+#ifdef XPG_EXP_STAMPS        /* diagnostic build only: where does a pivot's time go (cycles via s_memtime) */
+            const long long t0 = clock64();
+            if (threadIdx.x < 64) sm_select_wave0(P);
+            const long long t1 = clock64();
+            __syncthreads();
+            const long long t2 = clock64();
+            P.t_sel += t1 - t0; P.t_b1 += t2 - t1;
+#else
             if (threadIdx.x < 64) sm_select_wave0(P);
             __syncthreads();
+#endif
             const int action = P.sh_w[0];
             if (action == ACT_PIVOT) {
                 const int enter_f = P.sh_w[1], leave_f = P.sh_w[2];
                 const S * park = (const S *)P.sh_c;
                 const S piv = park[0], cnv = park[1];
-                sm_pivot_fast(P, enter_f, leave_f, piv, cnv);
+                sm_pivot_fast(P, enter_f, leave_f, P.sh_w[3], piv, cnv);
+#ifdef XPG_EXP_STAMPS
+                P.t_piv += clock64() - t2;
+#endif
                 done++;
                 continue;
             }
@@ -499,6 +546,9 @@ template <class S> __global__ __launch_bounds__(256) void k_batch(int nb, const 
         src.leq = leq + (size_t)lp * m * cols; src.tgtf = tgtf + (size_t)lp * cols;
         src.m = m; src.cols = cols; src.is_max = is_max;
         P.pivots = 0; P.closes = 0;
+#ifdef XPG_EXP_STAMPS
+        P.t_sel = P.t_b1 = P.t_piv = P.t_stage = 0;
+#endif
         __syncthreads();
         // stage1 trigger (lpsol.h:1794-1803)
         if (threadIdx.x == 0) { P.sh_w[3] = 0; P.sh_w[4] = 0; }
@@ -539,6 +589,13 @@ template <class S> __global__ __launch_bounds__(256) void k_batch(int nb, const 
         } else if (threadIdx.x == 0) {
             out_v[lp] = zero<S>();
         }
+#ifdef XPG_EXP_STAMPS
+        if ((threadIdx.x & 63) == 0) {   // per wave: cycles in selection, barrier-1 wait, pivot, staging part of it
+            S * dbg = out_sol + (size_t)lp * cols + 8 * (threadIdx.x >> 6);
+            double v4[4] = { (double)P.t_sel, (double)P.t_b1, (double)P.t_piv, (double)P.t_stage };
+            for (int q = 0; q < 4; q++) __builtin_memcpy(&dbg[q], &v4[q], 8);
+        }
+#endif
         if (threadIdx.x == 0) {
             out_status[lp] = status;
             if (out_pivots) out_pivots[lp] = getenv_closes ? P.closes : P.pivots;
