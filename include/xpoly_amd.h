@@ -218,6 +218,13 @@ int xpg_lineq_remove_iden_batch_rat32(xpg_ctx * ctx, int nb, xpg_rat32 * mats, i
 int xpg_lineq_fme_batch_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols,
                               int rhs_idx, int u, int darkshadow, xpg_rat32 * outs, int cap_rows,
                               int32_t * out_rows, int32_t * out_ok);
+/* Lineq::calcBound, src/com/linsys.cpp:1047-1078, for nb systems: for each variable j every
+ * other variable is eliminated (innermost first) by chained fme launches that stay on the
+ * device.  bounds is [nb][rhs_idx][cap_rows][cols], out_rows is [nb][rhs_idx];
+ * out_ok[b] = 1, 0 (an elimination found the system inconsistent) or -rows_needed. */
+int xpg_lineq_calc_bound_batch_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols,
+                                     int rhs_idx, int cap_rows, xpg_rat32 * bounds, int32_t * out_rows,
+                                     int32_t * out_ok);
 int xpg_rat_rank_batch(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols,
                        int32_t * out_rank);
 int xpg_rat_det_batch(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int n, xpg_rat32 * out_det);

@@ -213,6 +213,20 @@ class _Lib:
                   _vp(vc), C.c_int(vc.shape[0]), C.c_int(cols), C.c_int(rhs_idx),
                   C.c_int(int(is_int_sol)), C.c_int(int(is_unique_sol)))
 
+    def calc_bound(self, mat, rhs_idx, cap_rows=None):
+        """Lineq::calcBound (linsys.cpp:1047-1078): (ok, [bounds of variable j as rows x cols x 2])."""
+        mat = as_kind(mat, RAT)
+        rows, cols = mat.shape[0], mat.shape[1]
+        cap = cap_rows or max(16, 4 * rows * rows)
+        out = empty_kind((rhs_idx, cap, cols), RAT)
+        orows = np.zeros(rhs_idx, dtype=np.int32)
+        fn = self._f("calc_bound")
+        fn.restype = C.c_int
+        ok = fn(_vp(mat), C.c_int(rows), C.c_int(cols), C.c_int(rhs_idx), _vp(out), C.c_int(cap), _vp(orows))
+        if ok < 0:
+            raise RuntimeError("calc_bound result does not fit")
+        return ok, [out[j, : orows[j]].copy() for j in range(rhs_idx)]
+
     def rat_rank(self, mat):
         mat = as_kind(mat, RAT)
         fn = self._f("rat_rank")

@@ -213,6 +213,24 @@ inline bool fme(const RM & coeff, int rhs, int u, bool darkshadow, RM & res)
     return true;                                   // 0 x cols, as res.reinit(0, cols) leaves it
 }
 
+// Lineq::calcBound (linsys.cpp:1047-1078): for each variable j eliminate every other
+// variable (innermost first) by fme; what is left bounds j alone. Returns false at the
+// first inconsistent elimination (bounds of earlier variables stay filled).
+inline bool calc_bound(const RM & coeff, int rhs, std::vector<RM> & limits)
+{
+    limits.assign(rhs, RM());
+    for (int j = 0; j < rhs; j++) {
+        RM work = coeff, res;
+        for (int i = rhs - 1; i >= 0; i--) {
+            if (i == j) continue;
+            if (!fme(work, rhs, i, false, res)) return false;
+            work = res;
+        }
+        limits[j] = work;
+    }
+    return true;
+}
+
 // SIX::reviseTargetFunc (lpsol.h:2053-2074).
 inline void revise_target(std::vector<R32> & tgtf, const RM & eqs, const RM & leq, int rhs)
 {

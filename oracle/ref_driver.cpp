@@ -315,6 +315,26 @@ int ref_has_solution(const void * leq, int leq_rows, const void * eq,
                             is_unique_sol != 0) ? 1 : 0;
 }
 
+// Lineq::calcBound (linsys.cpp:1047): out is [rhs_idx][cap_rows][cols], out_rows[rhs_idx].
+int ref_calc_bound(const void * in, int rows, int cols, int rhs_idx, void * out, int cap_rows, int * out_rows)
+{
+    RMat m;
+    load(m, in, rows, cols);
+    RMat * v = new RMat[rhs_idx];
+    List<RMat*> bd;
+    for (int i = 0; i < rhs_idx; i++) bd.append_tail(&v[i]);
+    Lineq lin(&m, rhs_idx);
+    bool ok = lin.calcBound(bd);
+    int rc = ok ? 1 : 0;
+    for (int j = 0; j < rhs_idx; j++) {
+        out_rows[j] = v[j].get_row_size();
+        if ((int)v[j].get_row_size() > cap_rows) { rc = -1; break; }
+        if (v[j].size() > 0) store(v[j], (char*)out + (size_t)j * cap_rows * cols * sizeof(R32));
+    }
+    delete [] v;
+    return rc;
+}
+
 // Matrix<Rational>::rank / det / inv (matt.h:2614, :1621, :1743).
 int ref_rat_rank(const void * in, int rows, int cols)
 {

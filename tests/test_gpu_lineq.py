@@ -87,6 +87,39 @@ def test_batched_systems_match_oracle(lq, port, rows, nv):
             assert rows_equal(res[b], wres), (b, dark)
 
 
+def test_calc_bound_chain_matches_oracle(lq, port):
+    """Lineq::calcBound: chained fme launches on the device; incl. the authors' example
+    (linsys.cpp:1035-1040): 1<=i1<=4, 5-i1<=i2<=12-i1  =>  1<=i1<=4 and 1<=i2<=11."""
+    ex = gen.to_rat(np.array([[-1, 0, -1], [1, 0, 4], [-1, -1, -5], [1, 1, 12]], dtype=np.int32))
+    ok, bounds = lq.calcBound(ex, 2)
+    assert ok[0] == 1
+    b1 = sorted((int(r[0][0]), int(r[2][0])) for r in bounds[0][0])
+    b2 = sorted((int(r[1][0]), int(r[2][0])) for r in bounds[0][1])
+    assert b1 == [(-1, -1), (1, 4)] and b2 == [(-1, -1), (1, 11)]
+    g = json.load(open(os.path.join(GOLD, "g5_lineq.json")))
+    for c in g["calc_bound"]:                      # outputs of the real reference
+        mat = dec(c["mat"]["data"], c["mat"]["shape"])
+        ok, bounds = lq.calcBound(mat, c["rhs"], cap_rows=256)
+        assert ok[0] == c["ok"]
+        if c["ok"]:
+            for j, w in enumerate(c["limits"]):
+                assert rows_equal(bounds[0][j], dec(w["data"], w["shape"]))
+    rng = np.random.default_rng(8)
+    seen = set()
+    for (rows, nv) in ((3, 2), (5, 3), (6, 4)):
+        nb = 32
+        mats = np.stack([gen.random_system(rng, rows, nv) for _ in range(nb)])
+        ok, bounds = lq.calcBound(mats, nv, cap_rows=256)
+        for b in range(nb):
+            wok, wb = port.calc_bound(mats[b], nv, cap_rows=256)
+            assert ok[b] == wok, (rows, nv, b, ok[b], wok)
+            seen.add(wok)
+            if wok:
+                for j in range(nv):
+                    assert rows_equal(bounds[b][j], wb[j]), (rows, nv, b, j)
+    assert seen == {0, 1}
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 6, 9])
 def test_batched_gauss_match_oracle(lq, port, n):
     rng = np.random.default_rng(n)

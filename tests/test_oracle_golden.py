@@ -177,6 +177,14 @@ def test_g5_lineq_and_gauss(port):
         assert r == c["result"]
         seen.add(r)
     assert seen == {0, 1}
+    for c in g["calc_bound"]:
+        mat = dec(c["mat"]["data"], RAT, c["mat"]["shape"])
+        ok, lim = port.calc_bound(mat, c["rhs"])
+        assert ok == c["ok"]
+        if ok:
+            for got, w in zip(lim, c["limits"]):
+                want = dec(w["data"], RAT, w["shape"])
+                assert (got.shape[0] == 0 and want.shape[0] == 0) or same(got, want)
     for c in g["gauss"]:
         sq = dec(c["sq"]["data"], RAT, c["sq"]["shape"])
         assert port.rat_rank(sq) == c["rank"]

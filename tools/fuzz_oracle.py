@@ -139,6 +139,12 @@ def fuzz_lineq(ref, port, n, rng):
         u = int(rng.integers(0, nv))
         r = ref.fme(mat, rhs, u); o = port.fme(mat, rhs, u)
         assert r[0] == o[0] and same(r[1], o[1]), ("fme", it, u, mat[..., 0], r, o)
+        if rows <= 6 and nv <= 4:
+            r = ref.calc_bound(mat, rhs); o = port.calc_bound(mat, rhs)
+            assert r[0] == o[0], ("calc_bound", it, mat[..., 0], r[0], o[0])
+            if r[0]:
+                assert all(same(a, b) or (a.shape[0] == 0 and b.shape[0] == 0) for a, b in zip(r[1], o[1])), \
+                    ("calc_bound", it, mat[..., 0], r[1], o[1])
         sq = gen.random_square(rng, int(rng.integers(1, 6)))
         assert ref.rat_rank(sq) == port.rat_rank(sq), ("rank", sq[..., 0])
         assert ref.rat_det(sq) == port.rat_det(sq), ("det", sq[..., 0], ref.rat_det(sq), port.rat_det(sq))

@@ -191,6 +191,15 @@ def main():
         g5["gauss"].append(dict(sq=dict(shape=list(sq.shape), data=enc(sq, RAT)), rank=ref.rat_rank(sq),
                                 det=list(ref.rat_det(sq)), inv_ok=okinv, inv=enc(inv, RAT) if okinv else None,
                                 rect=dict(shape=list(rk.shape), data=enc(rk, RAT)), rect_rank=ref.rat_rank(rk)))
+    # Lineq::calcBound incl. the authors' example (linsys.cpp:1035-1040)
+    g5["calc_bound"] = []
+    ex = gen.to_rat(np.array([[-1, 0, -1], [1, 0, 4], [-1, -1, -5], [1, 1, 12]], dtype=np.int32))
+    systems = [ex] + [gen.random_system(rng, int(rng.integers(2, 7)), int(rng.integers(1, 5))) for _ in range(24)]
+    for mat in systems:
+        nv = mat.shape[1] - 1
+        ok, lim = ref.calc_bound(mat, nv)
+        g5["calc_bound"].append(dict(mat=dict(shape=list(mat.shape), data=enc(mat, RAT)), rhs=nv, ok=ok,
+                                     limits=[dict(shape=list(l.shape), data=enc(l, RAT)) for l in lim] if ok else None))
     json.dump(g5, open(os.path.join(OUT, "g5_lineq.json"), "w"))
     print("golden vectors written to", OUT)
 

@@ -63,11 +63,66 @@ inline int lineq_fme_batch(xpg_ctx * ctx, int nb, const R32 * mats, int rows, in
     XPG_TRY(hipMemsetAsync(dout.p, 0, bo, ctx->stream));
     XPG_TRY(hipFuncSetAttribute((const void *)k_fme_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_fme_batch, dim3(lineq_grid(nb)), dim3(64), lds, ctx->stream, nb, (const R32 *)di.p, rows,
-                       cols, rhs, u, darkshadow, (R32 *)dout.p, cap, (int *)dr.p, (int *)dk.p, res_global);
+                       (const int *)0, cols, rhs, u, darkshadow, (R32 *)dout.p, cap, (int *)dr.p, (int *)dk.p,
+                       res_global, (int *)0);
     XPG_TRY(hipGetLastError());
     XPG_TRY(hipMemcpyAsync(outs, dout.p, bo, hipMemcpyDeviceToHost, ctx->stream));
     XPG_TRY(hipMemcpyAsync(out_rows, dr.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
     XPG_TRY(hipMemcpyAsync(out_ok, dk.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+    XPG_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// Lineq::calcBound (linsys.cpp:1047-1078) for nb systems at once: for every variable j the
+// other variables are eliminated innermost-first by chained k_fme_batch launches that stay on
+// the device (ragged row counts travel in an int array). bounds is [nb][rhs][cap][cols],
+// out_rows [nb][rhs]; out_ok[b] = 1, 0 (inconsistent) or -needed_rows (cap too small).
+inline int lineq_calc_bound_batch(xpg_ctx * ctx, int nb, const R32 * mats, int rows, int cols, int rhs, int cap,
+                                  R32 * bounds, int32_t * out_rows, int32_t * out_ok)
+{
+    if (!ctx || nb < 0 || !mats || !bounds || rows <= 0 || cols <= 1 || rhs < 1 || rhs >= cols || cap < rows ||
+        !out_rows || !out_ok)
+        return XPG_ERR_SHAPE;
+    if (nb == 0) return 0;
+    size_t lds = lineq_lds_bytes(cap, cols) + (size_t)cap * cols * 8;
+    int res_global = 0;
+    if (lds > 64 * 1024) { res_global = 1; lds = lineq_lds_bytes(cap, cols) + 16; }
+    if (lds > 160 * 1024 || cap > 32767) return XPG_ERR_UNSUPPORTED;
+    const size_t slot = (size_t)cap * cols * 8, bsz = (size_t)nb * slot;
+    DevBuf d0, da, db, ra, rb, step_ok, chain, dres, drows;
+    XPG_TRY(d0.alloc(bsz)); XPG_TRY(da.alloc(bsz)); XPG_TRY(db.alloc(bsz));
+    XPG_TRY(ra.alloc((size_t)nb * 4)); XPG_TRY(rb.alloc((size_t)nb * 4)); XPG_TRY(step_ok.alloc((size_t)nb * 4));
+    XPG_TRY(chain.alloc((size_t)nb * 4)); XPG_TRY(dres.alloc(bsz * rhs)); XPG_TRY(drows.alloc((size_t)nb * rhs * 4));
+    // the input, repacked to the [nb][cap][cols] slot layout
+    XPG_TRY(hipMemsetAsync(d0.p, 0, bsz, ctx->stream));
+    XPG_TRY(hipMemcpy2DAsync(d0.p, slot, mats, (size_t)rows * cols * 8, (size_t)rows * cols * 8, nb,
+                             hipMemcpyHostToDevice, ctx->stream));
+    std::vector<int32_t> ones(nb, 1), init_rows(nb, rows);
+    XPG_TRY(hipMemcpyAsync(chain.p, ones.data(), (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream));
+    XPG_TRY(hipFuncSetAttribute((const void *)k_fme_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (int j = 0; j < rhs; j++) {
+        void * cur = d0.p; void * cur_rows = ra.p;
+        XPG_TRY(hipMemcpyAsync(ra.p, init_rows.data(), (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream));
+        bool flip = false;
+        for (int i = rhs - 1; i >= 0; i--) {
+            if (i == j) continue;
+            void * nxt = flip ? da.p : db.p;
+            void * nxt_rows = (cur_rows == ra.p) ? rb.p : ra.p;
+            hipLaunchKernelGGL(k_fme_batch, dim3(lineq_grid(nb)), dim3(64), lds, ctx->stream, nb, (const R32 *)cur, cap,
+                               (const int *)cur_rows, cols, rhs, i, 0, (R32 *)nxt, cap, (int *)nxt_rows,
+                               (int *)step_ok.p, res_global, (int *)chain.p);
+            cur = nxt; cur_rows = nxt_rows; flip = !flip;
+        }
+        XPG_TRY(hipGetLastError());
+        // bounds of variable j: slot j of every system
+        XPG_TRY(hipMemcpy2DAsync((char *)dres.p + (size_t)j * slot, slot * rhs, cur, slot, slot, nb,
+                                 hipMemcpyDeviceToDevice, ctx->stream));
+        XPG_TRY(hipMemcpy2DAsync((char *)drows.p + (size_t)j * 4, (size_t)rhs * 4, cur_rows, 4, 4, nb,
+                                 hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    XPG_TRY(hipMemcpyAsync(bounds, dres.p, bsz * rhs, hipMemcpyDeviceToHost, ctx->stream));
+    XPG_TRY(hipMemcpyAsync(out_rows, drows.p, (size_t)nb * rhs * 4, hipMemcpyDeviceToHost, ctx->stream));
+    XPG_TRY(hipMemcpyAsync(out_ok, chain.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
     XPG_TRY(hipStreamSynchronize(ctx->stream));
     return 0;
 }

@@ -260,17 +260,23 @@ __global__ __launch_bounds__(64) void k_reduce_batch(int nb, R32 * mats, int row
 // Lineq::fme (linsys.cpp:656-774) for one system per wave. out has cap rows.
 // res_global != 0: the P*N result does not fit LDS next to the input, so it is built and
 // reduced directly in its HBM output slot (flat pointers; L2-resident at these sizes).
-__global__ __launch_bounds__(64) void k_fme_batch(int nb, const R32 * mats, int rows, int cols, int rhs, int u,
-                                                  int darkshadow, R32 * outs, int cap, int * out_rows, int * out_ok,
-                                                  int res_global)
+// Inputs are [nb][cap_in][cols] with in_rows[b] live rows each (NULL: all cap_in rows), which
+// lets eliminations be chained on the device (Lineq::calcBound). chain_ok (may be NULL) carries
+// a system's state through a chain: only systems whose entry is 1 are processed, and the entry
+// becomes 0 when this elimination finds the system inconsistent.
+__global__ __launch_bounds__(64) void k_fme_batch(int nb, const R32 * mats, int cap_in, const int * in_rows, int cols,
+                                                  int rhs, int u, int darkshadow, R32 * outs, int cap, int * out_rows,
+                                                  int * out_ok, int res_global, int * chain_ok)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    // LDS layout: [result matrix (cap x cols) unless res_global] [normalised input (rows x cols)] [scratch]
+    // LDS layout: [result matrix (cap x cols) unless res_global] [normalised input (cap_in x cols)] [scratch]
     WMat res; res.a = (R32 *)lds; res.ld = cols; res.c = cols;
     WMat tmp; tmp.a = res_global ? (R32 *)lds : res.a + (size_t)cap * cols; tmp.ld = cols;
-    WScratch s = carve_scratch((unsigned char *)(tmp.a + (size_t)rows * cols), cap);
+    WScratch s = carve_scratch((unsigned char *)(tmp.a + (size_t)cap_in * cols), cap > cap_in ? cap : cap_in);
     for (int b = blockIdx.x; b < nb; b += gridDim.x) {
-        const R32 * g = mats + (size_t)b * rows * cols;
+        if (chain_ok && chain_ok[b] != 1) { if (lane_id() == 0) { out_rows[b] = 0; out_ok[b] = 0; } continue; }
+        const int rows = in_rows ? in_rows[b] : cap_in;
+        const R32 * g = mats + (size_t)b * cap_in * cols;
         if (res_global) res.a = outs + (size_t)b * cap * cols;
         w_load(tmp, g, rows, cols);
         res.r = 0;
@@ -350,6 +356,7 @@ __global__ __launch_bounds__(64) void k_fme_batch(int nb, const R32 * mats, int 
         if (lane_id() == 0) {
             out_rows[b] = status_rows < 0 ? res.r : -status_rows;       // negative: did not fit, needs that many rows
             out_ok[b] = ok ? 1 : 0;
+            if (chain_ok && !ok) chain_ok[b] = status_rows < 0 ? 0 : -status_rows;
         }
         wave_sync();
     }

@@ -448,6 +448,9 @@ int xpg_lineq_fme_batch_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int
     return lineq_fme_batch(ctx, nb, (const R32 *)mats, rows, cols, rhs_idx, u, darkshadow, (R32 *)outs, cap_rows,
                            out_rows, out_ok);
 }
+int xpg_lineq_calc_bound_batch_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols, int rhs_idx,
+                                     int cap_rows, xpg_rat32 * bounds, int32_t * out_rows, int32_t * out_ok)
+{ return lineq_calc_bound_batch(ctx, nb, (const R32 *)mats, rows, cols, rhs_idx, cap_rows, (R32 *)bounds, out_rows, out_ok); }
 int xpg_rat_rank_batch(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols, int32_t * out_rank)
 { return out_rank ? gauss_batch(ctx, nb, (const R32 *)mats, rows, cols, 0, out_rank, 0, 0) : XPG_ERR_SHAPE; }
 int xpg_rat_det_batch(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int n, xpg_rat32 * out_det)

@@ -57,6 +57,19 @@ class Lineq:
             raise ValueError("fme result needs %d rows, cap_rows is %d" % (-out_rows.min(), cap))
         return ok, [outs[b, : out_rows[b]].copy() for b in range(nb)]
 
+    def calcBound(self, mats, rhs_idx, cap_rows=None):
+        """Lineq::calcBound (linsys.cpp:1047-1078): chained eliminations on the device.
+        Returns (ok[nb], bounds[b][j] = rows x cols x 2 array bounding variable j alone)."""
+        a = _stack(mats)
+        nb, rows, cols = a.shape[:3]
+        cap = cap_rows or max(16, rows * rows)
+        out = np.zeros((nb, rhs_idx, cap, cols, 2), dtype=np.int32)
+        out_rows = np.zeros((nb, rhs_idx), dtype=np.int32); ok = np.zeros(nb, dtype=np.int32)
+        self.ctx.check(lib().xpg_lineq_calc_bound_batch_rat32(self.ctx._h, C.c_int(nb), vp(a), C.c_int(rows), C.c_int(cols),
+                                                              C.c_int(rhs_idx), C.c_int(cap), vp(out), vp(out_rows), vp(ok)),
+                       "xpg_lineq_calc_bound_batch_rat32")
+        return ok, [[out[b, j, : max(out_rows[b, j], 0)].copy() for j in range(rhs_idx)] for b in range(nb)]
+
     def rank(self, mats):
         a = _stack(mats)
         nb, rows, cols = a.shape[:3]
