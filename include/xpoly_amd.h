@@ -230,6 +230,27 @@ int xpg_rat_rank_batch(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, 
 int xpg_rat_det_batch(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int n, xpg_rat32 * out_det);
 int xpg_rat_inv_batch(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int n, xpg_rat32 * out_inv,
                       int32_t * out_ok);
+/* Matrix<Rational>::rank(&basis, is_unitarize), src/com/matt.h:2614-2726 (caller
+ * src/eng/ldtran.cpp:440-449).  basis is [nb][rows][cols]; basis_rows[b] = rows, except
+ * without unitarising and rank < rows, where the reference returns the rank original rows in
+ * pivot order (matt.h:2710-2719).  Rows past basis_rows[b] are zero. */
+int xpg_rat_rank_basis_batch(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols,
+                             int is_unitarize, int32_t * out_rank, xpg_rat32 * basis,
+                             int32_t * basis_rows);
+/* Matrix<Rational>::null, src/com/matt.h:2546-2584: ns is [nb][cols][cols], column convention. */
+int xpg_rat_null_batch(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols,
+                       xpg_rat32 * ns);
+/* INTMat::hnf, src/com/xmat.cpp:912-992 (with gen_elim_mat :853-868, exgcd comf.cpp:295-321;
+ * caller src/eng/ldtran.cpp:208): h = mat * u, h [nb][rows][cols] lower triangular, u
+ * [nb][cols][cols] unimodular.  INT arithmetic is two's-complement 32 bit.  status[b] = 0, or
+ * XPG_ERR_REF_UNDEFINED where the reference divides by zero (zero diagonal below row 0) or
+ * multiplies by its rows x cols identity read out of bounds (cols > rows, negative diagonal);
+ * h and u of such a matrix are left zero. */
+int xpg_int_hnf_batch(xpg_ctx * ctx, int nb, const int32_t * mats, int rows, int cols, int32_t * h,
+                      int32_t * u, int32_t * status);
+/* INTMat::gcd, src/com/xmat.cpp:996-1030: every row divided by the gcd of its nonzero
+ * magnitudes, in place. */
+int xpg_int_gcd_batch(xpg_ctx * ctx, int nb, int32_t * mats, int rows, int cols);
 
 #ifdef __cplusplus
 }

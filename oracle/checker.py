@@ -247,6 +247,40 @@ class _Lib:
         ok = fn(_vp(mat), C.c_int(mat.shape[0]), _vp(out))
         return ok, out
 
+    def rat_rank_basis(self, mat, unitarize):
+        """Matrix<Rational>::rank(&basis, is_unitarize) (matt.h:2614-2726): (rank, basis)."""
+        mat = as_kind(mat, RAT)
+        rows, cols = mat.shape[0], mat.shape[1]
+        out = empty_kind((rows, cols), RAT)
+        orows = C.c_int()
+        fn = self._f("rat_rank_basis")
+        fn.restype = C.c_int
+        rk = fn(_vp(mat), C.c_int(rows), C.c_int(cols), C.c_int(int(unitarize)), _vp(out), C.byref(orows))
+        return rk, out[: orows.value].copy()
+
+    def rat_null(self, mat):
+        """Matrix<Rational>::null (matt.h:2546-2584): cols x cols, column convention."""
+        mat = as_kind(mat, RAT)
+        out = empty_kind((mat.shape[1], mat.shape[1]), RAT)
+        self._f("rat_null")(_vp(mat), C.c_int(mat.shape[0]), C.c_int(mat.shape[1]), _vp(out))
+        return out
+
+    def int_hnf(self, mat):
+        """INTMat::hnf (xmat.cpp:912-992): (status, h, u) with h = mat * u."""
+        mat = np.ascontiguousarray(mat, dtype=np.int32)
+        rows, cols = mat.shape
+        h = np.zeros((rows, cols), dtype=np.int32); u = np.zeros((cols, cols), dtype=np.int32)
+        fn = self._f("int_hnf")
+        fn.restype = C.c_int
+        st = fn(_vp(mat), C.c_int(rows), C.c_int(cols), _vp(h), _vp(u))
+        return st, h, u
+
+    def int_gcd(self, mat):
+        """INTMat::gcd (xmat.cpp:996-1030)."""
+        mat = np.ascontiguousarray(mat, dtype=np.int32).copy()
+        self._f("int_gcd")(_vp(mat), C.c_int(mat.shape[0]), C.c_int(mat.shape[1]))
+        return mat
+
     def appro_count(self):
         fn = self._f("appro_count")
         fn.restype = C.c_longlong

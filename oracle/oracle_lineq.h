@@ -276,6 +276,193 @@ inline void axpy_row(RM & m, int from, R32 v, int to)                     // mul
     for (int j = 0; j < m.c; j++) m.at(to, j) = add(mul(m.at(from, j), v), m.at(to, j));
 }
 
+// Matrix<Rational>::rank(basis, is_unitarize) (matt.h:2614-2726). Without unitarising, the
+// eliminated trapezoid is returned only when the rank is full; otherwise `basis` becomes the
+// ORIGINAL rows in pivot order (matt.h:2710-2719).
+inline int rank_basis(const RM & in, bool unitarize, RM & basis)
+{
+    RM p = in;
+    std::vector<int> rowpos(p.r);
+    for (int i = 0; i < p.r; i++) rowpos[i] = i;
+    int rankv = 0;
+    for (int row = 0, col = 0; row < p.r && col < p.c; row++, col++) {
+        int swap_row = -1;
+        R32 pivot = R32(0);
+        for (int w = col; w < p.c; w++) {
+            for (int k = row; k < p.r; k++) {
+                R32 t = p.at(k, w);
+                if (eq(t, R32(0))) continue;
+                if (swap_row == -1) {
+                    swap_row = k; pivot = t;
+                    if (eq(pivot, R32(1))) break;
+                } else if (eq(t, R32(1))) {
+                    swap_row = k; pivot = t;
+                    break;
+                } else if (lt(abs_r(pivot), abs_r(t))) {
+                    swap_row = k; pivot = t;
+                }
+            }
+            if (swap_row == -1) continue;
+            swap_rows(p, swap_row, row);
+            std::swap(rowpos[swap_row], rowpos[row]);
+            col = w;
+            break;
+        }
+        if (swap_row == -1) break;
+        if (unitarize && ne(p.at(row, col), R32(1))) scale_row(p, row, div(R32(1), p.at(row, col)));
+        for (int i = unitarize ? 0 : row + 1; i < p.r; i++) {
+            if (i == row || eq(p.at(i, col), R32(0))) continue;
+            R32 t = div(neg(p.at(i, col)), p.at(row, col));
+            axpy_row(p, row, t, i);
+        }
+        rankv++;
+    }
+    if (!unitarize && rankv < in.r) {
+        p = RM(rankv, in.c);
+        for (int i = 0; i < rankv; i++)
+            for (int j = 0; j < in.c; j++) p.at(i, j) = in.at(rowpos[i], j);
+    }
+    basis = p;
+    return rankv;
+}
+
+// Matrix<Rational>::null (matt.h:2546-2584): column-convention basis of the null space.
+inline void null_of(const RM & in, RM & ns)
+{
+    RM tmp;
+    rank_basis(in, true, tmp);
+    ns = RM(in.c, in.c);
+    for (int i = 0; i < in.c; i++) for (int j = 0; j < in.c; j++) ns.at(i, j) = R32(i == j ? 1 : 0);
+    for (int nsrow = 0, row = 0; row < tmp.r; row++) {
+        int col;
+        bool found = false;
+        for (col = row; col < tmp.c; col++)
+            if (!eq(tmp.at(row, col), R32(0))) { nsrow = col; found = true; break; }
+        if (!found) break;
+        ns.at(nsrow, col) = R32(0);
+        for (int k = col + 1; k < tmp.c; k++) ns.at(nsrow, k) = neg(tmp.at(row, k));
+    }
+}
+
+// ---- INTMat (xmat.cpp:853-1030): 32-bit two's-complement integers -------------------------
+typedef Mat<int32_t> IM;
+inline int32_t wmul(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
+inline int32_t wadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+inline int32_t iabs(int32_t a) { return a < 0 ? (int32_t)(0u - (uint32_t)a) : a; }
+
+inline int32_t exgcd_rec(int32_t a, int32_t b, int32_t & x, int32_t & y)     // comf.cpp:295-307
+{
+    if (b == 0) { x = 1; y = 0; return a; }
+    int32_t x1, y1;
+    int32_t g = exgcd_rec(b, a % b, x1, y1);
+    x = y1;
+    y = wadd(x1, -wmul(a / b, y1));
+    return g;
+}
+inline int32_t exgcd(int32_t a, int32_t b, int32_t & x, int32_t & y)         // comf.cpp:312-321
+{
+    int32_t g = exgcd_rec(a, b, x, y);
+    if (g < 0) { g = -g; x = -x; y = -y; }
+    return g;
+}
+inline int32_t sgcd(int32_t x, int32_t y)                                     // comf.cpp:226-243
+{
+    if (x < 0) x = -x;
+    if (y < 0) y = -y;
+    if (x > y) std::swap(x, y);
+    while (x) { int32_t t = x; x = y % x; y = t; }
+    return y;
+}
+
+inline IM imul(const IM & a, const IM & b)                                    // xmat.cpp:99-117
+{
+    IM c(a.r, b.c);
+    for (int i = 0; i < a.r; i++)
+        for (int j = 0; j < b.c; j++) {
+            int32_t t = 0;
+            for (int k = 0; k < a.c; k++) t = wadd(t, wmul(a.at(i, k), b.at(k, j)));
+            c.at(i, j) = t;
+        }
+    return c;
+}
+inline IM ieye(int n) { IM e(n, n); for (int i = 0; i < n; i++) e.at(i, i) = 1; return e; }
+
+// INTMat::hnf (xmat.cpp:912-992): h = this * u, h lower triangular. Written with the
+// reference's own full elimination-matrix products. Returns 0, or ORC_REF_UNDEFINED where the
+// x86-64 reference divides by zero (zero diagonal below row 0, xmat.cpp:956-980) or multiplies
+// by a rows x cols "identity" read out of bounds (cols > rows and a negative diagonal, :936-941).
+inline int int_hnf(const IM & a, IM & h, IM & u)
+{
+    const int n = a.c;
+    u = ieye(n);
+    h = a;
+    const int lim = a.r < a.c ? a.r : a.c;
+    for (int i = 0; i < lim; i++) {
+        for (int j = i + 1; j < n; j++) {
+            if (h.at(i, j) == 0) continue;
+            int32_t aii = h.at(i, i), aij = h.at(i, j), x, y;                 // gen_elim_mat, :853-868
+            if ((aii == INT32_MIN || aij == INT32_MIN)) return ORC_REF_UNDEFINED;
+            int32_t g = exgcd(aii, aij, x, y);
+            IM elim = ieye(n);
+            elim.at(i, i) = x; elim.at(j, i) = y;
+            elim.at(i, j) = -aij / g; elim.at(j, j) = aii / g;
+            u = imul(u, elim);
+            h = imul(h, elim);
+        }
+        if (h.at(i, i) < 0) {
+            if (a.c > a.r) return ORC_REF_UNDEFINED;
+            IM neg = ieye(n);
+            neg.at(i, i) = -1;
+            h = imul(h, neg);
+            u = imul(u, neg);
+        }
+        for (int j = 0; j < i; j++) {
+            if (h.at(i, j) >= 0) continue;
+            if (h.at(i, i) == 0 || h.at(i, j) == INT32_MIN) return ORC_REF_UNDEFINED;
+            int32_t v = iabs(h.at(i, j)) <= iabs(h.at(i, i)) ? 1 : iabs(h.at(i, j) / h.at(i, i)) + 1;
+            IM elim = ieye(n);
+            elim.at(i, j) = v;
+            h = imul(h, elim);
+            u = imul(u, elim);
+        }
+        for (int j = 0; j < i; j++) {
+            if (h.at(i, j) < h.at(i, i)) continue;
+            if (h.at(i, i) == 0) return ORC_REF_UNDEFINED;
+            int32_t d = h.at(i, j) / h.at(i, i);
+            IM elim = ieye(n);
+            elim.at(i, j) = -d;
+            h = imul(h, elim);
+            u = imul(u, elim);
+        }
+    }
+    return 0;
+}
+
+// INTMat::gcd (xmat.cpp:996-1030): divide each row by the gcd of its nonzero magnitudes.
+inline void int_gcd(IM & m)
+{
+    if (m.c == 1) return;
+    for (int i = 0; i < m.r; i++) {
+        uint32_t mn = (uint32_t)-1;
+        bool allzero = true;
+        for (int j = 0; j < m.c; j++) {
+            uint32_t x = (uint32_t)iabs(m.at(i, j));
+            if (x != 0) { mn = mn < x ? mn : x; allzero = false; }
+        }
+        if (mn == 1 || mn == 0 || allzero) continue;
+        uint32_t g = mn;
+        for (int j = 0; j < m.c; j++) {
+            uint32_t q = (uint32_t)iabs(m.at(i, j));
+            if (q != 0 && q != g) {
+                g = (uint32_t)sgcd((int32_t)g, (int32_t)q);
+                if (g == 1) break;
+            }
+        }
+        if (g == 1) continue;
+        for (int j = 0; j < m.c; j++) m.at(i, j) = m.at(i, j) / (int32_t)g;
+    }
+}
+
 // Matrix<Rational>::rank with basis == NULL (matt.h:2614-2726): unitarising Gauss-Jordan.
 inline int rank_of(const RM & in)
 {

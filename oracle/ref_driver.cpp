@@ -360,6 +360,44 @@ int ref_rat_inv(const void * in, int n, void * out)
     return ok ? 1 : 0;
 }
 
+// Matrix<Rational>::rank(&basis, is_unitarize) (matt.h:2614) and null (matt.h:2546).
+int ref_rat_rank_basis(const void * in, int rows, int cols, int unitarize, void * out, int * out_rows)
+{
+    RMat m, b;
+    load(m, in, rows, cols);
+    int rk = (int)m.rank(&b, unitarize != 0);
+    *out_rows = (int)b.get_row_size();
+    if (b.get_row_size() > 0 && b.get_col_size() > 0) store(b, out);
+    return rk;
+}
+
+void ref_rat_null(const void * in, int rows, int cols, void * out)
+{
+    RMat m, ns;
+    load(m, in, rows, cols);
+    m.null(ns);
+    store(ns, out);
+}
+
+// INTMat::hnf / gcd (xmat.cpp:912, :996).
+int ref_int_hnf(const int32_t * in, int rows, int cols, int32_t * h, int32_t * u)
+{
+    INTMat a(rows, cols), hh, uu;
+    for (int i = 0; i < rows; i++) for (int j = 0; j < cols; j++) a.set(i, j, in[i * cols + j]);
+    a.hnf(hh, uu);
+    for (int i = 0; i < rows; i++) for (int j = 0; j < cols; j++) h[i * cols + j] = hh.get(i, j);
+    for (int i = 0; i < cols; i++) for (int j = 0; j < cols; j++) u[i * cols + j] = uu.get(i, j);
+    return 0;
+}
+
+void ref_int_gcd(int32_t * inout, int rows, int cols)
+{
+    INTMat a(rows, cols);
+    for (int i = 0; i < rows; i++) for (int j = 0; j < cols; j++) a.set(i, j, inout[i * cols + j]);
+    a.gcd();
+    for (int i = 0; i < rows; i++) for (int j = 0; j < cols; j++) inout[i * cols + j] = a.get(i, j);
+}
+
 long long ref_appro_count(void) { return g_appro_count; }
 long long ref_reduce_count(void) { return g_red_count; }
 

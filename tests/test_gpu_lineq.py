@@ -120,6 +120,80 @@ def test_calc_bound_chain_matches_oracle(lq, port):
     assert seen == {0, 1}
 
 
+def int_cases(rng, nb, rows, cols):
+    lo = int(rng.choice([2, 4, 10]))
+    a = rng.integers(-lo, lo + 1, size=(nb, rows, cols)).astype(np.int32)
+    a[0] = 0
+    if nb > 3:
+        a[1, :, int(rng.integers(0, cols))] = 0
+        a[2, int(rng.integers(0, rows))] = 0
+        a[3] = np.abs(a[3]) * 6
+    return a
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 1), (2, 2), (3, 3), (4, 4), (6, 6), (5, 3), (6, 2), (3, 5), (8, 8)])
+def test_hnf_gcd_match_oracle(lq, port, rows, cols):
+    """INTMat::hnf / gcd (xmat.cpp:912-1030), one wavefront per matrix; matrices on which the
+    reference itself is undefined must come back as XPG_ERR_REF_UNDEFINED, like the oracle says."""
+    rng = np.random.default_rng(rows * 16 + cols)
+    nb = 96
+    a = int_cases(rng, nb, rows, cols)
+    st, h, u = lq.hnf(a)
+    defined = 0
+    for b in range(nb):
+        wst, wh, wu = port.int_hnf(a[b])
+        assert st[b] == wst, (b, a[b])
+        if wst == 0:
+            defined += 1
+            assert np.array_equal(h[b], wh) and np.array_equal(u[b], wu), (b, a[b], h[b], wh)
+            assert np.array_equal((a[b].astype(np.int64) @ u[b].astype(np.int64)).astype(np.int32), h[b])
+            assert np.array_equal(np.triu(h[b], 1), np.zeros_like(h[b]))          # lower triangular
+    assert defined > 0 or cols > rows
+    k = rng.integers(1, 7, size=(nb, rows, 1)).astype(np.int32)
+    g = lq.gcd(a * k)
+    for b in range(nb):
+        assert np.array_equal(g[b], port.int_gcd(a[b] * k[b])), (b, a[b] * k[b])
+
+
+def test_golden_intmat(lq):
+    g = json.load(open(os.path.join(GOLD, "g7_intmat.json")))
+    for c in g["hnf"]:
+        a = np.array(c["a"], dtype=np.int32)
+        st, h, u = lq.hnf(a)
+        assert st[0] == 0 and h[0].tolist() == c["h"] and u[0].tolist() == c["u"]
+    for c in g["gcd"]:
+        assert lq.gcd(np.array(c["a"], dtype=np.int32))[0].tolist() == c["out"]
+    for c in g["rank_basis"]:
+        m = dec(c["mat"]["data"], c["mat"]["shape"])
+        rk, basis = lq.rankBasis(m, c["unitarize"])
+        assert rk[0] == c["rank"]
+        assert rows_equal(basis[0], dec(c["basis"]["data"], c["basis"]["shape"]))
+    for c in g["null"]:
+        m = dec(c["mat"]["data"], c["mat"]["shape"])
+        assert np.array_equal(lq.null(m)[0], dec(c["ns"]["data"], c["ns"]["shape"]))
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 1), (2, 3), (3, 3), (4, 6), (6, 4), (7, 7)])
+def test_rank_basis_and_null_match_oracle(lq, port, rows, cols):
+    rng = np.random.default_rng(rows * 32 + cols)
+    nb = 64
+    mats = np.stack([gen.random_system(rng, rows, cols - 1) if cols > 1 else gen.random_square(rng, 1)
+                     for _ in range(nb)])
+    if rows > 1:
+        mats[::3, -1] = mats[::3, 0]                    # dependent rows: rank < rows
+    if rows > 2:
+        mats[1::5, 1] = 0
+    for unit in (True, False):
+        rk, basis = lq.rankBasis(mats, unit)
+        for b in range(nb):
+            wrk, wb = port.rat_rank_basis(mats[b], unit)
+            assert rk[b] == wrk, (b, unit)
+            assert rows_equal(basis[b], wb), (b, unit, basis[b][..., 0], wb[..., 0])
+    ns = lq.null(mats)
+    for b in range(nb):
+        assert np.array_equal(ns[b], port.rat_null(mats[b])), b
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 6, 9])
 def test_batched_gauss_match_oracle(lq, port, n):
     rng = np.random.default_rng(n)

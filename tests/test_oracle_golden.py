@@ -197,6 +197,29 @@ def test_g5_lineq_and_gauss(port):
         assert port.rat_rank(rect) == c["rect_rank"]
 
 
+def test_g7_intmat_rank_basis_null(port):
+    g = json.load(open(os.path.join(GOLD, "g7_intmat.json")))
+    for c in g["hnf"]:
+        st, h, u = port.int_hnf(np.array(c["a"], dtype=np.int32))
+        assert st == 0 and h.tolist() == c["h"] and u.tolist() == c["u"]
+    for c in g["gcd"]:
+        assert port.int_gcd(np.array(c["a"], dtype=np.int32)).tolist() == c["out"]
+    ranks = set()
+    for c in g["rank_basis"]:
+        m = dec(c["mat"]["data"], RAT, c["mat"]["shape"])
+        rk, basis = port.rat_rank_basis(m, c["unitarize"])
+        want = dec(c["basis"]["data"], RAT, c["basis"]["shape"])
+        assert rk == c["rank"] and ((basis.shape[0] == 0 and want.shape[0] == 0) or same(basis, want))
+        ranks.add(rk < m.shape[0])
+    assert ranks == {True, False}
+    for c in g["null"]:
+        m = dec(c["mat"]["data"], RAT, c["mat"]["shape"])
+        assert same(port.rat_null(m), dec(c["ns"]["data"], RAT, c["ns"]["shape"]))
+    # the reference-undefined inputs are reported, not computed (xmat.cpp:936-941, :956-980)
+    assert port.int_hnf(np.array([[-1, 0, 0], [0, 1, 0]], dtype=np.int32))[0] == -7     # cols > rows, negative diagonal
+    assert port.int_hnf(np.array([[1, 0], [1, 0]], dtype=np.int32))[0] == -7            # zero diagonal below row 0
+
+
 def test_scalar_semantics(port):
     # Float '==' window of 1e-17 (flty.cpp:41-58)
     assert port.flt_cmp(4, 0.0, 1e-17) == 1 and port.flt_cmp(4, 0.0, 1.1e-17) == 0

@@ -163,6 +163,39 @@ def fuzz_lineq(ref, port, n, rng):
     print("lineq ok:", n)
 
 
+def fuzz_intmat(ref, port, n, rng):
+    """N3: rank-with-basis, null, INTMat::hnf / gcd. The port is asked first; where it says the
+    reference is undefined (SIGFPE / out-of-bounds read) the reference is not run."""
+    undefined = 0
+    for it in range(n):
+        rows, cols = int(rng.integers(1, 7)), int(rng.integers(1, 7))
+        rk = gen.random_system(rng, rows, cols - 1) if cols > 1 else gen.random_square(rng, 1)
+        if it % 3 == 0 and rk.shape[0] > 1:           # dependent rows: rank < rows
+            rk[-1] = rk[0]
+        for unit in (True, False):
+            r = ref.rat_rank_basis(rk, unit); o = port.rat_rank_basis(rk, unit)
+            assert r[0] == o[0] and (same(r[1], o[1]) or (r[1].shape[0] == 0 and o[1].shape[0] == 0)), \
+                ("rank_basis", it, unit, rk[..., 0], r, o)
+        assert same(ref.rat_null(rk), port.rat_null(rk)), ("null", it, rk[..., 0])
+        lo = int(rng.choice([2, 4, 10]))
+        a = rng.integers(-lo, lo + 1, size=(rows, cols)).astype(np.int32)
+        if it % 4 == 0:
+            a[:, int(rng.integers(0, cols))] = 0
+        if it % 5 == 0 and rows > 1:
+            a[int(rng.integers(0, rows))] = 0
+        k = int(rng.integers(1, 6))
+        assert same(ref.int_gcd(a * k), port.int_gcd(a * k)), ("gcd", it, a * k)
+        st, h, u = port.int_hnf(a)
+        if st == -7:
+            undefined += 1
+            continue
+        rs, rh, ru = ref.int_hnf(a)
+        assert same(rh, h) and same(ru, u), ("hnf", it, a, rh, h, ru, u)
+        prod = (a.astype(np.int64) @ u.astype(np.int64)).astype(np.int32)      # the INT ring is Z/2^32
+        assert np.array_equal(prod, h), ("h = a*u", it, a, h, u)
+    print("intmat ok:", n, "reference-undefined hnf inputs skipped:", undefined)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="?", default="all")
@@ -171,7 +204,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     ref, port = Ref(), Port()
-    todo = ["scalars", "six", "stage", "mip", "lineq"] if a.what == "all" else [a.what]
+    todo = ["scalars", "six", "stage", "mip", "lineq", "intmat"] if a.what == "all" else [a.what]
     for w in todo:
         {"scalars": fuzz_scalars, "six": fuzz_six, "stage": fuzz_stage, "mip": fuzz_mip,
-         "lineq": fuzz_lineq}[w](ref, port, a.n, rng)
+         "lineq": fuzz_lineq, "intmat": fuzz_intmat}[w](ref, port, a.n, rng)

@@ -201,6 +201,34 @@ def main():
         g5["calc_bound"].append(dict(mat=dict(shape=list(mat.shape), data=enc(mat, RAT)), rhs=nv, ok=ok,
                                      limits=[dict(shape=list(l.shape), data=enc(l, RAT)) for l in lim] if ok else None))
     json.dump(g5, open(os.path.join(OUT, "g5_lineq.json"), "w"))
+
+    # G7: INTMat::hnf / gcd (xmat.cpp:912-1030), rank with basis, null (matt.h:2546-2726). Only inputs
+    # on which the reference is defined (the port says which) are run through it.
+    rng = np.random.default_rng(77)
+    g7 = dict(hnf=[], gcd=[], rank_basis=[], null=[])
+    while len(g7["hnf"]) < 40:
+        rows, cols = int(rng.integers(1, 7)), int(rng.integers(1, 7))
+        a = rng.integers(-6, 7, size=(rows, cols)).astype(np.int32)
+        if port.int_hnf(a)[0] != 0:
+            continue
+        _, h, u = ref.int_hnf(a)
+        g7["hnf"].append(dict(a=a.tolist(), h=h.tolist(), u=u.tolist()))
+    for _ in range(30):
+        rows, cols = int(rng.integers(1, 6)), int(rng.integers(1, 6))
+        a = (rng.integers(-5, 6, size=(rows, cols)) * rng.integers(1, 7, size=(rows, 1))).astype(np.int32)
+        g7["gcd"].append(dict(a=a.tolist(), out=ref.int_gcd(a).tolist()))
+    for it in range(30):
+        rows, cols = int(rng.integers(1, 6)), int(rng.integers(2, 7))
+        m = gen.random_system(rng, rows, cols - 1)
+        if it % 3 == 0 and rows > 1:
+            m[-1] = m[0]
+        for unit in (True, False):
+            rk, b = ref.rat_rank_basis(m, unit)
+            g7["rank_basis"].append(dict(mat=dict(shape=list(m.shape), data=enc(m, RAT)), unitarize=unit, rank=rk,
+                                         basis=dict(shape=list(b.shape), data=enc(b, RAT))))
+        ns = ref.rat_null(m)
+        g7["null"].append(dict(mat=dict(shape=list(m.shape), data=enc(m, RAT)), ns=dict(shape=list(ns.shape), data=enc(ns, RAT))))
+    json.dump(g7, open(os.path.join(OUT, "g7_intmat.json"), "w"))
     print("golden vectors written to", OUT)
 
 

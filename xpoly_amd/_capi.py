@@ -23,6 +23,7 @@ SYMBOLS = [
     "xpg_has_solution_rat32", "xpg_mip_batch_rat32", "xpg_dep_is_empty_batch_rat32",
     "xpg_lineq_reduce_batch_rat32", "xpg_lineq_remove_iden_batch_rat32", "xpg_lineq_fme_batch_rat32",
     "xpg_lineq_calc_bound_batch_rat32", "xpg_rat_rank_batch", "xpg_rat_det_batch", "xpg_rat_inv_batch",
+    "xpg_rat_rank_basis_batch", "xpg_rat_null_batch", "xpg_int_hnf_batch", "xpg_int_gcd_batch",
 ]
 
 _lib = None

@@ -127,27 +127,72 @@ inline int lineq_calc_bound_batch(xpg_ctx * ctx, int nb, const R32 * mats, int r
     return 0;
 }
 
-// op 0: rank, 1: det, 2: inv
+// op 0: rank, 1: det, 2: inv, 3: rank with basis (flag = is_unitarize), 4: null space
 inline int gauss_batch(xpg_ctx * ctx, int nb, const R32 * mats, int rows, int cols, int op, int32_t * out_int,
-                       R32 * out_val, R32 * out_mat)
+                       R32 * out_val, R32 * out_mat, int flag = 0)
 {
-    if (!ctx || nb < 0 || !mats || rows <= 0 || cols <= 0 || (op != 0 && rows != cols)) return XPG_ERR_SHAPE;
+    if (!ctx || nb < 0 || !mats || rows <= 0 || cols <= 0 || ((op == 1 || op == 2) && rows != cols)) return XPG_ERR_SHAPE;
     if (nb == 0) return 0;
-    const size_t lds = ((size_t)rows * cols * 8 * (op == 2 ? 2 : 1) + 15) & ~(size_t)15;
+    size_t lds = ((size_t)rows * cols * 8 * (op == 2 ? 2 : 1) + 15) & ~(size_t)15;
+    if (op == 3) lds += ((size_t)rows * 4 + 15) & ~(size_t)15;
     if (lds > 160 * 1024) return XPG_ERR_UNSUPPORTED;
     const size_t bi = (size_t)nb * rows * cols * 8;
+    const size_t bo = op == 2 || op == 3 ? bi : (op == 4 ? (size_t)nb * cols * cols * 8 : 8);
     DevBuf di, dint, dval, dmat;
     XPG_TRY(di.alloc(bi)); XPG_TRY(dint.alloc((size_t)nb * 4)); XPG_TRY(dval.alloc((size_t)nb * 8));
-    XPG_TRY(dmat.alloc(op == 2 ? bi : 8));
+    XPG_TRY(dmat.alloc(bo));
     XPG_TRY(hipMemcpyAsync(di.p, mats, bi, hipMemcpyHostToDevice, ctx->stream));
-    if (op == 2) XPG_TRY(hipMemsetAsync(dmat.p, 0, bi, ctx->stream));
+    if (op >= 2) XPG_TRY(hipMemsetAsync(dmat.p, 0, bo, ctx->stream));
     XPG_TRY(hipFuncSetAttribute((const void *)k_gauss_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_gauss_batch, dim3(lineq_grid(nb)), dim3(64), lds, ctx->stream, nb, (const R32 *)di.p, rows,
-                       cols, op, (int *)dint.p, (R32 *)dval.p, (R32 *)dmat.p);
+                       cols, op, flag, (int *)dint.p, (R32 *)dval.p, (R32 *)dmat.p);
     XPG_TRY(hipGetLastError());
     if (out_int) XPG_TRY(hipMemcpyAsync(out_int, dint.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (out_val) XPG_TRY(hipMemcpyAsync(out_val, dval.p, (size_t)nb * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (out_mat && op == 2) XPG_TRY(hipMemcpyAsync(out_mat, dmat.p, bi, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_mat && op >= 2) XPG_TRY(hipMemcpyAsync(out_mat, dmat.p, bo, hipMemcpyDeviceToHost, ctx->stream));
+    XPG_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// INTMat::hnf for nb matrices: h [nb][rows][cols], u [nb][cols][cols], status [nb].
+inline int int_hnf_batch(xpg_ctx * ctx, int nb, const int32_t * mats, int rows, int cols, int32_t * h, int32_t * u,
+                         int32_t * status)
+{
+    if (!ctx || nb < 0 || !mats || !h || !u || !status || rows <= 0 || cols <= 0) return XPG_ERR_SHAPE;
+    if (nb == 0) return 0;
+    const size_t lds = ((size_t)(rows + cols) * cols * 4 + 15) & ~(size_t)15;
+    if (lds > 160 * 1024) return XPG_ERR_UNSUPPORTED;
+    const size_t bi = (size_t)nb * rows * cols * 4, bu = (size_t)nb * cols * cols * 4;
+    DevBuf di, dh, du, ds;
+    XPG_TRY(di.alloc(bi)); XPG_TRY(dh.alloc(bi)); XPG_TRY(du.alloc(bu)); XPG_TRY(ds.alloc((size_t)nb * 4));
+    XPG_TRY(hipMemcpyAsync(di.p, mats, bi, hipMemcpyHostToDevice, ctx->stream));
+    XPG_TRY(hipMemsetAsync(dh.p, 0, bi, ctx->stream));
+    XPG_TRY(hipMemsetAsync(du.p, 0, bu, ctx->stream));
+    XPG_TRY(hipFuncSetAttribute((const void *)k_hnf_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_hnf_batch, dim3(lineq_grid(nb)), dim3(64), lds, ctx->stream, nb, (const int *)di.p, rows, cols,
+                       (int *)dh.p, (int *)du.p, (int *)ds.p);
+    XPG_TRY(hipGetLastError());
+    XPG_TRY(hipMemcpyAsync(h, dh.p, bi, hipMemcpyDeviceToHost, ctx->stream));
+    XPG_TRY(hipMemcpyAsync(u, du.p, bu, hipMemcpyDeviceToHost, ctx->stream));
+    XPG_TRY(hipMemcpyAsync(status, ds.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+    XPG_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// INTMat::gcd for nb matrices, in place.
+inline int int_gcd_batch(xpg_ctx * ctx, int nb, int32_t * mats, int rows, int cols)
+{
+    if (!ctx || nb < 0 || !mats || rows <= 0 || cols <= 0) return XPG_ERR_SHAPE;
+    if (nb == 0) return 0;
+    const size_t bi = (size_t)nb * rows * cols * 4;
+    const long long total = (long long)nb * rows;
+    DevBuf di;
+    XPG_TRY(di.alloc(bi));
+    XPG_TRY(hipMemcpyAsync(di.p, mats, bi, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_int_gcd_batch, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, total,
+                       (int *)di.p, cols);
+    XPG_TRY(hipGetLastError());
+    XPG_TRY(hipMemcpyAsync(mats, di.p, bi, hipMemcpyDeviceToHost, ctx->stream));
     XPG_TRY(hipStreamSynchronize(ctx->stream));
     return 0;
 }

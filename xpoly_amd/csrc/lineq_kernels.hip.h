@@ -397,8 +397,9 @@ __device__ inline int w_find_pivot(const WMat & m, int col, int from, bool & uni
     return swap_row;
 }
 
-// Matrix<Rational>::rank with basis == NULL (matt.h:2614-2726).
-__device__ inline int w_rank(WMat & p)
+// Matrix<Rational>::rank(basis, is_unitarize) (matt.h:2614-2726). basis == NULL in the
+// reference forces unitarize; rowpos (LDS, one int per row) tracks the row interchanges.
+__device__ inline int w_rank(WMat & p, bool unitarize = true, int * rowpos = nullptr)
 {
     int rankv = 0;
     for (int row = 0, col = 0; row < p.r && col < p.c; row++, col++) {
@@ -407,14 +408,15 @@ __device__ inline int w_rank(WMat & p)
             swap_row = w_find_pivot(p, w, row, ub);
             if (swap_row == -1) continue;
             w_swap_rows(p, swap_row, row);
+            if (rowpos && lane_id() == 0) { const int t = rowpos[swap_row]; rowpos[swap_row] = rowpos[row]; rowpos[row] = t; }
             col = w;
             break;
         }
         if (swap_row == -1) break;
         const R32 d = p.a[row * p.ld + col];
         wave_sync();
-        if (ne(d, R32(1, 1))) w_scale_row(p, row, div(R32(1, 1), d));
-        for (int i = 0; i < p.r; i++) {
+        if (unitarize && ne(d, R32(1, 1))) w_scale_row(p, row, div(R32(1, 1), d));
+        for (int i = unitarize ? 0 : row + 1; i < p.r; i++) {
             if (i == row) continue;
             const R32 e = p.a[i * p.ld + col];
             if (eq(e, R32(0, 1))) continue;
@@ -522,8 +524,10 @@ __device__ inline bool w_inv(WMat & pe, int n)
 #undef E_
 }
 
-// op 0: rank (rows x cols), 1: det (n x n), 2: inv (n x n -> out n x n). One wave per matrix.
-__global__ __launch_bounds__(64) void k_gauss_batch(int nb, const R32 * mats, int rows, int cols, int op,
+// op 0: rank (rows x cols), 1: det (n x n), 2: inv (n x n -> out n x n), 3: rank with basis
+// (flag = is_unitarize; out_mat rows x cols, rows past the basis left zero), 4: null space
+// (out_mat cols x cols, matt.h:2546-2584). One wave per matrix.
+__global__ __launch_bounds__(64) void k_gauss_batch(int nb, const R32 * mats, int rows, int cols, int op, int flag,
                                                     int * out_int, R32 * out_val, R32 * out_mat)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -542,6 +546,38 @@ __global__ __launch_bounds__(64) void k_gauss_batch(int nb, const R32 * mats, in
             wave_sync();
             if (ok) for (int t = lane_id(); t < n * n; t += 64) out_mat[(size_t)b * n * n + t] = m.a[(t / n) * m.ld + n + (t % n)];
             if (lane_id() == 0) out_int[b] = ok ? 1 : 0;
+        } else if (op == 3) {
+            int * rowpos = (int *)(lds + (((size_t)rows * cols * 8 + 15) & ~(size_t)15));
+            m.ld = cols;
+            w_load(m, g, rows, cols);
+            for (int t = lane_id(); t < rows; t += 64) rowpos[t] = t;
+            wave_sync();
+            const bool unit = flag != 0;
+            const int rk = w_rank(m, unit, rowpos);
+            wave_sync();
+            R32 * o = out_mat + (size_t)b * rows * cols;
+            if (!unit && rk < rows) {           // the original rows in pivot order (matt.h:2710-2719)
+                for (int t = lane_id(); t < rk * cols; t += 64) o[t] = g[rowpos[t / cols] * cols + t % cols];
+            } else {
+                for (int t = lane_id(); t < rows * cols; t += 64) o[t] = m.a[t];
+            }
+            if (lane_id() == 0) out_int[b] = rk;
+        } else if (op == 4) {
+            m.ld = cols;
+            w_load(m, g, rows, cols);
+            w_rank(m, true, nullptr);
+            wave_sync();
+            R32 * ns = out_mat + (size_t)b * cols * cols;
+            for (int t = lane_id(); t < cols * cols; t += 64) ns[t] = (t / cols == t % cols) ? R32(1, 1) : R32(0, 1);
+            wave_sync();
+            for (int row = 0; row < rows; row++) {
+                int col = row;
+                while (col < cols && eq(m.a[row * cols + col], R32(0, 1))) col++;
+                if (col >= cols) break;
+                for (int k = col + lane_id(); k < cols; k += 64)
+                    ns[col * cols + k] = (k == col) ? R32(0, 1) : neg(m.a[row * cols + k]);
+                wave_sync();
+            }
         } else {
             m.ld = cols;
             w_load(m, g, rows, cols);
@@ -550,6 +586,136 @@ __global__ __launch_bounds__(64) void k_gauss_batch(int nb, const R32 * mats, in
         }
         wave_sync();
     }
+}
+
+// ---- INTMat::hnf / gcd (xmat.cpp:853-1030): INT is the ring Z/2^32 ---------------------------------
+__device__ __forceinline__ int wmul(int a, int b) { return (int)((unsigned)a * (unsigned)b); }
+__device__ __forceinline__ int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
+__device__ __forceinline__ int iabs32(int a) { return a < 0 ? (int)(0u - (unsigned)a) : a; }
+
+// exgcd (comf.cpp:295-321): the reference recurses; here the quotients are kept and unwound.
+__device__ inline int d_exgcd(int a, int b, int & x, int & y)
+{
+    int q[48];
+    int depth = 0;
+    while (b != 0 && depth < 48) { q[depth++] = a / b; const int t = a % b; a = b; b = t; }
+    int g = a;
+    x = 1; y = 0;
+    while (depth > 0) {
+        const int x1 = x, y1 = y;
+        depth--;
+        x = y1;
+        y = (int)((unsigned)x1 - (unsigned)q[depth] * (unsigned)y1);
+    }
+    if (g < 0) { g = -g; x = -x; y = -y; }
+    return g;
+}
+
+// INTMat::hnf (xmat.cpp:912-992). h (rows x cols) and u (cols x cols) are stacked into one
+// (rows + cols) x cols LDS matrix: every elimination matrix of the reference differs from the
+// identity in at most two columns, so `h = h * elim; u = u * elim` is one column operation over
+// the stacked rows, one lane per row. In Z/2^32 that equals the full product bit for bit.
+// status[b] = 0, or XPG_ERR_REF_UNDEFINED (-7) where the reference divides by zero or reads its
+// mis-shaped rows x cols "identity" out of bounds (xmat.cpp:936-941, :956-980).
+__global__ __launch_bounds__(64) void k_hnf_batch(int nb, const int * mats, int rows, int cols, int * hs, int * us,
+                                                  int * status)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    int * M = (int *)lds;
+    const int tot = rows + cols, lim = rows < cols ? rows : cols, lane = lane_id();
+    const int IMIN = (int)0x80000000;
+#define H_(i, j) M[(i) * cols + (j)]
+    for (int b = blockIdx.x; b < nb; b += gridDim.x) {
+        const int * g = mats + (size_t)b * rows * cols;
+        for (int t = lane; t < tot * cols; t += 64) {
+            const int r = t / cols, c = t % cols;
+            M[t] = r < rows ? g[t] : (r - rows == c ? 1 : 0);
+        }
+        wave_sync();
+        int st = 0;
+        for (int i = 0; i < lim && st == 0; i++) {
+            for (int j = i + 1; j < cols; j++) {                      // 1. clear row i right of the diagonal
+                const int aii = H_(i, i), aij = H_(i, j);
+                wave_sync();
+                if (aij == 0) continue;
+                if (aii == IMIN || aij == IMIN) { st = -7; break; }
+                int x, y;
+                const int gg = d_exgcd(aii, aij, x, y);               // gen_elim_mat, xmat.cpp:853-868
+                const int p = -aij / gg, q = aii / gg;
+                for (int t = lane; t < tot; t += 64) {
+                    const int a = H_(t, i), c = H_(t, j);
+                    H_(t, i) = wadd(wmul(a, x), wmul(c, y));
+                    H_(t, j) = wadd(wmul(a, p), wmul(c, q));
+                }
+                wave_sync();
+            }
+            if (st) break;
+            const int dg = H_(i, i);
+            wave_sync();
+            if (dg < 0) {                                             // 2. positive diagonal
+                if (cols > rows) { st = -7; break; }
+                for (int t = lane; t < tot; t += 64) H_(t, i) = wmul(H_(t, i), -1);
+                wave_sync();
+            }
+            for (int j = 0; j < i; j++) {                             // 3. non-negative left of the diagonal
+                const int hij = H_(i, j), hii = H_(i, i);
+                wave_sync();
+                if (hij >= 0) continue;
+                if (hii == 0 || hij == IMIN) { st = -7; break; }
+                const int v = iabs32(hij) <= iabs32(hii) ? 1 : iabs32(hij / hii) + 1;
+                for (int t = lane; t < tot; t += 64) H_(t, j) = wadd(H_(t, j), wmul(H_(t, i), v));
+                wave_sync();
+            }
+            if (st) break;
+            for (int j = 0; j < i; j++) {                             // 4. smaller than the diagonal
+                const int hij = H_(i, j), hii = H_(i, i);
+                wave_sync();
+                if (hij < hii) continue;
+                if (hii == 0) { st = -7; break; }
+                const int d = hij / hii;
+                for (int t = lane; t < tot; t += 64) H_(t, j) = wadd(H_(t, j), wmul(H_(t, i), -d));
+                wave_sync();
+            }
+        }
+        wave_sync();
+        if (st == 0) {
+            for (int t = lane; t < rows * cols; t += 64) hs[(size_t)b * rows * cols + t] = M[t];
+            for (int t = lane; t < cols * cols; t += 64) us[(size_t)b * cols * cols + t] = M[rows * cols + t];
+        }
+        if (lane == 0) status[b] = st;
+        wave_sync();
+    }
+#undef H_
+}
+
+// INTMat::gcd (xmat.cpp:996-1030): one thread per row, rows of all matrices side by side.
+__global__ __launch_bounds__(256) void k_int_gcd_batch(long long total_rows, int * mats, int cols)
+{
+    const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= total_rows || cols == 1) return;
+    int * r = mats + row * cols;
+    unsigned mn = 0xFFFFFFFFu;
+    bool allzero = true;
+    for (int j = 0; j < cols; j++) {
+        const unsigned x = (unsigned)iabs32(r[j]);
+        if (x != 0) { mn = mn < x ? mn : x; allzero = false; }
+    }
+    if (mn == 1 || mn == 0 || allzero) return;
+    unsigned g = mn;
+    for (int j = 0; j < cols; j++) {
+        const unsigned q = (unsigned)iabs32(r[j]);
+        if (q != 0 && q != g) {
+            int x = (int)g, y = (int)q;                               // sgcd, comf.cpp:226-243
+            if (x < 0) x = -x;
+            if (y < 0) y = -y;
+            if (x > y) { const int t = x; x = y; y = t; }
+            while (x) { const int t = x; x = y % x; y = t; }
+            g = (unsigned)y;
+            if (g == 1) break;
+        }
+    }
+    if (g == 1) return;
+    for (int j = 0; j < cols; j++) r[j] = r[j] / (int)g;
 }
 
 } // namespace xpg

@@ -457,5 +457,21 @@ int xpg_rat_det_batch(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int n, xpg_
 { return out_det ? gauss_batch(ctx, nb, (const R32 *)mats, n, n, 1, 0, (R32 *)out_det, 0) : XPG_ERR_SHAPE; }
 int xpg_rat_inv_batch(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int n, xpg_rat32 * out_inv, int32_t * out_ok)
 { return (out_inv && out_ok) ? gauss_batch(ctx, nb, (const R32 *)mats, n, n, 2, out_ok, 0, (R32 *)out_inv) : XPG_ERR_SHAPE; }
+int xpg_rat_rank_basis_batch(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols, int is_unitarize,
+                             int32_t * out_rank, xpg_rat32 * basis, int32_t * basis_rows)
+{
+    if (!out_rank || !basis || !basis_rows) return XPG_ERR_SHAPE;
+    const int st = gauss_batch(ctx, nb, (const R32 *)mats, rows, cols, 3, out_rank, 0, (R32 *)basis, is_unitarize ? 1 : 0);
+    if (st != 0) return st;
+    for (int b = 0; b < nb; b++) basis_rows[b] = (!is_unitarize && out_rank[b] < rows) ? out_rank[b] : rows;
+    return 0;
+}
+int xpg_rat_null_batch(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols, xpg_rat32 * ns)
+{ return ns ? gauss_batch(ctx, nb, (const R32 *)mats, rows, cols, 4, 0, 0, (R32 *)ns) : XPG_ERR_SHAPE; }
+int xpg_int_hnf_batch(xpg_ctx * ctx, int nb, const int32_t * mats, int rows, int cols, int32_t * h, int32_t * u,
+                      int32_t * status)
+{ return int_hnf_batch(ctx, nb, mats, rows, cols, h, u, status); }
+int xpg_int_gcd_batch(xpg_ctx * ctx, int nb, int32_t * mats, int rows, int cols)
+{ return int_gcd_batch(ctx, nb, mats, rows, cols); }
 
 } // extern "C"

@@ -78,6 +78,48 @@ class Lineq:
                        "xpg_rat_rank_batch")
         return out
 
+    def rankBasis(self, mats, is_unitarize):
+        """Matrix<Rational>::rank(&basis, is_unitarize) (matt.h:2614-2726): (rank[nb], [basis b])."""
+        a = _stack(mats)
+        nb, rows, cols = a.shape[:3]
+        rk = np.zeros(nb, dtype=np.int32); brows = np.zeros(nb, dtype=np.int32)
+        out = np.zeros((nb, rows, cols, 2), dtype=np.int32)
+        self.ctx.check(lib().xpg_rat_rank_basis_batch(self.ctx._h, C.c_int(nb), vp(a), C.c_int(rows), C.c_int(cols),
+                                                      C.c_int(int(is_unitarize)), vp(rk), vp(out), vp(brows)),
+                       "xpg_rat_rank_basis_batch")
+        return rk, [out[b, : brows[b]].copy() for b in range(nb)]
+
+    def null(self, mats):
+        """Matrix<Rational>::null (matt.h:2546-2584): [nb, cols, cols, 2], column convention."""
+        a = _stack(mats)
+        nb, rows, cols = a.shape[:3]
+        out = np.zeros((nb, cols, cols, 2), dtype=np.int32)
+        self.ctx.check(lib().xpg_rat_null_batch(self.ctx._h, C.c_int(nb), vp(a), C.c_int(rows), C.c_int(cols), vp(out)),
+                       "xpg_rat_null_batch")
+        return out
+
+    def hnf(self, imats):
+        """INTMat::hnf (xmat.cpp:912-992) of int32 matrices [nb, rows, cols]: (status[nb], h, u)."""
+        a = np.ascontiguousarray(imats, dtype=np.int32)
+        if a.ndim == 2:
+            a = a[None]
+        nb, rows, cols = a.shape
+        h = np.zeros((nb, rows, cols), dtype=np.int32); u = np.zeros((nb, cols, cols), dtype=np.int32)
+        st = np.zeros(nb, dtype=np.int32)
+        self.ctx.check(lib().xpg_int_hnf_batch(self.ctx._h, C.c_int(nb), vp(a), C.c_int(rows), C.c_int(cols), vp(h), vp(u),
+                                               vp(st)), "xpg_int_hnf_batch")
+        return st, h, u
+
+    def gcd(self, imats):
+        """INTMat::gcd (xmat.cpp:996-1030): rows divided by the gcd of their nonzero magnitudes."""
+        a = np.ascontiguousarray(imats, dtype=np.int32).copy()
+        if a.ndim == 2:
+            a = a[None]
+        nb, rows, cols = a.shape
+        self.ctx.check(lib().xpg_int_gcd_batch(self.ctx._h, C.c_int(nb), vp(a), C.c_int(rows), C.c_int(cols)),
+                       "xpg_int_gcd_batch")
+        return a
+
     def det(self, mats):
         a = _stack(mats)
         nb, n = a.shape[0], a.shape[1]
