@@ -197,7 +197,9 @@ def main():
             traffic_src = "profiles/round1_pmc_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, KiB->B)"
         roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src,
-                        kernel="k_update_f64<32,8>", launches_sampled=launches,
+                        kernel=("k_update_f64<32,8>" if os.environ.get("XPG_LOOP", "").startswith("se")
+                                else "k_pipe_sweep<32,8> (sweep + the next pivot's pick workgroups)"),
+                        launches_sampled=launches,
                         avg_launch_us=round(sweep_avg_s * 1e6, 2),
                         algorithmic_bytes_per_launch=ALG_BYTES_PER_PIVOT)
     lp.close()

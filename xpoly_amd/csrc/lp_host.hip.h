@@ -6,6 +6,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <string>
+#include <type_traits>
 #include <vector>
 #include <stdio.h>
 #include "../../include/xpoly_amd.h"
@@ -18,6 +19,7 @@ struct xpg_ctx {
     // scratch of the one-shot K1 entry points (xpg_pivot_*_dev)
     void * rowbuf; void * colbuf; xpg::LoopState * st; size_t row_cap, col_cap;
     int update_variant;     // tuning knob for the fp64 sweep (see launch_update_f64)
+    int loop_mode;          // 0: pipelined fp64 loop (2 launches per pivot), 1: serial pick/prep/update
     // xpg_profile_begin/end: event pairs around each sweep launch
     std::vector<hipEvent_t> ev0, ev1;
     int prof_cap, prof_n, prof_stride, prof_seen;
@@ -82,6 +84,21 @@ template <> inline void launch_update<F64>(xpg_ctx * ctx, const LpView<F64> & v,
                       (double *)v.nextcol, (double *)v.bcol, v.rhs);
     if (timed) prof_close(ctx);
 }
+template <class S> inline void launch_pipe_sweep(xpg_ctx *, const LpView<S> &, int, int, bool) {}
+template <> inline void launch_pipe_sweep<F64>(xpg_ctx * ctx, const LpView<F64> & v, int slot, int colstride,
+                                               bool sample)
+{
+    const bool timed = sample && prof_open(ctx);
+    const int strips = (v.W + 511) / 512;
+    const int fused = ctx->loop_mode == 2 ? 0 : 1;
+    hipLaunchKernelGGL((k_pipe_sweep<32, 8>), dim3(strips, (v.m + 31) / 32 + 1), dim3(256), 0, ctx->stream, v, slot,
+                       colstride, fused, (double *)v.tab, (const double *)v.rowbuf,
+                       (const double *)v.colbuf + (size_t)slot * colstride);
+    if (timed) prof_close(ctx);
+    if (!fused)
+        hipLaunchKernelGGL(k_pipe_pick, dim3(strips < PICK_MAX_WGS ? strips : PICK_MAX_WGS), dim3(256), 0, ctx->stream,
+                           v, slot, colstride);
+}
 template <> inline void launch_update<R32>(xpg_ctx * ctx, const LpView<R32> & v, int guarded)
 {
     const bool timed = prof_open(ctx);
@@ -107,6 +124,9 @@ template <class S> struct Lp : LpBase {
     bool began;
     int final_status;
     hipEvent_t throttle[2] = {nullptr, nullptr};
+    unsigned pipe_t = 0;    // pipelined loop: iteration counter since reset_loop (slot = pipe_t & 1)
+    bool pipe_primed = false;
+    int colstride = 0;      // elements per colbuf half
 
     int alloc(void ** p, size_t bytes)
     {
@@ -136,7 +156,8 @@ template <class S> struct Lp : LpBase {
         if ((rc = alloc((void **)&v.tab, tab_elems * sizeof(S)))) return rc;
         if ((rc = alloc((void **)&v.obj, (size_t)ld * sizeof(S)))) return rc;
         if ((rc = alloc((void **)&v.rowbuf, (size_t)ld * sizeof(S)))) return rc;
-        if ((rc = alloc((void **)&v.colbuf, (size_t)round_up(m, 16) * sizeof(S)))) return rc;
+        colstride = round_up(m, 16);                // two halves: the pipelined loop double-buffers -column
+        if ((rc = alloc((void **)&v.colbuf, (size_t)2 * colstride * sizeof(S)))) return rc;
         if ((rc = alloc((void **)&v.x, (size_t)ld * sizeof(S)))) return rc;
         if ((rc = alloc((void **)&v.nextcol, (size_t)round_up(m, 16) * sizeof(S)))) return rc;
         if ((rc = alloc((void **)&v.bcol, (size_t)round_up(m, 16) * sizeof(S)))) return rc;
@@ -150,6 +171,7 @@ template <class S> struct Lp : LpBase {
         if ((rc = alloc((void **)&v.colcnt, (size_t)ld * 4))) return rc;
         if ((rc = alloc((void **)&v.ppt, (size_t)nmax * v.pw * 4))) return rc;
         if ((rc = alloc((void **)&v.st, sizeof(LoopState)))) return rc;
+        if ((rc = alloc((void **)&v.pickrec, (size_t)PICK_WORDS * 8))) return rc;
         if ((rc = alloc((void **)&v.trace, (size_t)v.trace_cap * 8))) return rc;
         if ((rc = alloc((void **)&d_leq, (size_t)m * cols * sizeof(S)))) return rc;
         if ((rc = alloc((void **)&d_tgtf, (size_t)cols * sizeof(S)))) return rc;
@@ -165,6 +187,7 @@ template <class S> struct Lp : LpBase {
         XPG_HIP(ctx, hipMemcpyAsync(v.vcd, hd.data(), (size_t)ld * sizeof(S), hipMemcpyHostToDevice, s));
         XPG_HIP(ctx, hipMemcpyAsync(v.vcr, hr.data(), (size_t)ld * sizeof(S), hipMemcpyHostToDevice, s));
         XPG_HIP(ctx, hipMemsetAsync(v.st, 0, sizeof(LoopState), s));
+        XPG_HIP(ctx, hipMemsetAsync(v.pickrec, 0, (size_t)PICK_WORDS * 8, s));
         // launch-throttle events, exercised once so their first use is not inside a solve
         for (int i = 0; i < 2; i++) {
             XPG_HIP(ctx, hipEventCreateWithFlags(&throttle[i], hipEventDisableTiming));
@@ -192,6 +215,7 @@ template <class S> struct Lp : LpBase {
     void reset_loop(unsigned max_iter)
     {
         hipLaunchKernelGGL((k_reset_loop<S>), dim3(1024), dim3(256), 0, ctx->stream, v, max_iter);
+        pipe_t = 0; pipe_primed = false;
     }
     void queue_pivot(int guarded, int counted)
     {
@@ -207,10 +231,23 @@ template <class S> struct Lp : LpBase {
     void queue_iterations(unsigned k)
     {
         unsigned blk = 0;
+        const bool pipelined = std::is_same<S, F64>::value && ctx->loop_mode != 1;
+        if (pipelined && k > 0 && !pipe_primed) {
+            // the first pivot is chosen by a sweep launch that has nothing to sweep (pd[1].row < 0)
+            launch_pipe_sweep(ctx, v, 1, colstride, false);
+            pipe_primed = true;
+        }
         for (unsigned t = 0; t < k; t++) {
-            hipLaunchKernelGGL((k_pick<S>), dim3(1), dim3(1024), 0, ctx->stream, v);
-            hipLaunchKernelGGL((k_prep<S>), dim3((v.W + 255) / 256), dim3(256), 0, ctx->stream, v, 1, 1, 0, 1);
-            launch_update<S>(ctx, v, 1);
+            if (pipelined) {
+                // two launches per pivot; the next pivot is chosen inside the sweep launch
+                const int slot = (int)(pipe_t++ & 1u);
+                hipLaunchKernelGGL((k_pipe_prep<S>), dim3((v.W + 255) / 256), dim3(256), 0, ctx->stream, v, slot);
+                launch_pipe_sweep(ctx, v, slot, colstride, true);
+            } else {
+                hipLaunchKernelGGL((k_pick<S>), dim3(1), dim3(1024), 0, ctx->stream, v);
+                hipLaunchKernelGGL((k_prep<S>), dim3((v.W + 255) / 256), dim3(256), 0, ctx->stream, v, 1, 1, 0, 1);
+                launch_update<S>(ctx, v, 1);
+            }
             if ((t & 63) == 63) {
                 hipEvent_t e = throttle[blk & 1];
                 if (blk >= 2) (void)hipEventSynchronize(e);

@@ -45,8 +45,24 @@ struct LoopState {
     int anypos;            // some nonbasic reduced cost is > 0
     int cached_col;        // column currently held in nextcol[] (-1: none), set by the sweep
     int bcol_valid;        // bcol[] holds the current constant column
+    // Pipelined loop (k_pipe_prep / k_pipe_sweep): iteration t works from pd[t & 1] while the
+    // pick workgroup riding in its sweep launch writes pd[(t + 1) & 1].
+    struct PipeDesc {
+        int row, col, leave;           // the pivot of this iteration (row < 0: none)
+        int next_first, anypos;        // look-ahead pricing for the following iteration
+        int stop;                      // != 0: final status, promoted to `status` by k_pipe_prep
+        int cached_col, bcol_valid;    // what nextcol[] / bcol[] hold for the following pick
+        int zero_upto;                 // basic objective entries below this index are still to be zeroed
+        unsigned done_after, total_after;   // LoopState::done / total_pivots once this pivot is committed
+        int pad_;
+        unsigned long long cnv_bits, piv_bits;
+    } pd[2];
 };
 enum { NF_UNKNOWN = -2 };
+typedef LoopState::PipeDesc PipeDesc;
+// LpView::pickrec layout (8-byte words): PICK_MAX_WGS records of PICK_REC_WORDS, then one arrival
+// counter per descriptor slot, each on a 128-byte line of its own.
+enum { PICK_MAX_WGS = 16, PICK_REC_WORDS = 4, PICK_CTR_OFF = 128, PICK_WORDS = PICK_CTR_OFF + 32 };
 
 template <class S> struct LpView {
     S * tab; int m, W, ld, rhs;
@@ -55,6 +71,7 @@ template <class S> struct LpView {
     uint32_t * ppt; int pw; int * rowcnt; int * colcnt;
     S * rowbuf; S * colbuf; S * x; S * vcd; S * vcr;
     S * nextcol; S * bcol;   // contiguous copies of the predicted entering column / constant column
+    unsigned long long * pickrec;   // pipelined loop: per-workgroup ratio-test records + arrival counters
     LoopState * st;
     int * trace; int trace_cap;
 };
@@ -117,19 +134,36 @@ template <class S> __device__ __forceinline__ bool ppt_seen(const LpView<S> & v,
 // The column and the constant column come from the contiguous copies the
 // previous sweep exported when they are current (col_cached / b_cached), else
 // from the tableau (one 64-byte sector per element).
+// pass0: -2 run both passes; -1 the caller already ran the first pass and found no row.
 template <class S> __device__ int ratio_test(const LpView<S> & v, int nv, Cand<S> * sh,
-                                             bool col_cached = false, bool b_cached = false)
+                                             bool col_cached = false, bool b_cached = false, int pass0 = -2)
 {
-    const int lim = v.rhs - 1;
-    for (int pass = 0; pass < 2; pass++) {
+    const int lim = v.rhs - 1, T = blockDim.x;
+    constexpr int U = 4;
+    for (int pass = pass0 == -1 ? 1 : 0; pass < 2; pass++) {
         Cand<S> best; best.q = zero<S>(); best.idx = INT_MAX;
-        for (int i = threadIdx.x; i < v.m; i += blockDim.x) {
-            S a = col_cached ? v.nextcol[i] : v.tab[(size_t)i * v.ld + nv];
-            if (pass == 0 ? le(a, zero<S>()) : eq(a, zero<S>())) continue;
-            int b = v.eq2bv[i];
-            if (ppt_seen(v, nv, b) || v.colcnt[b] >= lim) continue;
-            Cand<S> c; c.q = div(b_cached ? v.bcol[i] : v.tab[(size_t)i * v.ld + v.rhs], a); c.idx = i;
-            best = better(best, c);
+        // every load of a row is issued before the first test (two dependent rounds per U rows
+        // instead of four per row): this workgroup is latency-bound, not bandwidth-bound
+        for (int i0 = threadIdx.x; i0 < v.m; i0 += U * T) {
+            S a[U], bb[U]; int b[U], cc[U]; uint32_t w[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = min(i0 + u * T, v.m - 1);
+                a[u] = col_cached ? v.nextcol[i] : v.tab[(size_t)i * v.ld + nv];
+                bb[u] = b_cached ? v.bcol[i] : v.tab[(size_t)i * v.ld + v.rhs];
+                b[u] = v.eq2bv[i];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) { w[u] = v.ppt[(size_t)nv * v.pw + (b[u] >> 5)]; cc[u] = v.colcnt[b[u]]; }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = i0 + u * T;
+                if (i >= v.m) continue;
+                if (pass == 0 ? le(a[u], zero<S>()) : eq(a[u], zero<S>())) continue;
+                if (((w[u] >> (b[u] & 31)) & 1u) || cc[u] >= lim) continue;
+                Cand<S> c; c.q = div(bb[u], a[u]); c.idx = i;
+                best = better(best, c);
+            }
         }
         best = block_argmin(best, sh);
         if (best.idx != INT_MAX) return v.eq2bv[best.idx];
@@ -165,34 +199,60 @@ template <class S> __device__ void price_scan(const LpView<S> & v, int * sh_i, i
 // the basis (lpsol.h:1504-1510) and writes -column to colbuf (lpsol.h:1485).
 // Every rare branch of solveSlackForm (optimum, findPivotNVandBVPair, relaxed
 // ratio pass, disableNV) is handled here by the generic single-workgroup code.
-template <class S> __global__ __launch_bounds__(1024) void k_pick(LpView<S> v)
+// Where a pick leaves its decision: the serial loop's LoopState fields or a PipeDesc.
+struct PickOut {
+    int * status; int * row; int * col; int * leave; int * next_first; int * anypos;
+    unsigned long long * cnv_bits; unsigned long long * piv_bits;
+};
+// `concurrent`: a sweep is rewriting the tableau while this runs, so only the contiguous column
+// copies may be read; the one branch that needs other tableau columns (findPivotNVandBVPair) is
+// deferred to the next iteration (row = -1, look-ahead carried over), which has no sweep.
+// `zero_upto` != nullptr (pipelined loop): the zeroing of basic objective entries below the
+// entering index (lpsol.h:1055-1060) and the basis swap are NOT done here; the bound is
+// returned and the consumer of the decision applies both (k_pipe_prep / pick_commit), so that
+// after k iterations exactly k pivots are visible. Returns true when a pivot was chosen.
+template <class S> __device__ void pick_commit(const LpView<S> & v, int r, int enter, int leave)
 {
-    __shared__ __attribute__((aligned(8))) unsigned char sh_c_raw[16 * sizeof(Cand<S>)];
-    Cand<S> * sh_c = (Cand<S> *)sh_c_raw;
-    __shared__ int sh_i[16];
-    __shared__ int sh_flag;
     LoopState * st = v.st;
-    if (st->status != ST_RUNNING) return;
+    v.nv[enter] = 0; v.nv[leave] = 1; v.bv[enter] = 1; v.bv[leave] = 0;   // lpsol.h:1504-1510
+    v.eq2bv[r] = enter; v.bv2eq[enter] = r; v.bv2eq[leave] = -1;
+    const unsigned t = st->total_pivots;
+    if ((int)t < v.trace_cap) { v.trace[2 * t] = enter; v.trace[2 * t + 1] = leave; }
+    st->total_pivots = t + 1;
+    st->done += 1;
+}
+
+template <class S> __device__ bool pick_body(const LpView<S> & v, int first, int anypos, int cached_col,
+                                             bool b_cached, bool concurrent, const PickOut o,
+                                             S * colbuf_out, Cand<S> * sh_c, int * sh_i, int * sh_flag,
+                                             int * zero_upto = nullptr, int pass0 = -2)
+{
+    LoopState * st = v.st;
     if (st->done >= st->max_iter) {                    // while (cnt < m_max_iter), lpsol.h:1039
         __syncthreads();
-        if (threadIdx.x == 0) { st->status = 4; st->row = -1; }
-        return;
+        if (threadIdx.x == 0) { *o.status = 4; *o.row = -1; }
+        return false;
     }
     const int rhs = v.rhs, lim = rhs - 1;
-    const int cached_col = st->cached_col;
-    const bool b_cached = st->bcol_valid != 0;
-    int first = st->next_first, anypos = st->anypos;
     __syncthreads();
-    if (first == NF_UNKNOWN) price_scan(v, sh_i, &sh_flag, first, anypos);
+    if (first == NF_UNKNOWN) price_scan(v, sh_i, sh_flag, first, anypos);
     const int stop = first == INT_MAX ? rhs : first;
-    for (int j = threadIdx.x; j < stop; j += blockDim.x)
-        if (!v.nv[j]) v.obj[j] = zero<S>();           // lpsol.h:1055-1060
+    if (zero_upto) {
+        if (threadIdx.x == 0) *zero_upto = stop;
+    } else {
+        for (int j = threadIdx.x; j < stop; j += blockDim.x)
+            if (!v.nv[j]) v.obj[j] = zero<S>();       // lpsol.h:1055-1060
+    }
     __syncthreads();
     int enter = -1, leave = -1;
     if (first == INT_MAX) {
         if (!anypos) {                                 // optimum reached: lpsol.h:1089
-            if (threadIdx.x == 0) { st->status = ST_CHECK_OPT; st->row = -1; }
-            return;
+            if (threadIdx.x == 0) { *o.status = ST_CHECK_OPT; *o.row = -1; }
+            return false;
+        }
+        if (concurrent) {
+            if (threadIdx.x == 0) { *o.row = -1; *o.next_first = INT_MAX; *o.anypos = 1; }
+            return false;
         }
         // SIX::findPivotNVandBVPair (lpsol.h:671-773)
         for (int pass = 0; pass < 2 && enter < 0; pass++) {
@@ -208,11 +268,11 @@ template <class S> __global__ __launch_bounds__(1024) void k_pick(LpView<S> v)
             }
         }
         if (enter < 0) {
-            if (threadIdx.x == 0) { st->status = 1; st->row = -1; }   // SIX_UNBOUND
-            return;
+            if (threadIdx.x == 0) { *o.status = 1; *o.row = -1; }   // SIX_UNBOUND
+            return false;
         }
     } else {
-        leave = ratio_test(v, first, sh_c, first == cached_col, b_cached);
+        leave = ratio_test(v, first, sh_c, first == cached_col, b_cached, pass0);
         if (leave < 0) {                               // disableNV + continue, lpsol.h:1146-1151
             int add = 0;
             for (int j = threadIdx.x; j < rhs; j += blockDim.x) {
@@ -225,9 +285,9 @@ template <class S> __global__ __launch_bounds__(1024) void k_pick(LpView<S> v)
             __threadfence_block();
             __syncthreads();
             int nf, any;                               // no sweep follows: re-price here
-            price_scan(v, sh_i, &sh_flag, nf, any);
-            if (threadIdx.x == 0) { st->row = -1; st->next_first = nf; st->anypos = any; }
-            return;
+            price_scan(v, sh_i, sh_flag, nf, any);
+            if (threadIdx.x == 0) { *o.row = -1; *o.next_first = nf; *o.anypos = any; }
+            return false;
         }
         enter = first;
     }
@@ -236,23 +296,33 @@ template <class S> __global__ __launch_bounds__(1024) void k_pick(LpView<S> v)
     const int r = v.bv2eq[leave];
     __syncthreads();                                   // everyone has read bv2eq[leave]
     for (int i = threadIdx.x; i < v.m; i += blockDim.x)
-        v.colbuf[i] = neg(col_cached ? v.nextcol[i] : v.tab[(size_t)i * v.ld + enter]);   // :1485
+        colbuf_out[i] = neg(col_cached ? v.nextcol[i] : v.tab[(size_t)i * v.ld + enter]);   // :1485
     if (threadIdx.x == 0) {
         if (!ppt_seen(v, enter, leave)) {              // genPair, lpsol.h:100-104
             v.ppt[(size_t)enter * v.pw + (leave >> 5)] |= 1u << (leave & 31);
             v.rowcnt[enter] += 1; v.colcnt[leave] += 1;
         }
-        st->row = r; st->col = enter; st->leave = leave;
-        st->cnv_bits = to_bits(v.obj[enter]);
-        st->piv_bits = to_bits(col_cached ? v.nextcol[r] : v.tab[(size_t)r * v.ld + enter]);
-        v.nv[enter] = 0; v.nv[leave] = 1; v.bv[enter] = 1; v.bv[leave] = 0;   // :1504-1510
-        v.eq2bv[r] = enter; v.bv2eq[enter] = r; v.bv2eq[leave] = -1;
-        const unsigned t = st->total_pivots;
-        if ((int)t < v.trace_cap) { v.trace[2 * t] = enter; v.trace[2 * t + 1] = leave; }
-        st->total_pivots = t + 1;
-        st->done += 1;
-        st->next_first = INT_MAX; st->anypos = 0;      // k_prep's look-ahead fills these
+        *o.row = r; *o.col = enter; *o.leave = leave;
+        *o.cnv_bits = to_bits(v.obj[enter]);
+        *o.piv_bits = to_bits(col_cached ? v.nextcol[r] : v.tab[(size_t)r * v.ld + enter]);
+        if (!zero_upto) pick_commit(v, r, enter, leave);
+        *o.next_first = INT_MAX; *o.anypos = 0;        // the prep kernel's look-ahead fills these
     }
+    return true;
+}
+
+template <class S> __global__ __launch_bounds__(1024) void k_pick(LpView<S> v)
+{
+    __shared__ __attribute__((aligned(8))) unsigned char sh_c_raw[16 * sizeof(Cand<S>)];
+    __shared__ int sh_i[16];
+    __shared__ int sh_flag;
+    LoopState * st = v.st;
+    if (st->status != ST_RUNNING) return;
+    const PickOut o = { &st->status, &st->row, &st->col, &st->leave, &st->next_first, &st->anypos,
+                        &st->cnv_bits, &st->piv_bits };
+    const int first = st->next_first, anypos = st->anypos, cached_col = st->cached_col;
+    const bool b_cached = st->bcol_valid != 0;
+    pick_body<S>(v, first, anypos, cached_col, b_cached, false, o, v.colbuf, (Cand<S> *)sh_c_raw, sh_i, &sh_flag);
 }
 
 // Row / column staging, objective update and basis swap for the pivot chosen in
@@ -411,6 +481,344 @@ void k_update_f64(double * __restrict__ tab, int m, int W, int ld,
     }
 }
 
+// ---- Pipelined fp64 loop: two launches per pivot ------------------------------------------------
+// Iteration t:  k_pipe_prep(slot = t & 1)  ->  k_pipe_sweep(slot).
+// k_pipe_prep stages the scaled pivot row, updates the objective row and prices the NEXT
+// iteration (atomicMin into pd[slot].next_first). k_pipe_sweep's grid carries one extra
+// workgroup (blockIdx.y == 0, dispatched first) that commits this iteration's basis swap and
+// chooses the pivot of iteration t + 1 WHILE the other workgroups sweep. What it needs of the
+// post-sweep tableau it produces itself with the sweep's own mul-then-add:
+//   * the constant column lives in the contiguous bcol[] for the whole loop (b_i += k_i e_b);
+//     the sweep updates the tableau's copy as part of its normal work, bit-identically;
+//   * the predicted entering column: the sweep leaves that 16-byte column pair untouched and
+//     the pick workgroup updates exactly that pair, keeping the column in nextcol[].
+// Nothing the sweep reads is written by the pick workgroup and vice versa (pd[slot ^ 1], the
+// other half of colbuf, the basis arrays, the pair table), so there is no intra-kernel
+// hand-off; launch boundaries order everything else. pd[].stop defers a final status by one
+// launch so that the sweep in flight completes.
+template <class S> __global__ __launch_bounds__(256) void k_pipe_prep(LpView<S> v, int slot)
+{
+    LoopState * st = v.st;
+    if (st->status != ST_RUNNING) return;
+    PipeDesc & D = st->pd[slot];
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+    const int zu = D.zero_upto;
+    if (D.stop != 0) {
+        for (int j = gid; j < zu; j += gsz)
+            if (!v.nv[j]) v.obj[j] = zero<S>();                // lpsol.h:1055-1060, deferred by the pick
+        if (gid == 0) st->status = D.stop;
+        return;
+    }
+    if (D.row < 0) return;
+    if (gid == 0) v.pickrec[PICK_CTR_OFF + 16 * slot] = 0ull;  // arrival counter of this iteration's pick
+    const int r = D.row, enter = D.col, leave = D.leave;
+    const S s = div(one<S>(), from_bits<S>(D.piv_bits));      // 1/(eq.get(eqnum, nv)), :1471
+    const int smode = scale_mode(s);
+    const S cnv = from_bits<S>(D.cnv_bits);
+    const int cmode = scale_mode(cnv);
+    const int lim = v.rhs - 1;
+    int nf = INT_MAX, any = 0;
+    for (int j = gid; j < v.W; j += gsz) {
+        S e = scaled(v.tab[(size_t)r * v.ld + j], s, smode);
+        v.rowbuf[j] = e;
+        S t = mul(e, minus_one<S>());                          // nvexp.mul(-1), :1496
+        if (j >= v.rhs) t = neg(t);                            // :1497-1499
+        t = scaled(t, cnv, cmode);                             // nvexp.mul(tgtf(nv)), :1500
+        const bool nvj = j < v.rhs && v.nv[j] != 0;            // basis BEFORE this pivot's swap
+        S oj = v.obj[j];
+        if (j < zu && !nvj) oj = zero<S>();                    // lpsol.h:1055-1060, deferred by the pick
+        const S o = add(t, oj);                                // addRowToRow, :1501
+        v.obj[j] = o;
+        // look-ahead pricing of the next iteration, on the basis AFTER the swap
+        const bool nv_next = j == enter ? false : (j == leave ? true : nvj);
+        if (j < v.rhs && nv_next && gt(o, zero<S>())) {
+            any = 1;
+            if (v.rowcnt[j] < lim) nf = min(nf, j);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { nf = min(nf, __shfl_xor(nf, o)); any |= __shfl_xor(any, o); }
+    if ((threadIdx.x & 63) == 0) {
+        if (nf != INT_MAX) atomicMin(&D.next_first, nf);
+        if (any) atomicOr(&D.anypos, 1);
+    }
+}
+
+// The pick workgroups of k_pipe_sweep: the first PICK_WGS(gridDim.x) workgroups of row 0 of the
+// grid, 256 threads each. They are latency-bound (HBM is saturated by the sweep around them: a
+// dependent round trip costs ~6 us then), so the work is spread over up to 16 workgroups with
+// every load of a row in flight at once, and the common case is ONE fused pass per workgroup
+// over its rows: new constant column, new entering column (the pair the sweep skips), -column
+// for the next sweep, and the ratio test's first pass on those fresh values. Each workgroup
+// publishes its best row as four 8-byte agent-scope atomic stores, one lane adds to an
+// agent-scope counter, and the lane whose add came last combines the records and writes the
+// next pivot (MI355X_MICROARCH visibility table, row 1: sc1 stores, counter add after the
+// storing lane's vmcnt(0), sc1 loads by the last adder). Bulk data never crosses workgroups
+// inside the launch. Anything but "first pass found a row" (relaxed second pass, disableNV,
+// findPivotNVandBVPair) is deferred by one iteration: row = -1 with the look-ahead carried
+// over, and the next launch, which has nothing to sweep, runs the generic single-workgroup
+// pick_body on a quiescent tableau.
+__device__ __forceinline__ int pick_wgs(int strips) { return strips < PICK_MAX_WGS ? strips : PICK_MAX_WGS; }
+
+__device__ inline void write_desc(PipeDesc & O, int row, int col, int leave, int next_first, int anypos, int stop,
+                                  int cached_col, int zero_upto, unsigned done_after, unsigned total_after,
+                                  unsigned long long cnv_bits, unsigned long long piv_bits)
+{
+    O.row = row; O.col = col; O.leave = leave; O.next_first = next_first; O.anypos = anypos; O.stop = stop;
+    O.cached_col = cached_col; O.bcol_valid = 1; O.zero_upto = zero_upto; O.done_after = done_after;
+    O.total_after = total_after; O.cnv_bits = cnv_bits; O.piv_bits = piv_bits;
+}
+
+__device__ inline void pipe_pick_f64(const LpView<F64> & v, int slot, int colstride, int p, int N)
+{
+    __shared__ __attribute__((aligned(8))) unsigned char sh_c_raw[16 * sizeof(Cand<F64>)];
+    __shared__ int sh_i[16];
+    __shared__ int sh_flag;
+    Cand<F64> * sh_c = (Cand<F64> *)sh_c_raw;
+    LoopState * st = v.st;
+    PipeDesc & I = st->pd[slot];
+    PipeDesc & O = st->pd[slot ^ 1];
+    const int r = I.row, ienter = I.col, ileave = I.leave, first = I.next_first, anypos = I.anypos;
+    const unsigned done_now = I.done_after, total_now = I.total_after, max_iter = st->max_iter;
+    const int W = v.W, rhs = v.rhs, ld = v.ld, m = v.m, lim = v.rhs - 1;
+    double * __restrict__ tab = (double *)v.tab;
+    double * __restrict__ nextcol = (double *)v.nextcol;
+    double * __restrict__ bcol = (double *)v.bcol;
+    double * __restrict__ cbo = (double *)v.colbuf + (size_t)(slot ^ 1) * colstride;
+    const int tid = threadIdx.x;
+
+    if (r < 0) {
+        // ---- nothing is being swept: one workgroup, generic code, tableau quiescent
+        if (p != 0) return;
+        const int izero = I.zero_upto, cached_col = I.cached_col;
+        const bool b_was_cached = I.bcol_valid != 0;
+        for (int j = tid; j < izero; j += 256)
+            if (!v.nv[j]) v.obj[j] = zero<F64>();                              // deferred lpsol.h:1055-1060
+        if (!b_was_cached)
+            for (int i = tid; i < m; i += 256) bcol[i] = tab[(size_t)i * ld + rhs];
+        if (tid == 0)
+            write_desc(O, -1, 0, 0, INT_MAX, 0, 0, cached_col, 0, done_now, total_now, 0ull, 0ull);
+        __threadfence_block();
+        __syncthreads();
+        if (done_now >= max_iter) {                    // while (cnt < m_max_iter), lpsol.h:1039
+            if (tid == 0) O.stop = 4;
+            return;
+        }
+        const PickOut o = { &O.stop, &O.row, &O.col, &O.leave, &O.next_first, &O.anypos, &O.cnv_bits, &O.piv_bits };
+        const bool chosen = pick_body<F64>(v, first, anypos, cached_col, true, false, o, (F64 *)cbo, sh_c, sh_i,
+                                           &sh_flag, &O.zero_upto);
+        if (chosen && tid == 0) { O.done_after = done_now + 1; O.total_after = total_now + 1; }
+        return;
+    }
+
+    // ---- a sweep is running around us
+    if (p == 0 && tid == 0) {                          // commit this iteration's pivot (lpsol.h:1504-1510)
+        v.nv[ienter] = 0; v.nv[ileave] = 1; v.bv[ienter] = 1; v.bv[ileave] = 0;
+        v.eq2bv[r] = ienter; v.bv2eq[ienter] = r; v.bv2eq[ileave] = -1;
+        const unsigned t = total_now - 1;
+        if ((int)t < v.trace_cap) { v.trace[2 * t] = ienter; v.trace[2 * t + 1] = ileave; }
+        st->total_pivots = total_now; st->done = done_now;
+    }
+    const int xc = (first >= 0 && first < W) ? first : -1;
+    const double * __restrict__ cb = (const double *)v.colbuf + (size_t)slot * colstride;
+    const double * __restrict__ rb = (const double *)v.rowbuf;
+    const double eb = rb[rhs];
+    const int stride = 256 * N;                        // rows are dealt to the workgroups in blocks of 256
+    if (xc < 0 || done_now >= max_iter) {
+        // no ratio test this time: keep the columns current, workgroup 0 records the outcome
+        if (xc >= 0) {
+            const int pc = xc & ~1;
+            const bool wide = pc + 1 < W;
+            const double e0 = rb[pc], e1 = wide ? rb[pc + 1] : 0.0;
+            for (int i = p * 256 + tid; i < m; i += stride) {
+                double * q = tab + (size_t)i * ld + pc;
+                const double k = cb[i];
+                double n0 = q[0] + k * e0, n1 = wide ? q[1] + k * e1 : 0.0;
+                if (i == r) { n0 = e0; n1 = e1; }
+                q[0] = n0; if (wide) q[1] = n1;
+                nextcol[i] = (xc & 1) ? n1 : n0;
+            }
+        }
+        for (int i = p * 256 + tid; i < m; i += stride) {
+            const double q = cb[i] * eb;
+            bcol[i] = (i == r) ? eb : (bcol[i] + q);
+        }
+        if (p == 0 && tid == 0) {
+            if (done_now >= max_iter)                  // while (cnt < m_max_iter), lpsol.h:1039
+                write_desc(O, -1, 0, 0, first, anypos, 4, xc, 0, done_now, total_now, 0ull, 0ull);
+            else if (first == INT_MAX && !anypos)      // optimum reached: lpsol.h:1089
+                write_desc(O, -1, 0, 0, first, anypos, ST_CHECK_OPT, -1, rhs, done_now, total_now, 0ull, 0ull);
+            else                                       // findPivotNVandBVPair needs the whole tableau: next launch
+                write_desc(O, -1, 0, 0, first, anypos, 0, -1, 0, done_now, total_now, 0ull, 0ull);
+        }
+        return;
+    }
+
+    // ---- fused pass over this workgroup's rows
+    const int pc = xc & ~1;
+    const bool wide = pc + 1 < W, odd = (xc & 1) != 0;
+    const double e0 = rb[pc], e1 = wide ? rb[pc + 1] : 0.0;
+    unsigned long long cnv_bits = 0; int rc_enter = 0;
+    if (tid == 0) { cnv_bits = to_bits(v.obj[xc]); rc_enter = v.rowcnt[xc]; }   // for the last adder's tail
+    constexpr int U = 2;
+    Cand<F64> best; best.q = zero<F64>(); best.idx = INT_MAX;
+    double best_a = 0.0; int best_b = 0, best_cc = 0; uint32_t best_w = 0;
+    for (int i0 = p * 256 + tid; i0 < m; i0 += stride * U) {
+        double k[U], bo[U], c0[U], c1[U];
+        int bi[U], cc[U]; uint32_t w[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = min(i0 + u * stride, m - 1);
+            const double * q = tab + (size_t)i * ld + pc;
+            k[u] = cb[i]; bo[u] = bcol[i];
+            if (wide) { const double2 t = *reinterpret_cast<const double2 *>(q); c0[u] = t.x; c1[u] = t.y; }
+            else { c0[u] = q[0]; c1[u] = 0.0; }
+            bi[u] = v.eq2bv[i];
+            if (i == r) bi[u] = ienter;                // the commit above, seen without waiting for it
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) { w[u] = v.ppt[(size_t)xc * v.pw + (bi[u] >> 5)]; cc[u] = v.colcnt[bi[u]]; }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = i0 + u * stride;
+            if (i >= m) continue;
+            double * q = tab + (size_t)i * ld + pc;
+            const double qb = k[u] * eb, s0 = k[u] * e0, s1 = k[u] * e1;
+            double nb = bo[u] + qb, n0 = c0[u] + s0, n1 = c1[u] + s1;         // the sweep's a + k*e
+            if (i == r) { nb = eb; n0 = e0; n1 = e1; }
+            bcol[i] = nb;
+            if (wide) { double2 t; t.x = n0; t.y = n1; *reinterpret_cast<double2 *>(q) = t; }
+            else q[0] = n0;
+            const double a = odd ? n1 : n0;
+            nextcol[i] = a;
+            cbo[i] = -a;                                                      // -column, lpsol.h:1485
+            if (le(F64(a), zero<F64>())) continue;                            // findPivotBV, lpsol.h:553-663
+            if (((w[u] >> (bi[u] & 31)) & 1u) || cc[u] >= lim) continue;
+            Cand<F64> c; c.q = div(F64(nb), F64(a)); c.idx = i;
+            const Cand<F64> nbest = better(best, c);
+            if (nbest.idx != best.idx) { best_a = a; best_b = bi[u]; best_cc = cc[u]; best_w = w[u]; }
+            best = nbest;
+        }
+    }
+    const Cand<F64> wbest = block_argmin(best, sh_c);
+    // one lane publishes this workgroup's record: the owner of the winning row, else lane 0
+    const bool publisher = wbest.idx != INT_MAX ? (best.idx == wbest.idx) : (tid == 0);
+    __shared__ unsigned long long sh_cnv; __shared__ int sh_rc;
+    if (tid == 0) { sh_cnv = cnv_bits; sh_rc = rc_enter; }
+    __syncthreads();
+    if (!publisher) return;
+    unsigned long long * rec = v.pickrec + (size_t)p * PICK_REC_WORDS;
+    unsigned long long * ctr = v.pickrec + PICK_CTR_OFF + 16 * slot;
+    __hip_atomic_store(rec + 0, to_bits(wbest.q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(rec + 1, to_bits(F64(best_a)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(rec + 2, ((unsigned long long)(unsigned)wbest.idx << 32) | (unsigned)best_b, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(rec + 3, ((unsigned long long)best_w << 32) | (unsigned)best_cc, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long arrived = __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (arrived != (unsigned long long)(N - 1)) return;
+    // ---- last adder: combine the records in workgroup order (ties: lowest row, lpsol.h:604-611)
+    Cand<F64> g; g.q = zero<F64>(); g.idx = INT_MAX;
+    double g_a = 0.0; int g_b = 0, g_cc = 0; uint32_t g_w = 0;
+    for (int k = 0; k < N; k++) {
+        const unsigned long long * rk = v.pickrec + (size_t)k * PICK_REC_WORDS;
+        const unsigned long long w0 = __hip_atomic_load(rk + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long w1 = __hip_atomic_load(rk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long w2 = __hip_atomic_load(rk + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long w3 = __hip_atomic_load(rk + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        Cand<F64> c; c.q = from_bits<F64>(w0); c.idx = (int)(unsigned)(w2 >> 32);
+        const Cand<F64> ng = better(g, c);
+        if (ng.idx != g.idx) { g_a = from_bits<F64>(w1).v; g_b = (int)(unsigned)w2; g_w = (uint32_t)(w3 >> 32); g_cc = (int)(unsigned)w3; }
+        g = ng;
+    }
+    if (g.idx == INT_MAX) {                            // first pass empty: second pass / disableNV next launch
+        write_desc(O, -1, 0, 0, first, anypos, 0, xc, 0, done_now, total_now, 0ull, 0ull);
+        return;
+    }
+    const int enter = xc, leave = g_b;
+    if (!((g_w >> (leave & 31)) & 1u)) {               // genPair, lpsol.h:100-104
+        v.ppt[(size_t)enter * v.pw + (leave >> 5)] = g_w | (1u << (leave & 31));
+        v.rowcnt[enter] = sh_rc + 1; v.colcnt[leave] = g_cc + 1;
+    }
+    write_desc(O, g.idx, enter, leave, INT_MAX, 0, 0, xc, first, done_now + 1, total_now + 1, sh_cnv,
+               to_bits(F64(g_a)));
+}
+
+// A/B aid (XPG_LOOP=split): the pick as a launch of its own after a sweep launched without it.
+__global__ __launch_bounds__(256) void k_pipe_pick(LpView<F64> v, int slot, int colstride)
+{
+    if (v.st->status != ST_RUNNING) return;
+    pipe_pick_f64(v, slot, colstride, blockIdx.x, gridDim.x);
+}
+
+template <int ROWS, int UNROLL> __global__ __launch_bounds__(256)
+void k_pipe_sweep(LpView<F64> v, int slot, int colstride, int with_pick,
+                  double * __restrict__ tab, const double * __restrict__ rowbuf,
+                  const double * __restrict__ colbuf)
+{
+    // tab / rowbuf / colbuf (this slot's half) repeat v's pointers as restrict PARAMETERS: only then
+    // does -a_i,nv arrive through the scalar cache (restrict on a local is not enough; measured
+    // 84.5 us against 73 us per sweep).
+    LoopState * st = v.st;
+    if (st->status != ST_RUNNING) return;
+    if (blockIdx.y == 0) {
+        const int N = pick_wgs(gridDim.x);
+        if ((int)blockIdx.x < N && with_pick) pipe_pick_f64(v, slot, colstride, blockIdx.x, N);
+        return;
+    }
+    const PipeDesc & D = st->pd[slot];
+    const int r = D.row;
+    if (r < 0) return;
+    const int W = v.W, ld = v.ld, m = v.m;
+    const int j = blockIdx.x * 512 + threadIdx.x * 2;
+    if (j >= W) return;
+    const int first = D.next_first;
+    const int xc = (first >= 0 && first < W) ? first : -1;
+    if (xc >= 0 && j == (xc & ~1)) return;                    // the pick workgroup's pair
+    const int i0 = (blockIdx.y - 1) * ROWS;
+    const int iend = min(i0 + ROWS, m);
+    if (j + 1 < W) {
+        const double2 e = *reinterpret_cast<const double2 *>(rowbuf + j);
+        double * base = tab + (size_t)i0 * ld + j;
+        int i = i0;
+        for (; i + UNROLL <= iend; i += UNROLL) {
+            double2 a[UNROLL];
+            double k[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+                a[u] = *reinterpret_cast<const double2 *>(base + (size_t)u * ld);
+                k[u] = colbuf[i + u];
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+                double2 o;
+                const double p0 = k[u] * e.x, p1 = k[u] * e.y;
+                o.x = a[u].x + p0; o.y = a[u].y + p1;
+                if (i + u == r) o = e;
+                *reinterpret_cast<double2 *>(base + (size_t)u * ld) = o;
+            }
+            base += (size_t)UNROLL * ld;
+        }
+        for (; i < iend; i++) {
+            double2 a = *reinterpret_cast<const double2 *>(base);
+            const double k = colbuf[i];
+            double2 o;
+            const double p0 = k * e.x, p1 = k * e.y;
+            o.x = a.x + p0; o.y = a.y + p1;
+            if (i == r) o = e;
+            *reinterpret_cast<double2 *>(base) = o;
+            base += ld;
+        }
+    } else {                                                  // odd last column
+        const double e = rowbuf[j];
+        for (int i = i0; i < iend; i++) {
+            double * p = tab + (size_t)i * ld + j;
+            const double q = colbuf[i] * e;
+            *p = (i == r) ? e : (*p + q);
+        }
+    }
+}
+
 // ---- optimum: solution read-out + SIX::is_feasible (lpsol.h:1104-1110, :784-822)
 template <class S> __global__ void k_solution(LpView<S> v)
 {
@@ -495,6 +903,12 @@ template <class S> __global__ void k_reset_loop(LpView<S> v, unsigned max_iter)
         st->status = ST_RUNNING; st->done = 0; st->max_iter = max_iter;
         st->row = -1; st->infeasible = 0;
         st->next_first = NF_UNKNOWN; st->anypos = 0; st->cached_col = -1; st->bcol_valid = 0;
+        for (int k = 0; k < 2; k++) {                  // pipelined loop: iteration 0 has no pivot yet
+            PipeDesc & D = st->pd[k];
+            D.row = -1; D.col = 0; D.leave = 0; D.next_first = NF_UNKNOWN; D.anypos = 0; D.stop = 0;
+            D.cached_col = -1; D.bcol_valid = 0; D.zero_upto = 0; D.pad_ = 0; D.cnv_bits = 0; D.piv_bits = 0;
+            D.done_after = 0; D.total_after = st->total_pivots;
+        }
     }
 }
 
