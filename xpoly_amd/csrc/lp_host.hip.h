@@ -20,6 +20,7 @@ struct xpg_ctx {
     void * rowbuf; void * colbuf; xpg::LoopState * st; size_t row_cap, col_cap;
     int update_variant;     // tuning knob for the fp64 sweep (see launch_update_f64)
     int loop_mode;          // 0: pipelined fp64 loop (2 launches per pivot), 1: serial pick/prep/update
+    int zigzag;             // pipelined sweep alternates its tile order (Infinity Cache reuse)
     // xpg_profile_begin/end: event pairs around each sweep launch
     std::vector<hipEvent_t> ev0, ev1;
     int prof_cap, prof_n, prof_stride, prof_seen;
@@ -93,7 +94,7 @@ template <> inline void launch_pipe_sweep<F64>(xpg_ctx * ctx, const LpView<F64> 
     const int fused = ctx->loop_mode == 2 ? 0 : 1;
     hipLaunchKernelGGL((k_pipe_sweep<32, 8>), dim3(strips, (v.m + 31) / 32 + 1), dim3(256), 0, ctx->stream, v, slot,
                        colstride, fused, (double *)v.tab, (const double *)v.rowbuf,
-                       (const double *)v.colbuf + (size_t)slot * colstride);
+                       (const double *)v.colbuf + (size_t)slot * colstride, ctx->zigzag ? (slot & 1) : 0);
     if (timed) prof_close(ctx);
     if (!fused)
         hipLaunchKernelGGL(k_pipe_pick, dim3(strips < PICK_MAX_WGS ? strips : PICK_MAX_WGS), dim3(256), 0, ctx->stream,

@@ -48,6 +48,8 @@ int xpg_create(xpg_ctx ** out, int device)
     const char * var = getenv("XPG_UPDATE_VARIANT");
     c->update_variant = var ? atoi(var) : 0;
     const char * lm = getenv("XPG_LOOP");              // "serial": the three-launch loop, for A/B runs
+    const char * zz = getenv("XPG_ZIGZAG");
+    c->zigzag = zz ? atoi(zz) : 0;                      // measured slower (79.7 vs 77.8 us per sweep): off
     c->loop_mode = (lm && lm[0] == 's' && lm[1] == 'e') ? 1 : ((lm && lm[0] == 's' && lm[1] == 'p') ? 2 : 0);
     c->prof_cap = 0; c->prof_n = 0; c->prof_stride = 1; c->prof_seen = 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return XPG_ERR_HIP; }
