@@ -173,6 +173,31 @@ def test_medium_lp_trace_f64(ctx, port):
             assert same(got[k], want[k]), (K, k)
 
 
+def test_device_loop_rare_branches_f64(ctx, port):
+    """Dependence-test-like LPs (entries in {-3..3}, many ties and zero pivots candidates) drive the
+    device-resident loop through its rare branches -- relaxed second ratio pass, disableNV,
+    findPivotNVandBVPair, exhaustion of the anti-cycling pair table -- which the pipelined loop defers
+    to a launch without a sweep. Status, tableau, objective row, basis maps: bit-identical to the
+    oracle at several pivot counts and at the end."""
+    import xpoly_amd
+    six = xpoly_amd.SIX(ctx, F64)
+    leqs, tgs = gen.small_lp_batch_f64(6, 24, 33, family=1, seed=gen.XS_SEED + 77)
+    finals = set()
+    for b in range(6):
+        for K in (3, 17, 64, 0xFFFFFFFF):
+            want = port.two_stage(F64, leqs[b], tgs[b], K)
+            six.set_param(0, K)
+            got = six.TwoStageMethod(leqs[b], tgs[b])
+            assert got["status"] == want["status"], (b, K, got["status"], want["status"])
+            if want["status"] == 2:
+                continue
+            for k in KEYS:
+                assert same(got[k], want[k]), (b, K, k)
+            if K == 0xFFFFFFFF:
+                finals.add(want["status"])
+    assert len(finals) >= 1
+
+
 # ---- batches ---------------------------------------------------------------------------------
 @pytest.mark.parametrize("kind", [F64, RAT])
 @pytest.mark.parametrize("is_max", [True, False])
