@@ -216,6 +216,39 @@ def test_batch_matches_oracle(ctx, port, kind, is_max):
                 assert same(sol[b], want[2]), (m, nv, fam, b)
 
 
+@pytest.mark.parametrize("variant", ["m", "w"])
+@pytest.mark.parametrize("kind", [F64, RAT])
+def test_batch_register_resident_loops(ctx, port, kind, variant, monkeypatch):
+    """The opt-in register-resident pivot loops of the batch kernel (XPG_BATCH_REGS=m: four waves
+    per LP, =w: one wavefront per LP) give the same statuses, objectives and solutions as the oracle,
+    on both families of the 32x64 shape (fp64) and on random rational problems incl. phase 1."""
+    monkeypatch.setenv("XPG_BATCH_REGS", variant)
+    if kind == F64:
+        for fam in (0, 1):
+            leq, tg = gen.small_lp_batch_f64(24, 32, 64, fam, seed=gen.XS_SEED + 5 + fam)
+            for is_max in (True, False):
+                status, v, sol = ctx.six_batch(F64, is_max, tg, leq)
+                for b in range(24):
+                    want = port.six_solve(F64, is_max, tg[b], gen.vc_nonneg(63), None, leq[b])
+                    assert status[b] == want[0], (fam, is_max, b, status[b], want[0])
+                    assert same(np.atleast_1d(v[b]), np.atleast_1d(want[1]))
+                    if want[0] == 0:
+                        assert same(sol[b], want[2])
+    else:
+        rng = np.random.default_rng(17)
+        for m, nv in ((6, 5), (12, 9), (20, 30), (32, 40)):
+            probs = [gen.random_problem(rng, RAT, 1, m, nv, plain=True) for _ in range(16)]
+            leq = np.stack([p["leq"] for p in probs]); tg = np.stack([p["tgtf"] for p in probs])
+            for is_max in (True, False):
+                status, v, sol = ctx.six_batch(RAT, is_max, tg, leq)
+                for b in range(16):
+                    want = port.six_solve(RAT, is_max, probs[b]["tgtf"], probs[b]["vc"], None, probs[b]["leq"])
+                    assert status[b] == want[0], (m, nv, is_max, b)
+                    assert same(v[b], want[1])
+                    if want[0] == 0:
+                        assert same(sol[b], want[2])
+
+
 def test_batch_cfg3_shape_sample(ctx, port):
     """32x64 LPs of both benchmark families (SURVEY section 8d cfg 3): status and objective of a
     64-LP sample against the oracle, bug-compatibly (incl. the 'wrong' statuses)."""
