@@ -136,47 +136,64 @@ template <class S> __device__ __forceinline__ Cand<S> wave_argmin(Cand<S> c)
 // c_nv are parked in sh_c so that nobody re-reads them after the row has been rescaled.
 template <class S> __device__ __forceinline__ void sm_select_wave0(Small<S> & P)
 {
-    const int lane = threadIdx.x, rhs = P.rhs, lim = rhs - 1;
+    // The selection is a latency chain: every LDS load of a stage is issued before the first use
+    // (indices clamped instead of tested: the reference's short-circuit order would serialise them)
+    // and the bookkeeping takes its values from the lanes' registers through v_readlane.
+    const int lane = threadIdx.x, rhs = P.rhs, lim = rhs - 1, R = P.R;
     const int j0 = lane, j1 = lane + 64;
     const bool in0 = j0 < rhs, in1 = j1 < rhs;
-    const bool nb0 = in0 && P.nv[j0], nb1 = in1 && P.nv[j1];
-    const bool c0 = nb0 && gt(P.obj[j0], zero<S>()), c1 = nb1 && gt(P.obj[j1], zero<S>());
-    const bool o0 = c0 && P.rowcnt[j0] < lim, o1 = c1 && P.rowcnt[j1] < lim;
+    const int q0 = in0 ? j0 : 0, q1 = in1 ? j1 : 0;
+    const int nv0 = P.nv[q0], nv1 = P.nv[q1];
+    const S ob0 = P.obj[q0], ob1 = P.obj[q1];
+    const int rc0 = P.rowcnt[q0], rc1 = P.rowcnt[q1];
+    const bool nb0 = in0 && nv0 != 0, nb1 = in1 && nv1 != 0;
+    const bool c0 = nb0 && gt(ob0, zero<S>()), c1 = nb1 && gt(ob1, zero<S>());
+    const bool o0 = c0 && rc0 < lim, o1 = c1 && rc1 < lim;
     const unsigned long long m0 = __ballot(o0), m1 = __ballot(o1), any = __ballot(c0 || c1);
     const int first = m0 ? __ffsll((long long)m0) - 1 : (m1 ? 64 + __ffsll((long long)m1) - 1 : INT_MAX);
     const int stop = first == INT_MAX ? rhs : first;
     if (in0 && j0 < stop && !nb0) P.obj[j0] = zero<S>();             // lpsol.h:1055-1060
     if (in1 && j1 < stop && !nb1) P.obj[j1] = zero<S>();
-    int action, leave = -1, row = -1;
-    if (first == INT_MAX) action = any ? ACT_FINDPAIR : ACT_OPT;
-    else {
-        Cand<S> best; best.q = zero<S>(); best.idx = INT_MAX;
-        for (int pass = 0; pass < 2 && best.idx == INT_MAX; pass++) {
-            Cand<S> c; c.q = zero<S>(); c.idx = INT_MAX;
-            if (lane < P.R) {
-                const S a = P.tab[lane * P.ld + first];
-                const bool skip = pass == 0 ? le(a, zero<S>()) : eq(a, zero<S>());
-                if (!skip) {
-                    const int b = P.eq2bv[lane];
-                    if (!sm_seen(P, first, b) && P.colcnt[b] < lim) { c.q = div(P.tab[lane * P.ld + rhs], a); c.idx = lane; }
-                }
-            }
-            best = wave_argmin(c);
-        }
-        if (best.idx == INT_MAX) action = ACT_CLOSE;
-        else { action = ACT_PIVOT; row = best.idx; leave = P.eq2bv[row]; }
+    if (first == INT_MAX) {
+        if (lane == 0) { P.sh_w[0] = any ? ACT_FINDPAIR : ACT_OPT; P.sh_w[1] = first; P.sh_w[2] = -1; P.sh_w[3] = -1; }
+        return;
     }
+    // ratio test (lpsol.h:553-663): two LDS rounds, one division, arg-min on the VALU
+    const int li = lane < R ? lane : 0;
+    const S a = P.tab[li * P.ld + first], bc = P.tab[li * P.ld + rhs];
+    const int b = P.eq2bv[li];
+    const uint32_t w = P.ppt[first * P.pw + (b >> 5)];
+    const int cc = P.colcnt[b];
+    const bool open = lane < R && !((w >> (b & 31)) & 1u) && cc < lim;
+    const bool nonzero = open && !eq(a, zero<S>());
+    Cand<S> c; c.q = nonzero ? div(bc, a) : zero<S>();
+    c.idx = (nonzero && !le(a, zero<S>())) ? lane : INT_MAX;
+    Cand<S> best = wave_argmin(c);
+    if (best.idx == INT_MAX) {                                       // relaxed second pass: a != 0
+        c.idx = nonzero ? lane : INT_MAX;
+        best = wave_argmin(c);
+    }
+    const int row = __builtin_amdgcn_readfirstlane(best.idx);
+    if (row == INT_MAX) {
+        if (lane == 0) { P.sh_w[0] = ACT_CLOSE; P.sh_w[1] = first; P.sh_w[2] = -1; P.sh_w[3] = -1; }
+        return;
+    }
+    const int leave = __builtin_amdgcn_readlane(b, row);
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readlane((int)w, row);
+    const int ccv = __builtin_amdgcn_readlane(cc, row);
+    Cand<S> pa; pa.q = a; pa.idx = 0;
+    Cand<S> po0; po0.q = ob0; po0.idx = rc0;
+    Cand<S> po1; po1.q = ob1; po1.idx = rc1;
+    const S piv = read_lane(pa, row).q;
+    const Cand<S> pf = first < 64 ? read_lane(po0, first) : read_lane(po1, first - 64);
     if (lane == 0) {
-        P.sh_w[0] = action; P.sh_w[1] = first; P.sh_w[2] = leave; P.sh_w[3] = row;
-        if (action == ACT_PIVOT) {
-            if (!sm_seen(P, first, leave)) {                              // genPair, lpsol.h:100-104
-                P.ppt[first * P.pw + (leave >> 5)] |= 1u << (leave & 31);
-                P.rowcnt[first] += 1; P.colcnt[leave] += 1;
-            }
-            S * park = (S *)P.sh_c;
-            park[0] = P.tab[row * P.ld + first];
-            park[1] = P.obj[first];
-        }
+        P.sh_w[0] = ACT_PIVOT; P.sh_w[1] = first; P.sh_w[2] = leave; P.sh_w[3] = row;
+        // genPair (lpsol.h:100-104): a candidate row was by construction not yet paired
+        P.ppt[first * P.pw + (leave >> 5)] = wv | (1u << (leave & 31));
+        P.rowcnt[first] = pf.idx + 1; P.colcnt[leave] = ccv + 1;
+        S * park = (S *)P.sh_c;
+        park[0] = piv;
+        park[1] = pf.q;
     }
 }
 
