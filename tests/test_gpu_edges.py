@@ -123,6 +123,37 @@ def test_full_size_tableau_properties(ctx, port):
     assert np.array_equal(eq2bv, want["eq2bv"])
 
 
+def test_full_size_pipelined_loop_against_serial_loop_and_oracle(port, monkeypatch):
+    """4096 x 8192 fp64, 300 pivots under full load (2048 sweep workgroups around the 16 pick
+    workgroups and their in-launch hand-off): the pipelined loop, the serial three-launch loop and
+    the CPU oracle must agree bit for bit -- same (entering, leaving) trace, same basis, same
+    tableau (all of it between the two GPU loops, a 96-row sample against the oracle)."""
+    import xpoly_amd
+    m, n, K = 4096, 4095, 300
+    leq, tg = gen.hard_lp_f64(m, n)
+    got = {}
+    for mode in ("pipe", "serial"):
+        monkeypatch.setenv("XPG_LOOP", mode)             # read when the context is created
+        c = xpoly_amd.Context(0)
+        lp = xpoly_amd.DeviceLP(c, F64, leq, tg)
+        lp.begin()
+        for k in (7, 93, 200):                           # uneven chunks: 300 pivots in all
+            assert lp.iterate(k) == xpoly_amd.six.XPG_RUNNING
+        got[mode] = (lp.read(), lp.trace().copy(), lp.pivots_done())
+        lp.close(); c.close()
+    (a, ta, na), (b, tb, nb) = got["pipe"], got["serial"]
+    assert na == nb == K and np.array_equal(ta, tb)
+    for k in ("tab", "tgtf"):
+        assert np.array_equal(a[k].view(np.uint64), b[k].view(np.uint64)), k
+    for k in ("nvset", "bvset", "bv2eq", "eq2bv"):
+        assert np.array_equal(a[k], b[k]), k
+    want = port.two_stage(F64, leq, tg, K)
+    rows = np.random.default_rng(1).integers(0, m, 96)
+    assert np.array_equal(a["tab"][rows].view(np.uint64), want["tab"][rows].view(np.uint64))
+    assert np.array_equal(a["tgtf"].view(np.uint64), want["tgtf"].view(np.uint64))
+    assert np.array_equal(a["eq2bv"], want["eq2bv"])
+
+
 def test_batch_sizes_ragged_and_single(ctx, port):
     """nb = 1, nb not a multiple of anything, 1 x 1 LPs."""
     rng = np.random.default_rng(4)
