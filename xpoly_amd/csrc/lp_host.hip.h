@@ -5,6 +5,7 @@
 // data happens on the host.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -89,13 +90,16 @@ template <class S> inline void launch_pipe_sweep(xpg_ctx *, const LpView<S> &, i
 template <> inline void launch_pipe_sweep<F64>(xpg_ctx * ctx, const LpView<F64> & v, int slot, int colstride,
                                                bool sample)
 {
-    const bool timed = sample && prof_open(ctx);
     const int strips = (v.W + 511) / 512;
     const int fused = ctx->loop_mode == 2 ? 0 : 1;
-    hipLaunchKernelGGL((k_pipe_sweep<32, 8>), dim3(strips, (v.m + 31) / 32 + 1), dim3(256), 0, ctx->stream, v, slot,
-                       colstride, fused, (double *)v.tab, (const double *)v.rowbuf,
-                       (const double *)v.colbuf + (size_t)slot * colstride, ctx->zigzag ? (slot & 1) : 0);
-    if (timed) prof_close(ctx);
+    // a sampled launch carries its own start/stop events (timestamps of the dispatch itself, as
+    // rocprofv3 reports them) instead of being bracketed by two marker packets
+    const bool timed = sample && ctx->prof_n < ctx->prof_cap && (ctx->prof_seen++ % ctx->prof_stride) == 0;
+    hipEvent_t e0 = timed ? ctx->ev0[ctx->prof_n] : nullptr, e1 = timed ? ctx->ev1[ctx->prof_n] : nullptr;
+    hipExtLaunchKernelGGL((k_pipe_sweep<32, 8>), dim3(strips, (v.m + 31) / 32 + 1), dim3(256), 0, ctx->stream, e0, e1, 0,
+                          v, slot, colstride, fused, (double *)v.tab, (const double *)v.rowbuf,
+                          (const double *)v.colbuf + (size_t)slot * colstride, ctx->zigzag ? (slot & 1) : 0);
+    if (timed) ctx->prof_n++;
     if (!fused)
         hipLaunchKernelGGL(k_pipe_pick, dim3(strips < PICK_MAX_WGS ? strips : PICK_MAX_WGS), dim3(256), 0, ctx->stream,
                            v, slot, colstride);
