@@ -109,6 +109,16 @@ int  xpg_lp_begin(xpg_lp * lp);
 int  xpg_lp_iterate(xpg_lp * lp, unsigned pivots);
 #define XPG_RUNNING (-1000)
 int  xpg_lp_pivots_done(xpg_lp * lp, unsigned * out);
+/* OPT-IN, NON-PARITY (results are no longer the reference's bit for bit, and
+ * nothing else in this header changes behaviour): before xpg_lp_begin / xpg_lp_two_stage,
+ *   pricing = 1        Dantzig's rule -- the largest reduced cost enters -- instead of the reference's
+ *                      first positive one (src/com/lpsol.h:1054-1069); the ratio test and the
+ *                      anti-cycling pair table stay as they are;
+ *   feas_rel_tol > 0   SIX::is_feasible (src/com/lpsol.h:784-822) with this relative tolerance
+ *                      instead of Float's 1e-17 '==' (src/com/flty.cpp:41-58), which reports most
+ *                      fp64 optima as SIX_OPTIMAL_IS_INFEASIBLE.
+ * (0, 0.0) restores the reference's behaviour.  fp64 handles only (XPG_ERR_UNSUPPORTED otherwise). */
+int  xpg_lp_set_options(xpg_lp * lp, int pricing, double feas_rel_tol);
 /* shape of the live tableau: rows, columns W (= rhs_idx + 1), rhs_idx */
 int  xpg_lp_shape(xpg_lp * lp, int * rows, int * W, int * rhs_idx);
 /* download the live state; any pointer may be NULL.  tab: rows*W, obj: W,

@@ -132,6 +132,18 @@ template <class S> struct Lp : LpBase {
     unsigned pipe_t = 0;    // pipelined loop: iteration counter since reset_loop (slot = pipe_t & 1)
     bool pipe_primed = false;
     int colstride = 0;      // elements per colbuf half
+    int opt_pricing = 0;    // xpg_lp_set_options: 0 the reference's rule, 1 Dantzig (non-parity)
+    double opt_feas_tol = 0.0;
+
+    // Opt-in non-parity modes: fp64 pipelined loop only.
+    int set_options(int pricing, double feas_tol)
+    {
+        if (pricing < 0 || pricing > 1 || !(feas_tol >= 0.0)) return XPG_ERR_SHAPE;
+        if ((pricing != 0 || feas_tol != 0.0) && (!std::is_same<S, F64>::value || ctx->loop_mode == 1))
+            return XPG_ERR_UNSUPPORTED;
+        opt_pricing = pricing; opt_feas_tol = feas_tol;
+        return 0;
+    }
 
     int alloc(void ** p, size_t bytes)
     {
@@ -219,7 +231,8 @@ template <class S> struct Lp : LpBase {
     }
     void reset_loop(unsigned max_iter)
     {
-        hipLaunchKernelGGL((k_reset_loop<S>), dim3(1024), dim3(256), 0, ctx->stream, v, max_iter);
+        hipLaunchKernelGGL((k_reset_loop<S>), dim3(1024), dim3(256), 0, ctx->stream, v, max_iter, opt_pricing,
+                           opt_feas_tol);
         pipe_t = 0; pipe_primed = false;
     }
     void queue_pivot(int guarded, int counted)

@@ -57,7 +57,12 @@ struct LoopState {
         unsigned done_after, total_after;   // LoopState::done / total_pivots once this pivot is committed
         int pad_;
         unsigned long long cnv_bits, piv_bits;
+        unsigned long long price_key;  // Dantzig look-ahead (atomicMax of dz_key), 0: none / not used
     } pd[2];
+    // opt-in NON-PARITY modes of the fp64 loop; both 0 = the reference's behaviour
+    int pricing;           // 1: Dantzig's rule (largest reduced cost) instead of the first positive one
+    int pad2_;
+    double feas_tol;       // > 0: SIX::is_feasible with this relative tolerance instead of Float's 1e-17 '=='
 };
 enum { NF_UNKNOWN = -2 };
 typedef LoopState::PipeDesc PipeDesc;
@@ -175,11 +180,60 @@ template <class S> __device__ int ratio_test(const LpView<S> & v, int nv, Cand<S
 // In-workgroup pricing scan (lpsol.h:1054-1069 without the side effect): lowest
 // nonbasic j with c_j > 0 whose pair-table row is still open, and whether any
 // nonbasic c_j > 0 exists at all.
+// Opt-in NON-PARITY pricing: Dantzig's rule, the largest reduced cost instead of
+// the reference's first positive one. A candidate is one 64-bit key -- the fp64 bits of c_j > 0 (which
+// order like integers) with the low 20 mantissa bits replaced by ~j, so that an integer max picks
+// the largest cost and, among costs equal to 2^-32 relative, the lowest column.
+__device__ __forceinline__ unsigned long long dz_key(double c, int j)
+{ unsigned long long b; __builtin_memcpy(&b, &c, 8); return (b & ~0xFFFFFull) | (unsigned long long)(0xFFFFF - j); }
+__device__ __forceinline__ int dz_col(unsigned long long key) { return key ? 0xFFFFF - (int)(key & 0xFFFFFull) : INT_MAX; }
+template <class S> __device__ __forceinline__ unsigned long long dz_key_of(S c, int j) { return 0ull; }
+template <> __device__ __forceinline__ unsigned long long dz_key_of<F64>(F64 c, int j) { return dz_key(c.v, j); }
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
+{
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)k, o), hi = __shfl_xor((unsigned)(k >> 32), o);
+        const unsigned long long t = ((unsigned long long)hi << 32) | lo;
+        k = t > k ? t : k;
+    }
+    return k;
+}
+
 template <class S> __device__ void price_scan(const LpView<S> & v, int * sh_i, int * sh_flag,
                                               int & first, int & anypos)
 {
     const int rhs = v.rhs, lim = rhs - 1;
     int f = INT_MAX, any = 0;
+    if (v.st->pricing == 1) {                                  // Dantzig (non-parity mode, fp64 only)
+        unsigned long long key = 0;
+        for (int j = threadIdx.x; j < rhs; j += blockDim.x)
+            if (v.nv[j] && gt(v.obj[j], zero<S>())) {
+                any = 1;
+                if (v.rowcnt[j] < lim) { const unsigned long long kj = dz_key_of<S>(v.obj[j], j); key = kj > key ? kj : key; }
+            }
+        key = wave_max_u64(key);
+        unsigned long long * shk = (unsigned long long *)sh_i; // 16 ints = 8 keys: waves in two rounds of 8
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 8) shk[threadIdx.x >> 6] = key;
+        __syncthreads();
+        unsigned long long best = 0;
+        const int nw = blockDim.x >> 6;
+        for (int k = 0; k < (nw < 8 ? nw : 8); k++) best = shk[k] > best ? shk[k] : best;
+        __syncthreads();
+        if (nw > 8) {                                          // waves 8..15 (1024-thread pick)
+            if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) >= 8) shk[(threadIdx.x >> 6) - 8] = key;
+            __syncthreads();
+            for (int k = 0; k < nw - 8; k++) best = shk[k] > best ? shk[k] : best;
+            __syncthreads();
+        }
+        first = dz_col(best);
+        if (threadIdx.x == 0) *sh_flag = 0;
+        __syncthreads();
+        if (any) *sh_flag = 1;
+        __syncthreads();
+        anypos = *sh_flag;
+        return;
+    }
     for (int j = threadIdx.x; j < rhs; j += blockDim.x)
         if (v.nv[j] && gt(v.obj[j], zero<S>())) {
             any = 1;
@@ -502,7 +556,7 @@ template <class S> __global__ __launch_bounds__(256) void k_pipe_prep(LpView<S> 
     LoopState * st = v.st;
     PipeDesc & D = st->pd[slot];
     // every scalar this kernel branches on is loaded before the first branch: one round trip
-    const int status = st->status;
+    const int status = st->status, pricing = st->pricing;
     const int stop = D.stop, r = D.row, enter = D.col, leave = D.leave, zu = D.zero_upto;
     const unsigned long long piv_bits = D.piv_bits, cnv_bits = D.cnv_bits;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
@@ -524,7 +578,9 @@ template <class S> __global__ __launch_bounds__(256) void k_pipe_prep(LpView<S> 
     const S cnv = from_bits<S>(cnv_bits);
     const int cmode = scale_mode(cnv);
     const int lim = v.rhs - 1;
+    const bool dantzig = pricing == 1;                         // opt-in non-parity pricing (N4)
     int nf = INT_MAX, any = 0;
+    unsigned long long key = 0;
     for (int j = gid; j < v.W; j += gsz) {
         const S a = v.tab[(size_t)r * v.ld + j];               // all four loads in flight together
         S oj = v.obj[j];
@@ -542,12 +598,17 @@ template <class S> __global__ __launch_bounds__(256) void k_pipe_prep(LpView<S> 
         const bool nv_next = j == enter ? false : (j == leave ? true : nvj);
         if (j < v.rhs && nv_next && gt(o, zero<S>())) {
             any = 1;
-            if (rcj < lim) nf = min(nf, j);
+            if (rcj < lim) {
+                if (dantzig) { const unsigned long long kj = dz_key_of<S>(o, j); key = kj > key ? kj : key; }
+                else nf = min(nf, j);
+            }
         }
     }
     for (int o = 32; o > 0; o >>= 1) { nf = min(nf, __shfl_xor(nf, o)); any |= __shfl_xor(any, o); }
+    if (dantzig) key = wave_max_u64(key);
     if ((threadIdx.x & 63) == 0) {
         if (nf != INT_MAX) atomicMin(&D.next_first, nf);
+        if (key) atomicMax(&D.price_key, key);
         if (any) atomicOr(&D.anypos, 1);
     }
 }
@@ -574,8 +635,12 @@ __device__ inline void write_desc(PipeDesc & O, int row, int col, int leave, int
 {
     O.row = row; O.col = col; O.leave = leave; O.next_first = next_first; O.anypos = anypos; O.stop = stop;
     O.cached_col = cached_col; O.bcol_valid = 1; O.zero_upto = zero_upto; O.done_after = done_after;
-    O.total_after = total_after; O.cnv_bits = cnv_bits; O.piv_bits = piv_bits;
+    O.total_after = total_after; O.cnv_bits = cnv_bits; O.piv_bits = piv_bits; O.price_key = 0ull;
 }
+// The entering column a descriptor predicts: the Dantzig key when the prep kernel priced that way,
+// else next_first (the reference's rule, or whatever a pick carried over).
+__device__ __forceinline__ int desc_first(const PipeDesc & D)
+{ const unsigned long long key = D.price_key; return key ? dz_col(key) : D.next_first; }
 
 __device__ inline void pipe_pick_f64(const LpView<F64> & v, int slot, int colstride, int p, int N)
 {
@@ -586,7 +651,7 @@ __device__ inline void pipe_pick_f64(const LpView<F64> & v, int slot, int colstr
     LoopState * st = v.st;
     PipeDesc & I = st->pd[slot];
     PipeDesc & O = st->pd[slot ^ 1];
-    const int r = I.row, ienter = I.col, ileave = I.leave, first = I.next_first, anypos = I.anypos;
+    const int r = I.row, ienter = I.col, ileave = I.leave, first = desc_first(I), anypos = I.anypos;
     const unsigned done_now = I.done_after, total_now = I.total_after, max_iter = st->max_iter;
     const int W = v.W, rhs = v.rhs, ld = v.ld, m = v.m, lim = v.rhs - 1;
     double * __restrict__ tab = (double *)v.tab;
@@ -773,7 +838,7 @@ void k_pipe_sweep(LpView<F64> v, int slot, int colstride, int with_pick,
     // 84.5 us against 73 us per sweep).
     LoopState * st = v.st;
     const PipeDesc & D = st->pd[slot];
-    const int status = st->status, r = D.row, first = D.next_first;     // one round trip, then branch
+    const int status = st->status, r = D.row, first = desc_first(D);    // one round trip, then branch
     if (status != ST_RUNNING) return;
     if (blockIdx.y == 0) {
         const int N = pick_wgs(gridDim.x);
@@ -832,6 +897,15 @@ void k_pipe_sweep(LpView<F64> v, int slot, int colstride, int with_pick,
     }
 }
 
+// SIX::is_feasible's two tests (lpsol.h:798-816). tol == 0: the reference's own comparisons (Float's
+// 1e-17 '=='); tol > 0 (opt-in non-parity mode, fp64 only): relative tolerance.
+template <class S> __device__ __forceinline__ bool exceeds(S lhs, S rhs, double) { return gt(lhs, rhs); }
+template <> __device__ __forceinline__ bool exceeds<F64>(F64 lhs, F64 rhs, double tol)
+{ return tol > 0.0 ? lhs.v > rhs.v + tol * fmax(1.0, fabs(rhs.v)) : gt(lhs, rhs); }
+template <class S> __device__ __forceinline__ bool differs(S a, S b, double) { return ne(a, b); }
+template <> __device__ __forceinline__ bool differs<F64>(F64 a, F64 b, double tol)
+{ return tol > 0.0 ? fabs(a.v - b.v) > tol * fmax(1.0, fabs(b.v)) : ne(a, b); }
+
 // ---- optimum: solution read-out + SIX::is_feasible (lpsol.h:1104-1110, :784-822)
 template <class S> __global__ void k_solution(LpView<S> v)
 {
@@ -840,7 +914,7 @@ template <class S> __global__ void k_solution(LpView<S> v)
         S x = zero<S>();
         if (j < v.rhs && v.bv[j]) x = v.tab[(size_t)v.bv2eq[j] * v.ld + v.rhs];
         v.x[j] = x;
-        if (j < v.rhs && gt(mul(v.vcd[j], x), v.vcr[j])) v.st->infeasible = 1;
+        if (j < v.rhs && exceeds(mul(v.vcd[j], x), v.vcr[j], v.st->feas_tol)) v.st->infeasible = 1;
     }
 }
 // One thread per row; the sum runs over j ascending exactly as the reference
@@ -858,7 +932,7 @@ template <class S> __global__ void k_rowcheck(LpView<S> v)
     S b = row[v.rhs];
     reduce(b);
     v.tab[(size_t)i * v.ld + v.rhs] = b;                       // lc.reduce(i, rhs_idx) writes back
-    if (ne(sum, b)) v.st->infeasible = 1;
+    if (differs(sum, b, v.st->feas_tol)) v.st->infeasible = 1;
 }
 template <class S> __global__ void k_finish(LpView<S> v, S * maxv)
 {
@@ -905,7 +979,7 @@ template <class S> __global__ void k_init_basis(LpView<S> v, int first_slack)
         if (slack) v.eq2bv[i - first_slack] = i;
     }
 }
-template <class S> __global__ void k_reset_loop(LpView<S> v, unsigned max_iter)
+template <class S> __global__ void k_reset_loop(LpView<S> v, unsigned max_iter, int pricing, double feas_tol)
 {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
     for (int i = gid; i < v.rhs; i += gsz) { v.rowcnt[i] = 0; v.colcnt[i] = 0; }
@@ -916,11 +990,12 @@ template <class S> __global__ void k_reset_loop(LpView<S> v, unsigned max_iter)
         st->status = ST_RUNNING; st->done = 0; st->max_iter = max_iter;
         st->row = -1; st->infeasible = 0;
         st->next_first = NF_UNKNOWN; st->anypos = 0; st->cached_col = -1; st->bcol_valid = 0;
+        st->pricing = pricing; st->pad2_ = 0; st->feas_tol = feas_tol;
         for (int k = 0; k < 2; k++) {                  // pipelined loop: iteration 0 has no pivot yet
             PipeDesc & D = st->pd[k];
             D.row = -1; D.col = 0; D.leave = 0; D.next_first = NF_UNKNOWN; D.anypos = 0; D.stop = 0;
             D.cached_col = -1; D.bcol_valid = 0; D.zero_upto = 0; D.pad_ = 0; D.cnv_bits = 0; D.piv_bits = 0;
-            D.done_after = 0; D.total_after = st->total_pivots;
+            D.done_after = 0; D.total_after = st->total_pivots; D.price_key = 0ull;
         }
     }
 }

@@ -292,6 +292,13 @@ int xpg_lp_shape(xpg_lp * lp, int * rows, int * W, int * rhs_idx)
     return 0;
 }
 
+int xpg_lp_set_options(xpg_lp * lp, int pricing, double feas_rel_tol)
+{
+    if (!lp || !lp->impl) return XPG_ERR_SHAPE;
+    if (lp->impl->kind == 0) return ((Lp<F64> *)lp->impl)->set_options(pricing, feas_rel_tol);
+    return ((Lp<R32> *)lp->impl)->set_options(pricing, feas_rel_tol);
+}
+
 int xpg_lp_pivots_done(xpg_lp * lp, unsigned * out)
 {
     if (!lp || !lp->impl || !out) return XPG_ERR_SHAPE;

@@ -151,6 +151,12 @@ class DeviceLP:
                                       vp(vd), vp(vr), C.c_int(int(on_device)), C.byref(self._h)),
                   "xpg_lp_create")
 
+    def set_options(self, pricing=0, feas_rel_tol=0.0):
+        """Opt-in NON-PARITY modes (xpg_lp_set_options): pricing=1 Dantzig's rule, feas_rel_tol>0 a
+        tolerant SIX::is_feasible. (0, 0.0) is the reference's behaviour."""
+        return self.ctx.check(lib().xpg_lp_set_options(self._h, C.c_int(pricing), C.c_double(feas_rel_tol)),
+                              "xpg_lp_set_options")
+
     def two_stage(self, max_iter=0xFFFFFFFF):
         return self.ctx.check(lib().xpg_lp_two_stage(self._h, C.c_uint(max_iter)), "xpg_lp_two_stage")
 
