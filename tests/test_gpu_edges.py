@@ -140,13 +140,17 @@ def test_full_size_pipelined_loop_against_serial_loop_and_oracle(port, monkeypat
         for k in (7, 93, 200):                           # uneven chunks: 300 pivots in all
             assert lp.iterate(k) == xpoly_amd.six.XPG_RUNNING
         got[mode] = (lp.read(), lp.trace().copy(), lp.pivots_done())
+        assert lp.iterate(1700) == xpoly_amd.six.XPG_RUNNING     # and on to 2000 pivots, GPU loops only
+        got[mode + "+"] = (lp.read(), lp.trace().copy(), lp.pivots_done())
         lp.close(); c.close()
-    (a, ta, na), (b, tb, nb) = got["pipe"], got["serial"]
-    assert na == nb == K and np.array_equal(ta, tb)
-    for k in ("tab", "tgtf"):
-        assert np.array_equal(a[k].view(np.uint64), b[k].view(np.uint64)), k
-    for k in ("nvset", "bvset", "bv2eq", "eq2bv"):
-        assert np.array_equal(a[k], b[k]), k
+    for tag, total in (("", K), ("+", 2000)):
+        (a, ta, na), (b, tb, nb) = got["pipe" + tag], got["serial" + tag]
+        assert na == nb == total and np.array_equal(ta, tb)
+        for k in ("tab", "tgtf"):
+            assert np.array_equal(a[k].view(np.uint64), b[k].view(np.uint64)), (tag, k)
+        for k in ("nvset", "bvset", "bv2eq", "eq2bv"):
+            assert np.array_equal(a[k], b[k]), (tag, k)
+    a = got["pipe"][0]
     want = port.two_stage(F64, leq, tg, K)
     rows = np.random.default_rng(1).integers(0, m, 96)
     assert np.array_equal(a["tab"][rows].view(np.uint64), want["tab"][rows].view(np.uint64))

@@ -539,18 +539,19 @@ void k_update_f64(double * __restrict__ tab, int m, int W, int ld,
 // ---- Pipelined fp64 loop: two launches per pivot ------------------------------------------------
 // Iteration t:  k_pipe_prep(slot = t & 1)  ->  k_pipe_sweep(slot).
 // k_pipe_prep stages the scaled pivot row, updates the objective row and prices the NEXT
-// iteration (atomicMin into pd[slot].next_first). k_pipe_sweep's grid carries one extra
-// workgroup (blockIdx.y == 0, dispatched first) that commits this iteration's basis swap and
-// chooses the pivot of iteration t + 1 WHILE the other workgroups sweep. What it needs of the
-// post-sweep tableau it produces itself with the sweep's own mul-then-add:
+// iteration (atomicMin into pd[slot].next_first). k_pipe_sweep's grid carries up to 16 extra
+// workgroups (blockIdx.y == 0, dispatched first) that commit this iteration's basis swap and
+// choose the pivot of iteration t + 1 WHILE the other workgroups sweep. What they need of the
+// post-sweep tableau they produce themselves with the sweep's own mul-then-add:
 //   * the constant column lives in the contiguous bcol[] for the whole loop (b_i += k_i e_b);
 //     the sweep updates the tableau's copy as part of its normal work, bit-identically;
 //   * the predicted entering column: the sweep leaves that 16-byte column pair untouched and
-//     the pick workgroup updates exactly that pair, keeping the column in nextcol[].
-// Nothing the sweep reads is written by the pick workgroup and vice versa (pd[slot ^ 1], the
-// other half of colbuf, the basis arrays, the pair table), so there is no intra-kernel
-// hand-off; launch boundaries order everything else. pd[].stop defers a final status by one
-// launch so that the sweep in flight completes.
+//     the pick workgroups update exactly that pair, keeping the column in nextcol[].
+// Nothing the sweep reads is written by the pick workgroups and vice versa (pd[slot ^ 1], the
+// other half of colbuf, the basis arrays, the pair table); the only data crossing workgroups
+// inside the launch are the pick workgroups' 32-byte ratio-test records (pipe_pick_f64 below);
+// launch boundaries order everything else. pd[].stop defers a final status by one launch so
+// that the sweep in flight completes.
 template <class S> __global__ __launch_bounds__(256) void k_pipe_prep(LpView<S> v, int slot)
 {
     LoopState * st = v.st;
