@@ -37,6 +37,7 @@ HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 BATCH_PER_GPU = 8192                       # 65 536 LPs over 8 GPUs (BASELINE.json configs[2])
 BATCH_M, BATCH_COLS = 32, 64
 PREWARM = 256                              # untimed set-up iterations before the warmup
+PREWARM_SECONDS = 0.5
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "round1_pmc_hbm_traffic.json")
 
 
@@ -167,11 +168,20 @@ def main():
     # set-up, not measured: one pass through every code path of the timed region (launch
     # throttling, event pairs) so lazy runtime initialisation does not land inside it
     ctx.profile_begin(8, 32)
+    # (the ROCm runtime was measured to stall the stream once for 60-80 ms somewhere in the first
+    # ~100 ms of queued-loop activity of a process -- tools/probe_stall.py -- so the set-up pass runs
+    # for at least PREWARM_SECONDS of wall time, not just PREWARM iterations)
+    t_pre = time.perf_counter()
     run_pivots(PREWARM)
+    ctx.sync()
+    while time.perf_counter() - t_pre < PREWARM_SECONDS:
+        run_pivots(PREWARM)
+        ctx.sync()
     ctx.profile_end()
     run_pivots(a.warmup)
     barrier()
-    stride = max(1, a.steps // 128)           # ~128 sampled sweep launches spread over the region
+    stride = max(1, a.steps // 1024)          # sampled sweep launches spread over the region (a blocked
+                                              # sweep applies up to 16 pivots, so there are ~steps/16 of them)
     ctx.profile_begin(0 if a.no_events else a.steps, stride)
     start_count = lp.pivots_done()
     t0 = time.perf_counter()
@@ -197,8 +207,10 @@ def main():
             traffic_src = "profiles/round1_pmc_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, KiB->B)"
         roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src,
-                        kernel=("k_update_f64<32,8>" if os.environ.get("XPG_LOOP", "").startswith("se")
-                                else "k_pipe_sweep<32,8> (sweep + the next pivot's pick workgroups)"),
+                        kernel={"se": "k_update_f64<32,8>", "pi": "k_pipe_sweep<32,8> (sweep + the next pivot's pick workgroups)",
+                                "sp": "k_pipe_sweep<32,8>"}.get(os.environ.get("XPG_LOOP", "")[:2],
+                                                               "k_blk_sweep<32,4,16> (one pass applies up to XPG_BLOCK=16 staged pivots)"),
+                        pivots_per_launch=round(a.steps / max(1, launches * stride), 2),
                         launches_sampled=launches,
                         avg_launch_us=round(sweep_avg_s * 1e6, 2),
                         algorithmic_bytes_per_launch=ALG_BYTES_PER_PIVOT)

@@ -123,16 +123,17 @@ def test_full_size_tableau_properties(ctx, port):
     assert np.array_equal(eq2bv, want["eq2bv"])
 
 
-def test_full_size_pipelined_loop_against_serial_loop_and_oracle(port, monkeypatch):
-    """4096 x 8192 fp64, 300 pivots under full load (2048 sweep workgroups around the 16 pick
-    workgroups and their in-launch hand-off): the pipelined loop, the serial three-launch loop and
-    the CPU oracle must agree bit for bit -- same (entering, leaving) trace, same basis, same
-    tableau (all of it between the two GPU loops, a 96-row sample against the oracle)."""
+def test_full_size_loops_against_each_other_and_oracle(port, monkeypatch):
+    """4096 x 8192 fp64 under full load: the three device loops -- blocked (16 pivots staged per
+    sweep, the default at this size), pipelined (pick workgroups inside the sweep launch) and the
+    serial three-launch loop -- and the CPU oracle must agree bit for bit: same (entering, leaving)
+    trace, same basis, same tableau (all of it between the GPU loops after 300 and after 2000
+    pivots, a 96-row sample against the oracle after 300)."""
     import xpoly_amd
     m, n, K = 4096, 4095, 300
     leq, tg = gen.hard_lp_f64(m, n)
     got = {}
-    for mode in ("pipe", "serial"):
+    for mode in ("block", "pipe", "serial"):
         monkeypatch.setenv("XPG_LOOP", mode)             # read when the context is created
         c = xpoly_amd.Context(0)
         lp = xpoly_amd.DeviceLP(c, F64, leq, tg)
@@ -144,18 +145,51 @@ def test_full_size_pipelined_loop_against_serial_loop_and_oracle(port, monkeypat
         got[mode + "+"] = (lp.read(), lp.trace().copy(), lp.pivots_done())
         lp.close(); c.close()
     for tag, total in (("", K), ("+", 2000)):
-        (a, ta, na), (b, tb, nb) = got["pipe" + tag], got["serial" + tag]
-        assert na == nb == total and np.array_equal(ta, tb)
-        for k in ("tab", "tgtf"):
-            assert np.array_equal(a[k].view(np.uint64), b[k].view(np.uint64)), (tag, k)
-        for k in ("nvset", "bvset", "bv2eq", "eq2bv"):
-            assert np.array_equal(a[k], b[k]), (tag, k)
-    a = got["pipe"][0]
+        b, tb, nb = got["serial" + tag]
+        for mode in ("block", "pipe"):
+            a, ta, na = got[mode + tag]
+            assert na == nb == total and np.array_equal(ta, tb), (mode, tag)
+            for k in ("tab", "tgtf"):
+                assert np.array_equal(a[k].view(np.uint64), b[k].view(np.uint64)), (mode, tag, k)
+            for k in ("nvset", "bvset", "bv2eq", "eq2bv"):
+                assert np.array_equal(a[k], b[k]), (mode, tag, k)
+    a = got["block"][0]
     want = port.two_stage(F64, leq, tg, K)
     rows = np.random.default_rng(1).integers(0, m, 96)
     assert np.array_equal(a["tab"][rows].view(np.uint64), want["tab"][rows].view(np.uint64))
     assert np.array_equal(a["tgtf"].view(np.uint64), want["tgtf"].view(np.uint64))
     assert np.array_equal(a["eq2bv"], want["eq2bv"])
+
+
+@pytest.mark.parametrize("B", [1, 3, 16])
+def test_blocked_loop_small_and_rare_branches(ctx, port, B, monkeypatch):
+    """The blocked loop forced onto small LPs (where it is not the default), batch lengths 1, 3 and
+    16: dependence-test-like data drive it through closed batches and the generic pick; random
+    problems through phase 1. Status, tableau, objective row, basis: bit-identical to the oracle."""
+    import xpoly_amd
+    monkeypatch.setenv("XPG_LOOP", "block")
+    monkeypatch.setenv("XPG_BLOCK", str(B))
+    c = xpoly_amd.Context(0)
+    six = xpoly_amd.SIX(c, F64)
+    leqs, tgs = gen.small_lp_batch_f64(4, 20, 29, family=1, seed=gen.XS_SEED + 91)
+    rng = np.random.default_rng(5 + B)
+    cases = [(leqs[b], tgs[b]) for b in range(4)]
+    for _ in range(6):
+        p = gen.random_problem(rng, F64, int(rng.integers(0, 3)), int(rng.integers(2, 14)), int(rng.integers(2, 14)), plain=True)
+        cases.append((p["leq"], p["tgtf"]))
+    for leq, tg in cases:
+        for K in (5, 37, 0xFFFFFFFF):
+            want = port.two_stage(F64, leq, tg, K)
+            six.set_param(0, K)
+            got = six.TwoStageMethod(leq, tg)
+            assert got["status"] == want["status"], (B, K, got["status"], want["status"])
+            if want["status"] == 2:
+                continue
+            for k in ("tab", "tgtf", "nvset", "bvset", "bv2eq", "eq2bv"):
+                a, b = np.asarray(got[k]), np.asarray(want[k])
+                assert a.shape == b.shape and (np.array_equal(a.view(np.uint64), b.view(np.uint64))
+                                               if a.dtype == np.float64 else np.array_equal(a, b)), (B, K, k)
+    c.close()
 
 
 def test_batch_sizes_ragged_and_single(ctx, port):

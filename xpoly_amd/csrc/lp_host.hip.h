@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include "../../include/xpoly_amd.h"
 #include "lp_kernels.hip.h"
+#include "lp_block.hip.h"
 
 struct xpg_ctx {
     int device;
@@ -22,6 +23,8 @@ struct xpg_ctx {
     int update_variant;     // tuning knob for the fp64 sweep (see launch_update_f64)
     int loop_mode;          // 0: pipelined fp64 loop (2 launches per pivot), 1: serial pick/prep/update
     int zigzag;             // pipelined sweep alternates its tile order (Infinity Cache reuse)
+    int block_len;          // blocked loop (loop_mode 3): pivots staged per sweep, 1..16
+    int loop_auto;          // XPG_LOOP unset: blocked loop where the sweep is what costs (large fp64 tableaux)
     // xpg_profile_begin/end: event pairs around each sweep launch
     std::vector<hipEvent_t> ev0, ev1;
     int prof_cap, prof_n, prof_stride, prof_seen;
@@ -104,6 +107,29 @@ template <> inline void launch_pipe_sweep<F64>(xpg_ctx * ctx, const LpView<F64> 
         hipLaunchKernelGGL(k_pipe_pick, dim3(strips < PICK_MAX_WGS ? strips : PICK_MAX_WGS), dim3(256), 0, ctx->stream,
                            v, slot, colstride);
 }
+// One batch of the blocked loop: B x (pick, prep) -- the generic pick once after pick(0) -- and a sweep.
+template <class S> inline void launch_blk_batch(xpg_ctx *, const LpView<S> &, int, int) {}
+template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> & v, int batch, int B)
+{
+    const int strips = (v.W + 511) / 512;
+    const int npick = strips < PICK_MAX_WGS ? strips : PICK_MAX_WGS;
+    const dim3 gprep((v.W + 255) / 256);
+    for (int t = 0; t < B; t++) {
+        hipLaunchKernelGGL(k_blk_pick, dim3(npick), dim3(256), 0, ctx->stream, v, batch, t);
+        if (t == 0) hipLaunchKernelGGL(k_blk_pick_generic, dim3(1), dim3(1024), 0, ctx->stream, v, batch);
+        hipLaunchKernelGGL(k_blk_prep, gprep, dim3(256), 0, ctx->stream, v, batch, t);
+    }
+    const bool timed = ctx->prof_n < ctx->prof_cap && (ctx->prof_seen++ % ctx->prof_stride) == 0;
+    hipEvent_t e0 = timed ? ctx->ev0[ctx->prof_n] : nullptr, e1 = timed ? ctx->ev1[ctx->prof_n] : nullptr;
+    const dim3 g(strips, (v.m + 31) / 32);
+    if (B <= 8)
+        hipExtLaunchKernelGGL((k_blk_sweep<32, 8, 8>), g, dim3(256), 0, ctx->stream, e0, e1, 0, (double *)v.tab, v.m, v.W,
+                              v.ld, (const double *)v.blkE, (const double *)v.blkK, v.st, batch);
+    else
+        hipExtLaunchKernelGGL((k_blk_sweep<32, 4, 16>), g, dim3(256), 0, ctx->stream, e0, e1, 0, (double *)v.tab, v.m, v.W,
+                              v.ld, (const double *)v.blkE, (const double *)v.blkK, v.st, batch);
+    if (timed) ctx->prof_n++;
+}
 template <> inline void launch_update<R32>(xpg_ctx * ctx, const LpView<R32> & v, int guarded)
 {
     const bool timed = prof_open(ctx);
@@ -131,6 +157,7 @@ template <class S> struct Lp : LpBase {
     hipEvent_t throttle[2] = {nullptr, nullptr};
     unsigned pipe_t = 0;    // pipelined loop: iteration counter since reset_loop (slot = pipe_t & 1)
     bool pipe_primed = false;
+    int blk_batch = 0;      // blocked loop: id of the next batch since reset_loop
     int colstride = 0;      // elements per colbuf half
     int opt_pricing = 0;    // xpg_lp_set_options: 0 the reference's rule, 1 Dantzig (non-parity)
     double opt_feas_tol = 0.0;
@@ -189,6 +216,8 @@ template <class S> struct Lp : LpBase {
         if ((rc = alloc((void **)&v.ppt, (size_t)nmax * v.pw * 4))) return rc;
         if ((rc = alloc((void **)&v.st, sizeof(LoopState)))) return rc;
         if ((rc = alloc((void **)&v.pickrec, (size_t)PICK_WORDS * 8))) return rc;
+        if ((rc = alloc((void **)&v.blkK, (size_t)round_up(m, 16) * BLK_MAX * sizeof(S)))) return rc;
+        if ((rc = alloc((void **)&v.blkE, (size_t)BLK_MAX * ld * sizeof(S)))) return rc;
         if ((rc = alloc((void **)&v.trace, (size_t)v.trace_cap * 8))) return rc;
         if ((rc = alloc((void **)&d_leq, (size_t)m * cols * sizeof(S)))) return rc;
         if ((rc = alloc((void **)&d_tgtf, (size_t)cols * sizeof(S)))) return rc;
@@ -233,7 +262,7 @@ template <class S> struct Lp : LpBase {
     {
         hipLaunchKernelGGL((k_reset_loop<S>), dim3(1024), dim3(256), 0, ctx->stream, v, max_iter, opt_pricing,
                            opt_feas_tol);
-        pipe_t = 0; pipe_primed = false;
+        pipe_t = 0; pipe_primed = false; blk_batch = 0;
     }
     void queue_pivot(int guarded, int counted)
     {
@@ -249,6 +278,11 @@ template <class S> struct Lp : LpBase {
     void queue_iterations(unsigned k)
     {
         unsigned blk = 0;
+        // blocked loop: chosen explicitly, or by default where one sweep moves >= 16 MB (it trades
+        // launches for HBM traffic; on small tableaux the pipelined loop's two launches per pivot win)
+        const bool blocked = std::is_same<S, F64>::value &&
+                             (ctx->loop_mode == 3 || (ctx->loop_auto && (size_t)v.m * v.W * 16 >= ((size_t)16 << 20)));
+        if (blocked) { queue_blocked(k); return; }
         const bool pipelined = std::is_same<S, F64>::value && ctx->loop_mode != 1;
         if (pipelined && k > 0 && !pipe_primed) {
             // the first pivot is chosen by a sweep launch that has nothing to sweep (pd[1].row < 0)
@@ -271,6 +305,25 @@ template <class S> struct Lp : LpBase {
                 if (blk >= 2) (void)hipEventSynchronize(e);
                 (void)hipEventRecord(e, ctx->stream);
                 blk++;
+            }
+        }
+    }
+
+    // Blocked loop (lp_block.hip.h): at most k loop iterations as ceil(k / B) batches of
+    // B x (pick, prep) + one sweep; the device-side budget stops the last batch where k ends.
+    void queue_blocked(unsigned k)
+    {
+        if (k == 0) return;
+        const int B = ctx->block_len;
+        hipLaunchKernelGGL(k_blk_budget, dim3(1), dim3(64), 0, ctx->stream, v.st, k);
+        const unsigned nb = (k + (unsigned)B - 1) / (unsigned)B;
+        for (unsigned b = 0; b < nb; b++) {
+            const int batch = blk_batch++;
+            launch_blk_batch(ctx, v, batch, B);
+            if ((b & 7) == 7) {                         // throttle: at most 2 x 8 batches in flight
+                hipEvent_t e = throttle[(b >> 3) & 1];
+                if ((b >> 3) >= 2) (void)hipEventSynchronize(e);
+                (void)hipEventRecord(e, ctx->stream);
             }
         }
     }

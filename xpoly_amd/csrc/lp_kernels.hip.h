@@ -63,7 +63,20 @@ struct LoopState {
     int pricing;           // 1: Dantzig's rule (largest reduced cost) instead of the first positive one
     int pad2_;
     double feas_tol;       // > 0: SIX::is_feasible with this relative tolerance instead of Float's 1e-17 '=='
+    // Blocked fp64 loop (lp_block.hip.h): up to BLK_MAX pivots are chosen and staged against the
+    // un-swept tableau, then ONE sweep applies them all. Fields tagged with the batch they belong to.
+    struct Blk {
+        int batch;             // batch the fields below belong to (stale otherwise: n = 0, open)
+        int n;                 // pivots staged so far in this batch
+        int closed;            // no further pivot may join this batch (rare branch met): sweep, then retry
+        int generic;           // the first pick of the batch hands over to the generic single-workgroup pick
+        int from_generic;      // the pivot now in row/col/leave was chosen by the generic pick (column in colbuf)
+        unsigned budget;       // loop iterations the host still allows (xpg_lp_iterate)
+        int r[16];             // pivot rows of the staged pivots
+        unsigned long long price_key;   // Dantzig look-ahead of the blocked loop's prep
+    } blk;
 };
+enum { BLK_MAX = 16 };
 enum { NF_UNKNOWN = -2 };
 typedef LoopState::PipeDesc PipeDesc;
 // LpView::pickrec layout (8-byte words): PICK_MAX_WGS records of PICK_REC_WORDS, then one arrival
@@ -78,6 +91,7 @@ template <class S> struct LpView {
     S * rowbuf; S * colbuf; S * x; S * vcd; S * vcr;
     S * nextcol; S * bcol;   // contiguous copies of the predicted entering column / constant column
     unsigned long long * pickrec;   // pipelined loop: per-workgroup ratio-test records + arrival counters
+    S * blkK; S * blkE;             // blocked loop: -column of staged pivot s at blkK[i * BLK_MAX + s], its scaled row at blkE[s * ld + j]
     LoopState * st;
     int * trace; int trace_cap;
 };
@@ -992,6 +1006,9 @@ template <class S> __global__ void k_reset_loop(LpView<S> v, unsigned max_iter, 
         st->row = -1; st->infeasible = 0;
         st->next_first = NF_UNKNOWN; st->anypos = 0; st->cached_col = -1; st->bcol_valid = 0;
         st->pricing = pricing; st->pad2_ = 0; st->feas_tol = feas_tol;
+        st->blk.batch = -1; st->blk.n = 0; st->blk.closed = 0; st->blk.generic = 0; st->blk.from_generic = 0;
+        st->blk.budget = 0xFFFFFFFFu; st->blk.price_key = 0ull;
+        for (int k = 0; k < 2; k++) v.pickrec[PICK_CTR_OFF + 16 * k] = 0ull;   // arrival counters
         for (int k = 0; k < 2; k++) {                  // pipelined loop: iteration 0 has no pivot yet
             PipeDesc & D = st->pd[k];
             D.row = -1; D.col = 0; D.leave = 0; D.next_first = NF_UNKNOWN; D.anypos = 0; D.stop = 0;

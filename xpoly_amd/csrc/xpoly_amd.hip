@@ -51,6 +51,13 @@ int xpg_create(xpg_ctx ** out, int device)
     const char * zz = getenv("XPG_ZIGZAG");
     c->zigzag = zz ? atoi(zz) : 0;                      // measured slower (79.7 vs 77.8 us per sweep): off
     c->loop_mode = (lm && lm[0] == 's' && lm[1] == 'e') ? 1 : ((lm && lm[0] == 's' && lm[1] == 'p') ? 2 : 0);
+    if (lm && lm[0] == 'b') c->loop_mode = 3;          // "block": B pivots per sweep (lp_block.hip.h)
+    if (lm && lm[0] == 'p') c->loop_mode = 0;          // "pipe": always the pipelined loop
+    c->loop_auto = lm ? 0 : 1;                         // unset: blocked loop for large fp64 tableaux, else pipelined
+    const char * bl = getenv("XPG_BLOCK");
+    c->block_len = bl ? atoi(bl) : 16;
+    if (c->block_len < 1) c->block_len = 1;
+    if (c->block_len > 16) c->block_len = 16;
     c->prof_cap = 0; c->prof_n = 0; c->prof_stride = 1; c->prof_seen = 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return XPG_ERR_HIP; }
     if (hipMalloc((void **)&c->st, sizeof(LoopState)) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return XPG_ERR_ALLOC; }
