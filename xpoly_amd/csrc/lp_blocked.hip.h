@@ -1,0 +1,448 @@
+// Blocked fp64 simplex loop: B pivots per pass over the tableau.
+//
+// The rank-1 sweep (lpsol.h:1481-1490) is HBM-bound at 2*m*W*8 bytes per pivot. Nothing in
+// SIX::solveSlackForm needs the swept tableau to CHOOSE the next pivot except one row and two
+// columns of it -- and those can be had from the un-swept tableau by replaying the pending
+// updates on just that row / column with the sweep's own arithmetic:
+//     x := tab[i][c];  for each staged pivot s:  x := (i == r_s) ? e_s[c] : x + k_s[i] * e_s[c]
+// (k_s = -column of pivot s as the reference negates it, e_s = its scaled row; both rounded exactly
+// as a sweep would have left them, because every operand is itself produced this way). So a batch
+// stages up to B pivots -- pick, prep, pick, prep, ... each O((m + W) * staged) -- and then ONE
+// sweep applies them all to every cell in registers, in order, with the same two roundings per
+// update:
+//     a := tab[i][j];  for s < n:  a := (i == r_s) ? e_s[j] : a + k_s[i] * e_s[j];  tab[i][j] := a
+// HBM traffic per pivot drops by the batch length; results stay bit-identical to n separate sweeps.
+//
+// Per batch (host-enqueued, no host round trip), t = 0 .. B-1:
+//   k_blk_pick(t)        runs iff exactly t pivots are staged: first pass of the ratio test
+//                        (lpsol.h:553-663) on the replayed entering and constant columns by <= 16
+//                        workgroups; each stages its rows of k_t = -column and leaves ONE record (its
+//                        best row) tagged with (batch, t). No atomics, no last-adder: the launch
+//                        boundary orders the records for ...
+//   k_blk_prep(t)        ... whose every workgroup combines the <= 16 records (lowest row wins ties,
+//                        lpsol.h:604-611), replays the pivot row -> scaled row e_t, updates the
+//                        objective row (with the zeroing of lpsol.h:1055-1060) and leaves its look-ahead
+//                        pricing partial (lowest eligible column / Dantzig key) for the next pick; one
+//                        thread commits the pivot: pair table, basis swap, trace, counters, batch length
+//   k_blk_pick_generic   after pick(0) only, when that asked for it: the generic single-workgroup
+//                        pick_body for whatever the fast path does not do (second ratio pass, disableNV,
+//                        findPivotNVandBVPair, optimum, iteration limits) -- legal because nothing is
+//                        staged, i.e. the tableau is fully swept
+//   k_blk_sweep          applies the staged pivots
+// Control state is only ever written by one thread of a kernel whose other workgroups do not read what
+// it writes (they decide from the records / partials of the previous launch), so there is no
+// intra-launch hand-off anywhere. A pick that cannot take the fast path while pivots are staged closes
+// the batch: the remaining launches of the batch do nothing, the sweep applies what is staged and the
+// next batch starts with pick(0) + generic on a swept tableau.
+#pragma once
+#include "lp_kernels.hip.h"
+
+namespace xpg {
+
+__device__ __forceinline__ unsigned blk_epoch(int batch, int t) { return (((unsigned)batch << 5) | (unsigned)t) + 1u; }
+
+__device__ __forceinline__ unsigned long long shfl_u64(unsigned long long x, int src)
+{
+    const unsigned lo = __shfl((unsigned)x, src), hi = __shfl((unsigned)(x >> 32), src);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// The look-ahead the last prep left: every wave reduces the partials itself (one load round).
+struct BlkLook { int first; int anypos; };
+__device__ __forceinline__ BlkLook blk_lookahead(const LpView<F64> & v, unsigned want_epoch, int nparts)
+{
+    const int lane = threadIdx.x & 63;
+    int nf = INT_MAX, any = 0;
+    unsigned long long key = 0;
+    for (int k = lane; k < nparts; k += 64) {
+        const int * P = v.blkP + (size_t)k * BLK_PART_INTS;
+        const bool ok = (unsigned)P[4] == want_epoch;
+        const int pn = P[0], pa = P[1];
+        const unsigned long long pk = ((unsigned long long)(unsigned)P[3] << 32) | (unsigned)P[2];
+        if (ok) { nf = min(nf, pn); any |= pa; key = pk > key ? pk : key; }
+    }
+    for (int o = 32; o > 0; o >>= 1) { nf = min(nf, __shfl_xor(nf, o)); any |= __shfl_xor(any, o); }
+    key = wave_max_u64(key);
+    BlkLook L;
+    L.first = key ? dz_col(key) : nf;
+    L.anypos = any;
+    return L;
+}
+
+// ---- pick(t): first ratio-test pass by up to PICK_MAX_WGS workgroups of 256 threads --------------
+__global__ __launch_bounds__(256) void k_blk_pick(LpView<F64> v, int batch, int t, int nparts)
+{
+    __shared__ __attribute__((aligned(8))) unsigned char sh_c_raw[16 * sizeof(Cand<F64>)];
+    Cand<F64> * sh_c = (Cand<F64> *)sh_c_raw;
+    LoopState * st = v.st;
+    const int status = st->status;
+    const int bb = st->blk.batch, bn = st->blk.n, bclosed = st->blk.closed, want_generic = st->blk.want_generic;
+    const int la_state = st->blk.la_from_state;
+    const unsigned la_epoch = st->blk.la_epoch;
+    const unsigned budget = st->blk.budget, done = st->done, max_iter = st->max_iter;
+    const int sfirst = st->next_first;
+    int rs[BLK_MAX];
+#pragma unroll
+    for (int s = 0; s < BLK_MAX; s++) rs[s] = st->blk.r[s];
+    const int tid = threadIdx.x, p = blockIdx.x, N = gridDim.x;
+    const int n = (bb == batch) ? bn : 0;
+    if (status != ST_RUNNING || (bb == batch && bclosed) || n != t || budget == 0) return;
+    int first = sfirst;
+    if (!la_state) first = blk_lookahead(v, la_epoch, nparts).first;
+    const int rhs = v.rhs, ld = v.ld, m = v.m, lim = v.rhs - 1;
+    const bool fast = !want_generic && first >= 0 && first < rhs && done < max_iter;
+    if (!fast) {
+        // nothing staged: the generic pick (next launch) decides; else close the batch and sweep first
+        if (p == 0 && tid == 0) {
+            if (bb != batch) { st->blk.batch = batch; st->blk.n = 0; st->blk.closed = 0; st->blk.from_generic = 0; st->blk.generic = 0; }
+            if (n == 0) { st->blk.generic = 1; st->blk.want_generic = 0; }
+            else st->blk.closed = 1;
+        }
+        return;
+    }
+    const double * __restrict__ tab = (const double *)v.tab;
+    double * __restrict__ K = (double *)v.blkK;
+    const double * __restrict__ E = (const double *)v.blkE;
+    double ec[BLK_MAX], eb[BLK_MAX];                            // e_s[first], e_s[rhs]: wave-uniform loads
+#pragma unroll
+    for (int s = 0; s < BLK_MAX; s++) {
+        ec[s] = s < n ? E[(size_t)s * ld + first] : 0.0;
+        eb[s] = s < n ? E[(size_t)s * ld + rhs] : 0.0;
+    }
+    const unsigned long long cnv_bits = to_bits(v.obj[first]);
+    // fused pass over this workgroup's rows: replayed entering column (its negation staged as k_t),
+    // replayed constant column, first pass of the ratio test
+    Cand<F64> best; best.q = zero<F64>(); best.idx = INT_MAX;
+    double best_a = 0.0; int best_b = 0, best_cc = 0; uint32_t best_w = 0;
+    for (int i = p * 256 + tid; i < m; i += 256 * N) {
+        const double x0 = tab[(size_t)i * ld + first], b0 = tab[(size_t)i * ld + rhs];
+        const int bi = v.eq2bv[i];
+        const double * kr = K + (size_t)i * BLK_MAX;
+        double a = x0, bc = b0;
+#pragma unroll
+        for (int s = 0; s < BLK_MAX; s++) {
+            if (s < n) {
+                const double k = kr[s];
+                const double pa = k * ec[s], pb = k * eb[s];
+                a = (i == rs[s]) ? ec[s] : (a + pa);
+                bc = (i == rs[s]) ? eb[s] : (bc + pb);
+            }
+        }
+        const uint32_t w = v.ppt[(size_t)first * v.pw + (bi >> 5)];
+        const int cc = v.colcnt[bi];
+        K[(size_t)i * BLK_MAX + n] = -a;                                  // -a_i,nv (lpsol.h:1485)
+        if (le(F64(a), zero<F64>())) continue;                            // findPivotBV, lpsol.h:553-663
+        if (((w >> (bi & 31)) & 1u) || cc >= lim) continue;
+        Cand<F64> c; c.q = div(F64(bc), F64(a)); c.idx = i;
+        const Cand<F64> nbest = better(best, c);
+        if (nbest.idx != best.idx) { best_a = a; best_b = bi; best_cc = cc; best_w = w; }
+        best = nbest;
+    }
+    const Cand<F64> wbest = block_argmin(best, sh_c);
+    const bool publisher = wbest.idx != INT_MAX ? (best.idx == wbest.idx) : (tid == 0);
+    if (!publisher) return;
+    unsigned long long * rec = v.blkR + (size_t)p * BLK_REC_WORDS;
+    rec[0] = to_bits(wbest.q);
+    rec[1] = to_bits(F64(best_a));
+    rec[2] = ((unsigned long long)(unsigned)wbest.idx << 32) | (unsigned)best_b;
+    rec[3] = ((unsigned long long)best_w << 32) | (unsigned)best_cc;
+    rec[4] = cnv_bits;
+    rec[5] = (unsigned long long)(unsigned)first;
+    rec[6] = (unsigned long long)blk_epoch(batch, t);
+}
+
+// ---- the generic pick, only when pick(0) of this batch asked for it ------------------------------
+__global__ __launch_bounds__(1024) void k_blk_pick_generic(LpView<F64> v, int batch, int nparts)
+{
+    __shared__ __attribute__((aligned(8))) unsigned char sh_c_raw[16 * sizeof(Cand<F64>)];
+    __shared__ int sh_i[16];
+    __shared__ int sh_flag;
+    __shared__ int sh_la[2];
+    LoopState * st = v.st;
+    if (st->status != ST_RUNNING) return;
+    if (!(st->blk.batch == batch && st->blk.generic && st->blk.n == 0)) return;
+    const unsigned budget = st->blk.budget;
+    if (budget == 0) return;
+    const PickOut o = { &st->status, &st->row, &st->col, &st->leave, &st->next_first, &st->anypos,
+                        &st->cnv_bits, &st->piv_bits };
+    int first = st->next_first, anypos = st->anypos;
+    const int la_state = st->blk.la_from_state;
+    const unsigned la_epoch = st->blk.la_epoch;
+    if (!la_state) {
+        if (threadIdx.x < 64) {
+            const BlkLook L = blk_lookahead(v, la_epoch, nparts);
+            if (threadIdx.x == 0) { sh_la[0] = L.first; sh_la[1] = L.anypos; }
+        }
+        __syncthreads();
+        first = sh_la[0]; anypos = sh_la[1];
+    }
+    __syncthreads();
+    // the tableau is fully swept (nothing staged): every column comes from it. Whatever look-ahead
+    // pick_body leaves (re-pricing after disableNV, ...) goes to next_first / anypos.
+    if (threadIdx.x == 0) {
+        st->blk.generic = 0; st->row = -1; st->blk.la_from_state = 1;
+        st->next_first = first; st->anypos = anypos;
+    }
+    __syncthreads();
+    const bool chosen = pick_body<F64>(v, first, anypos, -1, false, false, o, v.colbuf, (Cand<F64> *)sh_c_raw, sh_i, &sh_flag);
+    if (threadIdx.x == 0) {
+        st->blk.budget = budget - 1;
+        if (chosen) { st->blk.from_generic = 1; st->blk.r[0] = st->row; st->blk.n = 1; }
+    }
+}
+
+// ---- prep(t): combine the pick's records, replayed pivot row -> e_t, objective row, pricing --------
+__global__ __launch_bounds__(256) void k_blk_prep(LpView<F64> v, int batch, int t)
+{
+    __shared__ int sh_nf[4], sh_any[4];
+    __shared__ unsigned long long sh_key[4];
+    LoopState * st = v.st;
+    const int status = st->status, pricing = st->pricing;
+    const int bb = st->blk.batch, bn = st->blk.n, from_generic = st->blk.from_generic;
+    const int srow = st->row, scol = st->col, sleave = st->leave;
+    const unsigned long long spiv = st->piv_bits, scnv = st->cnv_bits;
+    const unsigned budget = st->blk.budget, done = st->done;
+    int rs[BLK_MAX];
+#pragma unroll
+    for (int s = 0; s < BLK_MAX; s++) rs[s] = st->blk.r[s];
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+    if (status != ST_RUNNING) return;
+    const unsigned epoch = blk_epoch(batch, t);
+    int r, enter, leave, g_cc = 0; uint32_t g_w = 0;
+    unsigned long long piv_bits, cnv_bits;
+    bool generic_pivot = false;
+    // the fast pick's records, if it ran: every wave combines them the same way -- lane l loads record l
+    // (one round of loads), a 16-lane butterfly picks the best row, the winner's payload comes by shuffle
+    Cand<F64> g; g.q = zero<F64>(); g.idx = INT_MAX;
+    double g_a = 0.0; int g_b = 0, cand_first = -1; unsigned long long g_cnv = 0;
+    bool any_rec = false;
+    {
+        const int lane = threadIdx.x & 63;
+        unsigned long long w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0, w5 = 0;
+        bool valid = false;
+        if (lane < PICK_MAX_WGS) {
+            const unsigned long long * rk = v.blkR + (size_t)lane * BLK_REC_WORDS;
+            w0 = rk[0]; w1 = rk[1]; w2 = rk[2]; w3 = rk[3]; w4 = rk[4]; w5 = rk[5];
+            valid = (unsigned)rk[6] == epoch;
+        }
+        const unsigned long long vmask = __ballot(valid);
+        any_rec = vmask != 0;
+        if (any_rec) {
+            Cand<F64> c; c.q = from_bits<F64>(w0); c.idx = valid ? (int)(unsigned)(w2 >> 32) : INT_MAX;
+            g = c;
+            for (int o = 8; o > 0; o >>= 1) {
+                Cand<F64> tq; tq.q = shfl_xor_s(g.q, o); tq.idx = __shfl_xor(g.idx, o);
+                g = better(g, tq);
+            }
+            g.idx = __shfl(g.idx, 0); g.q = from_bits<F64>(shfl_u64(to_bits(g.q), 0));
+            const int fv = __ffsll((long long)vmask) - 1;                 // any valid record: first, cnv
+            cand_first = (int)(unsigned)shfl_u64(w5, fv); g_cnv = shfl_u64(w4, fv);
+            if (g.idx != INT_MAX) {
+                const unsigned long long wm = __ballot(valid && c.idx == g.idx);
+                const int src = __ffsll((long long)wm) - 1;
+                const unsigned long long p1 = shfl_u64(w1, src), p2 = shfl_u64(w2, src), p3 = shfl_u64(w3, src);
+                g_a = from_bits<F64>(p1).v; g_b = (int)(unsigned)p2; g_w = (uint32_t)(p3 >> 32); g_cc = (int)(unsigned)p3;
+            }
+        }
+    }
+    if (any_rec) {
+        if (g.idx == INT_MAX) {                                // first pass empty: second pass / disableNV are generic
+            if (gid == 0) {
+                st->blk.closed = 1;
+                if (t == 0) { st->blk.want_generic = 1; st->blk.batch = batch; st->blk.n = 0; }
+            }
+            return;
+        }
+        r = g.idx; enter = cand_first; leave = g_b; piv_bits = to_bits(F64(g_a)); cnv_bits = g_cnv;
+    } else if (t == 0 && bb == batch && from_generic && bn == 1) {
+        generic_pivot = true;                                  // the generic pick chose pivot 0 of this batch
+        r = srow; enter = scol; leave = sleave; piv_bits = spiv; cnv_bits = scnv;
+    } else {
+        return;                                                // this batch's pick(t) did not run
+    }
+    const int n = t, W = v.W, rhs = v.rhs, ld = v.ld, m = v.m, lim = v.rhs - 1;
+    double * __restrict__ K = (double *)v.blkK;
+    double * __restrict__ E = (double *)v.blkE;
+    double kq[BLK_MAX];                                        // k_q[r]: wave-uniform loads
+#pragma unroll
+    for (int q = 0; q < BLK_MAX; q++) kq[q] = q < n ? K[(size_t)r * BLK_MAX + q] : 0.0;
+    const F64 s = div(one<F64>(), from_bits<F64>(piv_bits));  // 1/(eq.get(eqnum, nv)), lpsol.h:1471
+    const int smode = scale_mode(s);
+    const F64 cnv = from_bits<F64>(cnv_bits);
+    const int cmode = scale_mode(cnv);
+    const bool dantzig = pricing == 1;
+    int nf = INT_MAX, any = 0;
+    unsigned long long key = 0;
+    for (int j = gid; j < W; j += gsz) {
+        double x = ((const double *)v.tab)[(size_t)r * ld + j];
+        F64 oj = v.obj[j];
+        // the basis before and after this pivot's swap, without reading the two entries the committing
+        // thread rewrites (the generic pick has swapped already)
+        const bool in = j < rhs;
+        const bool nv_mem = in && j != enter && j != leave && v.nv[j] != 0;
+        const bool nv_old = in && (j == enter ? true : (j == leave ? false : nv_mem));
+        const bool nv_new = in && (j == enter ? false : (j == leave ? true : nv_mem));
+        const int rcj = (in && j != enter) ? v.rowcnt[j] : INT_MAX;
+#pragma unroll
+        for (int q = 0; q < BLK_MAX; q++) {                    // the pivot row as the pending sweeps would leave it
+            if (q < n) {
+                const double e_q = E[(size_t)q * ld + j];
+                const double pr = kq[q] * e_q;
+                x = (r == rs[q]) ? e_q : (x + pr);
+            }
+        }
+        const F64 e = scaled(F64(x), s, smode);
+        E[(size_t)n * ld + j] = e.v;
+        F64 tt = mul(e, minus_one<F64>());                     // nvexp.mul(-1), lpsol.h:1496
+        if (j >= rhs) tt = neg(tt);                            // :1497-1499
+        tt = scaled(tt, cnv, cmode);                           // nvexp.mul(tgtf(nv)), :1500
+        // lpsol.h:1055-1060, left to this kernel by the fast pick: entries basic BEFORE the swap below the
+        // entering index (the generic pick has done its own zeroing)
+        if (!generic_pivot && j < enter && in && !nv_old) oj = zero<F64>();
+        const F64 o = add(tt, oj);                             // addRowToRow, :1501
+        v.obj[j] = o;
+        if (nv_new && gt(o, zero<F64>())) {                    // look-ahead pricing of the next pivot
+            any = 1;
+            if (rcj < lim) {
+                if (dantzig) { const unsigned long long kj = dz_key(o.v, j); key = kj > key ? kj : key; }
+                else nf = min(nf, j);
+            }
+        }
+    }
+    // this workgroup's pricing partial for the next pick
+    for (int o = 32; o > 0; o >>= 1) { nf = min(nf, __shfl_xor(nf, o)); any |= __shfl_xor(any, o); }
+    key = wave_max_u64(key);
+    if ((threadIdx.x & 63) == 0) { sh_nf[threadIdx.x >> 6] = nf; sh_any[threadIdx.x >> 6] = any; sh_key[threadIdx.x >> 6] = key; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; k++) { nf = min(nf, sh_nf[k]); any |= sh_any[k]; key = sh_key[k] > key ? sh_key[k] : key; }
+        int * P = v.blkP + (size_t)blockIdx.x * BLK_PART_INTS;
+        P[0] = nf; P[1] = any; P[2] = (int)(unsigned)key; P[3] = (int)(unsigned)(key >> 32); P[4] = (int)epoch;
+    }
+    // -column from the generic pick's colbuf when it chose this pivot
+    if (generic_pivot)
+        for (int i = gid; i < m; i += gsz) K[(size_t)i * BLK_MAX + n] = ((const double *)v.colbuf)[i];
+    // ---- one thread commits the pivot
+    if (gid == 0) {
+        if (!generic_pivot) {
+            const int rc_enter = v.rowcnt[enter];
+            if (!((g_w >> (leave & 31)) & 1u)) {               // genPair, lpsol.h:100-104
+                v.ppt[(size_t)enter * v.pw + (leave >> 5)] = g_w | (1u << (leave & 31));
+                v.rowcnt[enter] = rc_enter + 1; v.colcnt[leave] = g_cc + 1;
+            }
+            v.nv[enter] = 0; v.nv[leave] = 1; v.bv[enter] = 1; v.bv[leave] = 0;       // lpsol.h:1504-1510
+            v.eq2bv[r] = enter; v.bv2eq[enter] = r; v.bv2eq[leave] = -1;
+            const unsigned tp = st->total_pivots;
+            if ((int)tp < v.trace_cap) { v.trace[2 * tp] = enter; v.trace[2 * tp + 1] = leave; }
+            st->total_pivots = tp + 1;
+            st->done = done + 1;
+            st->blk.budget = budget - 1;
+            if (bb != batch) { st->blk.batch = batch; st->blk.closed = 0; st->blk.generic = 0; }
+            st->blk.r[n] = r; st->blk.n = n + 1;
+        }
+        st->blk.from_generic = 0;
+        st->blk.la_from_state = 0;
+        st->blk.la_epoch = epoch;
+        st->row = -1;
+    }
+}
+
+// ---- the sweep: every cell once, all staged pivots in order --------------------------------------
+// NB is the batch length as a compile-time constant (the kernel switches on the wave-uniform count),
+// so the update loop is straight-line code on NB register-resident row pairs e_s; -a_i,nv arrives
+// through the scalar cache (blkK row of 16 doubles, wave-uniform address).
+template <int ROWS, int UNROLL, int NB, bool HASR> __device__ __forceinline__
+void blk_sweep_body(double * __restrict__ tab, int m, int W, int ld, const double * __restrict__ E,
+                    const double * __restrict__ K, const LoopState * __restrict__ st)
+{
+    const int j = blockIdx.x * 512 + threadIdx.x * 2;
+    if (j >= W) return;
+    int rs[NB];
+#pragma unroll
+    for (int s = 0; s < NB; s++) rs[s] = st->blk.r[s];
+    const int i0 = blockIdx.y * ROWS;
+    const int iend = min(i0 + ROWS, m);
+    if (j + 1 < W) {
+        double2 e[NB];
+#pragma unroll
+        for (int s = 0; s < NB; s++) e[s] = *reinterpret_cast<const double2 *>(E + (size_t)s * ld + j);
+        double * base = tab + (size_t)i0 * ld + j;
+        int i = i0;
+        for (; i + UNROLL <= iend; i += UNROLL) {
+            double2 a[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) a[u] = *reinterpret_cast<const double2 *>(base + (size_t)u * ld);
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+                const double * kr = K + (size_t)(i + u) * BLK_MAX;
+#pragma unroll
+                for (int s = 0; s < NB; s++) {
+                    const double k = kr[s];
+                    const double p0 = k * e[s].x, p1 = k * e[s].y;
+                    double2 o;
+                    o.x = a[u].x + p0; o.y = a[u].y + p1;
+                    a[u] = (HASR && i + u == rs[s]) ? e[s] : o;
+                }
+                *reinterpret_cast<double2 *>(base + (size_t)u * ld) = a[u];
+            }
+            base += (size_t)UNROLL * ld;
+        }
+        for (; i < iend; i++) {
+            double2 a = *reinterpret_cast<const double2 *>(base);
+            const double * kr = K + (size_t)i * BLK_MAX;
+#pragma unroll
+            for (int s = 0; s < NB; s++) {
+                const double k = kr[s];
+                const double p0 = k * e[s].x, p1 = k * e[s].y;
+                double2 o;
+                o.x = a.x + p0; o.y = a.y + p1;
+                a = (HASR && i == rs[s]) ? e[s] : o;
+            }
+            *reinterpret_cast<double2 *>(base) = a;
+            base += ld;
+        }
+    } else {                                                  // odd last column
+        for (int i = i0; i < iend; i++) {
+            double * p = tab + (size_t)i * ld + j;
+            double a = *p;
+#pragma unroll
+            for (int s = 0; s < NB; s++) {
+                const double es = E[(size_t)s * ld + j];
+                const double q = K[(size_t)i * BLK_MAX + s] * es;
+                a = (i == rs[s]) ? es : (a + q);
+            }
+            *p = a;
+        }
+    }
+}
+
+template <int ROWS, int UNROLL, int BCAP> __global__ __launch_bounds__(256)
+void k_blk_sweep(double * __restrict__ tab, int m, int W, int ld, const double * __restrict__ E,
+                 const double * __restrict__ K, LoopState * __restrict__ st, int batch)
+{
+    const int status = st->status;
+    const int n = (st->blk.batch == batch) ? st->blk.n : 0;
+    if (status != ST_RUNNING || n == 0) return;
+    // only the row blocks that hold one of the pivot rows pay for the "row r := e" test per cell
+    bool hasr = false;
+    {
+        const int lo = blockIdx.y * ROWS, hi = lo + ROWS;
+        for (int s = 0; s < n; s++) { const int r = st->blk.r[s]; hasr = hasr || (r >= lo && r < hi); }
+    }
+#define XPG_BLK_CASE(NB_) case NB_: if constexpr (NB_ <= BCAP) {                                              \
+        if (hasr) blk_sweep_body<ROWS, UNROLL, NB_, true>(tab, m, W, ld, E, K, st);                          \
+        else blk_sweep_body<ROWS, UNROLL, NB_, false>(tab, m, W, ld, E, K, st); } break;
+    switch (n) {
+        XPG_BLK_CASE(1) XPG_BLK_CASE(2) XPG_BLK_CASE(3) XPG_BLK_CASE(4)
+        XPG_BLK_CASE(5) XPG_BLK_CASE(6) XPG_BLK_CASE(7) XPG_BLK_CASE(8)
+        XPG_BLK_CASE(9) XPG_BLK_CASE(10) XPG_BLK_CASE(11) XPG_BLK_CASE(12)
+        XPG_BLK_CASE(13) XPG_BLK_CASE(14) XPG_BLK_CASE(15) XPG_BLK_CASE(16)
+        default: break;
+    }
+#undef XPG_BLK_CASE
+}
+
+// Host-set budget of loop iterations (xpg_lp_iterate).
+__global__ void k_blk_budget(LoopState * st, unsigned budget) { if (threadIdx.x == 0 && blockIdx.x == 0) st->blk.budget = budget; }
+
+} // namespace xpg

@@ -12,7 +12,7 @@
 #include <stdio.h>
 #include "../../include/xpoly_amd.h"
 #include "lp_kernels.hip.h"
-#include "lp_block.hip.h"
+#include "lp_blocked.hip.h"
 
 struct xpg_ctx {
     int device;
@@ -115,8 +115,8 @@ template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> &
     const int npick = strips < PICK_MAX_WGS ? strips : PICK_MAX_WGS;
     const dim3 gprep((v.W + 255) / 256);
     for (int t = 0; t < B; t++) {
-        hipLaunchKernelGGL(k_blk_pick, dim3(npick), dim3(256), 0, ctx->stream, v, batch, t);
-        if (t == 0) hipLaunchKernelGGL(k_blk_pick_generic, dim3(1), dim3(1024), 0, ctx->stream, v, batch);
+        hipLaunchKernelGGL(k_blk_pick, dim3(npick), dim3(256), 0, ctx->stream, v, batch, t, (int)gprep.x);
+        if (t == 0) hipLaunchKernelGGL(k_blk_pick_generic, dim3(1), dim3(1024), 0, ctx->stream, v, batch, (int)gprep.x);
         hipLaunchKernelGGL(k_blk_prep, gprep, dim3(256), 0, ctx->stream, v, batch, t);
     }
     const bool timed = ctx->prof_n < ctx->prof_cap && (ctx->prof_seen++ % ctx->prof_stride) == 0;
@@ -218,6 +218,8 @@ template <class S> struct Lp : LpBase {
         if ((rc = alloc((void **)&v.pickrec, (size_t)PICK_WORDS * 8))) return rc;
         if ((rc = alloc((void **)&v.blkK, (size_t)round_up(m, 16) * BLK_MAX * sizeof(S)))) return rc;
         if ((rc = alloc((void **)&v.blkE, (size_t)BLK_MAX * ld * sizeof(S)))) return rc;
+        if ((rc = alloc((void **)&v.blkR, (size_t)PICK_MAX_WGS * BLK_REC_WORDS * 8))) return rc;
+        if ((rc = alloc((void **)&v.blkP, (size_t)((ld + 255) / 256 + 2) * BLK_PART_INTS * 4))) return rc;
         if ((rc = alloc((void **)&v.trace, (size_t)v.trace_cap * 8))) return rc;
         if ((rc = alloc((void **)&d_leq, (size_t)m * cols * sizeof(S)))) return rc;
         if ((rc = alloc((void **)&d_tgtf, (size_t)cols * sizeof(S)))) return rc;

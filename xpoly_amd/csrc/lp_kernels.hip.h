@@ -74,9 +74,13 @@ struct LoopState {
         unsigned budget;       // loop iterations the host still allows (xpg_lp_iterate)
         int r[16];             // pivot rows of the staged pivots
         unsigned long long price_key;   // Dantzig look-ahead of the blocked loop's prep
+        unsigned la_epoch;     // tag of the prep whose partials (blkP) hold the current look-ahead
+        int want_generic;      // a fast pick found no row in its first pass: the next batch starts generic
+        int la_from_state;     // the current look-ahead is next_first / anypos (left by reset or the generic
+                               // pick), not the per-workgroup partials of the last prep
     } blk;
 };
-enum { BLK_MAX = 16 };
+enum { BLK_MAX = 16, BLK_REC_WORDS = 8, BLK_PART_INTS = 8 };
 enum { NF_UNKNOWN = -2 };
 typedef LoopState::PipeDesc PipeDesc;
 // LpView::pickrec layout (8-byte words): PICK_MAX_WGS records of PICK_REC_WORDS, then one arrival
@@ -92,6 +96,8 @@ template <class S> struct LpView {
     S * nextcol; S * bcol;   // contiguous copies of the predicted entering column / constant column
     unsigned long long * pickrec;   // pipelined loop: per-workgroup ratio-test records + arrival counters
     S * blkK; S * blkE;             // blocked loop: -column of staged pivot s at blkK[i * BLK_MAX + s], its scaled row at blkE[s * ld + j]
+    unsigned long long * blkR;      // blocked loop: ratio-test records of the pick workgroups (BLK_REC_WORDS each)
+    int * blkP;                     // blocked loop: look-ahead pricing partials of the prep workgroups (BLK_PART_INTS each)
     LoopState * st;
     int * trace; int trace_cap;
 };
@@ -1008,6 +1014,9 @@ template <class S> __global__ void k_reset_loop(LpView<S> v, unsigned max_iter, 
         st->pricing = pricing; st->pad2_ = 0; st->feas_tol = feas_tol;
         st->blk.batch = -1; st->blk.n = 0; st->blk.closed = 0; st->blk.generic = 0; st->blk.from_generic = 0;
         st->blk.budget = 0xFFFFFFFFu; st->blk.price_key = 0ull;
+        st->blk.want_generic = 0; st->blk.la_from_state = 1; st->blk.la_epoch = 0u;
+        for (int k = 0; k < PICK_MAX_WGS; k++) v.blkR[(size_t)k * BLK_REC_WORDS + 6] = 0ull;       // record epochs
+        for (int k = 0; k < (v.ld + 255) / 256 + 1; k++) v.blkP[(size_t)k * BLK_PART_INTS + 4] = 0;  // partial epochs
         for (int k = 0; k < 2; k++) v.pickrec[PICK_CTR_OFF + 16 * k] = 0ull;   // arrival counters
         for (int k = 0; k < 2; k++) {                  // pipelined loop: iteration 0 has no pivot yet
             PipeDesc & D = st->pd[k];
