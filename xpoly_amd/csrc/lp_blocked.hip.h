@@ -85,10 +85,19 @@ __global__ __launch_bounds__(256) void k_blk_pick(LpView<F64> v, int batch, int 
 #pragma unroll
     for (int s = 0; s < BLK_MAX; s++) rs[s] = st->blk.r[s];
     const int tid = threadIdx.x, p = blockIdx.x, N = gridDim.x;
+    // in the same round as the state: the look-ahead partials, and what this thread's first row needs
+    // that does not depend on the entering column
+    const BlkLook look = blk_lookahead(v, la_epoch, nparts);
+    const int i_pre = p * 256 + tid;
+    const int i_clamped = i_pre < v.m ? i_pre : 0;
+    const int bi_pre = v.eq2bv[i_clamped];
+    double k_pre[BLK_MAX];
+#pragma unroll
+    for (int s = 0; s < BLK_MAX; s++) k_pre[s] = s < t ? ((const double *)v.blkK)[(size_t)i_clamped * BLK_MAX + s] : 0.0;
     const int n = (bb == batch) ? bn : 0;
     if (status != ST_RUNNING || (bb == batch && bclosed) || n != t || budget == 0) return;
     int first = sfirst;
-    if (!la_state) first = blk_lookahead(v, la_epoch, nparts).first;
+    if (!la_state) first = look.first;
     const int rhs = v.rhs, ld = v.ld, m = v.m, lim = v.rhs - 1;
     const bool fast = !want_generic && first >= 0 && first < rhs && done < max_iter;
     if (!fast) {
@@ -115,21 +124,24 @@ __global__ __launch_bounds__(256) void k_blk_pick(LpView<F64> v, int batch, int 
     Cand<F64> best; best.q = zero<F64>(); best.idx = INT_MAX;
     double best_a = 0.0; int best_b = 0, best_cc = 0; uint32_t best_w = 0;
     for (int i = p * 256 + tid; i < m; i += 256 * N) {
+        // eq2bv and the blkK row of this thread's first row were loaded with the state (they do not depend
+        // on the entering column): everything that does goes out in ONE further round
+        const bool pre = i == i_pre;
+        const int bi = pre ? bi_pre : v.eq2bv[i];
         const double x0 = tab[(size_t)i * ld + first], b0 = tab[(size_t)i * ld + rhs];
-        const int bi = v.eq2bv[i];
+        const uint32_t w = v.ppt[(size_t)first * v.pw + (bi >> 5)];
+        const int cc = v.colcnt[bi];
         const double * kr = K + (size_t)i * BLK_MAX;
         double a = x0, bc = b0;
 #pragma unroll
         for (int s = 0; s < BLK_MAX; s++) {
             if (s < n) {
-                const double k = kr[s];
+                const double k = pre ? k_pre[s] : kr[s];
                 const double pa = k * ec[s], pb = k * eb[s];
                 a = (i == rs[s]) ? ec[s] : (a + pa);
                 bc = (i == rs[s]) ? eb[s] : (bc + pb);
             }
         }
-        const uint32_t w = v.ppt[(size_t)first * v.pw + (bi >> 5)];
-        const int cc = v.colcnt[bi];
         K[(size_t)i * BLK_MAX + n] = -a;                                  // -a_i,nv (lpsol.h:1485)
         if (le(F64(a), zero<F64>())) continue;                            // findPivotBV, lpsol.h:553-663
         if (((w >> (bi & 31)) & 1u) || cc >= lim) continue;
@@ -206,7 +218,14 @@ __global__ __launch_bounds__(256) void k_blk_prep(LpView<F64> v, int batch, int 
 #pragma unroll
     for (int s = 0; s < BLK_MAX; s++) rs[s] = st->blk.r[s];
     const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
-    if (status != ST_RUNNING) return;
+    // in the same round as the state and the records: everything of this thread's first column that does
+    // not depend on the pivot row
+    const int j_pre = gid < v.W ? gid : 0;
+    const F64 obj_pre = v.obj[j_pre];
+    const int nv_pre = v.nv[j_pre < v.rhs ? j_pre : 0], rc_pre = v.rowcnt[j_pre < v.rhs ? j_pre : 0];
+    double e_pre[BLK_MAX];
+#pragma unroll
+    for (int q = 0; q < BLK_MAX; q++) e_pre[q] = q < t ? ((const double *)v.blkE)[(size_t)q * v.ld + j_pre] : 0.0;
     const unsigned epoch = blk_epoch(batch, t);
     int r, enter, leave, g_cc = 0; uint32_t g_w = 0;
     unsigned long long piv_bits, cnv_bits;
@@ -245,6 +264,7 @@ __global__ __launch_bounds__(256) void k_blk_prep(LpView<F64> v, int batch, int 
             }
         }
     }
+    if (status != ST_RUNNING) return;
     if (any_rec) {
         if (g.idx == INT_MAX) {                                // first pass empty: second pass / disableNV are generic
             if (gid == 0) {
@@ -274,19 +294,20 @@ __global__ __launch_bounds__(256) void k_blk_prep(LpView<F64> v, int batch, int 
     int nf = INT_MAX, any = 0;
     unsigned long long key = 0;
     for (int j = gid; j < W; j += gsz) {
+        const bool pre = j == j_pre;                           // this thread's first column: loaded with the state
         double x = ((const double *)v.tab)[(size_t)r * ld + j];
-        F64 oj = v.obj[j];
-        // the basis before and after this pivot's swap, without reading the two entries the committing
+        F64 oj = pre ? obj_pre : v.obj[j];
+        // the basis before and after this pivot's swap, without using the two entries the committing
         // thread rewrites (the generic pick has swapped already)
         const bool in = j < rhs;
-        const bool nv_mem = in && j != enter && j != leave && v.nv[j] != 0;
+        const bool nv_mem = in && j != enter && j != leave && (pre ? nv_pre : (int)v.nv[j]) != 0;
         const bool nv_old = in && (j == enter ? true : (j == leave ? false : nv_mem));
         const bool nv_new = in && (j == enter ? false : (j == leave ? true : nv_mem));
-        const int rcj = (in && j != enter) ? v.rowcnt[j] : INT_MAX;
+        const int rcj = (in && j != enter) ? (pre ? rc_pre : v.rowcnt[j]) : INT_MAX;
 #pragma unroll
         for (int q = 0; q < BLK_MAX; q++) {                    // the pivot row as the pending sweeps would leave it
             if (q < n) {
-                const double e_q = E[(size_t)q * ld + j];
+                const double e_q = pre ? e_pre[q] : E[(size_t)q * ld + j];
                 const double pr = kq[q] * e_q;
                 x = (r == rs[q]) ? e_q : (x + pr);
             }
