@@ -46,6 +46,34 @@ def test_dantzig_tolerant_mode_reaches_the_optimum(ctx, m, n):
     print("m=%d n=%d: pivots parity %d -> dantzig %d" % (m, n, piv_parity, piv))
 
 
+@pytest.mark.parametrize("B", [4, 16])
+def test_dantzig_mode_through_the_blocked_loop(B, monkeypatch):
+    """The same non-parity mode through the blocked loop (Dantzig look-ahead as per-workgroup keys),
+    forced onto a small LP: same optimum as HiGHS, and the same pivot count as the pipelined loop."""
+    import xpoly_amd
+    from scipy.optimize import linprog
+    m, n = 96, 80
+    leq, tg = gen.hard_lp_f64(m, n)
+    A, b, c = leq[:, :-1], leq[:, -1], tg[:-1]
+    ref = linprog(-c, A_ub=A, b_ub=b, bounds=[(0, None)] * n, method="highs")
+    want = -ref.fun + tg[-1]
+    res = {}
+    for mode in ("pipe", "block"):
+        monkeypatch.setenv("XPG_LOOP", mode)
+        monkeypatch.setenv("XPG_BLOCK", str(B))
+        c2 = xpoly_amd.Context(0)
+        lp = xpoly_amd.DeviceLP(c2, F64, leq, tg)
+        lp.set_options(pricing=1, feas_rel_tol=1e-9)
+        st = lp.two_stage()
+        res[mode] = (st, lp.pivots_done(), lp.read(want_tab=True), lp.trace().copy())
+        lp.close(); c2.close()
+    for mode in res:
+        assert res[mode][0] == 0
+        assert abs(res[mode][2]["maxv"] - want) <= 1e-7 * max(1.0, abs(want))
+    assert res["pipe"][1] == res["block"][1] and np.array_equal(res["pipe"][3], res["block"][3])
+    assert np.array_equal(res["pipe"][2]["tab"].view(np.uint64), res["block"][2]["tab"].view(np.uint64))
+
+
 def test_options_are_fp64_only_and_reversible(ctx, port):
     import xpoly_amd
     rng = np.random.default_rng(3)
