@@ -209,7 +209,7 @@ def main():
                         frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src,
                         kernel={"se": "k_update_f64<32,8>", "pi": "k_pipe_sweep<32,8> (sweep + the next pivot's pick workgroups)",
                                 "sp": "k_pipe_sweep<32,8>"}.get(os.environ.get("XPG_LOOP", "")[:2],
-                                                               "k_blk_sweep<32,4,16> (one pass applies up to XPG_BLOCK=16 staged pivots)"),
+                                                               "k_blk_sweep_full<16,4> (one pass applies the XPG_BLOCK=16 staged pivots)"),
                         pivots_per_launch=round(a.steps / max(1, launches * stride), 2),
                         launches_sampled=launches,
                         avg_launch_us=round(sweep_avg_s * 1e6, 2),

@@ -35,6 +35,7 @@
 // the batch: the remaining launches of the batch do nothing, the sweep applies what is staged and the
 // next batch starts with pick(0) + generic on a swept tableau.
 #pragma once
+#include <type_traits>
 #include "lp_kernels.hip.h"
 
 namespace xpg {
@@ -437,6 +438,134 @@ void blk_sweep_body(double * __restrict__ tab, int m, int W, int ld, const doubl
     }
 }
 
+// The full batch (n == BLK_MAX, the steady state) as a kernel of its own, shaped by measurements on the
+// bench tableau (tools/sweep_lab.hip):
+//  * compiled alone the 16-stage body fits 128 VGPRs (four wavefronts per SIMD) with next to no SGPR
+//    spills; inside the switch kernel below the allocator settles on the union of all 32 bodies
+//    (131 VGPRs + 102 spilled SGPRs);
+//  * ping-pong row groups: the loads of the next U rows are in flight while this group's 16 x 2U
+//    multiply-adds run (the arithmetic alone is ~40 us of a ~77 us pass, so it must overlap);
+//  * stages outermost, the U rows in lockstep: 2U independent add chains; every cell still sees its
+//    stages in order, so the bits are those of the row-by-row form;
+//  * 16-row blocks: 4096 workgroups keep the tail of the launch short (32- and 64-row blocks were
+//    slower although they re-read E less often);
+//  * no "row r := e" selects and no row list in the loop: the stream treats the staged pivot rows like
+//    any other row (what it leaves there is meaningless) and the workgroup that owns them rewrites
+//    them once its stream is through -- their final contents depend on E and K only (e_s, then stages
+//    s+1.. applied to it with the same two roundings per stage), and e is still in registers.
+template <int ROWS, int U> __global__ __launch_bounds__(256)
+void k_blk_sweep_full(double * __restrict__ tab, int m, int W, int ld, const double * __restrict__ E,
+                      const double * __restrict__ K, const LoopState * __restrict__ st, int batch)
+{
+    constexpr int NB = BLK_MAX;
+    static_assert(ROWS % (2 * U) == 0, "a row block holds whole ping-pong pairs");
+    const int j = blockIdx.x * 512 + threadIdx.x * 2;
+    const int i0 = blockIdx.y * ROWS;
+    const int iend = min(i0 + ROWS, m);
+    const int status = st->status;
+    const int n = (st->blk.batch == batch) ? st->blk.n : 0;
+    if (status != ST_RUNNING || n == 0 || j >= W) return;
+
+    if (n != NB || j + 1 >= W) {
+        // A partial batch (the iteration budget ran out, or a pick closed the batch early) and the odd
+        // last column: the plain form, stage count and row list read at run time, e_s re-read from the
+        // cache per row. Rare, and kept light on registers so that it does not weigh on the path below.
+        const bool pair = j + 1 < W;
+        for (int i = i0; i < iend; i++) {
+            double * p = tab + (size_t)i * ld + j;
+            double ax = p[0], ay = pair ? p[1] : 0.0;
+            for (int s = 0; s < n; s++) {
+                const double k = K[(size_t)i * BLK_MAX + s];
+                const double ex = E[(size_t)s * ld + j], ey = pair ? E[(size_t)s * ld + j + 1] : 0.0;
+                const double p0 = k * ex, p1 = k * ey;
+                const bool piv = st->blk.r[s] == i;
+                ax = piv ? ex : ax + p0;
+                ay = piv ? ey : ay + p1;
+            }
+            p[0] = ax;
+            if (pair) p[1] = ay;
+        }
+        return;
+    }
+
+    double2 e[NB];
+#pragma unroll
+    for (int s = 0; s < NB; s++) e[s] = *reinterpret_cast<const double2 *>(E + (size_t)s * ld + j);
+    auto load = [&](double2 (&d)[U], const double * p) {
+#pragma unroll
+        for (int u = 0; u < U; u++) d[u] = *reinterpret_cast<const double2 *>(p + (size_t)u * ld);
+    };
+    auto apply = [&](double2 (&d)[U], double * p, int row0) {
+#pragma unroll
+        for (int s = 0; s < NB; s++) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const double k = K[(size_t)(row0 + u) * BLK_MAX + s];
+                const double p0 = k * e[s].x, p1 = k * e[s].y;
+                d[u].x = d[u].x + p0; d[u].y = d[u].y + p1;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) *reinterpret_cast<double2 *>(p + (size_t)u * ld) = d[u];
+    };
+    double * base = tab + (size_t)i0 * ld + j;
+    if (i0 + ROWS <= m) {
+        double2 a[U], b[U];
+        load(a, base);
+#pragma unroll 1
+        for (int i = i0; i < i0 + ROWS; i += 2 * U) {
+            load(b, base + (size_t)U * ld);
+            apply(a, base, i);
+            if (i + 2 * U < i0 + ROWS) load(a, base + (size_t)2 * U * ld);
+            apply(b, base + (size_t)U * ld, i + U);
+            base += (size_t)2 * U * ld;
+        }
+    } else {                                                  // the short last row block
+        for (int i = i0; i < iend; i++) {
+            double2 a = *reinterpret_cast<const double2 *>(base);
+#pragma unroll
+            for (int s = 0; s < NB; s++) {
+                const double k = K[(size_t)i * BLK_MAX + s];
+                const double p0 = k * e[s].x, p1 = k * e[s].y;
+                a.x = a.x + p0; a.y = a.y + p1;
+            }
+            *reinterpret_cast<double2 *>(base) = a;
+            base += ld;
+        }
+    }
+
+    // The staged pivot rows of this block, now that the stream is through (the row list is not read
+    // before this point, so it is not live in the loop): row r_s is e_s after stage s, then every later
+    // stage s2 does x := x + K[r_s][s2] * e_s2 -- unless the row pivots again at s2, in which case that
+    // later stage's value is the one that survives. Same thread, same address as the streamed store
+    // above, so program order puts this one last.
+    asm volatile("" ::: "memory");
+    int rs[NB];
+#pragma unroll
+    for (int s = 0; s < NB; s++) rs[s] = st->blk.r[s];
+    bool hasr = false;
+#pragma unroll
+    for (int s = 0; s < NB; s++) hasr = hasr || (rs[s] >= i0 && rs[s] < iend);
+    if (!hasr) return;
+#pragma unroll
+    for (int s = 0; s < NB; s++) {
+        const int r = rs[s];
+        bool skip = r < i0 || r >= iend;
+#pragma unroll
+        for (int s2 = s + 1; s2 < NB; s2++) skip = skip || (rs[s2] == r);
+        if (skip) continue;
+        double2 x = e[s];
+#pragma unroll
+        for (int s2 = s + 1; s2 < NB; s2++) {
+            const double k = K[(size_t)r * BLK_MAX + s2];
+            const double p0 = k * e[s2].x, p1 = k * e[s2].y;
+            x.x = x.x + p0; x.y = x.y + p1;
+        }
+        *reinterpret_cast<double2 *>(tab + (size_t)r * ld + j) = x;
+    }
+}
+
+// The batch length as a template switch (block lengths below 16, and the A/B switch XPG_BLK_ROWS=1).
 template <int ROWS, int UNROLL, int BCAP> __global__ __launch_bounds__(256)
 void k_blk_sweep(double * __restrict__ tab, int m, int W, int ld, const double * __restrict__ E,
                  const double * __restrict__ K, LoopState * __restrict__ st, int batch)
@@ -451,7 +580,7 @@ void k_blk_sweep(double * __restrict__ tab, int m, int W, int ld, const double *
         for (int s = 0; s < n; s++) { const int r = st->blk.r[s]; hasr = hasr || (r >= lo && r < hi); }
     }
 #define XPG_BLK_CASE(NB_) case NB_: if constexpr (NB_ <= BCAP) {                                              \
-        if (hasr) blk_sweep_body<ROWS, UNROLL, NB_, true>(tab, m, W, ld, E, K, st);                          \
+        if (hasr) blk_sweep_body<ROWS, UNROLL, NB_, true>(tab, m, W, ld, E, K, st);                      \
         else blk_sweep_body<ROWS, UNROLL, NB_, false>(tab, m, W, ld, E, K, st); } break;
     switch (n) {
         XPG_BLK_CASE(1) XPG_BLK_CASE(2) XPG_BLK_CASE(3) XPG_BLK_CASE(4)

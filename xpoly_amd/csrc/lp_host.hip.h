@@ -121,13 +121,23 @@ template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> &
     }
     const bool timed = ctx->prof_n < ctx->prof_cap && (ctx->prof_seen++ % ctx->prof_stride) == 0;
     hipEvent_t e0 = timed ? ctx->ev0[ctx->prof_n] : nullptr, e1 = timed ? ctx->ev1[ctx->prof_n] : nullptr;
-    const dim3 g(strips, (v.m + 31) / 32);
-    if (B <= 8)
-        hipExtLaunchKernelGGL((k_blk_sweep<32, 8, 8>), g, dim3(256), 0, ctx->stream, e0, e1, 0, (double *)v.tab, v.m, v.W,
-                              v.ld, (const double *)v.blkE, (const double *)v.blkK, v.st, batch);
-    else
-        hipExtLaunchKernelGGL((k_blk_sweep<32, 4, 16>), g, dim3(256), 0, ctx->stream, e0, e1, 0, (double *)v.tab, v.m, v.W,
-                              v.ld, (const double *)v.blkE, (const double *)v.blkK, v.st, batch);
+    static const int rows_env = [] { const char * s = getenv("XPG_BLK_ROWS"); return s ? atoi(s) : 32; }();
+#define XPG_BLK_LAUNCH(ROWS_, UNR_, CAP_)                                                                                 \
+    hipExtLaunchKernelGGL((k_blk_sweep<ROWS_, UNR_, CAP_>), dim3(strips, (v.m + ROWS_ - 1) / ROWS_), dim3(256), 0,        \
+                          ctx->stream, e0, e1, 0, (double *)v.tab, v.m, v.W, v.ld, (const double *)v.blkE,                \
+                          (const double *)v.blkK, v.st, batch)
+#define XPG_BLK_FULL(ROWS_, UNR_)                                                                                         \
+    hipExtLaunchKernelGGL((k_blk_sweep_full<ROWS_, UNR_>), dim3(strips, (v.m + ROWS_ - 1) / ROWS_), dim3(256), 0,         \
+                          ctx->stream, e0, e1, 0, (double *)v.tab, v.m, v.W, v.ld, (const double *)v.blkE,                \
+                          (const double *)v.blkK, (const LoopState *)v.st, batch)
+    if (B <= 8) XPG_BLK_LAUNCH(32, 8, 8);
+    else if (B < BLK_MAX || rows_env == 1) XPG_BLK_LAUNCH(32, 4, 16);
+    else if (rows_env == 324) XPG_BLK_FULL(32, 4);
+    else if (rows_env == 162) XPG_BLK_FULL(16, 2);
+    else if (rows_env == 82) XPG_BLK_FULL(8, 2);
+    else XPG_BLK_FULL(16, 4);                           // the default: full batches of 16
+#undef XPG_BLK_LAUNCH
+#undef XPG_BLK_FULL
     if (timed) ctx->prof_n++;
 }
 template <> inline void launch_update<R32>(xpg_ctx * ctx, const LpView<R32> & v, int guarded)
@@ -311,7 +321,7 @@ template <class S> struct Lp : LpBase {
         }
     }
 
-    // Blocked loop (lp_block.hip.h): at most k loop iterations as ceil(k / B) batches of
+    // Blocked loop (lp_blocked.hip.h): at most k loop iterations as ceil(k / B) batches of
     // B x (pick, prep) + one sweep; the device-side budget stops the last batch where k ends.
     void queue_blocked(unsigned k)
     {

@@ -63,7 +63,7 @@ struct LoopState {
     int pricing;           // 1: Dantzig's rule (largest reduced cost) instead of the first positive one
     int pad2_;
     double feas_tol;       // > 0: SIX::is_feasible with this relative tolerance instead of Float's 1e-17 '=='
-    // Blocked fp64 loop (lp_block.hip.h): up to BLK_MAX pivots are chosen and staged against the
+    // Blocked fp64 loop (lp_blocked.hip.h): up to BLK_MAX pivots are chosen and staged against the
     // un-swept tableau, then ONE sweep applies them all. Fields tagged with the batch they belong to.
     struct Blk {
         int batch;             // batch the fields below belong to (stale otherwise: n = 0, open)

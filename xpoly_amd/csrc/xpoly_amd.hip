@@ -51,7 +51,7 @@ int xpg_create(xpg_ctx ** out, int device)
     const char * zz = getenv("XPG_ZIGZAG");
     c->zigzag = zz ? atoi(zz) : 0;                      // measured slower (79.7 vs 77.8 us per sweep): off
     c->loop_mode = (lm && lm[0] == 's' && lm[1] == 'e') ? 1 : ((lm && lm[0] == 's' && lm[1] == 'p') ? 2 : 0);
-    if (lm && lm[0] == 'b') c->loop_mode = 3;          // "block": B pivots per sweep (lp_block.hip.h)
+    if (lm && lm[0] == 'b') c->loop_mode = 3;          // "block": B pivots per sweep (lp_blocked.hip.h)
     if (lm && lm[0] == 'p') c->loop_mode = 0;          // "pipe": always the pipelined loop
     c->loop_auto = lm ? 0 : 1;                         // unset: blocked loop for large fp64 tableaux, else pipelined
     const char * bl = getenv("XPG_BLOCK");
