@@ -133,7 +133,7 @@ def test_full_size_loops_against_each_other_and_oracle(port, monkeypatch):
     m, n, K = 4096, 4095, 300
     leq, tg = gen.hard_lp_f64(m, n)
     got = {}
-    for mode in ("block", "pipe", "serial"):
+    for mode in ("block", "chain", "pipe", "serial"):    # "chain": stages 1..15 of a batch in ONE launch
         monkeypatch.setenv("XPG_LOOP", mode)             # read when the context is created
         c = xpoly_amd.Context(0)
         lp = xpoly_amd.DeviceLP(c, F64, leq, tg)
@@ -146,7 +146,7 @@ def test_full_size_loops_against_each_other_and_oracle(port, monkeypatch):
         lp.close(); c.close()
     for tag, total in (("", K), ("+", 2000)):
         b, tb, nb = got["serial" + tag]
-        for mode in ("block", "pipe"):
+        for mode in ("block", "chain", "pipe"):
             a, ta, na = got[mode + tag]
             assert na == nb == total and np.array_equal(ta, tb), (mode, tag)
             for k in ("tab", "tgtf"):
@@ -161,13 +161,16 @@ def test_full_size_loops_against_each_other_and_oracle(port, monkeypatch):
     assert np.array_equal(a["eq2bv"], want["eq2bv"])
 
 
-@pytest.mark.parametrize("B", [1, 3, 16])
-def test_blocked_loop_small_and_rare_branches(ctx, port, B, monkeypatch):
+@pytest.mark.parametrize("B,loop,same_xcd", [(1, "block", 1), (3, "block", 1), (16, "block", 1),
+                                              (16, "chain", 1), (5, "chain", 0)])
+def test_blocked_loop_small_and_rare_branches(ctx, port, B, loop, same_xcd, monkeypatch):
     """The blocked loop forced onto small LPs (where it is not the default), batch lengths 1, 3 and
     16: dependence-test-like data drive it through closed batches and the generic pick; random
-    problems through phase 1. Status, tableau, objective row, basis: bit-identical to the oracle."""
+    problems through phase 1. Status, tableau, objective row, basis: bit-identical to the oracle.
+    Also through the chain kernel (stages 1.. of a batch in one launch), with both barrier flavours."""
     import xpoly_amd
-    monkeypatch.setenv("XPG_LOOP", "block")
+    monkeypatch.setenv("XPG_LOOP", loop)
+    monkeypatch.setenv("XPG_CHAIN_SAME_XCD", str(same_xcd))
     monkeypatch.setenv("XPG_BLOCK", str(B))
     c = xpoly_amd.Context(0)
     six = xpoly_amd.SIX(c, F64)

@@ -48,8 +48,27 @@ __device__ __forceinline__ unsigned long long shfl_u64(unsigned long long x, int
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// Loads of anything another workgroup of the SAME launch may have written (the chain kernel, XW): an
+// agent-scope relaxed atomic load, i.e. a load that bypasses this CU's vector L1. Plain otherwise.
+template <bool XW, class T> __device__ __forceinline__ T ldx(const T * p)
+{
+    if constexpr (!XW) return *p;
+    else if constexpr (sizeof(T) == 1) {
+        return (T)__hip_atomic_load((const unsigned char *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if constexpr (sizeof(T) == 4) {
+        const unsigned u = __hip_atomic_load((const unsigned *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        T r; __builtin_memcpy(&r, &u, 4); return r;
+    } else {
+        static_assert(sizeof(T) == 8, "4- or 8-byte objects");
+        const unsigned long long u = __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        T r; __builtin_memcpy(&r, &u, 8); return r;
+    }
+}
+#define XLD(lvalue) ldx<XW>(&(lvalue))
+
 // The look-ahead the last prep left: every wave reduces the partials itself (one load round).
 struct BlkLook { int first; int anypos; };
+template <bool XW>
 __device__ __forceinline__ BlkLook blk_lookahead(const LpView<F64> & v, unsigned want_epoch, int nparts)
 {
     const int lane = threadIdx.x & 63;
@@ -57,9 +76,9 @@ __device__ __forceinline__ BlkLook blk_lookahead(const LpView<F64> & v, unsigned
     unsigned long long key = 0;
     for (int k = lane; k < nparts; k += 64) {
         const int * P = v.blkP + (size_t)k * BLK_PART_INTS;
-        const bool ok = (unsigned)P[4] == want_epoch;
-        const int pn = P[0], pa = P[1];
-        const unsigned long long pk = ((unsigned long long)(unsigned)P[3] << 32) | (unsigned)P[2];
+        const bool ok = (unsigned)XLD(P[4]) == want_epoch;
+        const int pn = XLD(P[0]), pa = XLD(P[1]);
+        const unsigned long long pk = ((unsigned long long)(unsigned)XLD(P[3]) << 32) | (unsigned)XLD(P[2]);
         if (ok) { nf = min(nf, pn); any |= pa; key = pk > key ? pk : key; }
     }
     for (int o = 32; o > 0; o >>= 1) { nf = min(nf, __shfl_xor(nf, o)); any |= __shfl_xor(any, o); }
@@ -71,32 +90,35 @@ __device__ __forceinline__ BlkLook blk_lookahead(const LpView<F64> & v, unsigned
 }
 
 // ---- pick(t): first ratio-test pass by up to PICK_MAX_WGS workgroups of 256 threads --------------
-__global__ __launch_bounds__(256) void k_blk_pick(LpView<F64> v, int batch, int t, int nparts)
+// p of N: this workgroup's share of the rows (p >= N: no rows -- a prep-only worker of the chain kernel,
+// which still needs the decision). Returns whether the fast path ran; the answer is the same in every
+// workgroup, because it depends on the committed state and the look-ahead partials only.
+template <bool XW>
+__device__ __forceinline__ bool blk_pick_body(const LpView<F64> & v, int batch, int t, int nparts, int p, int N,
+                                              Cand<F64> * sh_c)
 {
-    __shared__ __attribute__((aligned(8))) unsigned char sh_c_raw[16 * sizeof(Cand<F64>)];
-    Cand<F64> * sh_c = (Cand<F64> *)sh_c_raw;
     LoopState * st = v.st;
-    const int status = st->status;
-    const int bb = st->blk.batch, bn = st->blk.n, bclosed = st->blk.closed, want_generic = st->blk.want_generic;
-    const int la_state = st->blk.la_from_state;
-    const unsigned la_epoch = st->blk.la_epoch;
-    const unsigned budget = st->blk.budget, done = st->done, max_iter = st->max_iter;
-    const int sfirst = st->next_first;
+    const int status = XLD(st->status);
+    const int bb = XLD(st->blk.batch), bn = XLD(st->blk.n), bclosed = XLD(st->blk.closed), want_generic = XLD(st->blk.want_generic);
+    const int la_state = XLD(st->blk.la_from_state);
+    const unsigned la_epoch = XLD(st->blk.la_epoch);
+    const unsigned budget = XLD(st->blk.budget), done = XLD(st->done), max_iter = XLD(st->max_iter);
+    const int sfirst = XLD(st->next_first);
     int rs[BLK_MAX];
 #pragma unroll
-    for (int s = 0; s < BLK_MAX; s++) rs[s] = st->blk.r[s];
-    const int tid = threadIdx.x, p = blockIdx.x, N = gridDim.x;
+    for (int s = 0; s < BLK_MAX; s++) rs[s] = XLD(st->blk.r[s]);
+    const int tid = threadIdx.x;
     // in the same round as the state: the look-ahead partials, and what this thread's first row needs
     // that does not depend on the entering column
-    const BlkLook look = blk_lookahead(v, la_epoch, nparts);
+    const BlkLook look = blk_lookahead<XW>(v, la_epoch, nparts);
     const int i_pre = p * 256 + tid;
     const int i_clamped = i_pre < v.m ? i_pre : 0;
-    const int bi_pre = v.eq2bv[i_clamped];
+    const int bi_pre = XLD(v.eq2bv[i_clamped]);
     double k_pre[BLK_MAX];
 #pragma unroll
-    for (int s = 0; s < BLK_MAX; s++) k_pre[s] = s < t ? ((const double *)v.blkK)[(size_t)i_clamped * BLK_MAX + s] : 0.0;
+    for (int s = 0; s < BLK_MAX; s++) k_pre[s] = s < t ? XLD(((const double *)v.blkK)[(size_t)i_clamped * BLK_MAX + s]) : 0.0;
     const int n = (bb == batch) ? bn : 0;
-    if (status != ST_RUNNING || (bb == batch && bclosed) || n != t || budget == 0) return;
+    if (status != ST_RUNNING || (bb == batch && bclosed) || n != t || budget == 0) return false;
     int first = sfirst;
     if (!la_state) first = look.first;
     const int rhs = v.rhs, ld = v.ld, m = v.m, lim = v.rhs - 1;
@@ -108,18 +130,19 @@ __global__ __launch_bounds__(256) void k_blk_pick(LpView<F64> v, int batch, int 
             if (n == 0) { st->blk.generic = 1; st->blk.want_generic = 0; }
             else st->blk.closed = 1;
         }
-        return;
+        return false;
     }
+    if (p >= N) return true;
     const double * __restrict__ tab = (const double *)v.tab;
     double * __restrict__ K = (double *)v.blkK;
     const double * __restrict__ E = (const double *)v.blkE;
     double ec[BLK_MAX], eb[BLK_MAX];                            // e_s[first], e_s[rhs]: wave-uniform loads
 #pragma unroll
     for (int s = 0; s < BLK_MAX; s++) {
-        ec[s] = s < n ? E[(size_t)s * ld + first] : 0.0;
-        eb[s] = s < n ? E[(size_t)s * ld + rhs] : 0.0;
+        ec[s] = s < n ? XLD(E[(size_t)s * ld + first]) : 0.0;
+        eb[s] = s < n ? XLD(E[(size_t)s * ld + rhs]) : 0.0;
     }
-    const unsigned long long cnv_bits = to_bits(v.obj[first]);
+    const unsigned long long cnv_bits = to_bits(XLD(v.obj[first]));
     // fused pass over this workgroup's rows: replayed entering column (its negation staged as k_t),
     // replayed constant column, first pass of the ratio test
     Cand<F64> best; best.q = zero<F64>(); best.idx = INT_MAX;
@@ -128,16 +151,16 @@ __global__ __launch_bounds__(256) void k_blk_pick(LpView<F64> v, int batch, int 
         // eq2bv and the blkK row of this thread's first row were loaded with the state (they do not depend
         // on the entering column): everything that does goes out in ONE further round
         const bool pre = i == i_pre;
-        const int bi = pre ? bi_pre : v.eq2bv[i];
+        const int bi = pre ? bi_pre : XLD(v.eq2bv[i]);
         const double x0 = tab[(size_t)i * ld + first], b0 = tab[(size_t)i * ld + rhs];
-        const uint32_t w = v.ppt[(size_t)first * v.pw + (bi >> 5)];
-        const int cc = v.colcnt[bi];
+        const uint32_t w = XLD(v.ppt[(size_t)first * v.pw + (bi >> 5)]);
+        const int cc = XLD(v.colcnt[bi]);
         const double * kr = K + (size_t)i * BLK_MAX;
         double a = x0, bc = b0;
 #pragma unroll
         for (int s = 0; s < BLK_MAX; s++) {
             if (s < n) {
-                const double k = pre ? k_pre[s] : kr[s];
+                const double k = pre ? k_pre[s] : XLD(kr[s]);
                 const double pa = k * ec[s], pb = k * eb[s];
                 a = (i == rs[s]) ? ec[s] : (a + pa);
                 bc = (i == rs[s]) ? eb[s] : (bc + pb);
@@ -153,15 +176,23 @@ __global__ __launch_bounds__(256) void k_blk_pick(LpView<F64> v, int batch, int 
     }
     const Cand<F64> wbest = block_argmin(best, sh_c);
     const bool publisher = wbest.idx != INT_MAX ? (best.idx == wbest.idx) : (tid == 0);
-    if (!publisher) return;
-    unsigned long long * rec = v.blkR + (size_t)p * BLK_REC_WORDS;
-    rec[0] = to_bits(wbest.q);
-    rec[1] = to_bits(F64(best_a));
-    rec[2] = ((unsigned long long)(unsigned)wbest.idx << 32) | (unsigned)best_b;
-    rec[3] = ((unsigned long long)best_w << 32) | (unsigned)best_cc;
-    rec[4] = cnv_bits;
-    rec[5] = (unsigned long long)(unsigned)first;
-    rec[6] = (unsigned long long)blk_epoch(batch, t);
+    if (publisher) {
+        unsigned long long * rec = v.blkR + (size_t)p * BLK_REC_WORDS;
+        rec[0] = to_bits(wbest.q);
+        rec[1] = to_bits(F64(best_a));
+        rec[2] = ((unsigned long long)(unsigned)wbest.idx << 32) | (unsigned)best_b;
+        rec[3] = ((unsigned long long)best_w << 32) | (unsigned)best_cc;
+        rec[4] = cnv_bits;
+        rec[5] = (unsigned long long)(unsigned)first;
+        rec[6] = (unsigned long long)blk_epoch(batch, t);
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_blk_pick(LpView<F64> v, int batch, int t, int nparts)
+{
+    __shared__ __attribute__((aligned(8))) unsigned char sh_c_raw[16 * sizeof(Cand<F64>)];
+    (void)blk_pick_body<false>(v, batch, t, nparts, (int)blockIdx.x, (int)gridDim.x, (Cand<F64> *)sh_c_raw);
 }
 
 // ---- the generic pick, only when pick(0) of this batch asked for it ------------------------------
@@ -183,7 +214,7 @@ __global__ __launch_bounds__(1024) void k_blk_pick_generic(LpView<F64> v, int ba
     const unsigned la_epoch = st->blk.la_epoch;
     if (!la_state) {
         if (threadIdx.x < 64) {
-            const BlkLook L = blk_lookahead(v, la_epoch, nparts);
+            const BlkLook L = blk_lookahead<false>(v, la_epoch, nparts);
             if (threadIdx.x == 0) { sh_la[0] = L.first; sh_la[1] = L.anypos; }
         }
         __syncthreads();
@@ -205,28 +236,31 @@ __global__ __launch_bounds__(1024) void k_blk_pick_generic(LpView<F64> v, int ba
 }
 
 // ---- prep(t): combine the pick's records, replayed pivot row -> e_t, objective row, pricing --------
-__global__ __launch_bounds__(256) void k_blk_prep(LpView<F64> v, int batch, int t)
+// p of nwork workgroups of 256 threads. Returns whether a pivot was staged (the same answer in every
+// workgroup: it depends on the committed state and the pick's records only).
+template <bool XW>
+__device__ __forceinline__ bool blk_prep_body(const LpView<F64> & v, int batch, int t, int p, int nwork)
 {
     __shared__ int sh_nf[4], sh_any[4];
     __shared__ unsigned long long sh_key[4];
     LoopState * st = v.st;
-    const int status = st->status, pricing = st->pricing;
-    const int bb = st->blk.batch, bn = st->blk.n, from_generic = st->blk.from_generic;
-    const int srow = st->row, scol = st->col, sleave = st->leave;
-    const unsigned long long spiv = st->piv_bits, scnv = st->cnv_bits;
-    const unsigned budget = st->blk.budget, done = st->done;
+    const int status = XLD(st->status), pricing = XLD(st->pricing);
+    const int bb = XLD(st->blk.batch), bn = XLD(st->blk.n), from_generic = XLD(st->blk.from_generic);
+    const int srow = XLD(st->row), scol = XLD(st->col), sleave = XLD(st->leave);
+    const unsigned long long spiv = XLD(st->piv_bits), scnv = XLD(st->cnv_bits);
+    const unsigned budget = XLD(st->blk.budget), done = XLD(st->done), tp = XLD(st->total_pivots);
     int rs[BLK_MAX];
 #pragma unroll
-    for (int s = 0; s < BLK_MAX; s++) rs[s] = st->blk.r[s];
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+    for (int s = 0; s < BLK_MAX; s++) rs[s] = XLD(st->blk.r[s]);
+    const int gid = p * 256 + (int)threadIdx.x, gsz = nwork * 256;
     // in the same round as the state and the records: everything of this thread's first column that does
     // not depend on the pivot row
     const int j_pre = gid < v.W ? gid : 0;
-    const F64 obj_pre = v.obj[j_pre];
-    const int nv_pre = v.nv[j_pre < v.rhs ? j_pre : 0], rc_pre = v.rowcnt[j_pre < v.rhs ? j_pre : 0];
+    const F64 obj_pre = XLD(v.obj[j_pre]);
+    const int nv_pre = XLD(v.nv[j_pre < v.rhs ? j_pre : 0]), rc_pre = XLD(v.rowcnt[j_pre < v.rhs ? j_pre : 0]);
     double e_pre[BLK_MAX];
 #pragma unroll
-    for (int q = 0; q < BLK_MAX; q++) e_pre[q] = q < t ? ((const double *)v.blkE)[(size_t)q * v.ld + j_pre] : 0.0;
+    for (int q = 0; q < BLK_MAX; q++) e_pre[q] = q < t ? XLD(((const double *)v.blkE)[(size_t)q * v.ld + j_pre]) : 0.0;
     const unsigned epoch = blk_epoch(batch, t);
     int r, enter, leave, g_cc = 0; uint32_t g_w = 0;
     unsigned long long piv_bits, cnv_bits;
@@ -242,8 +276,8 @@ __global__ __launch_bounds__(256) void k_blk_prep(LpView<F64> v, int batch, int 
         bool valid = false;
         if (lane < PICK_MAX_WGS) {
             const unsigned long long * rk = v.blkR + (size_t)lane * BLK_REC_WORDS;
-            w0 = rk[0]; w1 = rk[1]; w2 = rk[2]; w3 = rk[3]; w4 = rk[4]; w5 = rk[5];
-            valid = (unsigned)rk[6] == epoch;
+            w0 = XLD(rk[0]); w1 = XLD(rk[1]); w2 = XLD(rk[2]); w3 = XLD(rk[3]); w4 = XLD(rk[4]); w5 = XLD(rk[5]);
+            valid = (unsigned)XLD(rk[6]) == epoch;
         }
         const unsigned long long vmask = __ballot(valid);
         any_rec = vmask != 0;
@@ -265,28 +299,31 @@ __global__ __launch_bounds__(256) void k_blk_prep(LpView<F64> v, int batch, int 
             }
         }
     }
-    if (status != ST_RUNNING) return;
+    if (status != ST_RUNNING) return false;
     if (any_rec) {
         if (g.idx == INT_MAX) {                                // first pass empty: second pass / disableNV are generic
             if (gid == 0) {
                 st->blk.closed = 1;
                 if (t == 0) { st->blk.want_generic = 1; st->blk.batch = batch; st->blk.n = 0; }
             }
-            return;
+            return false;
         }
         r = g.idx; enter = cand_first; leave = g_b; piv_bits = to_bits(F64(g_a)); cnv_bits = g_cnv;
     } else if (t == 0 && bb == batch && from_generic && bn == 1) {
         generic_pivot = true;                                  // the generic pick chose pivot 0 of this batch
         r = srow; enter = scol; leave = sleave; piv_bits = spiv; cnv_bits = scnv;
     } else {
-        return;                                                // this batch's pick(t) did not run
+        return false;                                          // this batch's pick(t) did not run
     }
     const int n = t, W = v.W, rhs = v.rhs, ld = v.ld, m = v.m, lim = v.rhs - 1;
+    // what the committing thread needs of the pair table goes out with the pivot row (one round fewer on
+    // the thread every other workgroup ends up waiting for)
+    const int rc_enter = XLD(v.rowcnt[(unsigned)enter < (unsigned)rhs ? enter : 0]);
     double * __restrict__ K = (double *)v.blkK;
     double * __restrict__ E = (double *)v.blkE;
     double kq[BLK_MAX];                                        // k_q[r]: wave-uniform loads
 #pragma unroll
-    for (int q = 0; q < BLK_MAX; q++) kq[q] = q < n ? K[(size_t)r * BLK_MAX + q] : 0.0;
+    for (int q = 0; q < BLK_MAX; q++) kq[q] = q < n ? XLD(K[(size_t)r * BLK_MAX + q]) : 0.0;
     const F64 s = div(one<F64>(), from_bits<F64>(piv_bits));  // 1/(eq.get(eqnum, nv)), lpsol.h:1471
     const int smode = scale_mode(s);
     const F64 cnv = from_bits<F64>(cnv_bits);
@@ -297,18 +334,18 @@ __global__ __launch_bounds__(256) void k_blk_prep(LpView<F64> v, int batch, int 
     for (int j = gid; j < W; j += gsz) {
         const bool pre = j == j_pre;                           // this thread's first column: loaded with the state
         double x = ((const double *)v.tab)[(size_t)r * ld + j];
-        F64 oj = pre ? obj_pre : v.obj[j];
+        F64 oj = pre ? obj_pre : XLD(v.obj[j]);
         // the basis before and after this pivot's swap, without using the two entries the committing
         // thread rewrites (the generic pick has swapped already)
         const bool in = j < rhs;
-        const bool nv_mem = in && j != enter && j != leave && (pre ? nv_pre : (int)v.nv[j]) != 0;
+        const bool nv_mem = in && j != enter && j != leave && (pre ? nv_pre : (int)XLD(v.nv[j])) != 0;
         const bool nv_old = in && (j == enter ? true : (j == leave ? false : nv_mem));
         const bool nv_new = in && (j == enter ? false : (j == leave ? true : nv_mem));
-        const int rcj = (in && j != enter) ? (pre ? rc_pre : v.rowcnt[j]) : INT_MAX;
+        const int rcj = (in && j != enter) ? (pre ? rc_pre : XLD(v.rowcnt[j])) : INT_MAX;
 #pragma unroll
         for (int q = 0; q < BLK_MAX; q++) {                    // the pivot row as the pending sweeps would leave it
             if (q < n) {
-                const double e_q = pre ? e_pre[q] : E[(size_t)q * ld + j];
+                const double e_q = pre ? e_pre[q] : XLD(E[(size_t)q * ld + j]);
                 const double pr = kq[q] * e_q;
                 x = (r == rs[q]) ? e_q : (x + pr);
             }
@@ -338,7 +375,7 @@ __global__ __launch_bounds__(256) void k_blk_prep(LpView<F64> v, int batch, int 
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int k = 1; k < 4; k++) { nf = min(nf, sh_nf[k]); any |= sh_any[k]; key = sh_key[k] > key ? sh_key[k] : key; }
-        int * P = v.blkP + (size_t)blockIdx.x * BLK_PART_INTS;
+        int * P = v.blkP + (size_t)p * BLK_PART_INTS;
         P[0] = nf; P[1] = any; P[2] = (int)(unsigned)key; P[3] = (int)(unsigned)(key >> 32); P[4] = (int)epoch;
     }
     // -column from the generic pick's colbuf when it chose this pivot
@@ -347,14 +384,12 @@ __global__ __launch_bounds__(256) void k_blk_prep(LpView<F64> v, int batch, int 
     // ---- one thread commits the pivot
     if (gid == 0) {
         if (!generic_pivot) {
-            const int rc_enter = v.rowcnt[enter];
             if (!((g_w >> (leave & 31)) & 1u)) {               // genPair, lpsol.h:100-104
                 v.ppt[(size_t)enter * v.pw + (leave >> 5)] = g_w | (1u << (leave & 31));
                 v.rowcnt[enter] = rc_enter + 1; v.colcnt[leave] = g_cc + 1;
             }
             v.nv[enter] = 0; v.nv[leave] = 1; v.bv[enter] = 1; v.bv[leave] = 0;       // lpsol.h:1504-1510
             v.eq2bv[r] = enter; v.bv2eq[enter] = r; v.bv2eq[leave] = -1;
-            const unsigned tp = st->total_pivots;
             if ((int)tp < v.trace_cap) { v.trace[2 * tp] = enter; v.trace[2 * tp + 1] = leave; }
             st->total_pivots = tp + 1;
             st->done = done + 1;
@@ -366,6 +401,99 @@ __global__ __launch_bounds__(256) void k_blk_prep(LpView<F64> v, int batch, int 
         st->blk.la_from_state = 0;
         st->blk.la_epoch = epoch;
         st->row = -1;
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_blk_prep(LpView<F64> v, int batch, int t)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) { v.st->blk.bar = 0; v.st->blk.xcc_mask = 0; }   // for the chain kernel
+    (void)blk_prep_body<false>(v, batch, t, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// ---- the chain: pick(t), prep(t) for t = t0 .. B-1 in ONE launch -----------------------------------
+// The same two bodies, separated by grid barriers instead of launch boundaries. Every worker takes the
+// same decisions -- both bodies decide from the committed state, the records and the partials, all
+// published before the barrier -- so they leave the loop together. All nwork workers are resident at once
+// (nwork <= 256 CUs x 8 and the stream runs nothing else meanwhile). A barrier that does not complete
+// within ~0.5 s puts ST_CHAIN_STUCK (= XPG_ERR_HIP for the caller) into the loop status instead of hanging.
+//
+// Two barrier flavours, chosen at run time, identically by every worker:
+//  * SAFE, any placement: agent-scope release (one L2 write-back per workgroup) -> counter -> agent-scope
+//    acquire; what a cooperative grid sync is made of. Measured: a phase + barrier costs about what a
+//    launch costs (7.5 us), because the write-back and the invalidate are ~1.7 us each.
+//  * SAME-XCD: workers are the workgroups with blockIdx.x % spread == 0; with spread = 8 they are
+//    OBSERVED to land on one XCD (workgroups are dealt round-robin), and then they share one L2, which
+//    is the coherence point of an XCD: plain stores (write-through L1, line kept in the L2), every
+//    storing wave's s_waitcnt vmcnt(0), counter, and loads that bypass the reader's L1 (ldx<true>) need
+//    no write-back and no invalidate. Placement is NOT assumed: each worker reads HW_REG_XCC_ID, the ids
+//    are OR-ed into a mask across the first (SAFE) barrier, and only a one-bit mask switches to this
+//    flavour.
+enum { ST_CHAIN_STUCK = -1 };
+__device__ __forceinline__ bool chain_barrier(unsigned * ctr, unsigned target, int * sh_ok, bool same_xcd)
+{
+    if (same_xcd) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // every wave: its stores have reached the L2
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (same_xcd) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // one L2 write-back
+        unsigned spins = 0;
+        int ok = 1;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (++spins > (1u << 22)) { ok = 0; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        *sh_ok = ok;
+    }
+    __syncthreads();
+    if (!same_xcd) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_s_dcache_inv();
+    return *sh_ok != 0;
+}
+
+__global__ __launch_bounds__(256) void k_blk_chain(LpView<F64> v, int batch, int t0, int B, int npick, int nwork, int spread,
+                                                   int allow_same_xcd)
+{
+    __shared__ __attribute__((aligned(8))) unsigned char sh_c_raw[16 * sizeof(Cand<F64>)];
+    __shared__ int sh_ok, sh_same;
+    if ((int)blockIdx.x % spread != 0) return;
+    const int p = (int)blockIdx.x / spread;
+    if (p >= nwork) return;
+    LoopState * st = v.st;
+    unsigned * ctr = &st->blk.bar;
+    unsigned target = 0;
+    bool same_xcd = false, asked = false;
+    if (threadIdx.x == 0) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u;       // HW_REG_XCC_ID[3:0]
+        __hip_atomic_fetch_or(&st->blk.xcc_mask, 1u << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const bool stamp = (allow_same_xcd & 2) != 0 && p == 0 && threadIdx.x == 0;   // XPG_CHAIN_DEBUG
+    unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 0, dn = 0;
+#pragma unroll 1
+    for (int t = t0; t < B; t++) {
+        if (stamp) { if (c0) { d3 += wall_clock64() - c3; } c0 = wall_clock64(); }
+        if (!blk_pick_body<true>(v, batch, t, nwork, p, npick, (Cand<F64> *)sh_c_raw)) break;
+        if (stamp) { c1 = wall_clock64(); d0 += c1 - c0; }
+        target += (unsigned)nwork;
+        if (!chain_barrier(ctr, target, &sh_ok, same_xcd)) { if (threadIdx.x == 0) st->status = ST_CHAIN_STUCK; break; }
+        if (stamp) { c2 = wall_clock64(); d1 += c2 - c1; }
+        if (!asked) {                                           // every worker's id is in the mask now
+            asked = true;
+            if (threadIdx.x == 0) {
+                const unsigned mask = __hip_atomic_load(&st->blk.xcc_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sh_same = (allow_same_xcd & 1) && mask != 0 && (mask & (mask - 1)) == 0;
+            }
+            __syncthreads();
+            same_xcd = sh_same != 0;
+        }
+        if (!blk_prep_body<true>(v, batch, t, p, nwork)) break;
+        if (stamp) { c3 = wall_clock64(); d2 += c3 - c2; dn++; }
+        target += (unsigned)nwork;
+        if (!chain_barrier(ctr, target, &sh_ok, same_xcd)) { if (threadIdx.x == 0) st->status = ST_CHAIN_STUCK; break; }
+    }
+    if (stamp) {
+        st->blk.dbg[0] += d0; st->blk.dbg[1] += d1; st->blk.dbg[2] += d2; st->blk.dbg[3] += d3; st->blk.dbg[4] += dn;
     }
 }
 

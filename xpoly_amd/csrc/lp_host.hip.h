@@ -25,6 +25,9 @@ struct xpg_ctx {
     int zigzag;             // pipelined sweep alternates its tile order (Infinity Cache reuse)
     int block_len;          // blocked loop (loop_mode 3): pivots staged per sweep, 1..16
     int loop_auto;          // XPG_LOOP unset: blocked loop where the sweep is what costs (large fp64 tableaux)
+    int chain;              // blocked loop: pick/prep of stages 1..B-1 in one launch (k_blk_chain)
+    int chain_spread;       // the chain's workers are the workgroups with blockIdx.x % spread == 0
+    int chain_same_xcd;     // allow the same-XCD barrier flavour where the workers verify they share an XCD
     // xpg_profile_begin/end: event pairs around each sweep launch
     std::vector<hipEvent_t> ev0, ev1;
     int prof_cap, prof_n, prof_stride, prof_seen;
@@ -115,6 +118,12 @@ template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> &
     const int npick = strips < PICK_MAX_WGS ? strips : PICK_MAX_WGS;
     const dim3 gprep((v.W + 255) / 256);
     for (int t = 0; t < B; t++) {
+        if (t == 1 && ctx->chain) {                     // stages 1 .. B-1 in one launch
+            hipLaunchKernelGGL(k_blk_chain, dim3(gprep.x * ctx->chain_spread), dim3(256), 0, ctx->stream, v, batch, 1, B,
+                               npick, (int)gprep.x, ctx->chain_spread,
+                               (ctx->chain_same_xcd ? 1 : 0) | (getenv("XPG_CHAIN_DEBUG") ? 2 : 0));
+            break;
+        }
         hipLaunchKernelGGL(k_blk_pick, dim3(npick), dim3(256), 0, ctx->stream, v, batch, t, (int)gprep.x);
         if (t == 0) hipLaunchKernelGGL(k_blk_pick_generic, dim3(1), dim3(1024), 0, ctx->stream, v, batch, (int)gprep.x);
         hipLaunchKernelGGL(k_blk_prep, gprep, dim3(256), 0, ctx->stream, v, batch, t);
@@ -387,6 +396,12 @@ template <class S> struct Lp : LpBase {
         LoopState hs;
         int rc = read_state(&hs);
         if (rc) return rc;
+        if (ctx->chain && getenv("XPG_CHAIN_DEBUG"))
+            fprintf(stderr, "xpoly_amd: chain kernel: XCD mask of the last batch's workers 0x%x; worker 0 per stage: "
+                    "pick %.2f us, barrier %.2f, prep %.2f, barrier %.2f (%llu stages)\n", hs.blk.xcc_mask,
+                    hs.blk.dbg[0] * 0.01 / (double)(hs.blk.dbg[4] ? hs.blk.dbg[4] : 1), hs.blk.dbg[1] * 0.01 / (double)(hs.blk.dbg[4] ? hs.blk.dbg[4] : 1),
+                    hs.blk.dbg[2] * 0.01 / (double)(hs.blk.dbg[4] ? hs.blk.dbg[4] : 1), hs.blk.dbg[3] * 0.01 / (double)(hs.blk.dbg[4] ? hs.blk.dbg[4] : 1),
+                    (unsigned long long)hs.blk.dbg[4]);
         if (hs.status == ST_RUNNING) return XPG_RUNNING;
         final_status = finish(hs.status);
         return final_status;

@@ -53,6 +53,15 @@ int xpg_create(xpg_ctx ** out, int device)
     c->loop_mode = (lm && lm[0] == 's' && lm[1] == 'e') ? 1 : ((lm && lm[0] == 's' && lm[1] == 'p') ? 2 : 0);
     if (lm && lm[0] == 'b') c->loop_mode = 3;          // "block": B pivots per sweep (lp_blocked.hip.h)
     if (lm && lm[0] == 'p') c->loop_mode = 0;          // "pipe": always the pipelined loop
+    // "chain": the blocked loop with pick(1..B-1) / prep(1..B-1) of a batch in one launch (grid barriers)
+    const char * ch = getenv("XPG_CHAIN");
+    c->chain = ch ? atoi(ch) : 0;
+    if (lm && lm[0] == 'c') { c->loop_mode = 3; c->chain = 1; }
+    const char * sp = getenv("XPG_CHAIN_SPREAD");
+    c->chain_spread = sp ? atoi(sp) : 8;
+    if (c->chain_spread < 1) c->chain_spread = 1;
+    const char * sx = getenv("XPG_CHAIN_SAME_XCD");
+    c->chain_same_xcd = sx ? atoi(sx) : 1;
     c->loop_auto = lm ? 0 : 1;                         // unset: blocked loop for large fp64 tableaux, else pipelined
     const char * bl = getenv("XPG_BLOCK");
     c->block_len = bl ? atoi(bl) : 16;
