@@ -180,8 +180,9 @@ def main():
     ctx.profile_end()
     run_pivots(a.warmup)
     barrier()
-    stride = max(1, a.steps // 1024)          # sampled sweep launches spread over the region (a blocked
-                                              # sweep applies up to 16 pivots, so there are ~steps/16 of them)
+    stride = max(1, a.steps // 320)           # sampled sweep launches spread over the region (a blocked
+                                              # sweep applies up to 16 pivots, so there are ~steps/16 of them:
+                                              # about 20 event pairs per 1000 steps)
     ctx.profile_begin(0 if a.no_events else a.steps, stride)
     start_count = lp.pivots_done()
     t0 = time.perf_counter()

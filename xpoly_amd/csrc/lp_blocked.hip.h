@@ -111,7 +111,8 @@ __device__ __forceinline__ bool blk_pick_body(const LpView<F64> & v, int batch, 
     // in the same round as the state: the look-ahead partials, and what this thread's first row needs
     // that does not depend on the entering column
     const BlkLook look = blk_lookahead<XW>(v, la_epoch, nparts);
-    const int i_pre = p * 256 + tid;
+    const int tpb = (int)blockDim.x;                    // 64 (one wave, no LDS round in the reduction) or 256
+    const int i_pre = p * tpb + tid;
     const int i_clamped = i_pre < v.m ? i_pre : 0;
     const int bi_pre = XLD(v.eq2bv[i_clamped]);
     double k_pre[BLK_MAX];
@@ -147,7 +148,7 @@ __device__ __forceinline__ bool blk_pick_body(const LpView<F64> & v, int batch, 
     // replayed constant column, first pass of the ratio test
     Cand<F64> best; best.q = zero<F64>(); best.idx = INT_MAX;
     double best_a = 0.0; int best_b = 0, best_cc = 0; uint32_t best_w = 0;
-    for (int i = p * 256 + tid; i < m; i += 256 * N) {
+    for (int i = p * tpb + tid; i < m; i += tpb * N) {
         // eq2bv and the blkK row of this thread's first row were loaded with the state (they do not depend
         // on the entering column): everything that does goes out in ONE further round
         const bool pre = i == i_pre;
@@ -252,7 +253,7 @@ __device__ __forceinline__ bool blk_prep_body(const LpView<F64> & v, int batch, 
     int rs[BLK_MAX];
 #pragma unroll
     for (int s = 0; s < BLK_MAX; s++) rs[s] = XLD(st->blk.r[s]);
-    const int gid = p * 256 + (int)threadIdx.x, gsz = nwork * 256;
+    const int gid = p * (int)blockDim.x + (int)threadIdx.x, gsz = nwork * (int)blockDim.x;
     // in the same round as the state and the records: everything of this thread's first column that does
     // not depend on the pivot row
     const int j_pre = gid < v.W ? gid : 0;
@@ -274,7 +275,7 @@ __device__ __forceinline__ bool blk_prep_body(const LpView<F64> & v, int batch, 
         const int lane = threadIdx.x & 63;
         unsigned long long w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0, w5 = 0;
         bool valid = false;
-        if (lane < PICK_MAX_WGS) {
+        if (lane < BLK_PICK_WGS) {
             const unsigned long long * rk = v.blkR + (size_t)lane * BLK_REC_WORDS;
             w0 = XLD(rk[0]); w1 = XLD(rk[1]); w2 = XLD(rk[2]); w3 = XLD(rk[3]); w4 = XLD(rk[4]); w5 = XLD(rk[5]);
             valid = (unsigned)XLD(rk[6]) == epoch;
@@ -284,7 +285,7 @@ __device__ __forceinline__ bool blk_prep_body(const LpView<F64> & v, int batch, 
         if (any_rec) {
             Cand<F64> c; c.q = from_bits<F64>(w0); c.idx = valid ? (int)(unsigned)(w2 >> 32) : INT_MAX;
             g = c;
-            for (int o = 8; o > 0; o >>= 1) {
+            for (int o = BLK_PICK_WGS / 2; o > 0; o >>= 1) {
                 Cand<F64> tq; tq.q = shfl_xor_s(g.q, o); tq.idx = __shfl_xor(g.idx, o);
                 g = better(g, tq);
             }
@@ -374,7 +375,7 @@ __device__ __forceinline__ bool blk_prep_body(const LpView<F64> & v, int batch, 
     if ((threadIdx.x & 63) == 0) { sh_nf[threadIdx.x >> 6] = nf; sh_any[threadIdx.x >> 6] = any; sh_key[threadIdx.x >> 6] = key; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int k = 1; k < 4; k++) { nf = min(nf, sh_nf[k]); any |= sh_any[k]; key = sh_key[k] > key ? sh_key[k] : key; }
+        for (int k = 1; k < (int)(blockDim.x >> 6); k++) { nf = min(nf, sh_nf[k]); any |= sh_any[k]; key = sh_key[k] > key ? sh_key[k] : key; }
         int * P = v.blkP + (size_t)p * BLK_PART_INTS;
         P[0] = nf; P[1] = any; P[2] = (int)(unsigned)key; P[3] = (int)(unsigned)(key >> 32); P[4] = (int)epoch;
     }
@@ -414,8 +415,10 @@ __global__ __launch_bounds__(256) void k_blk_prep(LpView<F64> v, int batch, int 
 // ---- the chain: pick(t), prep(t) for t = t0 .. B-1 in ONE launch -----------------------------------
 // The same two bodies, separated by grid barriers instead of launch boundaries. Every worker takes the
 // same decisions -- both bodies decide from the committed state, the records and the partials, all
-// published before the barrier -- so they leave the loop together. All nwork workers are resident at once
-// (nwork <= 256 CUs x 8 and the stream runs nothing else meanwhile). A barrier that does not complete
+// published before the barrier -- so they leave the loop together. The workers spin on each other, so all
+// must be resident at once: the host only takes this path while there is a CU per worker among the CUs
+// they can land on (nwork <= CUs / spread; the stream runs nothing else meanwhile) -- a wider tableau
+// (seen: 80 workers, 20 000 columns) takes the launch-per-stage path. A barrier that does not complete
 // within ~0.5 s puts ST_CHAIN_STUCK (= XPG_ERR_HIP for the caller) into the loop status instead of hanging.
 //
 // Two barrier flavours, chosen at run time, identically by every worker:

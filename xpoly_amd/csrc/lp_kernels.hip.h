@@ -83,7 +83,9 @@ struct LoopState {
         unsigned long long dbg[5];   // XPG_CHAIN_DEBUG: 100 MHz ticks worker 0 spent in pick / barrier / prep / barrier, and phases
     } blk;
 };
-enum { BLK_MAX = 16, BLK_REC_WORDS = 8, BLK_PART_INTS = 8 };
+enum { BLK_MAX = 16, BLK_REC_WORDS = 8, BLK_PART_INTS = 8,
+       BLK_PICK_WGS = 64,      // pick workgroups (= records) at most: one lane of a wave combines each
+       BLK_TPB_MIN = 64 };     // smallest workgroup of pick / prep: sizes the partial array
 enum { NF_UNKNOWN = -2 };
 typedef LoopState::PipeDesc PipeDesc;
 // LpView::pickrec layout (8-byte words): PICK_MAX_WGS records of PICK_REC_WORDS, then one arrival
@@ -1019,8 +1021,8 @@ template <class S> __global__ void k_reset_loop(LpView<S> v, unsigned max_iter, 
         st->blk.budget = 0xFFFFFFFFu; st->blk.price_key = 0ull;
         st->blk.want_generic = 0; st->blk.la_from_state = 1; st->blk.la_epoch = 0u; st->blk.bar = 0u; st->blk.xcc_mask = 0u;
         for (int k = 0; k < 5; k++) st->blk.dbg[k] = 0ull;
-        for (int k = 0; k < PICK_MAX_WGS; k++) v.blkR[(size_t)k * BLK_REC_WORDS + 6] = 0ull;       // record epochs
-        for (int k = 0; k < (v.ld + 255) / 256 + 1; k++) v.blkP[(size_t)k * BLK_PART_INTS + 4] = 0;  // partial epochs
+        for (int k = 0; k < BLK_PICK_WGS; k++) v.blkR[(size_t)k * BLK_REC_WORDS + 6] = 0ull;       // record epochs
+        for (int k = 0; k < (v.ld + BLK_TPB_MIN - 1) / BLK_TPB_MIN + 1; k++) v.blkP[(size_t)k * BLK_PART_INTS + 4] = 0;  // partial epochs
         for (int k = 0; k < 2; k++) v.pickrec[PICK_CTR_OFF + 16 * k] = 0ull;   // arrival counters
         for (int k = 0; k < 2; k++) {                  // pipelined loop: iteration 0 has no pivot yet
             PipeDesc & D = st->pd[k];

@@ -62,6 +62,8 @@ int xpg_create(xpg_ctx ** out, int device)
     if (c->chain_spread < 1) c->chain_spread = 1;
     const char * sx = getenv("XPG_CHAIN_SAME_XCD");
     c->chain_same_xcd = sx ? atoi(sx) : 1;
+    c->num_cus = 0;
+    if (hipDeviceGetAttribute(&c->num_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) c->num_cus = 0;
     c->loop_auto = lm ? 0 : 1;                         // unset: blocked loop for large fp64 tableaux, else pipelined
     const char * bl = getenv("XPG_BLOCK");
     c->block_len = bl ? atoi(bl) : 16;
