@@ -161,6 +161,32 @@ def test_full_size_loops_against_each_other_and_oracle(port, monkeypatch):
     assert np.array_equal(a["eq2bv"], want["eq2bv"])
 
 
+def test_midsize_whole_solve_every_loop(port, monkeypatch):
+    """A 300 x 300 fp64 LP solved to its (bug-compatible) end: 214 796 pivots with thousands of closed
+    batches and generic picks, many workgroups per launch. This is the case that exposed a state race
+    in the blocked loop (a flag cleared by one workgroup while the others of the same launch still read
+    it -- invisible in the 2000-pivot large-tableau check and in the small-LP checks): blocked, chain
+    and pipelined loops must end in the same status after the same number of pivots with the same
+    tableau, and that is the oracle's."""
+    import xpoly_amd
+    leq, tg = gen.hard_lp_f64(300, 300)
+    got = {}
+    for mode in ("pipe", "block", "chain"):
+        monkeypatch.setenv("XPG_LOOP", mode)
+        c = xpoly_amd.Context(0)
+        lp = xpoly_amd.DeviceLP(c, F64, leq, tg)
+        st = lp.two_stage()
+        got[mode] = (st, lp.pivots_done(), lp.read())
+        lp.close(); c.close()
+    want = port.two_stage(F64, leq, tg, 0xFFFFFFFF)
+    for mode, (st, piv, out) in got.items():
+        assert st == want["status"] and piv == got["pipe"][1], (mode, st, piv)
+        if want["status"] != 2:
+            assert np.array_equal(out["tab"].view(np.uint64), want["tab"].view(np.uint64)), mode
+            assert np.array_equal(out["tgtf"].view(np.uint64), want["tgtf"].view(np.uint64)), mode
+            assert np.array_equal(out["eq2bv"], want["eq2bv"]), mode
+
+
 @pytest.mark.parametrize("B,loop,same_xcd", [(1, "block", 1), (3, "block", 1), (16, "block", 1),
                                               (16, "chain", 1), (5, "chain", 0)])
 def test_blocked_loop_small_and_rare_branches(ctx, port, B, loop, same_xcd, monkeypatch):

@@ -128,7 +128,8 @@ __device__ __forceinline__ bool blk_pick_body(const LpView<F64> & v, int batch, 
         // nothing staged: the generic pick (next launch) decides; else close the batch and sweep first
         if (p == 0 && tid == 0) {
             if (bb != batch) { st->blk.batch = batch; st->blk.n = 0; st->blk.closed = 0; st->blk.from_generic = 0; st->blk.generic = 0; }
-            if (n == 0) { st->blk.generic = 1; st->blk.want_generic = 0; }
+            // (want_generic is read by every workgroup of this launch: the generic pick clears it, not this thread)
+            if (n == 0) st->blk.generic = 1;
             else st->blk.closed = 1;
         }
         return false;
@@ -205,6 +206,10 @@ __global__ __launch_bounds__(1024) void k_blk_pick_generic(LpView<F64> v, int ba
     __shared__ int sh_la[2];
     LoopState * st = v.st;
     if (st->status != ST_RUNNING) return;
+    // Housekeeping that must not happen inside a multi-workgroup launch whose other workgroups read the
+    // fields: an earlier batch's "chosen by the generic pick" mark (prep(0) of that batch read it in
+    // every workgroup, so its committing thread could not clear it).
+    if (threadIdx.x == 0 && st->blk.from_generic && st->blk.batch != batch) { st->blk.from_generic = 0; st->row = -1; }
     if (!(st->blk.batch == batch && st->blk.generic && st->blk.n == 0)) return;
     const unsigned budget = st->blk.budget;
     if (budget == 0) return;
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(1024) void k_blk_pick_generic(LpView<F64> v, int ba
     // the tableau is fully swept (nothing staged): every column comes from it. Whatever look-ahead
     // pick_body leaves (re-pricing after disableNV, ...) goes to next_first / anypos.
     if (threadIdx.x == 0) {
-        st->blk.generic = 0; st->row = -1; st->blk.la_from_state = 1;
+        st->blk.generic = 0; st->blk.want_generic = 0; st->row = -1; st->blk.la_from_state = 1;
         st->next_first = first; st->anypos = anypos;
     }
     __syncthreads();
@@ -398,10 +403,10 @@ __device__ __forceinline__ bool blk_prep_body(const LpView<F64> & v, int batch, 
             if (bb != batch) { st->blk.batch = batch; st->blk.closed = 0; st->blk.generic = 0; }
             st->blk.r[n] = r; st->blk.n = n + 1;
         }
-        st->blk.from_generic = 0;
+        // (from_generic and row are read by every workgroup of this launch in the generic case: they are
+        // left alone here and cleared by the next batch's generic-pick launch, a single workgroup)
         st->blk.la_from_state = 0;
         st->blk.la_epoch = epoch;
-        st->row = -1;
     }
     return true;
 }
