@@ -15,11 +15,11 @@
 //
 // Per batch (host-enqueued, no host round trip), t = 0 .. B-1:
 //   k_blk_pick(t)        runs iff exactly t pivots are staged: first pass of the ratio test
-//                        (lpsol.h:553-663) on the replayed entering and constant columns by <= 16
+//                        (lpsol.h:553-663) on the replayed entering and constant columns by <= 64 one-wave
 //                        workgroups; each stages its rows of k_t = -column and leaves ONE record (its
 //                        best row) tagged with (batch, t). No atomics, no last-adder: the launch
 //                        boundary orders the records for ...
-//   k_blk_prep(t)        ... whose every workgroup combines the <= 16 records (lowest row wins ties,
+//   k_blk_prep(t)        ... whose every workgroup combines the <= 64 records (lowest row wins ties,
 //                        lpsol.h:604-611), replays the pivot row -> scaled row e_t, updates the
 //                        objective row (with the zeroing of lpsol.h:1055-1060) and leaves its look-ahead
 //                        pricing partial (lowest eligible column / Dantzig key) for the next pick; one
@@ -31,7 +31,11 @@
 //   k_blk_sweep          applies the staged pivots
 // Control state is only ever written by one thread of a kernel whose other workgroups do not read what
 // it writes (they decide from the records / partials of the previous launch), so there is no
-// intra-launch hand-off anywhere. A pick that cannot take the fast path while pivots are staged closes
+// intra-launch hand-off anywhere. (Two fields once broke that rule -- want_generic, cleared by the
+// pick's thread 0 and read by every pick workgroup; from_generic / row, cleared by prep's committing
+// thread and read by every prep workgroup -- and a late workgroup then took a different branch from
+// the others; both are now cleared by the single-workgroup generic-pick launch.) A pick that cannot
+// take the fast path while pivots are staged closes
 // the batch: the remaining launches of the batch do nothing, the sweep applies what is staged and the
 // next batch starts with pick(0) + generic on a swept tableau.
 #pragma once
@@ -89,7 +93,7 @@ __device__ __forceinline__ BlkLook blk_lookahead(const LpView<F64> & v, unsigned
     return L;
 }
 
-// ---- pick(t): first ratio-test pass by up to PICK_MAX_WGS workgroups of 256 threads --------------
+// ---- pick(t): first ratio-test pass by up to BLK_PICK_WGS workgroups (one wave each by default) ----
 // p of N: this workgroup's share of the rows (p >= N: no rows -- a prep-only worker of the chain kernel,
 // which still needs the decision). Returns whether the fast path ran; the answer is the same in every
 // workgroup, because it depends on the committed state and the look-ahead partials only.
@@ -272,7 +276,7 @@ __device__ __forceinline__ bool blk_prep_body(const LpView<F64> & v, int batch, 
     unsigned long long piv_bits, cnv_bits;
     bool generic_pivot = false;
     // the fast pick's records, if it ran: every wave combines them the same way -- lane l loads record l
-    // (one round of loads), a 16-lane butterfly picks the best row, the winner's payload comes by shuffle
+    // (one round of loads), a 64-lane butterfly picks the best row, the winner's payload comes by shuffle
     Cand<F64> g; g.q = zero<F64>(); g.idx = INT_MAX;
     double g_a = 0.0; int g_b = 0, cand_first = -1; unsigned long long g_cnv = 0;
     bool any_rec = false;
