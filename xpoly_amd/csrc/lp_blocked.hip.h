@@ -602,6 +602,13 @@ void k_blk_sweep_full(double * __restrict__ tab, int m, int W, int ld, const dou
     const int j = blockIdx.x * 512 + threadIdx.x * 2;
     const int i0 = blockIdx.y * ROWS;
     const int iend = min(i0 + ROWS, m);
+    // the first row group goes out before anything else: it comes from HBM, the state and E from the L2
+    const bool full = i0 + ROWS <= m && j + 1 < W;
+    double2 a[U], b[U];
+    if (full) {
+#pragma unroll
+        for (int u = 0; u < U; u++) a[u] = *reinterpret_cast<const double2 *>(tab + (size_t)(i0 + u) * ld + j);
+    }
     const int status = st->status;
     const int n = (st->blk.batch == batch) ? st->blk.n : 0;
     if (status != ST_RUNNING || n == 0 || j >= W) return;
@@ -649,9 +656,7 @@ void k_blk_sweep_full(double * __restrict__ tab, int m, int W, int ld, const dou
         for (int u = 0; u < U; u++) *reinterpret_cast<double2 *>(p + (size_t)u * ld) = d[u];
     };
     double * base = tab + (size_t)i0 * ld + j;
-    if (i0 + ROWS <= m) {
-        double2 a[U], b[U];
-        load(a, base);
+    if (full) {
 #pragma unroll 1
         for (int i = i0; i < i0 + ROWS; i += 2 * U) {
             load(b, base + (size_t)U * ld);
