@@ -588,7 +588,8 @@ void blk_sweep_body(double * __restrict__ tab, int m, int W, int ld, const doubl
 //  * stages outermost, the U rows in lockstep: 2U independent add chains; every cell still sees its
 //    stages in order, so the bits are those of the row-by-row form;
 //  * 16-row blocks: 4096 workgroups keep the tail of the launch short (32- and 64-row blocks were
-//    slower although they re-read E less often);
+//    slower although they re-read E less often); the first row group is requested before the state
+//    and E are (it comes from HBM, they come from the L2);
 //  * no "row r := e" selects and no row list in the loop: the stream treats the staged pivot rows like
 //    any other row (what it leaves there is meaningless) and the workgroup that owns them rewrites
 //    them once its stream is through -- their final contents depend on E and K only (e_s, then stages
