@@ -1,20 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py -- simplex pivots/sec on a fp64 4096 x 8192 tableau (BASELINE.json's metric),
-plus batched small-LP throughput, on N MI355X GPUs of one node.
+"""bench.py -- simplex pivots/sec on a fp64 4096 x 8192 tableau (BASELINE.json's metric), batched
+small-LP throughput sharded over the GPUs of one node, and one leg per remaining BASELINE config.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is ONE simplex pivot of the device-resident loop -- pricing, ratio test,
-pivot-pair upkeep, row/column staging and the rank-1 tableau update
-(src/com/lpsol.h:1039-1188) -- on a dense LP with m = 4096 constraints and
-n = 4095 variables, whose slack tableau is exactly 4096 x 8192 fp64 (268 MB,
-resident in HBM before the timed region). A single tableau does not shard
-("replicas only"): with N ranks every rank runs its own replica and
-`value` is the sum. The batched leg (BASELINE.json configs[2]: independent 32 x 64
-LPs, the dependence-test shape, 8192 per GPU = 65 536 on 8 GPUs) shards contiguously
-(xpoly_amd/shard.py) with no data-path collective and ONE all_gather of the result
-records at the end, inside its timed region; it is reported under "batched".
+With N > 1 and no RANK in the environment bench.py starts its own N ranks (torch.distributed.run on
+127.0.0.1, one rank per GPU, backend nccl = RCCL) BEFORE anything touches a GPU and relays rank 0's
+JSON line; launched under torch.distributed.run by somebody else it just is a rank.
+
+Leg 1 (the headline, `value`): a STEP is one run of the device-resident SIX::solveSlackForm loop
+(src/com/lpsol.h:1039-1188: pricing, ratio test, pivot-pair upkeep, row / column staging, rank-1
+tableau update) over PIVOTS_PER_STEP = 3840 pivots = 240 full batches of 16 on a dense LP with
+m = 4096, n = 4095, whose slack tableau is exactly 4096 x 8192 fp64 (268 MB, resident in HBM before
+the timed region): xpg_lp_begin rebuilds the slack form on the device from the resident input
+(one kernel, inside the step) and xpg_lp_iterate(3840) runs the loop; the LP's bug-compatible end
+comes after 4165 pivots, so a step never meets it. A single tableau does not shard ("replicas
+only"): every rank runs its own replica and `value` is the sum.
+
+Leg 2 (BASELINE configs[2]): independent 32 x 64 LPs, 8192 per GPU (65 536 on 8), contiguous shards
+(xpoly_amd/shard.py), no data-path collective, ONE all_gather of the result records inside the
+timed region. Legs 3-5 run at N = 1 only (or shard like leg 2 where the problems are independent):
+cfg 2b (LP m=4096, n=8192: tableau 4096 x 12289), cfg 4 (exact rational simplex, tableau
+1024 x 2048, K = 16), cfg 5 (0-1 MIP branch and bound, node LPs as GPU batches).
 
 One JSON line is printed by rank 0.
 """
@@ -22,6 +29,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,16 +41,30 @@ sys.path.insert(0, ROOT)
 
 M, NVARS = 4096, 4095                      # tableau 4096 x (4095 + 4096 + 1) = 4096 x 8192
 TAB_W = NVARS + M + 1
-ALG_BYTES_PER_PIVOT = 2 * M * TAB_W * 8    # every entry read once and written once
+BLOCK = 16                                 # pivots one blocked sweep applies (XPG_BLOCK default)
+PIVOTS_PER_STEP = 3840                     # 240 full batches; the LP ends after 4165 (tools/probe_count.py)
+ALG_BYTES_PER_LAUNCH = 2 * M * TAB_W * 8   # one sweep LAUNCH reads and writes every entry once (SURVEY 8d:
+                                           # 2*m*W*8 B; the blocked loop pays it per 16 pivots, not per pivot)
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 BATCH_PER_GPU = 8192                       # 65 536 LPs over 8 GPUs (BASELINE.json configs[2])
 BATCH_M, BATCH_COLS = 32, 64
-PREWARM = 256                              # untimed set-up iterations before the warmup
 PREWARM_SECONDS = 0.5
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "round1_pmc_hbm_traffic.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "round2_pmc_hbm_traffic.json")
+LEGS = ("pivots", "batched", "cfg2b", "rational", "mip")
 
 
-def cpu_baseline_pivots(budget_s=12.0):
+# ---------------------------------------------------------------------------------------------------
+# CPU baselines (rank 0, N = 1 only): the oracle (kind "port") and, when it travelled, the real
+# reference build (kind "reference"). Test infrastructure used as the thing timed BESIDE the GPU.
+# ---------------------------------------------------------------------------------------------------
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline_pivots(budget_s=10.0):
     """The oracle's K1 (oracle/oracle.cpp orc_pivot_f64) on a 4096 x 8192 tableau, 1 core."""
     from oracle.checker import Port
     from tools import gen
@@ -81,59 +104,105 @@ def cpu_reference_pivots(leq, tgtf):
                        "(t[K=3]-t[K=1])/2 = %.3f s/pivot; set-up %.1f s per call" % (per, ts[1] - per))
 
 
-def cpu_baseline_batch(leq, tgtf, budget_s=6.0):
-    from oracle.checker import Port
-    from tools import gen
-    port = Port()
-    vc = gen.vc_nonneg(BATCH_COLS - 1)
-    n, t0 = 0, time.perf_counter()
-    while n < len(leq):
-        port.six_solve(0, True, tgtf[n], vc, None, leq[n])
-        n += 1
-        if time.perf_counter() - t0 > budget_s and n >= 8:
-            break
+def cpu_per_core(fn_one, n_items, budget_s, what):
+    """One worker thread per host core (ctypes releases the GIL inside the oracle), each solving a
+    disjoint slice of the items for about budget_s. Returns items/s over all cores."""
+    import threading
+    cores = host_cores()
+    counts = [0] * cores
+    t_end = time.perf_counter() + budget_s
+
+    def work(w):
+        i = w
+        while i < n_items and time.perf_counter() < t_end:
+            fn_one(i)
+            counts[w] += 1
+            i += cores
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(w,)) for w in range(cores)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
     dt = time.perf_counter() - t0
-    return dict(value=round(n / dt, 2), unit="LPs/s", cores=1, kind="port",
-                sample="%d LPs (32x64, SIX::maxm) through the oracle, 1 thread, %.1f s" % (n, dt))
+    n = sum(counts)
+    return dict(value=round(n / dt, 2), cores=cores, kind="port",
+                sample="%d %s through the oracle, one thread per host core (%d), %.1f s" % (n, what, cores, dt))
+
+
+# ---------------------------------------------------------------------------------------------------
+def spawn_ranks(a, argv):
+    """--gpus N without a launcher: start N ranks of this script, before any GPU call, and exit with
+    the launcher's code. A rank that cannot get its GPU fails loudly (XPG_ERR_NO_DEVICE) and the whole
+    run exits non-zero -- never a silent 1-rank run."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--legs", default=",".join(LEGS), help="comma-separated subset of " + ",".join(LEGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ref-baseline", action="store_true",
                     help="skip timing the real reference build (oracle/_ref, ~1 s on the GPU box's host)")
-    ap.add_argument("--no-batched", action="store_true")
-    ap.add_argument("--no-events", action="store_true", help="do not bracket sweep launches with HIP events")
+    ap.add_argument("--no-events", action="store_true", help="do not attach HIP events to sweep launches")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="gloo + --stub-solver: the rank-spawn / shard / gather path without GPUs (tests)")
+    ap.add_argument("--stub-solver", action="store_true",
+                    help="ranks fabricate their shard's records instead of solving (CPU test of the N > 1 path)")
     a = ap.parse_args()
+    legs = set(x for x in a.legs.split(",") if x)
+    assert legs <= set(LEGS), "unknown leg in --legs"
 
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(a, sys.argv[1:]))          # nothing has touched a GPU yet
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+
     import torch
+    from xpoly_amd.shard import gather_records, pack_records, shard_range
+    stub = a.stub_solver
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", local if world > 1 else 0)
+        if stub:
+            dist.init_process_group(backend=a.backend)
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend=a.backend, device_id=torch.device("cuda", local))
+    dev = torch.device("cpu") if stub else torch.device("cuda", local if world > 1 else 0)
+    if not stub:
+        torch.cuda.set_device(dev)
 
-    import xpoly_amd
-    from tools import gen
-    from xpoly_amd.shard import gather_records, pack_records, shard_range
-    RUNNING = xpoly_amd.six.XPG_RUNNING
-    ctx = xpoly_amd.Context(dev.index)
+    ctx = None
+    if not stub:
+        import xpoly_amd
+        from tools import gen
+        RUNNING = xpoly_amd.six.XPG_RUNNING
+        ctx = xpoly_amd.Context(dev.index)              # XPG_ERR_NO_DEVICE -> exception -> non-zero exit
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
-        ctx.sync()
+        if not stub:
+            torch.cuda.synchronize()
+            ctx.sync()
 
     def max_over_ranks(x):
         if dist is None:
@@ -142,115 +211,150 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    # ---- leg 1: pivots/s on the 4096 x 8192 tableau (one replica per rank) -------------------
-    leq, tgtf = gen.hard_lp_f64(M, NVARS)      # the same LP on every rank (identical replicas)
-    lp = xpoly_amd.DeviceLP(ctx, xpoly_amd.F64, leq, tgtf)
-    lp.begin()
-    state = dict(since_begin=0, restarts=0)
-    LP_LIFE = 3800      # this LP reaches its (bug-compatible) end after 4165 pivots (tools/probe_count.py)
+    def sum_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t)
+        return float(t.item())
 
-    def run_pivots(n):
-        """Exactly n pivots of the device loop. Before the LP would reach its end the slack tableau
-        is rebuilt on the device from the resident input (one 90 us kernel, inside the timed
-        region when it happens there) and the loop continues, so every queued launch does work."""
-        left = n
-        while left > 0:
-            if state["since_begin"] >= LP_LIFE:
-                lp.begin()
-                state["since_begin"] = 0
-                state["restarts"] += 1
-            chunk = min(left, LP_LIFE - state["since_begin"])
-            st = lp.iterate(chunk)
+    out = {"metric": "simplex pivots/sec (float tableau 4kx8k)", "value": None, "unit": "pivots/s",
+           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": None,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
+    if stub:
+        out["stub_solver"] = True
+    cpu = None
+
+    # ---- leg 1: pivots/s on the 4096 x 8192 tableau (one replica per rank) -------------------------
+    leq = tgtf = None
+    if "pivots" in legs and not stub:
+        leq, tgtf = gen.hard_lp_f64(M, NVARS)          # the same LP on every rank (identical replicas)
+        lp = xpoly_amd.DeviceLP(ctx, xpoly_amd.F64, leq, tgtf)
+
+        def run_step():
+            lp.begin()                                  # slack form rebuilt on the device (one kernel)
+            st = lp.iterate(PIVOTS_PER_STEP)
             assert st == RUNNING, "LP ended early (status %d)" % st
-            state["since_begin"] += chunk
-            left -= chunk
 
-    # set-up, not measured: one pass through every code path of the timed region (launch
-    # throttling, event pairs) so lazy runtime initialisation does not land inside it
-    ctx.profile_begin(8, 32)
-    # (the ROCm runtime was measured to stall the stream once for 60-80 ms somewhere in the first
-    # ~100 ms of queued-loop activity of a process -- tools/probe_stall.py -- so the set-up pass runs
-    # for at least PREWARM_SECONDS of wall time, not just PREWARM iterations)
-    t_pre = time.perf_counter()
-    run_pivots(PREWARM)
-    ctx.sync()
-    while time.perf_counter() - t_pre < PREWARM_SECONDS:
-        run_pivots(PREWARM)
+        # set-up, not measured: one pass through every code path of the timed region (launch throttling,
+        # event pairs) so lazy runtime initialisation does not land inside it. The ROCm runtime was measured
+        # to stall the stream once for 60-80 ms somewhere in the first ~100 ms of queued-loop activity of a
+        # process (tools/probe_stall.py), so the set-up pass runs for at least PREWARM_SECONDS of wall time.
+        ctx.profile_begin(8, 32)
+        t_pre = time.perf_counter()
+        run_step()
         ctx.sync()
-    ctx.profile_end()
-    run_pivots(a.warmup)
-    barrier()
-    stride = max(1, a.steps // 320)           # sampled sweep launches spread over the region (a blocked
-                                              # sweep applies up to 16 pivots, so there are ~steps/16 of them:
-                                              # about 20 event pairs per 1000 steps)
-    ctx.profile_begin(0 if a.no_events else a.steps, stride)
-    start_count = lp.pivots_done()
-    t0 = time.perf_counter()
-    run_pivots(a.steps)
-    ctx.sync()
-    barrier()
-    dt = time.perf_counter() - t0
-    launches, sweep_ms = ctx.profile_end()
-    done = lp.pivots_done() - start_count
-    assert done == a.steps, "expected %d pivots, device did %d" % (a.steps, done)
-    rows, W, rhs = lp.shape()
-    assert (rows, W) == (M, TAB_W)
-    dt = max_over_ranks(dt)
-    value = world * a.steps / dt
-    roofline = None
-    if launches:
-        sweep_avg_s = sweep_ms / 1e3 / launches
-        achieved = ALG_BYTES_PER_PIVOT / sweep_avg_s / 1e9
-        traffic, traffic_src = None, None
-        if os.path.exists(PMC_SUMMARY):      # measured with rocprofv3 --pmc (separate passes), not live
-            pm = json.load(open(PMC_SUMMARY))
-            traffic = round(pm["traffic_bytes_per_launch"])
-            traffic_src = "profiles/round1_pmc_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, KiB->B)"
-        roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src,
-                        kernel={"se": "k_update_f64<32,8>", "pi": "k_pipe_sweep<32,8> (sweep + the next pivot's pick workgroups)",
-                                "sp": "k_pipe_sweep<32,8>"}.get(os.environ.get("XPG_LOOP", "")[:2],
-                                                               "k_blk_sweep_full<16,4> (one pass applies the XPG_BLOCK=16 staged pivots)"),
-                        pivots_per_launch=round(a.steps / max(1, launches * stride), 2),
-                        launches_sampled=launches,
-                        avg_launch_us=round(sweep_avg_s * 1e6, 2),
-                        algorithmic_bytes_per_launch=ALG_BYTES_PER_PIVOT)
-    lp.close()
+        while time.perf_counter() - t_pre < PREWARM_SECONDS:
+            run_step()
+            ctx.sync()
+        ctx.profile_end()
+        for _ in range(a.warmup):
+            run_step()
+        barrier()
+        batches = a.steps * (PIVOTS_PER_STEP // BLOCK)
+        stride = max(1, batches // 320)                 # ~320 sampled sweep launches spread over the region
+        ctx.profile_begin(0 if a.no_events else batches // stride + 1, stride)
+        sweeps_full = sweeps_part = 0
+        pivots = 0
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            run_step()
+            if not a.no_events:                         # device counters of this step (the iterate call has
+                f, p = lp.counters()                    # synchronised already: no extra round trip inside)
+                sweeps_full += f
+                sweeps_part += p
+            pivots += PIVOTS_PER_STEP
+        ctx.sync()
+        barrier()
+        dt = time.perf_counter() - t0
+        launches, sweep_ms = ctx.profile_end()
+        assert lp.pivots_done() % PIVOTS_PER_STEP == 0
+        rows, W, rhs = lp.shape()
+        assert (rows, W) == (M, TAB_W)
+        dt = max_over_ranks(dt)
+        value = world * pivots / dt
+        out["value"] = round(value, 2)
+        out["ms_per_step"] = round(dt / a.steps * 1e3, 4)
+        out["config"] = {
+            "workload": "dense LP m=4096 n=4095 (gen.hard_lp_f64: A~U(0.1,1), b=A x*, c=A^T y*), slack tableau "
+                        "4096x8192 fp64 resident in HBM; one step = xpg_lp_begin (slack form rebuilt on the device) "
+                        "+ %d pivots of the device-resident SIX::solveSlackForm loop = %d full batches of %d"
+                        % (PIVOTS_PER_STEP, PIVOTS_PER_STEP // BLOCK, BLOCK),
+            "tableau": [M, TAB_W], "pivots_per_step": PIVOTS_PER_STEP, "timed_region_ms": round(dt * 1e3, 2),
+            "parallelism": "replicas only (1 tableau per GPU)"}
+        if launches:
+            sweep_avg_s = sweep_ms / 1e3 / launches
+            achieved = ALG_BYTES_PER_LAUNCH / sweep_avg_s / 1e9
+            n_sweeps = sweeps_full + sweeps_part
+            ppl = pivots / n_sweeps if n_sweeps else float(BLOCK)
+            traffic, traffic_src = None, None
+            if os.path.exists(PMC_SUMMARY):             # measured with rocprofv3 --pmc (separate passes), not live
+                pm = json.load(open(PMC_SUMMARY))
+                traffic = round(pm["traffic_bytes_per_launch"])
+                traffic_src = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes of this "
+                               "loop; not collected in this run)" % os.path.basename(PMC_SUMMARY))
+            per_pivot_s = dt / pivots
+            out["roofline"] = dict(
+                bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src,
+                kernel="k_blk_sweep_full<16,4>: one launch applies the 16 staged pivots of a batch to every cell",
+                algorithmic_bytes_per_launch=ALG_BYTES_PER_LAUNCH, launches_sampled=launches,
+                avg_launch_us=round(sweep_avg_s * 1e6, 2),
+                sweeps_in_region=dict(full=sweeps_full, partial=sweeps_part),
+                pivots_per_launch=round(ppl, 3),
+                loop_effective=dict(
+                    note="whole loop: bytes the sweeps move per pivot / wall time per pivot; the pick and prep "
+                         "launches between sweeps move next to nothing, so this is what the loop as a whole "
+                         "draws from HBM",
+                    bytes_per_pivot=round(ALG_BYTES_PER_LAUNCH / ppl), us_per_pivot=round(per_pivot_s * 1e6, 3),
+                    achieved=round(ALG_BYTES_PER_LAUNCH / ppl / per_pivot_s / 1e9, 1),
+                    frac=round(ALG_BYTES_PER_LAUNCH / ppl / per_pivot_s / 1e9 / HBM_PEAK_GBS, 4)),
+                caveat="fraction of the 8 TB/s HBM peak; the 268 MB tableau nearly fits the 256 MiB Infinity Cache "
+                       "(MALL) and FETCH_SIZE counts its hits, so part of the stream is served by the MALL -- which is "
+                       "how `achieved` can exceed the ~6.3 TB/s a pure HBM copy reaches")
+        lp.close()
 
-    # ---- leg 2: batched 32 x 64 LPs, sharded across ranks, one all_gather at the end ----------
-    batched = None
+    # ---- leg 2: batched 32 x 64 LPs, sharded across ranks, one all_gather at the end ----------------
     b_leq = b_tg = None
-    if not a.no_batched:
+    if "batched" in legs:
         total = BATCH_PER_GPU * world
         lo, hi = shard_range(total, rank, world)
         nloc = hi - lo
         fams = {}
-        for fam, name in ((0, "dense_positive"), (1, "dep_test_like")):
-            b_leq, b_tg = gen.small_lp_batch_f64(nloc, BATCH_M, BATCH_COLS, fam,
-                                                 seed=gen.XS_SEED + 1000 * (rank + 1) + fam)
-            d_leq = torch.from_numpy(b_leq).to(dev)
-            d_tg = torch.from_numpy(b_tg).to(dev)
-            d_st = torch.empty(nloc, dtype=torch.int32, device=dev)
-            d_v = torch.empty(nloc, dtype=torch.float64, device=dev)
-            d_sol = torch.zeros(nloc, BATCH_COLS, dtype=torch.float64, device=dev)
-            d_piv = torch.empty(nloc, dtype=torch.int32, device=dev)
-            full = None
+        for fam, name in ((1, "dep_test_like"), (0, "dense_positive")):
+            if stub:
+                idx = torch.arange(lo, hi, dtype=torch.float64)
+                d_st = (idx % 5).to(torch.int32)
+                d_v = idx * 0.5 + fam
+                d_sol = idx[:, None] + torch.arange(BATCH_COLS, dtype=torch.float64)[None, :] / 100.0
+                d_piv = torch.ones(nloc, dtype=torch.int32)
+            else:
+                b_leq, b_tg = gen.small_lp_batch_f64(nloc, BATCH_M, BATCH_COLS, fam,
+                                                     seed=gen.XS_SEED + 1000 * (rank + 1) + fam)
+                d_leq = torch.from_numpy(b_leq).to(dev)
+                d_tg = torch.from_numpy(b_tg).to(dev)
+                d_st = torch.empty(nloc, dtype=torch.int32, device=dev)
+                d_v = torch.empty(nloc, dtype=torch.float64, device=dev)
+                d_sol = torch.zeros(nloc, BATCH_COLS, dtype=torch.float64, device=dev)
+                d_piv = torch.empty(nloc, dtype=torch.int32, device=dev)
 
             def one_pass():
-                ctx.six_batch_dev(xpoly_amd.F64, True, nloc, d_tg.data_ptr(), d_leq.data_ptr(),
-                                  BATCH_M, BATCH_COLS, d_st.data_ptr(), d_v.data_ptr(), d_sol.data_ptr(),
-                                  d_piv.data_ptr())
-                ctx.sync()
+                if not stub:
+                    ctx.six_batch_dev(xpoly_amd.F64, True, nloc, d_tg.data_ptr(), d_leq.data_ptr(),
+                                      BATCH_M, BATCH_COLS, d_st.data_ptr(), d_v.data_ptr(), d_sol.data_ptr(),
+                                      d_piv.data_ptr())
+                    ctx.sync()
                 if dist is None:
                     return None
                 # the only collective of the path: fixed-size (status, v, sol) records
-                out = gather_records(pack_records(d_st, d_v, d_sol), total, rank, world, dist)
-                torch.cuda.synchronize()
-                return out
+                full = gather_records(pack_records(d_st, d_v, d_sol), total, rank, world, dist)
+                if not stub:
+                    torch.cuda.synchronize()
+                return full
 
             full = one_pass()
             barrier()
-            reps = 5
+            reps = 3 if fam == 1 else 5
             t0 = time.perf_counter()
             for _ in range(reps):
                 full = one_pass()
@@ -258,52 +362,192 @@ def main():
             bdt = max_over_ranks(time.perf_counter() - t0)
             if full is not None:
                 assert full.shape[0] == total
-            piv = float(d_piv.sum().item())
-            if dist is not None:
-                pt = torch.tensor([piv], dtype=torch.float64, device=dev)
-                dist.all_reduce(pt)
-                piv = float(pt.item())
+                if stub:                                # the gathered order is the global LP order
+                    gi = torch.arange(total, dtype=torch.float64)
+                    assert torch.equal(full[:, 0], gi % 5) and torch.equal(full[:, 1], gi * 0.5 + fam)
+                    assert torch.equal(full[:, 2], gi)
+            piv = sum_over_ranks(float(d_piv.sum().item()))
             hist = torch.bincount(d_st.clamp(min=0), minlength=5).tolist()
             fams[name] = dict(lps_per_s=round(total * reps / bdt, 1), pivots_per_s=round(piv * reps / bdt, 1),
                               status_hist_rank0=hist, ms_per_pass=round(bdt / reps * 1e3, 3))
-        tot = sum(f["lps_per_s"] for f in fams.values()) / len(fams)
-        batched = dict(metric="batched LPs/sec", value=round(tot, 1), unit="LPs/s", n_gpus=world,
-                       total_lps=total, lps_per_gpu=BATCH_PER_GPU,
+        batched = dict(metric="batched LPs/sec", value=fams["dep_test_like"]["lps_per_s"], unit="LPs/s",
+                       headline_family="dep_test_like (entries in {-3..3} at density 0.25: the shape "
+                                       "DepPoly::is_empty produces; the workload the kernel exists for)",
+                       n_gpus=world, ranks=world, total_lps=total, lps_per_rank=[shard_range(total, r, world)[1] -
+                                                                                 shard_range(total, r, world)[0]
+                                                                                 for r in range(world)],
                        shape="leq 32x64 (63 vars + rhs), SIX::maxm, x>=0, whole solve per LP in LDS",
-                       scaling="weak",
-                       collective="one all_gather_into_tensor of (status,v,sol) records" if dist else "none (1 GPU)",
+                       scaling="weak (8192 LPs per GPU: 65 536 at N = 8)",
+                       collective=("one all_gather_into_tensor of (status,v,sol) records over %s, world size %d"
+                                   % ("RCCL" if a.backend == "nccl" else a.backend, world)) if dist else "none (1 GPU)",
                        families=fams)
+        if world == 1 and not stub:
+            # N = 1 reference point for STRONG scaling: the whole 65 536-LP batch of cfg 3 on one GPU
+            full_n = BATCH_PER_GPU * 8
+            ref_pts = {}
+            for fam, name in ((1, "dep_test_like"), (0, "dense_positive")):
+                f_leq, f_tg = gen.small_lp_batch_f64(full_n, BATCH_M, BATCH_COLS, fam, seed=gen.XS_SEED + 77 + fam)
+                d_leq = torch.from_numpy(f_leq).to(dev); d_tg = torch.from_numpy(f_tg).to(dev)
+                d_st = torch.empty(full_n, dtype=torch.int32, device=dev)
+                d_v = torch.empty(full_n, dtype=torch.float64, device=dev)
+                d_sol = torch.zeros(full_n, BATCH_COLS, dtype=torch.float64, device=dev)
+                ctx.sync()
+                t0 = time.perf_counter()
+                ctx.six_batch_dev(xpoly_amd.F64, True, full_n, d_tg.data_ptr(), d_leq.data_ptr(), BATCH_M, BATCH_COLS,
+                                  d_st.data_ptr(), d_v.data_ptr(), d_sol.data_ptr(), None)
+                ctx.sync()
+                ref_pts[name] = round(full_n / (time.perf_counter() - t0), 1)
+                del d_leq, d_tg, d_st, d_v, d_sol, f_leq, f_tg
+            batched["n1_reference_points"] = dict(
+                weak="the `families` figures above (8192 LPs on this GPU)",
+                strong_65536_lps_on_one_gpu_lps_per_s=ref_pts)
+        out["batched"] = batched
 
-    # ---- CPU baseline (rank 0, N = 1 only) -----------------------------------------------------------
-    cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline_pivots()
-        if not a.no_ref_baseline:
-            cpu["reference"] = cpu_reference_pivots(leq, tgtf)
+    # ---- legs 3-5: the remaining BASELINE configs, rank 0 of an N = 1 run ---------------------------
+    if world == 1 and not stub:
+        if "cfg2b" in legs:
+            out["cfg2b"] = leg_cfg2b(ctx, xpoly_amd, gen)
+        if "rational" in legs:
+            out["rational"] = leg_rational(ctx, xpoly_amd, gen)
+        if "mip" in legs:
+            out["mip"] = leg_mip(ctx, xpoly_amd, gen)
+
+    # ---- CPU baselines (rank 0, N = 1 only) --------------------------------------------------------
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not stub:
+        from oracle.checker import Port
+        port = Port()
+        if "pivots" in legs:
+            cpu = cpu_baseline_pivots()
+            if not a.no_ref_baseline:
+                cpu["reference"] = cpu_reference_pivots(leq, tgtf)
+        else:
+            cpu = {}
         if b_leq is not None:
-            cpu["batched"] = cpu_baseline_batch(b_leq, b_tg)
-
+            vc = gen.vc_nonneg(BATCH_COLS - 1)
+            d_leq_f, d_tg_f = gen.small_lp_batch_f64(2048, BATCH_M, BATCH_COLS, 1, seed=gen.XS_SEED + 1001)
+            r = cpu_per_core(lambda i: port.six_solve(0, True, d_tg_f[i], vc, None, d_leq_f[i]), 2048, 6.0,
+                             "dep-test-like LPs (32x64, SIX::maxm)")
+            r["unit"] = "LPs/s"
+            cpu["batched"] = r
+        if "rational" in out:
+            cpu["rational"] = cpu_rational(port, gen)
+        if "mip" in out:
+            cpu["mip"] = cpu_mip(port, gen)
     if rank == 0:
-        out = {
-            "metric": "simplex pivots/sec (float tableau 4kx8k)",
-            "value": round(value, 2), "unit": "pivots/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "dense LP m=4096 n=4095 (gen.hard_lp_f64: A~U(0.1,1), b=A x*, c=A^T y*), "
-                                   "slack tableau 4096x8192 fp64 resident in HBM, device-resident "
-                                   "SIX::solveSlackForm loop, one pivot per step",
-                       "tableau": [M, TAB_W], "parallelism": "replicas only (1 tableau per GPU)",
-                       "lp_restarts_in_run": state["restarts"]},
-            "roofline": roofline,
-            "cpu_baseline": cpu,
-            "batched": batched,
-        }
+        out["cpu_baseline"] = cpu
         print(json.dumps(out))
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------
+def leg_cfg2b(ctx, xpoly_amd, gen, m=4096, n=8192):
+    """BASELINE configs[1] end to end: LP m=4096, n=8192 -> slack tableau 4096 x 12289 (lpsol.h:1406-1433).
+    The SURVEY 8d recipe (b = n U(0.5,1)) reaches its optimum in a few dozen pivots, too few to time, so the
+    LP is gen.hard_lp_f64 at this size (same A, optimum with every structural variable basic); rate =
+    (K2 - K1) / (t2 - t1) with K1 = 256, K2 = 1280."""
+    RUNNING = xpoly_amd.six.XPG_RUNNING
+    leq, tgtf = gen.hard_lp_f64(m, n)
+    lp = xpoly_amd.DeviceLP(ctx, xpoly_amd.F64, leq, tgtf)
+    del leq
+    W = n + m + 1
+    res = {}
+    for rep in range(2):                                # the first pass warms every launch path
+        lp.begin()
+        ts = {}
+        t0 = time.perf_counter()
+        assert lp.iterate(256) == RUNNING
+        ts[256] = time.perf_counter() - t0
+        assert lp.iterate(1024) == RUNNING
+        ts[1280] = time.perf_counter() - t0
+        res = ts
+    per = (res[1280] - res[256]) / 1024.0
+    f, p = lp.counters()
+    lp.close()
+    bytes_per_launch = 2 * m * W * 8
+    return dict(metric="simplex pivots/sec, LP m=4096 n=8192 (tableau 4096x12289 fp64)", value=round(1.0 / per, 1),
+                unit="pivots/s", us_per_pivot=round(per * 1e6, 3), tableau=[m, W],
+                algorithmic_bytes_per_launch=bytes_per_launch, pivots_per_launch=BLOCK,
+                sweeps=dict(full=f, partial=p),
+                loop_effective_gbs=round(bytes_per_launch / BLOCK / per / 1e9, 1),
+                loop_effective_frac=round(bytes_per_launch / BLOCK / per / 1e9 / HBM_PEAK_GBS, 4),
+                sample="(t[K=1280] - t[K=256]) / 1024 on one LP, device-resident blocked loop")
+
+
+RAT_M, RAT_N, RAT_K = 1024, 1023, 16                  # tableau 1024 x (1023 + 1024 + 1) = 1024 x 2048
+
+
+def leg_rational(ctx, xpoly_amd, gen):
+    """BASELINE configs[3]: exact rational simplex (int32 num/den, int64 intermediates, the reference's
+    float32 `appro` rescue, src/com/rational.cpp:163-226), tableau 1024 x 2048, K = 16 pivots from the
+    slack form (crosses the first appro activations). Integer-ALU bound (Euclid loops), not HBM."""
+    RUNNING = xpoly_amd.six.XPG_RUNNING
+    leq, tgtf = gen.int_lp_rat(RAT_M, RAT_N)
+    lp = xpoly_amd.DeviceLP(ctx, xpoly_amd.RAT, leq, tgtf)
+    reps, best = 6, None
+    for rep in range(reps):
+        lp.begin()
+        ctx.sync()
+        t0 = time.perf_counter()
+        st = lp.iterate(RAT_K)
+        dt = time.perf_counter() - t0
+        assert st == RUNNING
+        if rep > 0:
+            best = dt if best is None else min(best, dt)
+    lp.close()
+    W = RAT_N + RAT_M + 1
+    alg = 2 * RAT_M * W * 8
+    return dict(metric="exact rational simplex pivots/sec (tableau 1024x2048, K=16)", value=round(RAT_K / best, 1),
+                unit="pivots/s", us_per_pivot=round(best / RAT_K * 1e6, 2), tableau=[RAT_M, W], dtype="int32 num/den",
+                bound="integer ALU (gcd / appro per cell), not HBM",
+                algorithmic_bytes_per_pivot=alg, achieved_gbs=round(alg * RAT_K / best / 1e9, 1),
+                hbm_frac=round(alg * RAT_K / best / 1e9 / HBM_PEAK_GBS, 4),
+                sample="best of %d runs of xpg_lp_begin + xpg_lp_iterate(16)" % (reps - 1))
+
+
+def cpu_rational(port, gen):
+    from oracle.checker import RAT
+    leq, tgtf = gen.int_lp_rat(RAT_M, RAT_N)
+    ts = {}
+    for K in (1, 3):
+        t0 = time.perf_counter()
+        port.two_stage(RAT, leq, tgtf, K)
+        ts[K] = time.perf_counter() - t0
+    per = (ts[3] - ts[1]) / 2.0
+    return dict(value=round(1.0 / per, 3), unit="pivots/s", cores=1, kind="port",
+                sample="oracle TwoStageMethod on the cfg-4 LP, (t[K=3]-t[K=1])/2 = %.3f s/pivot" % per)
+
+
+MIP_NB, MIP_NV = 1024, 24
+
+
+def leg_mip(ctx, xpoly_amd, gen):
+    """BASELINE configs[4]: 0-1 knapsacks, MIP::maxm(is_bin) (src/com/lpsol.h:2427-2612). The reference's
+    depth-first order decides the result, so a tree is not split: MIP_NB independent trees advance in
+    lock step and the node LPs of one round share one launch of the LDS-resident kernel."""
+    from xpoly_amd.six import mip_batch
+    leq, tgtf = gen.knapsack_batch_rat(MIP_NB, MIP_NV)
+    mip_batch(ctx, True, True, tgtf[:64], leq[:64])     # warm
+    t0 = time.perf_counter()
+    st, v, sol, nodes = mip_batch(ctx, True, True, tgtf, leq)
+    dt = time.perf_counter() - t0
+    return dict(metric="0-1 MIP branch and bound, node LPs as GPU batches", value=round(nodes / dt, 1), unit="nodes/s",
+                mips_per_s=round(MIP_NB / dt, 1), problems=MIP_NB, vars=MIP_NV, rows=2 + MIP_NV, nodes=int(nodes),
+                nodes_per_problem=round(nodes / MIP_NB, 2), wall_ms=round(dt * 1e3, 2),
+                status_hist=np.bincount(np.clip(st, 0, 4), minlength=5).tolist(), dtype="int32 num/den",
+                sample="xpg_mip_batch_rat32, host arrays in and out (PCIe included)")
+
+
+def cpu_mip(port, gen):
+    from oracle.checker import RAT
+    leq, tgtf = gen.knapsack_batch_rat(MIP_NB, MIP_NV)
+    vc = gen.to_rat(gen.vc_nonneg(MIP_NV, False))
+    r = cpu_per_core(lambda i: port.mip_solve(RAT, True, True, tgtf[i], vc, None, leq[i]), MIP_NB, 6.0,
+                     "0-1 knapsack MIPs (%d vars)" % MIP_NV)
+    r["unit"] = "MIPs/s"
+    return r
 
 
 if __name__ == "__main__":

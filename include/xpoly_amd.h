@@ -109,6 +109,10 @@ int  xpg_lp_begin(xpg_lp * lp);
 int  xpg_lp_iterate(xpg_lp * lp, unsigned pivots);
 #define XPG_RUNNING (-1000)
 int  xpg_lp_pivots_done(xpg_lp * lp, unsigned * out);
+/* Blocked loop bookkeeping since xpg_lp_begin / xpg_lp_two_stage: sweeps that applied a full batch of
+ * 16 staged pivots, and sweeps that applied fewer (the tail of an iterate budget, or a batch closed
+ * early by a rare branch of SIX::solveSlackForm, src/com/lpsol.h:1138-1151).  Either may be NULL. */
+int  xpg_lp_counters(xpg_lp * lp, unsigned * sweeps_full, unsigned * sweeps_partial);
 /* OPT-IN, NON-PARITY (results are no longer the reference's bit for bit, and
  * nothing else in this header changes behaviour): before xpg_lp_begin / xpg_lp_two_stage,
  *   pricing = 1        Dantzig's rule -- the largest reduced cost enters -- instead of the reference's
@@ -168,6 +172,20 @@ int xpg_six_batch_rat32_dev(xpg_ctx * ctx, int is_max, int nb, const xpg_rat32 *
                             int32_t * out_status, xpg_rat32 * out_v, xpg_rat32 * out_sol,
                             uint32_t * out_pivots);
 
+/* The same batches spread over the GPUs of one node from ONE caller thread -- what a C++ xpoly
+ * caller of Lineq::has_solution (src/com/linsys.cpp:860-904) gets when it hands a SCoP's worth of
+ * problems over at once.  devices[ndev] lists the HIP devices (NULL: 0 .. ndev-1; a device may be
+ * listed twice).  Shard g is the contiguous range [g*nb/ndev + min(g, nb%ndev), ...) (sizes differ by
+ * at most one, as xpoly_amd/shard.py); each shard runs on a context and host thread of its own and
+ * writes straight into the caller's HOST arrays -- there is no collective and no second copy.
+ * Returns 0, or the first shard's XPG_ERR_* (XPG_ERR_NO_DEVICE when a listed device is absent). */
+int xpg_six_batch_f64_multi(int ndev, const int * devices, int is_max, int nb, const double * tgtf,
+                            const double * leq, int m, int cols, unsigned max_iter,
+                            int32_t * out_status, double * out_v, double * out_sol);
+int xpg_six_batch_rat32_multi(int ndev, const int * devices, int is_max, int nb, const xpg_rat32 * tgtf,
+                              const xpg_rat32 * leq, int m, int cols, unsigned max_iter,
+                              int32_t * out_status, xpg_rat32 * out_v, xpg_rat32 * out_sol);
+
 /* ---- MIP<Mat,T>::maxm / minm, src/com/lpsol.h:2636-2657 / :2681-2702 ---------------------
  * Depth-first branch and bound exactly as MIP::RecusivePart (lpsol.h:2427-2612): every
  * node is a from-scratch SIX solve (max_iter 10000, lpsol.h:2441) on the GPU; is_bin
@@ -208,6 +226,15 @@ int xpg_mip_batch_rat32(xpg_ctx * ctx, int nb, int is_max, int is_bin, const xpg
  * and, failing that, MIP::minm.  out_empty[b] = 1 / 0, or XPG_ERR_REF_UNDEFINED. */
 int xpg_dep_is_empty_batch_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols,
                                  int32_t * out_empty, long long * out_nodes);
+
+/* Multi-device forms of the two batches above (sharding and devices[] as xpg_six_batch_*_multi;
+ * out_nodes receives the sum over the shards). */
+int xpg_mip_batch_rat32_multi(int ndev, const int * devices, int nb, int is_max, int is_bin,
+                              const xpg_rat32 * tgtf, const xpg_rat32 * leq, int leq_rows, int cols,
+                              int32_t * out_status, xpg_rat32 * out_v, xpg_rat32 * out_sol,
+                              long long * out_nodes);
+int xpg_dep_is_empty_batch_rat32_multi(int ndev, const int * devices, int nb, const xpg_rat32 * mats,
+                                       int rows, int cols, int32_t * out_empty, long long * out_nodes);
 
 /* ---- rational row elimination, batches of small systems (one wavefront each) -------------
  * mats is [nb][rows][cols] of xpg_rat32 on the host; rhs_idx is the constant column,

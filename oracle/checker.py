@@ -40,13 +40,16 @@ def _vp(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
-def as_kind(a, kind):
-    """Coerce to the flat layout of `kind`; rational accepts plain ints."""
+def as_kind(a, kind, ndim):
+    """Coerce to the flat layout of `kind`. `ndim` = logical axes; a rational is either integers with
+    that many axes or (num, den) pairs with one more, trailing axis of 2 -- never guessed from shape."""
     if kind == F64:
         return np.ascontiguousarray(a, dtype=np.float64)
     a = np.asarray(a)
-    if a.ndim >= 1 and a.shape[-1] == 2 and a.dtype == np.int32:
-        return np.ascontiguousarray(a)
+    if a.ndim == ndim + 1:
+        assert a.shape[-1] == 2, a.shape
+        return np.ascontiguousarray(a, dtype=np.int32)
+    assert a.ndim == ndim, (a.shape, ndim)
     out = np.empty(a.shape + (2,), dtype=np.int32)
     out[..., 0] = a
     out[..., 1] = 1
@@ -71,14 +74,14 @@ class _Lib:
 
     # ---- SIX::maxm / minm (lpsol.h:1993 / :1662) -------------------------
     def six_solve(self, kind, is_max, tgtf, vc, eq, leq, max_iter=0xFFFFFFFF):
-        tgtf = as_kind(tgtf, kind)
+        tgtf = as_kind(tgtf, kind, 1)
         cols = tgtf.shape[-1] if kind == F64 else tgtf.shape[-2]
-        vc = as_kind(vc, kind)
+        vc = as_kind(vc, kind, 2)
         vc_rows = vc.shape[0]
         eq_rows = 0 if eq is None else len(eq)
         leq_rows = 0 if leq is None else len(leq)
-        eq_a = as_kind(eq, kind) if eq_rows else None
-        leq_a = as_kind(leq, kind) if leq_rows else None
+        eq_a = as_kind(eq, kind, 2) if eq_rows else None
+        leq_a = as_kind(leq, kind, 2) if leq_rows else None
         v = empty_kind((1,), kind)
         sol = empty_kind((cols,), kind)
         fn = self._f("six_solve")
@@ -91,15 +94,15 @@ class _Lib:
 
     # ---- SIX::TwoStageMethod (lpsol.h:1907) ------------------------------
     def two_stage(self, kind, leq, tgtf, max_iter, vc=None):
-        leq = as_kind(leq, kind)
+        leq = as_kind(leq, kind, 2)
         m, cols = leq.shape[0], leq.shape[1]
-        tgtf = as_kind(tgtf, kind)
+        tgtf = as_kind(tgtf, kind, 1)
         if vc is None:
             vc = np.zeros((cols - 1, cols), dtype=np.int64)
             vc[np.arange(cols - 1), np.arange(cols - 1)] = -1
-            vc = as_kind(vc.astype(np.float64) if kind == F64 else vc.astype(np.int32), kind)
+            vc = as_kind(vc.astype(np.float64) if kind == F64 else vc.astype(np.int32), kind, 2)
         else:
-            vc = as_kind(vc, kind)
+            vc = as_kind(vc, kind, 2)
         capc = cols + m + 1
         tab = empty_kind((m, capc), kind)
         otg = empty_kind((capc,), kind)
@@ -126,13 +129,13 @@ class _Lib:
 
     # ---- MIP::maxm / minm (lpsol.h:2636 / :2681) -------------------------
     def mip_solve(self, kind, is_max, is_bin, tgtf, vc, eq, leq, rat_ind=None):
-        tgtf = as_kind(tgtf, kind)
+        tgtf = as_kind(tgtf, kind, 1)
         cols = tgtf.shape[-1] if kind == F64 else tgtf.shape[-2]
-        vc = as_kind(vc, kind)
+        vc = as_kind(vc, kind, 2)
         eq_rows = 0 if eq is None else len(eq)
         leq_rows = 0 if leq is None else len(leq)
-        eq_a = as_kind(eq, kind) if eq_rows else None
-        leq_a = as_kind(leq, kind) if leq_rows else None
+        eq_a = as_kind(eq, kind, 2) if eq_rows else None
+        leq_a = as_kind(leq, kind, 2) if leq_rows else None
         ind = None if rat_ind is None else np.ascontiguousarray(rat_ind, dtype=np.uint8)
         v = empty_kind((1,), kind)
         sol = empty_kind((cols,), kind)
@@ -164,7 +167,7 @@ class _Lib:
 
     # ---- Lineq (linsys.cpp) ----------------------------------------------
     def fme(self, mat, rhs_idx, u, darkshadow=False, cap_rows=None):
-        mat = as_kind(mat, RAT)
+        mat = as_kind(mat, RAT, 2)
         rows, cols = mat.shape[0], mat.shape[1]
         cap = cap_rows or (rows * rows // 4 + rows + 4)
         out = empty_kind((cap, cols), RAT)
@@ -181,7 +184,7 @@ class _Lib:
         return ok, res
 
     def reduce(self, mat, rhs_idx, is_intersect=True):
-        mat = as_kind(mat, RAT).copy()
+        mat = as_kind(mat, RAT, 2).copy()
         rows, cols = mat.shape[0], mat.shape[1]
         orows, ocols = C.c_int(), C.c_int()
         fn = self._f("reduce")
@@ -193,7 +196,7 @@ class _Lib:
         return ok, res
 
     def remove_iden_row(self, mat):
-        mat = as_kind(mat, RAT).copy()
+        mat = as_kind(mat, RAT, 2).copy()
         rows, cols = mat.shape[0], mat.shape[1]
         orows = C.c_int()
         self._f("remove_iden_row")(_vp(mat), C.c_int(rows), C.c_int(cols), C.byref(orows))
@@ -201,12 +204,12 @@ class _Lib:
         return mat.reshape(-1)[: r * cols * 2].reshape(r, cols, 2).copy()
 
     def has_solution(self, leq, eq, vc, rhs_idx, is_int_sol, is_unique_sol):
-        vc = as_kind(vc, RAT)
+        vc = as_kind(vc, RAT, 2)
         cols = vc.shape[1]
         leq_rows = 0 if leq is None else len(leq)
         eq_rows = 0 if eq is None else len(eq)
-        leq_a = as_kind(leq, RAT) if leq_rows else None
-        eq_a = as_kind(eq, RAT) if eq_rows else None
+        leq_a = as_kind(leq, RAT, 2) if leq_rows else None
+        eq_a = as_kind(eq, RAT, 2) if eq_rows else None
         fn = self._f("has_solution")
         fn.restype = C.c_int
         return fn(_vp(leq_a), C.c_int(leq_rows), _vp(eq_a), C.c_int(eq_rows),
@@ -215,7 +218,7 @@ class _Lib:
 
     def calc_bound(self, mat, rhs_idx, cap_rows=None):
         """Lineq::calcBound (linsys.cpp:1047-1078): (ok, [bounds of variable j as rows x cols x 2])."""
-        mat = as_kind(mat, RAT)
+        mat = as_kind(mat, RAT, 2)
         rows, cols = mat.shape[0], mat.shape[1]
         cap = cap_rows or max(16, 4 * rows * rows)
         out = empty_kind((rhs_idx, cap, cols), RAT)
@@ -228,19 +231,19 @@ class _Lib:
         return ok, [out[j, : orows[j]].copy() for j in range(rhs_idx)]
 
     def rat_rank(self, mat):
-        mat = as_kind(mat, RAT)
+        mat = as_kind(mat, RAT, 2)
         fn = self._f("rat_rank")
         fn.restype = C.c_int
         return fn(_vp(mat), C.c_int(mat.shape[0]), C.c_int(mat.shape[1]))
 
     def rat_det(self, mat):
-        mat = as_kind(mat, RAT)
+        mat = as_kind(mat, RAT, 2)
         n, d = C.c_int32(), C.c_int32()
         self._f("rat_det")(_vp(mat), C.c_int(mat.shape[0]), C.byref(n), C.byref(d))
         return n.value, d.value
 
     def rat_inv(self, mat):
-        mat = as_kind(mat, RAT)
+        mat = as_kind(mat, RAT, 2)
         out = empty_kind((mat.shape[0], mat.shape[0]), RAT)
         fn = self._f("rat_inv")
         fn.restype = C.c_int
@@ -249,7 +252,7 @@ class _Lib:
 
     def rat_rank_basis(self, mat, unitarize):
         """Matrix<Rational>::rank(&basis, is_unitarize) (matt.h:2614-2726): (rank, basis)."""
-        mat = as_kind(mat, RAT)
+        mat = as_kind(mat, RAT, 2)
         rows, cols = mat.shape[0], mat.shape[1]
         out = empty_kind((rows, cols), RAT)
         orows = C.c_int()
@@ -260,7 +263,7 @@ class _Lib:
 
     def rat_null(self, mat):
         """Matrix<Rational>::null (matt.h:2546-2584): cols x cols, column convention."""
-        mat = as_kind(mat, RAT)
+        mat = as_kind(mat, RAT, 2)
         out = empty_kind((mat.shape[1], mat.shape[1]), RAT)
         self._f("rat_null")(_vp(mat), C.c_int(mat.shape[0]), C.c_int(mat.shape[1]), _vp(out))
         return out

@@ -216,13 +216,11 @@ def test_batch_matches_oracle(ctx, port, kind, is_max):
                 assert same(sol[b], want[2]), (m, nv, fam, b)
 
 
-@pytest.mark.parametrize("variant", ["m", "w"])
 @pytest.mark.parametrize("kind", [F64, RAT])
-def test_batch_register_resident_loops(ctx, port, kind, variant, monkeypatch):
-    """The opt-in register-resident pivot loops of the batch kernel (XPG_BATCH_REGS=m: four waves
-    per LP, =w: one wavefront per LP) give the same statuses, objectives and solutions as the oracle,
-    on both families of the 32x64 shape (fp64) and on random rational problems incl. phase 1."""
-    monkeypatch.setenv("XPG_BATCH_REGS", variant)
+def test_batch_bench_shape_and_rational_sizes(ctx, port, kind):
+    """The LDS-resident batch kernel gives the same statuses, objectives and solutions as the oracle
+    on both families of the 32x64 bench shape (fp64, maxm and minm) and on random rational problems
+    incl. phase 1 up to 32 x 40."""
     if kind == F64:
         for fam in (0, 1):
             leq, tg = gen.small_lp_batch_f64(24, 32, 64, fam, seed=gen.XS_SEED + 5 + fam)

@@ -71,3 +71,38 @@ def test_gather_two_ranks_gloo(total):
     for r in (0, 1):
         assert got[r].shape == (total, 2 + width)
         assert np.array_equal(got[r], want)
+
+
+def test_bench_spawns_its_own_ranks_and_gathers():
+    """`python bench.py --gpus 2` starts two ranks by itself (torch.distributed.run on 127.0.0.1) and the
+    batched leg's shard -> solve -> all_gather path runs in them; here with --backend gloo and a stub
+    solver (each rank fabricates the records of its own shard), so exactly bench.py's own spawn and
+    gather code is what is exercised. The gathered order is asserted inside bench.py."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                        "--stub-solver", "--legs", "batched", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["stub_solver"] is True
+    b = out["batched"]
+    assert b["ranks"] == 2 and b["total_lps"] == 2 * 8192 and b["lps_per_rank"] == [8192, 8192]
+    assert "world size 2" in b["collective"]
+
+
+def test_bench_without_gpus_fails_loudly():
+    """On a box without GPUs `bench.py --gpus 2` must not degrade to a silent 1-rank run: every rank
+    fails creating its context (XPG_ERR_NO_DEVICE) and the parent exits non-zero."""
+    import subprocess
+    from xpoly_amd import _capi
+    if _capi.lib().xpg_device_count() > 0:
+        pytest.skip("a GPU is present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--legs", "batched",
+                        "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "XPG_ERR_NO_DEVICE" in r.stderr or "No HIP GPUs" in r.stderr or "no GPU" in r.stderr.lower(), r.stderr[-3000:]

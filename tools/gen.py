@@ -237,3 +237,22 @@ def hard_lp_f64(m, n, seed=XS_SEED):
     leq = np.concatenate([A, b[:, None]], axis=1)
     tgtf = np.concatenate([c, [0.0]])
     return np.ascontiguousarray(leq), np.ascontiguousarray(tgtf)
+
+
+def knapsack_batch_rat(nb, nv, seed=XS_SEED):
+    """cfg 5: nb 0-1 multi-constraint knapsacks, integer data as (num, den) int32:
+    maximise c.x, 2 capacity rows A x <= floor(sum(A_row) / 2), x_j <= 1 rows, x >= 0;
+    A, c in {1..9} from the xorshift64 stream. leq [nb, 2 + nv, nv + 1, 2], tgtf [nb, nv + 1, 2]."""
+    m = 2
+    per = m * nv + nv
+    u = xs_uniform_block(nb * per, seed).reshape(nb, per)
+    A = np.floor(u[:, : m * nv] * 9).astype(np.int32).reshape(nb, m, nv) + 1
+    c = np.floor(u[:, m * nv:] * 9).astype(np.int32) + 1
+    b = A.sum(axis=2) // 2
+    cap = np.concatenate([A, b[:, :, None]], axis=2)
+    ub = np.zeros((nv, nv + 1), dtype=np.int32)
+    ub[np.arange(nv), np.arange(nv)] = 1
+    ub[:, nv] = 1
+    leq = np.concatenate([cap, np.broadcast_to(ub, (nb, nv, nv + 1))], axis=1)
+    tgtf = np.concatenate([c, np.zeros((nb, 1), dtype=np.int32)], axis=1)
+    return to_rat(np.ascontiguousarray(leq)), to_rat(tgtf)

@@ -1,6 +1,6 @@
 """Cross-checks the device-resident fp64 loops against each other on large tableaux of several shapes
 (status, pivot count, CRCs of tableau / objective row / trace after `PROBE_PIVOTS` iterations).
-PROBE_MODES=block,chain,pipe picks the loops (XPG_LOOP values); the first one is the reference."""
+PROBE_MODES=block,pipe picks the loops (XPG_LOOP values); the first one is the reference."""
 import os
 import time
 import zlib

@@ -16,7 +16,7 @@ SYMBOLS = [
     "xpg_sync", "xpg_profile_begin", "xpg_profile_end", "xpg_malloc", "xpg_free", "xpg_upload", "xpg_download",
     "xpg_pivot_f64_dev", "xpg_pivot_rat32_dev", "xpg_pivot_f64", "xpg_pivot_rat32",
     "xpg_lp_create", "xpg_lp_destroy", "xpg_lp_two_stage", "xpg_lp_begin", "xpg_lp_iterate",
-    "xpg_lp_pivots_done", "xpg_lp_set_options", "xpg_lp_shape", "xpg_lp_read", "xpg_lp_trace",
+    "xpg_lp_pivots_done", "xpg_lp_counters", "xpg_lp_set_options", "xpg_lp_shape", "xpg_lp_read", "xpg_lp_trace",
     "xpg_six_maxm_f64", "xpg_six_minm_f64", "xpg_six_maxm_rat32", "xpg_six_minm_rat32",
     "xpg_six_batch_f64", "xpg_six_batch_rat32", "xpg_six_batch_f64_dev", "xpg_six_batch_rat32_dev",
     "xpg_mip_maxm_rat32", "xpg_mip_minm_rat32", "xpg_mip_maxm_f64", "xpg_mip_minm_f64",
@@ -24,6 +24,8 @@ SYMBOLS = [
     "xpg_lineq_reduce_batch_rat32", "xpg_lineq_remove_iden_batch_rat32", "xpg_lineq_fme_batch_rat32",
     "xpg_lineq_calc_bound_batch_rat32", "xpg_rat_rank_batch", "xpg_rat_det_batch", "xpg_rat_inv_batch",
     "xpg_rat_rank_basis_batch", "xpg_rat_null_batch", "xpg_int_hnf_batch", "xpg_int_gcd_batch",
+    "xpg_six_batch_f64_multi", "xpg_six_batch_rat32_multi", "xpg_mip_batch_rat32_multi",
+    "xpg_dep_is_empty_batch_rat32_multi",
 ]
 
 _lib = None

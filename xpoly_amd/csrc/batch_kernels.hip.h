@@ -21,9 +21,6 @@ template <class S> struct Small {
     int * sh_w;                     // 8 words of broadcast scratch
     unsigned pivots;
     unsigned closes;                // iterations that ended in disableNV (no pivot), for profiling
-#ifdef XPG_EXP_STAMPS
-    long long t_sel, t_b1, t_piv, t_stage;
-#endif
 };
 
 template <class S> __device__ __forceinline__ bool sm_seen(const Small<S> & P, int nv, int b)
@@ -200,9 +197,6 @@ template <class S> __device__ __forceinline__ void sm_select_wave0(Small<S> & P)
 // SIX::pivot (lpsol.h:1456-1511) with the pivot element and c_nv handed in.
 template <class S> __device__ __forceinline__ void sm_pivot_fast(Small<S> & P, int nv, int bv, int r, S piv, S cnv)
 {
-#ifdef XPG_EXP_STAMPS
-    const long long t_in = clock64();
-#endif
     const int W = P.W, ld = P.ld;
     const S s = div(one<S>(), piv);
     const int smode = scale_mode(s), cmode = scale_mode(cnv);
@@ -218,16 +212,12 @@ template <class S> __device__ __forceinline__ void sm_pivot_fast(Small<S> & P, i
     for (int i = threadIdx.x; i < P.R; i += blockDim.x)
         P.k[i] = i != r ? neg(P.tab[i * ld + nv]) : zero<S>();
     __syncthreads();
-#ifdef XPG_EXP_STAMPS
-    P.t_stage += clock64() - t_in;
-#endif
     {
         const int CW = blockDim.x >= 128 && W > 64 ? 128 : 64;
         const int tx = threadIdx.x % CW, ty = threadIdx.x / CW, ny = blockDim.x / CW;
         // Four rows of LDS reads are issued before the first use: the loop is latency-bound
         // (one dependent ds_read -> mul -> add -> ds_write chain per cell otherwise).
         const int last = P.R - 1;
-#ifndef XPG_EXP_NOSWEEP      /* timing experiment only: results are wrong without the sweep */
         for (int j = tx; j < W; j += CW) {
             const S ej = P.e[j];
             for (int i0 = ty; i0 < P.R; i0 += ny * 4) {
@@ -242,9 +232,6 @@ template <class S> __device__ __forceinline__ void sm_pivot_fast(Small<S> & P, i
                 if (i3 <= last && i3 != r) P.tab[i3 * ld + j] = add(a3, mul(k3, ej));
             }
         }
-#else
-        (void)last; (void)tx; (void)ty; (void)ny;
-#endif
     }
     if (threadIdx.x == 0) {
         P.nv[nv] = 0; P.nv[bv] = 1; P.bv[nv] = 1; P.bv[bv] = 0;
@@ -254,53 +241,9 @@ template <class S> __device__ __forceinline__ void sm_pivot_fast(Small<S> & P, i
     __syncthreads();
 }
 
-} // namespace xpg
-#include "batch_regloop.hip.h"
-#include "batch_waveloop.hip.h"
-namespace xpg {
-
-// The register-resident loop (batch_regloop.hip.h) as a REAL function call: inlined into the (large) solve code its registers were
-// allocated together with everything live around it (248 VGPRs, 190 B of scratch, SGPRs spilled
-// through v_writelane inside the loop; measured 2.7x slower than the LDS loop). Out of line it gets
-// an allocation of its own. It finds its operands through a descriptor at the start of the
-// dynamic LDS: byte offsets of the arrays, the shape, and the pivot counter in / out.
-enum { RL_TAB = 0, RL_OBJ, RL_E, RL_K, RL_X, RL_NV, RL_BV, RL_BV2EQ, RL_EQ2BV, RL_PPT, RL_ROWCNT, RL_COLCNT,
-       RL_SHC, RL_SHW, RL_R, RL_W, RL_LD, RL_RHS, RL_PW, RL_DONE, RL_CLOSES, RL_MAXITER, RL_CW,
-       RL_WORDS = 48 };                                // words 32..41: XPG_EXP_STAMPS phase counters
-template <class S, int RT> __device__ __attribute__((noinline)) int sm_reg_loop_call()
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
-    int * d = (int *)lds_dyn;
-#define RL_GET(i) __builtin_amdgcn_readfirstlane(d[i])
-    Small<S> P;
-    P.tab = (S *)(lds_dyn + RL_GET(RL_TAB)); P.obj = (S *)(lds_dyn + RL_GET(RL_OBJ));
-    P.e = (S *)(lds_dyn + RL_GET(RL_E)); P.k = (S *)(lds_dyn + RL_GET(RL_K)); P.x = (S *)(lds_dyn + RL_GET(RL_X));
-    P.nv = (uint8_t *)(lds_dyn + RL_GET(RL_NV)); P.bv = (uint8_t *)(lds_dyn + RL_GET(RL_BV));
-    P.bv2eq = (int *)(lds_dyn + RL_GET(RL_BV2EQ)); P.eq2bv = (int *)(lds_dyn + RL_GET(RL_EQ2BV));
-    P.ppt = (uint32_t *)(lds_dyn + RL_GET(RL_PPT));
-    P.rowcnt = (int *)(lds_dyn + RL_GET(RL_ROWCNT)); P.colcnt = (int *)(lds_dyn + RL_GET(RL_COLCNT));
-    P.sh_c = (Cand<S> *)(lds_dyn + RL_GET(RL_SHC)); P.sh_i = nullptr; P.sh_w = (int *)(lds_dyn + RL_GET(RL_SHW));
-    P.R = RL_GET(RL_R); P.W = RL_GET(RL_W); P.ld = RL_GET(RL_LD); P.rhs = RL_GET(RL_RHS); P.pw = RL_GET(RL_PW);
-    P.pivots = 0; P.closes = 0;
-    unsigned done = (unsigned)RL_GET(RL_DONE);
-    const unsigned max_iter = (unsigned)RL_GET(RL_MAXITER);
-    const int CW = RL_GET(RL_CW);
-#undef RL_GET
-    __syncthreads();                                   // everybody has read the descriptor
-    int act;
-    if constexpr (RT == 64) {                          // one wavefront per LP: 32 rows x 1 or 2 columns per lane
-        act = CW == 128 ? sm_wave_loop<S, true>(P, max_iter, done) : sm_wave_loop<S, false>(P, max_iter, done);
-    } else {
-        act = CW == 128 ? sm_reg_loop<S, RT, 2, 1, 256>(P, max_iter, done) : sm_reg_loop<S, RT, 4, 1, 256>(P, max_iter, done);
-    }
-    if (threadIdx.x == 0) { d[RL_DONE] = (int)done; d[RL_CLOSES] += (int)P.closes; }
-    __syncthreads();
-    return act;
-}
-
 // SIX::solveSlackForm (lpsol.h:1008-1191) incl. is_feasible (lpsol.h:784-822,
 // vc = "-x_i <= 0" for every variable). Returns a SIX_* status; maxv on success.
-template <class S, int RT> __device__ __forceinline__ int sm_solve(Small<S> & P, unsigned max_iter, S & maxv)
+template <class S> __device__ __forceinline__ int sm_solve(Small<S> & P, unsigned max_iter, S & maxv)
 {
     const int rhs = P.rhs, lim = rhs - 1;
     for (int i = threadIdx.x; i < rhs; i += blockDim.x) { P.rowcnt[i] = 0; P.colcnt[i] = 0; }
@@ -309,59 +252,16 @@ template <class S, int RT> __device__ __forceinline__ int sm_solve(Small<S> & P,
     __syncthreads();
     unsigned done = 0;
     const bool fast = rhs <= 128 && P.R <= 64;
-    // register-resident loop: the column strip must fit the workgroup and the rows RT registers
-    const int CW = P.W > 64 ? 128 : 64;
-    const bool in_regs = RT == 64 ? (blockDim.x == 64 && P.R <= 32 && P.W <= 128)
-                                  : (RT > 0 && fast && P.W <= CW && blockDim.x == 256 &&
-                                     (P.R + (int)blockDim.x / CW - 1) / ((int)blockDim.x / CW) <= RT);
     while (done < max_iter) {
-        if (in_regs) {
-            // returns for the optimum check / findPivotNVandBVPair (generic code below, on the LDS
-            // tableau it has just written back) or with the budget spent
-            extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
-            int * d = (int *)lds_dyn;
-            if (threadIdx.x == 0) {
-                const unsigned char * base = lds_dyn;
-                d[RL_TAB] = (int)((const unsigned char *)P.tab - base); d[RL_OBJ] = (int)((const unsigned char *)P.obj - base);
-                d[RL_E] = (int)((const unsigned char *)P.e - base); d[RL_K] = (int)((const unsigned char *)P.k - base);
-                d[RL_X] = (int)((const unsigned char *)P.x - base); d[RL_NV] = (int)((const unsigned char *)P.nv - base);
-                d[RL_BV] = (int)((const unsigned char *)P.bv - base); d[RL_BV2EQ] = (int)((const unsigned char *)P.bv2eq - base);
-                d[RL_EQ2BV] = (int)((const unsigned char *)P.eq2bv - base); d[RL_PPT] = (int)((const unsigned char *)P.ppt - base);
-                d[RL_ROWCNT] = (int)((const unsigned char *)P.rowcnt - base);
-                d[RL_COLCNT] = (int)((const unsigned char *)P.colcnt - base);
-                d[RL_SHC] = (int)((const unsigned char *)P.sh_c - base); d[RL_SHW] = (int)((const unsigned char *)P.sh_w - base);
-                d[RL_R] = P.R; d[RL_W] = P.W; d[RL_LD] = P.ld; d[RL_RHS] = P.rhs; d[RL_PW] = P.pw;
-                d[RL_DONE] = (int)done; d[RL_CLOSES] = 0; d[RL_MAXITER] = (int)max_iter; d[RL_CW] = CW;
-            }
-            __syncthreads();
-            const int act = sm_reg_loop_call<S, (RT > 0 ? RT : 8)>();
-            const unsigned done_now = (unsigned)d[RL_DONE];
-            P.pivots += done_now - done;
-            P.closes += (unsigned)d[RL_CLOSES];
-            done = done_now;
-            __syncthreads();                           // the descriptor is rewritten on the next entry
-            if (act == ACT_BUDGET) break;
-        } else if (fast) {
-#ifdef XPG_EXP_STAMPS        /* diagnostic build only: where does a pivot's time go (cycles via s_memtime) */
-            const long long t0 = clock64();
-            if (threadIdx.x < 64) sm_select_wave0(P);
-            const long long t1 = clock64();
-            __syncthreads();
-            const long long t2 = clock64();
-            P.t_sel += t1 - t0; P.t_b1 += t2 - t1;
-#else
+        if (fast) {
             if (threadIdx.x < 64) sm_select_wave0(P);
             __syncthreads();
-#endif
             const int action = P.sh_w[0];
             if (action == ACT_PIVOT) {
                 const int enter_f = P.sh_w[1], leave_f = P.sh_w[2];
                 const S * park = (const S *)P.sh_c;
                 const S piv = park[0], cnv = park[1];
                 sm_pivot_fast(P, enter_f, leave_f, P.sh_w[3], piv, cnv);
-#ifdef XPG_EXP_STAMPS
-                P.t_piv += clock64() - t2;
-#endif
                 done++;
                 continue;
             }
@@ -498,7 +398,7 @@ template <class S> __device__ __forceinline__ void sm_build(Small<S> & P, const 
 // SIX::constructBasicFeasibleSolution (lpsol.h:839-988). Returns 1 when a
 // feasible slack form stands in P, 0 when there is none, -7 where the
 // reference's behaviour is undefined.
-template <class S, int RT> __device__ __forceinline__ int sm_phase_one(Small<S> & P, const Source<S> & src, unsigned max_iter)
+template <class S> __device__ __forceinline__ int sm_phase_one(Small<S> & P, const Source<S> & src, unsigned max_iter)
 {
     const int V = src.vars(), xa = V;
     sm_build(P, src, 1);
@@ -510,7 +410,7 @@ template <class S, int RT> __device__ __forceinline__ int sm_phase_one(Small<S> 
     best = block_argmin(best, P.sh_c);
     sm_pivot(P, xa, P.eq2bv[best.idx]);
     S top;
-    if (sm_solve<S, RT>(P, max_iter, top) != 0) return 0;
+    if (sm_solve<S>(P, max_iter, top) != 0) return 0;
     reduce(top);
     if (ne(top, zero<S>())) return 0;
     if (P.bv[xa]) {
@@ -591,10 +491,9 @@ template <class S, int RT> __device__ __forceinline__ int sm_phase_one(Small<S> 
 template <class S> __host__ __device__ inline size_t small_lds_bytes(int R, int V)
 {
     const int Wmax = V + 1 + R + 1, nmax = Wmax - 1, pw = (nmax + 31) / 32;
-    size_t b = RL_WORDS * 4;              // descriptor of the register-resident loop, at offset 0
-    b += (size_t)R * Wmax * 8;            // tab
+    size_t b = (size_t)R * Wmax * 8;      // tab
     b += (size_t)Wmax * 8 * 3;            // obj, e, x
-    b += (size_t)(((R + 1) & ~1) > 136 ? ((R + 1) & ~1) : 136) * 8;   // k (padded for the register loop)
+    b += (size_t)((R + 1) & ~1) * 8;      // k
     b += 16 * sizeof(Cand<S>);            // sh_c
     b += (size_t)nmax * 4 * 3;            // bv2eq, rowcnt, colcnt
     b += (size_t)R * 4;                   // eq2bv
@@ -604,8 +503,7 @@ template <class S> __host__ __device__ inline size_t small_lds_bytes(int R, int 
     return (b + 15) & ~(size_t)15;
 }
 
-// RT: rows per thread of the register-resident loop (0: LDS-resident loop only), chosen by the host per shape.
-template <class S, int RT> __global__ __launch_bounds__(RT == 64 ? 64 : 256, RT == 64 ? 1 : 4) void k_batch(int nb, const S * tgtf, const S * leq, int m, int cols,
+template <class S> __global__ __launch_bounds__(256, 4) void k_batch(int nb, const S * tgtf, const S * leq, int m, int cols,
                                            int is_max, unsigned max_iter, int32_t * out_status,
                                            S * out_v, S * out_sol, uint32_t * out_pivots, int raw_sol)
 {
@@ -616,13 +514,12 @@ template <class S, int RT> __global__ __launch_bounds__(RT == 64 ? 64 : 256, RT 
     const int R = is_max ? m : n, V = is_max ? n : m;
     const int Wmax = V + 1 + R + 1, nmax = Wmax - 1;
     Small<S> P;
-    unsigned char * p = lds + RL_WORDS * 4;
+    unsigned char * p = lds;
     P.tab = (S *)p; p += (size_t)R * Wmax * 8;
     P.obj = (S *)p; p += (size_t)Wmax * 8;
     P.e = (S *)p; p += (size_t)Wmax * 8;
     P.x = (S *)p; p += (size_t)Wmax * 8;
-    const int kcap = RT > 0 ? 136 : ((R + 1) & ~1);       // register loop: zero-padded to G*RT rows
-    P.k = (S *)p; p += (size_t)(kcap > ((R + 1) & ~1) ? kcap : ((R + 1) & ~1)) * 8;
+    P.k = (S *)p; p += (size_t)((R + 1) & ~1) * 8;
     P.sh_c = (Cand<S> *)p; p += 16 * sizeof(Cand<S>);
     P.bv2eq = (int *)p; p += (size_t)nmax * 4;
     P.rowcnt = (int *)p; p += (size_t)nmax * 4;
@@ -640,11 +537,6 @@ template <class S, int RT> __global__ __launch_bounds__(RT == 64 ? 64 : 256, RT 
         src.leq = leq + (size_t)lp * m * cols; src.tgtf = tgtf + (size_t)lp * cols;
         src.m = m; src.cols = cols; src.is_max = is_max;
         P.pivots = 0; P.closes = 0;
-        if (RT > 0) for (int i = threadIdx.x; i < 136; i += blockDim.x) P.k[i] = zero<S>();
-#ifdef XPG_EXP_STAMPS
-        P.t_sel = P.t_b1 = P.t_piv = P.t_stage = 0;
-        if (threadIdx.x < 10) ((int *)lds)[32 + threadIdx.x] = 0;
-#endif
         __syncthreads();
         // stage1 trigger (lpsol.h:1794-1803)
         if (threadIdx.x == 0) { P.sh_w[3] = 0; P.sh_w[4] = 0; }
@@ -656,14 +548,14 @@ template <class S, int RT> __global__ __launch_bounds__(RT == 64 ? 64 : 256, RT 
         __syncthreads();
         int status = -1;
         if (phase1) {
-            const int ok = sm_phase_one<S, RT>(P, src, max_iter);
+            const int ok = sm_phase_one<S>(P, src, max_iter);
             if (ok == 0) status = 2;
             else if (ok < 0) status = XPG_ERR_REF_UNDEFINED;
         } else {
             sm_build(P, src, 0);
         }
         S top = zero<S>();
-        if (status == -1) status = sm_solve<S, RT>(P, max_iter, top);
+        if (status == -1) status = sm_solve<S>(P, max_iter, top);
         // SIX::calcFinalSolution (lpsol.h:1851-1899) / minm read-out (lpsol.h:1713-1716)
         if (status == 0) {
             S * sol = out_sol + (size_t)lp * cols;
@@ -685,18 +577,6 @@ template <class S, int RT> __global__ __launch_bounds__(RT == 64 ? 64 : 256, RT 
         } else if (threadIdx.x == 0) {
             out_v[lp] = zero<S>();
         }
-#ifdef XPG_EXP_STAMPS
-        if (threadIdx.x < 10) {          // register loop: phase cycles / 16 of waves 0 and 3
-            S * dbg = out_sol + (size_t)lp * cols + 32 + threadIdx.x;
-            const double v1 = 16.0 * (double)((int *)lds)[32 + threadIdx.x];
-            __builtin_memcpy(dbg, &v1, 8);
-        }
-        if ((threadIdx.x & 63) == 0) {   // per wave: cycles in selection, barrier-1 wait, pivot, staging part of it
-            S * dbg = out_sol + (size_t)lp * cols + 8 * (threadIdx.x >> 6);
-            double v4[4] = { (double)P.t_sel, (double)P.t_b1, (double)P.t_piv, (double)P.t_stage };
-            for (int q = 0; q < 4; q++) __builtin_memcpy(&dbg[q], &v4[q], 8);
-        }
-#endif
         if (threadIdx.x == 0) {
             out_status[lp] = status;
             if (out_pivots) out_pivots[lp] = getenv_closes ? P.closes : P.pivots;
@@ -722,41 +602,12 @@ int batch_dev(xpg_ctx * ctx, int is_max, int nb, const S * tgtf, const S * leq, 
     int threads = cells >= 2048 ? 256 : (cells >= 1024 ? 128 : 64);
     if (const char * c = getenv("XPG_BATCH_COUNT_CLOSES")) { if (c[0] == '1') raw_sol |= 2; }   // profiling aid
     if (const char * t = getenv("XPG_BATCH_THREADS")) { const int v = atoi(t); if (v >= 64 && v <= 256 && v % 64 == 0) threads = v; }
-    // Register-resident pivot loops (batch_regloop.hip.h, batch_waveloop.hip.h) are opt-in A/B variants:
-    //   XPG_BATCH_REGS=m  four wavefronts per LP, RT rows per thread in registers
-    //   XPG_BATCH_REGS=w  one wavefront per LP, 32 rows x 2 columns per lane
-    // Measured on MI355X, 8192 LPs of 32x64 (LPs/s, dense family / dependence-test-like family):
-    //   LDS-resident loop (default) 127 k / 28.7 k;  m: 166 k / 24.5 k;  w: 117 k / 24.5 k.
-    // The loop is a latency chain of ~700 dependent instructions per pivot either way; the default is
-    // what is best on the dependence-test-like family, which is the workload this kernel exists for.
-    int rt = 0;
-    {
-        const int Wmax = V + 1 + R + 1, CW = Wmax > 64 ? 128 : 64;
-        const char * sel = getenv("XPG_BATCH_REGS");
-        if (sel && sel[0] == 'w' && Wmax <= 128 && R <= 32) {
-            threads = 64; rt = 64;
-        } else if (sel && sel[0] == 'm' && Wmax <= 128 && R <= 64 && threads == 256) {
-            const int G = threads / CW, need = (R + G - 1) / G;          // widest tableau: phase 1
-            rt = need <= 8 ? 8 : (need <= 16 ? 16 : 0);                  // 32 rows per thread would spill
-        }
-    }
     const int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
     int grid = 256 * (per_cu > 16 ? 16 : per_cu) * 4;
     if (grid > nb) grid = nb;
-#define XPG_BATCH_LAUNCH(RT_)                                                                                   \
-    do {                                                                                                        \
-        XPG_HIP(ctx, hipFuncSetAttribute((const void *)k_batch<S, RT_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                         (int)lds));                                                            \
-        hipLaunchKernelGGL((k_batch<S, RT_>), dim3(grid), dim3(threads), lds, ctx->stream, nb, tgtf, leq, m,    \
-                           cols, is_max ? 1 : 0, max_iter, out_status, out_v, out_sol, out_pivots, raw_sol);   \
-    } while (0)
-    switch (rt) {
-    case 8: XPG_BATCH_LAUNCH(8); break;
-    case 16: XPG_BATCH_LAUNCH(16); break;
-    case 64: XPG_BATCH_LAUNCH(64); break;
-    default: XPG_BATCH_LAUNCH(0); break;
-    }
-#undef XPG_BATCH_LAUNCH
+    XPG_HIP(ctx, hipFuncSetAttribute((const void *)k_batch<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_batch<S>), dim3(grid), dim3(threads), lds, ctx->stream, nb, tgtf, leq, m, cols,
+                       is_max ? 1 : 0, max_iter, out_status, out_v, out_sol, out_pivots, raw_sol);
     XPG_HIP(ctx, hipGetLastError());
     return 0;
 }

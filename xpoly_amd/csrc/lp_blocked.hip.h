@@ -44,6 +44,18 @@
 
 namespace xpg {
 
+// Diagnostic builds (-DXPG_STAMPS, tools/run_stamps.sh): 100 MHz ticks between points of pick / prep, summed by
+// workgroup 0 lane 0 into LoopState::blk.dbg (a full memory wait precedes every stamp).
+#ifdef XPG_STAMPS
+#define XPG_STAMP_DECL unsigned long long stamp_prev_ = wall_clock64()
+#define XPG_STAMP(st_, slot_) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+        const unsigned long long now_ = wall_clock64(); \
+        if (blockIdx.x == 0 && threadIdx.x == 0) (st_)->blk.dbg[slot_] += now_ - stamp_prev_; stamp_prev_ = now_; } while (0)
+#else
+#define XPG_STAMP_DECL do { } while (0)
+#define XPG_STAMP(st_, slot_) do { } while (0)
+#endif
+
 __device__ __forceinline__ unsigned blk_epoch(int batch, int t) { return (((unsigned)batch << 5) | (unsigned)t) + 1u; }
 
 __device__ __forceinline__ unsigned long long shfl_u64(unsigned long long x, int src)
@@ -52,27 +64,8 @@ __device__ __forceinline__ unsigned long long shfl_u64(unsigned long long x, int
     return ((unsigned long long)hi << 32) | lo;
 }
 
-// Loads of anything another workgroup of the SAME launch may have written (the chain kernel, XW): an
-// agent-scope relaxed atomic load, i.e. a load that bypasses this CU's vector L1. Plain otherwise.
-template <bool XW, class T> __device__ __forceinline__ T ldx(const T * p)
-{
-    if constexpr (!XW) return *p;
-    else if constexpr (sizeof(T) == 1) {
-        return (T)__hip_atomic_load((const unsigned char *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else if constexpr (sizeof(T) == 4) {
-        const unsigned u = __hip_atomic_load((const unsigned *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        T r; __builtin_memcpy(&r, &u, 4); return r;
-    } else {
-        static_assert(sizeof(T) == 8, "4- or 8-byte objects");
-        const unsigned long long u = __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        T r; __builtin_memcpy(&r, &u, 8); return r;
-    }
-}
-#define XLD(lvalue) ldx<XW>(&(lvalue))
-
 // The look-ahead the last prep left: every wave reduces the partials itself (one load round).
 struct BlkLook { int first; int anypos; };
-template <bool XW>
 __device__ __forceinline__ BlkLook blk_lookahead(const LpView<F64> & v, unsigned want_epoch, int nparts)
 {
     const int lane = threadIdx.x & 63;
@@ -80,9 +73,9 @@ __device__ __forceinline__ BlkLook blk_lookahead(const LpView<F64> & v, unsigned
     unsigned long long key = 0;
     for (int k = lane; k < nparts; k += 64) {
         const int * P = v.blkP + (size_t)k * BLK_PART_INTS;
-        const bool ok = (unsigned)XLD(P[4]) == want_epoch;
-        const int pn = XLD(P[0]), pa = XLD(P[1]);
-        const unsigned long long pk = ((unsigned long long)(unsigned)XLD(P[3]) << 32) | (unsigned)XLD(P[2]);
+        const bool ok = (unsigned)P[4] == want_epoch;
+        const int pn = P[0], pa = P[1];
+        const unsigned long long pk = ((unsigned long long)(unsigned)P[3] << 32) | (unsigned)P[2];
         if (ok) { nf = min(nf, pn); any |= pa; key = pk > key ? pk : key; }
     }
     for (int o = 32; o > 0; o >>= 1) { nf = min(nf, __shfl_xor(nf, o)); any |= __shfl_xor(any, o); }
@@ -97,32 +90,33 @@ __device__ __forceinline__ BlkLook blk_lookahead(const LpView<F64> & v, unsigned
 // p of N: this workgroup's share of the rows (p >= N: no rows -- a prep-only worker of the chain kernel,
 // which still needs the decision). Returns whether the fast path ran; the answer is the same in every
 // workgroup, because it depends on the committed state and the look-ahead partials only.
-template <bool XW>
 __device__ __forceinline__ bool blk_pick_body(const LpView<F64> & v, int batch, int t, int nparts, int p, int N,
                                               Cand<F64> * sh_c)
 {
     LoopState * st = v.st;
-    const int status = XLD(st->status);
-    const int bb = XLD(st->blk.batch), bn = XLD(st->blk.n), bclosed = XLD(st->blk.closed), want_generic = XLD(st->blk.want_generic);
-    const int la_state = XLD(st->blk.la_from_state);
-    const unsigned la_epoch = XLD(st->blk.la_epoch);
-    const unsigned budget = XLD(st->blk.budget), done = XLD(st->done), max_iter = XLD(st->max_iter);
-    const int sfirst = XLD(st->next_first);
+    XPG_STAMP_DECL;
+    const int status = st->status;
+    const int bb = st->blk.batch, bn = st->blk.n, bclosed = st->blk.closed, want_generic = st->blk.want_generic;
+    const int la_state = st->blk.la_from_state;
+    const unsigned la_epoch = st->blk.la_epoch;
+    const unsigned budget = st->blk.budget, done = st->done, max_iter = st->max_iter;
+    const int sfirst = st->next_first;
     int rs[BLK_MAX];
 #pragma unroll
-    for (int s = 0; s < BLK_MAX; s++) rs[s] = XLD(st->blk.r[s]);
+    for (int s = 0; s < BLK_MAX; s++) rs[s] = st->blk.r[s];
     const int tid = threadIdx.x;
     // in the same round as the state: the look-ahead partials, and what this thread's first row needs
     // that does not depend on the entering column
-    const BlkLook look = blk_lookahead<XW>(v, la_epoch, nparts);
+    const BlkLook look = blk_lookahead(v, la_epoch, nparts);
     const int tpb = (int)blockDim.x;                    // 64 (one wave, no LDS round in the reduction) or 256
     const int i_pre = p * tpb + tid;
     const int i_clamped = i_pre < v.m ? i_pre : 0;
-    const int bi_pre = XLD(v.eq2bv[i_clamped]);
+    const int bi_pre = v.eq2bv[i_clamped];
     double k_pre[BLK_MAX];
 #pragma unroll
-    for (int s = 0; s < BLK_MAX; s++) k_pre[s] = s < t ? XLD(((const double *)v.blkK)[(size_t)i_clamped * BLK_MAX + s]) : 0.0;
+    for (int s = 0; s < BLK_MAX; s++) k_pre[s] = s < t ? ((const double *)v.blkK)[(size_t)i_clamped * BLK_MAX + s] : 0.0;
     const int n = (bb == batch) ? bn : 0;
+    XPG_STAMP(st, 0);                                   // state + partials (reduced) + this thread's eq2bv / K row
     if (status != ST_RUNNING || (bb == batch && bclosed) || n != t || budget == 0) return false;
     int first = sfirst;
     if (!la_state) first = look.first;
@@ -145,10 +139,10 @@ __device__ __forceinline__ bool blk_pick_body(const LpView<F64> & v, int batch, 
     double ec[BLK_MAX], eb[BLK_MAX];                            // e_s[first], e_s[rhs]: wave-uniform loads
 #pragma unroll
     for (int s = 0; s < BLK_MAX; s++) {
-        ec[s] = s < n ? XLD(E[(size_t)s * ld + first]) : 0.0;
-        eb[s] = s < n ? XLD(E[(size_t)s * ld + rhs]) : 0.0;
+        ec[s] = s < n ? E[(size_t)s * ld + first] : 0.0;
+        eb[s] = s < n ? E[(size_t)s * ld + rhs] : 0.0;
     }
-    const unsigned long long cnv_bits = to_bits(XLD(v.obj[first]));
+    const unsigned long long cnv_bits = to_bits(v.obj[first]);
     // fused pass over this workgroup's rows: replayed entering column (its negation staged as k_t),
     // replayed constant column, first pass of the ratio test
     Cand<F64> best; best.q = zero<F64>(); best.idx = INT_MAX;
@@ -157,22 +151,23 @@ __device__ __forceinline__ bool blk_pick_body(const LpView<F64> & v, int batch, 
         // eq2bv and the blkK row of this thread's first row were loaded with the state (they do not depend
         // on the entering column): everything that does goes out in ONE further round
         const bool pre = i == i_pre;
-        const int bi = pre ? bi_pre : XLD(v.eq2bv[i]);
+        const int bi = pre ? bi_pre : v.eq2bv[i];
         const double x0 = tab[(size_t)i * ld + first], b0 = tab[(size_t)i * ld + rhs];
-        const uint32_t w = XLD(v.ppt[(size_t)first * v.pw + (bi >> 5)]);
-        const int cc = XLD(v.colcnt[bi]);
+        const uint32_t w = v.ppt[(size_t)first * v.pw + (bi >> 5)];
+        const int cc = v.colcnt[bi];
         const double * kr = K + (size_t)i * BLK_MAX;
         double a = x0, bc = b0;
 #pragma unroll
         for (int s = 0; s < BLK_MAX; s++) {
             if (s < n) {
-                const double k = pre ? k_pre[s] : XLD(kr[s]);
+                const double k = pre ? k_pre[s] : kr[s];
                 const double pa = k * ec[s], pb = k * eb[s];
                 a = (i == rs[s]) ? ec[s] : (a + pa);
                 bc = (i == rs[s]) ? eb[s] : (bc + pb);
             }
         }
         K[(size_t)i * BLK_MAX + n] = -a;                                  // -a_i,nv (lpsol.h:1485)
+        XPG_STAMP(st, 1);                               // round 2 (column gathers, E, pair word, counter) + replay
         if (le(F64(a), zero<F64>())) continue;                            // findPivotBV, lpsol.h:553-663
         if (((w >> (bi & 31)) & 1u) || cc >= lim) continue;
         Cand<F64> c; c.q = div(F64(bc), F64(a)); c.idx = i;
@@ -180,7 +175,9 @@ __device__ __forceinline__ bool blk_pick_body(const LpView<F64> & v, int batch, 
         if (nbest.idx != best.idx) { best_a = a; best_b = bi; best_cc = cc; best_w = w; }
         best = nbest;
     }
+    XPG_STAMP(st, 2);                                   // division + candidate
     const Cand<F64> wbest = block_argmin(best, sh_c);
+    XPG_STAMP(st, 3);                                   // arg-min
     const bool publisher = wbest.idx != INT_MAX ? (best.idx == wbest.idx) : (tid == 0);
     if (publisher) {
         unsigned long long * rec = v.blkR + (size_t)p * BLK_REC_WORDS;
@@ -198,7 +195,7 @@ __device__ __forceinline__ bool blk_pick_body(const LpView<F64> & v, int batch, 
 __global__ __launch_bounds__(256) void k_blk_pick(LpView<F64> v, int batch, int t, int nparts)
 {
     __shared__ __attribute__((aligned(8))) unsigned char sh_c_raw[16 * sizeof(Cand<F64>)];
-    (void)blk_pick_body<false>(v, batch, t, nparts, (int)blockIdx.x, (int)gridDim.x, (Cand<F64> *)sh_c_raw);
+    (void)blk_pick_body(v, batch, t, nparts, (int)blockIdx.x, (int)gridDim.x, (Cand<F64> *)sh_c_raw);
 }
 
 // ---- the generic pick, only when pick(0) of this batch asked for it ------------------------------
@@ -224,7 +221,7 @@ __global__ __launch_bounds__(1024) void k_blk_pick_generic(LpView<F64> v, int ba
     const unsigned la_epoch = st->blk.la_epoch;
     if (!la_state) {
         if (threadIdx.x < 64) {
-            const BlkLook L = blk_lookahead<false>(v, la_epoch, nparts);
+            const BlkLook L = blk_lookahead(v, la_epoch, nparts);
             if (threadIdx.x == 0) { sh_la[0] = L.first; sh_la[1] = L.anypos; }
         }
         __syncthreads();
@@ -248,29 +245,29 @@ __global__ __launch_bounds__(1024) void k_blk_pick_generic(LpView<F64> v, int ba
 // ---- prep(t): combine the pick's records, replayed pivot row -> e_t, objective row, pricing --------
 // p of nwork workgroups of 256 threads. Returns whether a pivot was staged (the same answer in every
 // workgroup: it depends on the committed state and the pick's records only).
-template <bool XW>
 __device__ __forceinline__ bool blk_prep_body(const LpView<F64> & v, int batch, int t, int p, int nwork)
 {
     __shared__ int sh_nf[4], sh_any[4];
     __shared__ unsigned long long sh_key[4];
     LoopState * st = v.st;
-    const int status = XLD(st->status), pricing = XLD(st->pricing);
-    const int bb = XLD(st->blk.batch), bn = XLD(st->blk.n), from_generic = XLD(st->blk.from_generic);
-    const int srow = XLD(st->row), scol = XLD(st->col), sleave = XLD(st->leave);
-    const unsigned long long spiv = XLD(st->piv_bits), scnv = XLD(st->cnv_bits);
-    const unsigned budget = XLD(st->blk.budget), done = XLD(st->done), tp = XLD(st->total_pivots);
+    XPG_STAMP_DECL;
+    const int status = st->status, pricing = st->pricing;
+    const int bb = st->blk.batch, bn = st->blk.n, from_generic = st->blk.from_generic;
+    const int srow = st->row, scol = st->col, sleave = st->leave;
+    const unsigned long long spiv = st->piv_bits, scnv = st->cnv_bits;
+    const unsigned budget = st->blk.budget, done = st->done, tp = st->total_pivots;
     int rs[BLK_MAX];
 #pragma unroll
-    for (int s = 0; s < BLK_MAX; s++) rs[s] = XLD(st->blk.r[s]);
+    for (int s = 0; s < BLK_MAX; s++) rs[s] = st->blk.r[s];
     const int gid = p * (int)blockDim.x + (int)threadIdx.x, gsz = nwork * (int)blockDim.x;
     // in the same round as the state and the records: everything of this thread's first column that does
     // not depend on the pivot row
     const int j_pre = gid < v.W ? gid : 0;
-    const F64 obj_pre = XLD(v.obj[j_pre]);
-    const int nv_pre = XLD(v.nv[j_pre < v.rhs ? j_pre : 0]), rc_pre = XLD(v.rowcnt[j_pre < v.rhs ? j_pre : 0]);
+    const F64 obj_pre = v.obj[j_pre];
+    const int nv_pre = v.nv[j_pre < v.rhs ? j_pre : 0], rc_pre = v.rowcnt[j_pre < v.rhs ? j_pre : 0];
     double e_pre[BLK_MAX];
 #pragma unroll
-    for (int q = 0; q < BLK_MAX; q++) e_pre[q] = q < t ? XLD(((const double *)v.blkE)[(size_t)q * v.ld + j_pre]) : 0.0;
+    for (int q = 0; q < BLK_MAX; q++) e_pre[q] = q < t ? ((const double *)v.blkE)[(size_t)q * v.ld + j_pre] : 0.0;
     const unsigned epoch = blk_epoch(batch, t);
     int r, enter, leave, g_cc = 0; uint32_t g_w = 0;
     unsigned long long piv_bits, cnv_bits;
@@ -286,8 +283,8 @@ __device__ __forceinline__ bool blk_prep_body(const LpView<F64> & v, int batch, 
         bool valid = false;
         if (lane < BLK_PICK_WGS) {
             const unsigned long long * rk = v.blkR + (size_t)lane * BLK_REC_WORDS;
-            w0 = XLD(rk[0]); w1 = XLD(rk[1]); w2 = XLD(rk[2]); w3 = XLD(rk[3]); w4 = XLD(rk[4]); w5 = XLD(rk[5]);
-            valid = (unsigned)XLD(rk[6]) == epoch;
+            w0 = rk[0]; w1 = rk[1]; w2 = rk[2]; w3 = rk[3]; w4 = rk[4]; w5 = rk[5];
+            valid = (unsigned)rk[6] == epoch;
         }
         const unsigned long long vmask = __ballot(valid);
         any_rec = vmask != 0;
@@ -309,6 +306,7 @@ __device__ __forceinline__ bool blk_prep_body(const LpView<F64> & v, int batch, 
             }
         }
     }
+    XPG_STAMP(st, 4);                                   // state + records (combined) + this thread's obj / nv / rowcnt / E column
     if (status != ST_RUNNING) return false;
     if (any_rec) {
         if (g.idx == INT_MAX) {                                // first pass empty: second pass / disableNV are generic
@@ -328,12 +326,12 @@ __device__ __forceinline__ bool blk_prep_body(const LpView<F64> & v, int batch, 
     const int n = t, W = v.W, rhs = v.rhs, ld = v.ld, m = v.m, lim = v.rhs - 1;
     // what the committing thread needs of the pair table goes out with the pivot row (one round fewer on
     // the thread every other workgroup ends up waiting for)
-    const int rc_enter = XLD(v.rowcnt[(unsigned)enter < (unsigned)rhs ? enter : 0]);
+    const int rc_enter = v.rowcnt[(unsigned)enter < (unsigned)rhs ? enter : 0];
     double * __restrict__ K = (double *)v.blkK;
     double * __restrict__ E = (double *)v.blkE;
     double kq[BLK_MAX];                                        // k_q[r]: wave-uniform loads
 #pragma unroll
-    for (int q = 0; q < BLK_MAX; q++) kq[q] = q < n ? XLD(K[(size_t)r * BLK_MAX + q]) : 0.0;
+    for (int q = 0; q < BLK_MAX; q++) kq[q] = q < n ? K[(size_t)r * BLK_MAX + q] : 0.0;
     const F64 s = div(one<F64>(), from_bits<F64>(piv_bits));  // 1/(eq.get(eqnum, nv)), lpsol.h:1471
     const int smode = scale_mode(s);
     const F64 cnv = from_bits<F64>(cnv_bits);
@@ -344,18 +342,18 @@ __device__ __forceinline__ bool blk_prep_body(const LpView<F64> & v, int batch, 
     for (int j = gid; j < W; j += gsz) {
         const bool pre = j == j_pre;                           // this thread's first column: loaded with the state
         double x = ((const double *)v.tab)[(size_t)r * ld + j];
-        F64 oj = pre ? obj_pre : XLD(v.obj[j]);
+        F64 oj = pre ? obj_pre : v.obj[j];
         // the basis before and after this pivot's swap, without using the two entries the committing
         // thread rewrites (the generic pick has swapped already)
         const bool in = j < rhs;
-        const bool nv_mem = in && j != enter && j != leave && (pre ? nv_pre : (int)XLD(v.nv[j])) != 0;
+        const bool nv_mem = in && j != enter && j != leave && (pre ? nv_pre : (int)v.nv[j]) != 0;
         const bool nv_old = in && (j == enter ? true : (j == leave ? false : nv_mem));
         const bool nv_new = in && (j == enter ? false : (j == leave ? true : nv_mem));
-        const int rcj = (in && j != enter) ? (pre ? rc_pre : XLD(v.rowcnt[j])) : INT_MAX;
+        const int rcj = (in && j != enter) ? (pre ? rc_pre : v.rowcnt[j]) : INT_MAX;
 #pragma unroll
         for (int q = 0; q < BLK_MAX; q++) {                    // the pivot row as the pending sweeps would leave it
             if (q < n) {
-                const double e_q = pre ? e_pre[q] : XLD(E[(size_t)q * ld + j]);
+                const double e_q = pre ? e_pre[q] : E[(size_t)q * ld + j];
                 const double pr = kq[q] * e_q;
                 x = (r == rs[q]) ? e_q : (x + pr);
             }
@@ -370,6 +368,7 @@ __device__ __forceinline__ bool blk_prep_body(const LpView<F64> & v, int batch, 
         if (!generic_pivot && j < enter && in && !nv_old) oj = zero<F64>();
         const F64 o = add(tt, oj);                             // addRowToRow, :1501
         v.obj[j] = o;
+        XPG_STAMP(st, 5);                               // round 2 (pivot row gather, K row of r) + replay + objective
         if (nv_new && gt(o, zero<F64>())) {                    // look-ahead pricing of the next pivot
             any = 1;
             if (rcj < lim) {
@@ -391,6 +390,7 @@ __device__ __forceinline__ bool blk_prep_body(const LpView<F64> & v, int batch, 
     // -column from the generic pick's colbuf when it chose this pivot
     if (generic_pivot)
         for (int i = gid; i < m; i += gsz) K[(size_t)i * BLK_MAX + n] = ((const double *)v.colbuf)[i];
+    XPG_STAMP(st, 6);                                   // pricing partial
     // ---- one thread commits the pivot
     if (gid == 0) {
         if (!generic_pivot) {
@@ -412,101 +412,13 @@ __device__ __forceinline__ bool blk_prep_body(const LpView<F64> & v, int batch, 
         st->blk.la_from_state = 0;
         st->blk.la_epoch = epoch;
     }
+    XPG_STAMP(st, 7);                                   // commit
     return true;
 }
 
 __global__ __launch_bounds__(256) void k_blk_prep(LpView<F64> v, int batch, int t)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) { v.st->blk.bar = 0; v.st->blk.xcc_mask = 0; }   // for the chain kernel
-    (void)blk_prep_body<false>(v, batch, t, (int)blockIdx.x, (int)gridDim.x);
-}
-
-// ---- the chain: pick(t), prep(t) for t = t0 .. B-1 in ONE launch -----------------------------------
-// The same two bodies, separated by grid barriers instead of launch boundaries. Every worker takes the
-// same decisions -- both bodies decide from the committed state, the records and the partials, all
-// published before the barrier -- so they leave the loop together. The workers spin on each other, so all
-// must be resident at once: the host only takes this path while there is a CU per worker among the CUs
-// they can land on (nwork <= CUs / spread; the stream runs nothing else meanwhile) -- a wider tableau
-// (seen: 80 workers, 20 000 columns) takes the launch-per-stage path. A barrier that does not complete
-// within ~0.5 s puts ST_CHAIN_STUCK (= XPG_ERR_HIP for the caller) into the loop status instead of hanging.
-//
-// Two barrier flavours, chosen at run time, identically by every worker:
-//  * SAFE, any placement: agent-scope release (one L2 write-back per workgroup) -> counter -> agent-scope
-//    acquire; what a cooperative grid sync is made of. Measured: a phase + barrier costs about what a
-//    launch costs (7.5 us), because the write-back and the invalidate are ~1.7 us each.
-//  * SAME-XCD: workers are the workgroups with blockIdx.x % spread == 0; with spread = 8 they are
-//    OBSERVED to land on one XCD (workgroups are dealt round-robin), and then they share one L2, which
-//    is the coherence point of an XCD: plain stores (write-through L1, line kept in the L2), every
-//    storing wave's s_waitcnt vmcnt(0), counter, and loads that bypass the reader's L1 (ldx<true>) need
-//    no write-back and no invalidate. Placement is NOT assumed: each worker reads HW_REG_XCC_ID, the ids
-//    are OR-ed into a mask across the first (SAFE) barrier, and only a one-bit mask switches to this
-//    flavour.
-enum { ST_CHAIN_STUCK = -1 };
-__device__ __forceinline__ bool chain_barrier(unsigned * ctr, unsigned target, int * sh_ok, bool same_xcd)
-{
-    if (same_xcd) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // every wave: its stores have reached the L2
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (same_xcd) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // one L2 write-back
-        unsigned spins = 0;
-        int ok = 1;
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            if (++spins > (1u << 22)) { ok = 0; break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        *sh_ok = ok;
-    }
-    __syncthreads();
-    if (!same_xcd) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __builtin_amdgcn_s_dcache_inv();
-    return *sh_ok != 0;
-}
-
-__global__ __launch_bounds__(256) void k_blk_chain(LpView<F64> v, int batch, int t0, int B, int npick, int nwork, int spread,
-                                                   int allow_same_xcd)
-{
-    __shared__ __attribute__((aligned(8))) unsigned char sh_c_raw[16 * sizeof(Cand<F64>)];
-    __shared__ int sh_ok, sh_same;
-    if ((int)blockIdx.x % spread != 0) return;
-    const int p = (int)blockIdx.x / spread;
-    if (p >= nwork) return;
-    LoopState * st = v.st;
-    unsigned * ctr = &st->blk.bar;
-    unsigned target = 0;
-    bool same_xcd = false, asked = false;
-    if (threadIdx.x == 0) {
-        const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u;       // HW_REG_XCC_ID[3:0]
-        __hip_atomic_fetch_or(&st->blk.xcc_mask, 1u << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    const bool stamp = (allow_same_xcd & 2) != 0 && p == 0 && threadIdx.x == 0;   // XPG_CHAIN_DEBUG
-    unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 0, dn = 0;
-#pragma unroll 1
-    for (int t = t0; t < B; t++) {
-        if (stamp) { if (c0) { d3 += wall_clock64() - c3; } c0 = wall_clock64(); }
-        if (!blk_pick_body<true>(v, batch, t, nwork, p, npick, (Cand<F64> *)sh_c_raw)) break;
-        if (stamp) { c1 = wall_clock64(); d0 += c1 - c0; }
-        target += (unsigned)nwork;
-        if (!chain_barrier(ctr, target, &sh_ok, same_xcd)) { if (threadIdx.x == 0) st->status = ST_CHAIN_STUCK; break; }
-        if (stamp) { c2 = wall_clock64(); d1 += c2 - c1; }
-        if (!asked) {                                           // every worker's id is in the mask now
-            asked = true;
-            if (threadIdx.x == 0) {
-                const unsigned mask = __hip_atomic_load(&st->blk.xcc_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sh_same = (allow_same_xcd & 1) && mask != 0 && (mask & (mask - 1)) == 0;
-            }
-            __syncthreads();
-            same_xcd = sh_same != 0;
-        }
-        if (!blk_prep_body<true>(v, batch, t, p, nwork)) break;
-        if (stamp) { c3 = wall_clock64(); d2 += c3 - c2; dn++; }
-        target += (unsigned)nwork;
-        if (!chain_barrier(ctr, target, &sh_ok, same_xcd)) { if (threadIdx.x == 0) st->status = ST_CHAIN_STUCK; break; }
-    }
-    if (stamp) {
-        st->blk.dbg[0] += d0; st->blk.dbg[1] += d1; st->blk.dbg[2] += d2; st->blk.dbg[3] += d3; st->blk.dbg[4] += dn;
-    }
+    (void)blk_prep_body(v, batch, t, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ---- the sweep: every cell once, all staged pivots in order --------------------------------------
@@ -596,7 +508,7 @@ void blk_sweep_body(double * __restrict__ tab, int m, int W, int ld, const doubl
 //    s+1.. applied to it with the same two roundings per stage), and e is still in registers.
 template <int ROWS, int U> __global__ __launch_bounds__(256)
 void k_blk_sweep_full(double * __restrict__ tab, int m, int W, int ld, const double * __restrict__ E,
-                      const double * __restrict__ K, const LoopState * __restrict__ st, int batch)
+                      const double * __restrict__ K, LoopState * __restrict__ st, int batch)
 {
     constexpr int NB = BLK_MAX;
     static_assert(ROWS % (2 * U) == 0, "a row block holds whole ping-pong pairs");
@@ -613,6 +525,9 @@ void k_blk_sweep_full(double * __restrict__ tab, int m, int W, int ld, const dou
     const int status = st->status;
     const int n = (st->blk.batch == batch) ? st->blk.n : 0;
     if (status != ST_RUNNING || n == 0 || j >= W) return;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {     // xpg_lp_counters
+        if (n == NB) st->blk.sweeps_full += 1u; else st->blk.sweeps_part += 1u;
+    }
 
     if (n != NB || j + 1 >= W) {
         // A partial batch (the iteration budget ran out, or a pick closed the batch early) and the odd
@@ -719,6 +634,9 @@ void k_blk_sweep(double * __restrict__ tab, int m, int W, int ld, const double *
     const int status = st->status;
     const int n = (st->blk.batch == batch) ? st->blk.n : 0;
     if (status != ST_RUNNING || n == 0) return;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {     // xpg_lp_counters
+        if (n == BLK_MAX) st->blk.sweeps_full += 1u; else st->blk.sweeps_part += 1u;
+    }
     // only the row blocks that hold one of the pivot rows pay for the "row r := e" test per cell
     bool hasr = false;
     {

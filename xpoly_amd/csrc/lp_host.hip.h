@@ -25,10 +25,7 @@ struct xpg_ctx {
     int zigzag;             // pipelined sweep alternates its tile order (Infinity Cache reuse)
     int block_len;          // blocked loop (loop_mode 3): pivots staged per sweep, 1..16
     int loop_auto;          // XPG_LOOP unset: blocked loop where the sweep is what costs (large fp64 tableaux)
-    int chain;              // blocked loop: pick/prep of stages 1..B-1 in one launch (k_blk_chain)
-    int chain_spread;       // the chain's workers are the workgroups with blockIdx.x % spread == 0
-    int chain_same_xcd;     // allow the same-XCD barrier flavour where the workers verify they share an XCD
-    int num_cus;            // compute units of the device (bounds the chain kernel's worker count)
+    int num_cus;            // compute units of the device
     // xpg_profile_begin/end: event pairs around each sweep launch
     std::vector<hipEvent_t> ev0, ev1;
     int prof_cap, prof_n, prof_stride, prof_seen;
@@ -44,6 +41,22 @@ struct xpg_ctx {
     } while (0)
 
 namespace xpg {
+
+// Every extern "C" entry point binds the handle's device for its own duration and puts the caller's
+// current device back: allocations, function attributes and launches of a handle created on device A
+// must not land on whatever device the calling thread (or its host framework) selected last.
+struct DeviceGuard {
+    int prev = -1, mine = -1;
+    explicit DeviceGuard(int device) : mine(device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (device >= 0 && prev != device) (void)hipSetDevice(device);
+    }
+    ~DeviceGuard() { if (prev >= 0 && mine >= 0 && prev != mine) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard & operator=(const DeviceGuard &) = delete;
+};
+#define XPG_BIND(ctx_) xpg::DeviceGuard xpg_bind_guard_((ctx_) ? (ctx_)->device : -1)
 
 inline int round_up(int x, int a) { return (x + a - 1) / a * a; }
 
@@ -120,27 +133,18 @@ template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> &
     // (measured at 4096 x 8192: 58.7 k pivots/s with a 64-thread pick against 55.7 k with 256; prep +0.8 %)
     static const int tpb_pick = [] { const char * s = getenv("XPG_BLK_TPB_PICK"); return s && atoi(s) == 256 ? 256 : 64; }();
     static const int tpb_prep = [] { const char * s = getenv("XPG_BLK_TPB_PREP"); return s && atoi(s) == 256 ? 256 : 64; }();
-    // The chain kernel's workers spin on each other, so all of them must be resident at once: one per
-    // CU of the CUs they can land on (a workgroup always fits an empty CU) -- wider tableaux take the
-    // launch-per-stage path. It runs both bodies at one workgroup size.
-    const bool chain = ctx->chain && (v.W + 255) / 256 <= ctx->num_cus / ctx->chain_spread;
-    const int tpb_chain = chain ? 256 : 0;
-    const int tq = tpb_chain ? tpb_chain : tpb_prep, tp = tpb_chain ? tpb_chain : tpb_pick;
+    const int tq = tpb_prep, tp = tpb_pick;
     const int want_pick = (v.m + tp - 1) / tp;
     const int npick = want_pick < BLK_PICK_WGS ? want_pick : BLK_PICK_WGS;
     const dim3 gprep((v.W + tq - 1) / tq);
     for (int t = 0; t < B; t++) {
-        if (t == 1 && chain) {                          // stages 1 .. B-1 in one launch
-            hipLaunchKernelGGL(k_blk_chain, dim3(gprep.x * ctx->chain_spread), dim3(256), 0, ctx->stream, v, batch, 1, B,
-                               npick < (int)gprep.x ? npick : (int)gprep.x, (int)gprep.x, ctx->chain_spread,
-                               (ctx->chain_same_xcd ? 1 : 0) | (getenv("XPG_CHAIN_DEBUG") ? 2 : 0));
-            break;
-        }
         hipLaunchKernelGGL(k_blk_pick, dim3(npick), dim3(tp), 0, ctx->stream, v, batch, t, (int)gprep.x);
         if (t == 0) hipLaunchKernelGGL(k_blk_pick_generic, dim3(1), dim3(1024), 0, ctx->stream, v, batch, (int)gprep.x);
         hipLaunchKernelGGL(k_blk_prep, gprep, dim3(tq), 0, ctx->stream, v, batch, t);
     }
-    const bool timed = ctx->prof_n < ctx->prof_cap && (ctx->prof_seen++ % ctx->prof_stride) == 0;
+    // only sweeps of full-length batches are sampled by xpg_profile_begin / end (a shorter batch -- the tail
+    // of an xpg_lp_iterate budget -- moves the same bytes for fewer pivots and runs a different kernel)
+    const bool timed = B == ctx->block_len && ctx->prof_n < ctx->prof_cap && (ctx->prof_seen++ % ctx->prof_stride) == 0;
     hipEvent_t e0 = timed ? ctx->ev0[ctx->prof_n] : nullptr, e1 = timed ? ctx->ev1[ctx->prof_n] : nullptr;
     static const int rows_env = [] { const char * s = getenv("XPG_BLK_ROWS"); return s ? atoi(s) : 32; }();
 #define XPG_BLK_LAUNCH(ROWS_, UNR_, CAP_)                                                                                 \
@@ -150,7 +154,7 @@ template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> &
 #define XPG_BLK_FULL(ROWS_, UNR_)                                                                                         \
     hipExtLaunchKernelGGL((k_blk_sweep_full<ROWS_, UNR_>), dim3(strips, (v.m + ROWS_ - 1) / ROWS_), dim3(256), 0,         \
                           ctx->stream, e0, e1, 0, (double *)v.tab, v.m, v.W, v.ld, (const double *)v.blkE,                \
-                          (const double *)v.blkK, (const LoopState *)v.st, batch)
+                          (const double *)v.blkK, v.st, batch)
     if (B <= 8) XPG_BLK_LAUNCH(32, 8, 8);
     else if (B < BLK_MAX || rows_env == 1) XPG_BLK_LAUNCH(32, 4, 16);
     else if (rows_env == 324) XPG_BLK_FULL(32, 4);
@@ -352,7 +356,10 @@ template <class S> struct Lp : LpBase {
         const unsigned nb = (k + (unsigned)B - 1) / (unsigned)B;
         for (unsigned b = 0; b < nb; b++) {
             const int batch = blk_batch++;
-            launch_blk_batch(ctx, v, batch, B);
+            // the last batch of a budget that is not a multiple of B is enqueued at its own length, so its
+            // sweep is the kernel specialised for that many stages (not the full-batch kernel's slow tail)
+            const unsigned left = k - b * (unsigned)B;
+            launch_blk_batch(ctx, v, batch, left < (unsigned)B ? (int)left : B);
             if ((b & 7) == 7) {                         // throttle: at most 2 x 8 batches in flight
                 hipEvent_t e = throttle[(b >> 3) & 1];
                 if ((b >> 3) >= 2) (void)hipEventSynchronize(e);
@@ -408,12 +415,6 @@ template <class S> struct Lp : LpBase {
         LoopState hs;
         int rc = read_state(&hs);
         if (rc) return rc;
-        if (ctx->chain && getenv("XPG_CHAIN_DEBUG"))
-            fprintf(stderr, "xpoly_amd: chain kernel: XCD mask of the last batch's workers 0x%x; worker 0 per stage: "
-                    "pick %.2f us, barrier %.2f, prep %.2f, barrier %.2f (%llu stages)\n", hs.blk.xcc_mask,
-                    hs.blk.dbg[0] * 0.01 / (double)(hs.blk.dbg[4] ? hs.blk.dbg[4] : 1), hs.blk.dbg[1] * 0.01 / (double)(hs.blk.dbg[4] ? hs.blk.dbg[4] : 1),
-                    hs.blk.dbg[2] * 0.01 / (double)(hs.blk.dbg[4] ? hs.blk.dbg[4] : 1), hs.blk.dbg[3] * 0.01 / (double)(hs.blk.dbg[4] ? hs.blk.dbg[4] : 1),
-                    (unsigned long long)hs.blk.dbg[4]);
         if (hs.status == ST_RUNNING) return XPG_RUNNING;
         final_status = finish(hs.status);
         return final_status;

@@ -78,9 +78,9 @@ struct LoopState {
         int want_generic;      // a fast pick found no row in its first pass: the next batch starts generic
         int la_from_state;     // the current look-ahead is next_first / anypos (left by reset or the generic
                                // pick), not the per-workgroup partials of the last prep
-        unsigned bar;          // arrival counter of the chain kernel's grid barriers (zeroed by k_blk_prep)
-        unsigned xcc_mask;     // XCDs the chain kernel's workers found themselves on (zeroed by k_blk_prep)
-        unsigned long long dbg[5];   // XPG_CHAIN_DEBUG: 100 MHz ticks worker 0 spent in pick / barrier / prep / barrier, and phases
+        unsigned sweeps_full;  // sweeps that applied a full batch of BLK_MAX pivots (xpg_lp_counters)
+        unsigned sweeps_part;  // sweeps that applied fewer (budget ran out, or a pick closed the batch early)
+        unsigned long long dbg[8];   // diagnostic builds (-DXPG_STAMPS): 100 MHz ticks between points of pick / prep
     } blk;
 };
 enum { BLK_MAX = 16, BLK_REC_WORDS = 8, BLK_PART_INTS = 8,
@@ -1019,8 +1019,9 @@ template <class S> __global__ void k_reset_loop(LpView<S> v, unsigned max_iter, 
         st->pricing = pricing; st->pad2_ = 0; st->feas_tol = feas_tol;
         st->blk.batch = -1; st->blk.n = 0; st->blk.closed = 0; st->blk.generic = 0; st->blk.from_generic = 0;
         st->blk.budget = 0xFFFFFFFFu; st->blk.price_key = 0ull;
-        st->blk.want_generic = 0; st->blk.la_from_state = 1; st->blk.la_epoch = 0u; st->blk.bar = 0u; st->blk.xcc_mask = 0u;
-        for (int k = 0; k < 5; k++) st->blk.dbg[k] = 0ull;
+        st->blk.want_generic = 0; st->blk.la_from_state = 1; st->blk.la_epoch = 0u;
+        st->blk.sweeps_full = 0u; st->blk.sweeps_part = 0u;
+        for (int k = 0; k < 8; k++) st->blk.dbg[k] = 0ull;
         for (int k = 0; k < BLK_PICK_WGS; k++) v.blkR[(size_t)k * BLK_REC_WORDS + 6] = 0ull;       // record epochs
         for (int k = 0; k < (v.ld + BLK_TPB_MIN - 1) / BLK_TPB_MIN + 1; k++) v.blkP[(size_t)k * BLK_PART_INTS + 4] = 0;  // partial epochs
         for (int k = 0; k < 2; k++) v.pickrec[PICK_CTR_OFF + 16 * k] = 0ull;   // arrival counters

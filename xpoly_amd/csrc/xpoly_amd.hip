@@ -5,7 +5,10 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <new>
+#include <thread>
+#include <vector>
 #include "../../include/xpoly_amd.h"
 #include "scalar.hip.h"
 #include "lp_kernels.hip.h"
@@ -40,7 +43,7 @@ int xpg_create(xpg_ctx ** out, int device)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n)
         return XPG_ERR_NO_DEVICE;
-    if (hipSetDevice(device) != hipSuccess) return XPG_ERR_HIP;
+    xpg::DeviceGuard bind(device);
     xpg_ctx * c = new (std::nothrow) xpg_ctx();
     if (!c) return XPG_ERR_ALLOC;
     c->device = device;
@@ -53,15 +56,6 @@ int xpg_create(xpg_ctx ** out, int device)
     c->loop_mode = (lm && lm[0] == 's' && lm[1] == 'e') ? 1 : ((lm && lm[0] == 's' && lm[1] == 'p') ? 2 : 0);
     if (lm && lm[0] == 'b') c->loop_mode = 3;          // "block": B pivots per sweep (lp_blocked.hip.h)
     if (lm && lm[0] == 'p') c->loop_mode = 0;          // "pipe": always the pipelined loop
-    // "chain": the blocked loop with pick(1..B-1) / prep(1..B-1) of a batch in one launch (grid barriers)
-    const char * ch = getenv("XPG_CHAIN");
-    c->chain = ch ? atoi(ch) : 0;
-    if (lm && lm[0] == 'c') { c->loop_mode = 3; c->chain = 1; }
-    const char * sp = getenv("XPG_CHAIN_SPREAD");
-    c->chain_spread = sp ? atoi(sp) : 8;
-    if (c->chain_spread < 1) c->chain_spread = 1;
-    const char * sx = getenv("XPG_CHAIN_SAME_XCD");
-    c->chain_same_xcd = sx ? atoi(sx) : 1;
     c->num_cus = 0;
     if (hipDeviceGetAttribute(&c->num_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) c->num_cus = 0;
     c->loop_auto = lm ? 0 : 1;                         // unset: blocked loop for large fp64 tableaux, else pipelined
@@ -79,7 +73,7 @@ int xpg_create(xpg_ctx ** out, int device)
 void xpg_destroy(xpg_ctx * ctx)
 {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
+    XPG_BIND(ctx);
     (void)hipStreamSynchronize(ctx->stream);
     for (hipEvent_t e : ctx->ev0) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev1) (void)hipEventDestroy(e);
@@ -92,6 +86,7 @@ void xpg_destroy(xpg_ctx * ctx)
 
 int xpg_profile_begin(xpg_ctx * ctx, int cap, int stride)
 {
+    XPG_BIND(ctx);
     if (!ctx || cap < 0 || stride < 1) return XPG_ERR_SHAPE;
     XPG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     while ((int)ctx->ev0.size() < cap) {
@@ -106,6 +101,7 @@ int xpg_profile_begin(xpg_ctx * ctx, int cap, int stride)
 
 int xpg_profile_end(xpg_ctx * ctx, int * launches, double * total_ms)
 {
+    XPG_BIND(ctx);
     if (!ctx) return XPG_ERR_SHAPE;
     XPG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     double sum = 0.0;
@@ -125,26 +121,29 @@ void * xpg_stream(const xpg_ctx * ctx) { return ctx ? (void *)ctx->stream : 0; }
 
 int xpg_sync(xpg_ctx * ctx)
 {
+    XPG_BIND(ctx);
     if (!ctx) return XPG_ERR_SHAPE;
     XPG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
 int xpg_malloc(xpg_ctx * ctx, void ** dptr, size_t bytes)
 {
+    XPG_BIND(ctx);
     if (!ctx || !dptr) return XPG_ERR_SHAPE;
-    XPG_HIP(ctx, hipSetDevice(ctx->device));
     hipError_t e = hipMalloc(dptr, bytes ? bytes : 8);
     if (e != hipSuccess) { ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e); return XPG_ERR_ALLOC; }
     return 0;
 }
 int xpg_free(xpg_ctx * ctx, void * dptr)
 {
+    XPG_BIND(ctx);
     if (!ctx) return XPG_ERR_SHAPE;
     XPG_HIP(ctx, hipFree(dptr));
     return 0;
 }
 int xpg_upload(xpg_ctx * ctx, void * dst_dev, const void * src_host, size_t bytes)
 {
+    XPG_BIND(ctx);
     if (!ctx) return XPG_ERR_SHAPE;
     XPG_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
     XPG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -152,6 +151,7 @@ int xpg_upload(xpg_ctx * ctx, void * dst_dev, const void * src_host, size_t byte
 }
 int xpg_download(xpg_ctx * ctx, void * dst_host, const void * src_dev, size_t bytes)
 {
+    XPG_BIND(ctx);
     if (!ctx) return XPG_ERR_SHAPE;
     XPG_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
     XPG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -241,23 +241,27 @@ extern "C" {
 
 int xpg_pivot_f64_dev(xpg_ctx * ctx, double * tab, int m, int W, int ld, double * obj,
                       int rhs_idx, int row, int col)
-{ return pivot_dev<F64>(ctx, (F64 *)tab, m, W, ld, (F64 *)obj, rhs_idx, row, col); }
+{
+    XPG_BIND(ctx); return pivot_dev<F64>(ctx, (F64 *)tab, m, W, ld, (F64 *)obj, rhs_idx, row, col); }
 int xpg_pivot_rat32_dev(xpg_ctx * ctx, xpg_rat32 * tab, int m, int W, int ld, xpg_rat32 * obj,
                         int rhs_idx, int row, int col)
-{ return pivot_dev<R32>(ctx, (R32 *)tab, m, W, ld, (R32 *)obj, rhs_idx, row, col); }
+{
+    XPG_BIND(ctx); return pivot_dev<R32>(ctx, (R32 *)tab, m, W, ld, (R32 *)obj, rhs_idx, row, col); }
 int xpg_pivot_f64(xpg_ctx * ctx, double * tab, int m, int W, double * obj, int rhs_idx, int row, int col)
-{ return pivot_host<F64>(ctx, (F64 *)tab, m, W, (F64 *)obj, rhs_idx, row, col); }
+{
+    XPG_BIND(ctx); return pivot_host<F64>(ctx, (F64 *)tab, m, W, (F64 *)obj, rhs_idx, row, col); }
 int xpg_pivot_rat32(xpg_ctx * ctx, xpg_rat32 * tab, int m, int W, xpg_rat32 * obj, int rhs_idx, int row, int col)
-{ return pivot_host<R32>(ctx, (R32 *)tab, m, W, (R32 *)obj, rhs_idx, row, col); }
+{
+    XPG_BIND(ctx); return pivot_host<R32>(ctx, (R32 *)tab, m, W, (R32 *)obj, rhs_idx, row, col); }
 
 // ---- device-resident LP ---------------------------------------------------------------
 int xpg_lp_create(xpg_ctx * ctx, int kind, const void * leq, int m, int cols, const void * tgtf,
                   const void * vc_diag, const void * vc_rhs, int src_on_device, xpg_lp ** out)
 {
+    XPG_BIND(ctx);
     if (!ctx || !out || !leq || !tgtf || m <= 0 || cols < 2 || (kind != 0 && kind != 1))
         return XPG_ERR_SHAPE;
     *out = 0;
-    XPG_HIP(ctx, hipSetDevice(ctx->device));
     xpg_lp * h = new (std::nothrow) xpg_lp();
     if (!h) return XPG_ERR_ALLOC;
     int rc;
@@ -280,6 +284,7 @@ int xpg_lp_create(xpg_ctx * ctx, int kind, const void * leq, int m, int cols, co
 void xpg_lp_destroy(xpg_lp * lp)
 {
     if (!lp) return;
+    XPG_BIND(lp->impl ? lp->impl->ctx : (xpg_ctx *)0);
     if (lp->impl) { (void)hipStreamSynchronize(lp->impl->ctx->stream); delete lp->impl; }
     delete lp;
 }
@@ -287,6 +292,7 @@ void xpg_lp_destroy(xpg_lp * lp)
 #define XPG_DISPATCH(lp, expr)                                                   \
     do {                                                                         \
         if (!(lp) || !(lp)->impl) return XPG_ERR_SHAPE;                          \
+        XPG_BIND((lp)->impl->ctx);                                               \
         if ((lp)->impl->kind == 0) { Lp<F64> * p = (Lp<F64> *)(lp)->impl; return expr; } \
         Lp<R32> * p = (Lp<R32> *)(lp)->impl; return expr;                        \
     } while (0)
@@ -313,6 +319,7 @@ int xpg_lp_shape(xpg_lp * lp, int * rows, int * W, int * rhs_idx)
 int xpg_lp_set_options(xpg_lp * lp, int pricing, double feas_rel_tol)
 {
     if (!lp || !lp->impl) return XPG_ERR_SHAPE;
+    XPG_BIND(lp->impl->ctx);
     if (lp->impl->kind == 0) return ((Lp<F64> *)lp->impl)->set_options(pricing, feas_rel_tol);
     return ((Lp<R32> *)lp->impl)->set_options(pricing, feas_rel_tol);
 }
@@ -320,6 +327,7 @@ int xpg_lp_set_options(xpg_lp * lp, int pricing, double feas_rel_tol)
 int xpg_lp_pivots_done(xpg_lp * lp, unsigned * out)
 {
     if (!lp || !lp->impl || !out) return XPG_ERR_SHAPE;
+    XPG_BIND(lp->impl->ctx);
     LoopState hs;
     int rc;
     if (lp->impl->kind == 0) rc = ((Lp<F64> *)lp->impl)->read_state(&hs);
@@ -329,10 +337,38 @@ int xpg_lp_pivots_done(xpg_lp * lp, unsigned * out)
     return 0;
 }
 
+int xpg_lp_counters(xpg_lp * lp, unsigned * sweeps_full, unsigned * sweeps_partial)
+{
+    if (!lp || !lp->impl) return XPG_ERR_SHAPE;
+    XPG_BIND(lp->impl->ctx);
+    LoopState hs;
+    int rc;
+    if (lp->impl->kind == 0) rc = ((Lp<F64> *)lp->impl)->read_state(&hs);
+    else rc = ((Lp<R32> *)lp->impl)->read_state(&hs);
+    if (rc) return rc;
+    if (sweeps_full) *sweeps_full = hs.blk.sweeps_full;
+    if (sweeps_partial) *sweeps_partial = hs.blk.sweeps_part;
+    return 0;
+}
+
+#ifdef XPG_STAMPS
+// diagnostic builds only (not declared in the header): the phase tick sums of the blocked loop
+int xpg_lp_debug(xpg_lp * lp, unsigned long long * out8)
+{
+    if (!lp || !lp->impl || lp->impl->kind != 0) return XPG_ERR_SHAPE;
+    LoopState hs;
+    int rc = ((Lp<F64> *)lp->impl)->read_state(&hs);
+    if (rc) return rc;
+    for (int k = 0; k < 8; k++) out8[k] = hs.blk.dbg[k];
+    return 0;
+}
+#endif
+
 int xpg_lp_trace(xpg_lp * lp, int32_t * pairs, int cap_pairs, int * n_pairs)
 {
     if (!lp || !lp->impl || !n_pairs) return XPG_ERR_SHAPE;
     xpg_ctx * ctx = lp->impl->ctx;
+    XPG_BIND(ctx);
     LoopState hs;
     int rc; int * d_trace; int cap;
     if (lp->impl->kind == 0) { Lp<F64> * p = (Lp<F64> *)lp->impl; rc = p->read_state(&hs); d_trace = p->v.trace; cap = p->v.trace_cap; }
@@ -354,6 +390,7 @@ int xpg_six_maxm_f64(xpg_ctx * ctx, const double * tgtf, const double * vc, int 
                      const double * eq, int eq_rows, const double * leq, int leq_rows, int cols,
                      unsigned max_iter, double * out_v, double * out_sol)
 {
+    XPG_BIND(ctx);
     return six_solve<F64>(ctx, 0, true, (const F64 *)tgtf, (const F64 *)vc, vc_rows, (const F64 *)eq,
                           eq_rows, (const F64 *)leq, leq_rows, cols, max_iter, (F64 *)out_v, (F64 *)out_sol);
 }
@@ -361,6 +398,7 @@ int xpg_six_minm_f64(xpg_ctx * ctx, const double * tgtf, const double * vc, int 
                      const double * eq, int eq_rows, const double * leq, int leq_rows, int cols,
                      unsigned max_iter, double * out_v, double * out_sol)
 {
+    XPG_BIND(ctx);
     return six_solve<F64>(ctx, 0, false, (const F64 *)tgtf, (const F64 *)vc, vc_rows, (const F64 *)eq,
                           eq_rows, (const F64 *)leq, leq_rows, cols, max_iter, (F64 *)out_v, (F64 *)out_sol);
 }
@@ -368,6 +406,7 @@ int xpg_six_maxm_rat32(xpg_ctx * ctx, const xpg_rat32 * tgtf, const xpg_rat32 * 
                        const xpg_rat32 * eq, int eq_rows, const xpg_rat32 * leq, int leq_rows,
                        int cols, unsigned max_iter, xpg_rat32 * out_v, xpg_rat32 * out_sol)
 {
+    XPG_BIND(ctx);
     return six_solve<R32>(ctx, 1, true, (const R32 *)tgtf, (const R32 *)vc, vc_rows, (const R32 *)eq,
                           eq_rows, (const R32 *)leq, leq_rows, cols, max_iter, (R32 *)out_v, (R32 *)out_sol);
 }
@@ -375,6 +414,7 @@ int xpg_six_minm_rat32(xpg_ctx * ctx, const xpg_rat32 * tgtf, const xpg_rat32 * 
                        const xpg_rat32 * eq, int eq_rows, const xpg_rat32 * leq, int leq_rows,
                        int cols, unsigned max_iter, xpg_rat32 * out_v, xpg_rat32 * out_sol)
 {
+    XPG_BIND(ctx);
     return six_solve<R32>(ctx, 1, false, (const R32 *)tgtf, (const R32 *)vc, vc_rows, (const R32 *)eq,
                           eq_rows, (const R32 *)leq, leq_rows, cols, max_iter, (R32 *)out_v, (R32 *)out_sol);
 }
@@ -384,6 +424,7 @@ int xpg_six_batch_f64_dev(xpg_ctx * ctx, int is_max, int nb, const double * tgtf
                           int m, int cols, unsigned max_iter, int32_t * out_status, double * out_v,
                           double * out_sol, uint32_t * out_pivots)
 {
+    XPG_BIND(ctx);
     return batch_dev<F64>(ctx, is_max, nb, (const F64 *)tgtf, (const F64 *)leq, m, cols, max_iter,
                           out_status, (F64 *)out_v, (F64 *)out_sol, out_pivots);
 }
@@ -392,6 +433,7 @@ int xpg_six_batch_rat32_dev(xpg_ctx * ctx, int is_max, int nb, const xpg_rat32 *
                             int32_t * out_status, xpg_rat32 * out_v, xpg_rat32 * out_sol,
                             uint32_t * out_pivots)
 {
+    XPG_BIND(ctx);
     return batch_dev<R32>(ctx, is_max, nb, (const R32 *)tgtf, (const R32 *)leq, m, cols, max_iter,
                           out_status, (R32 *)out_v, (R32 *)out_sol, out_pivots);
 }
@@ -399,6 +441,7 @@ int xpg_six_batch_f64(xpg_ctx * ctx, int is_max, int nb, const double * tgtf, co
                       int m, int cols, unsigned max_iter, int32_t * out_status, double * out_v,
                       double * out_sol)
 {
+    XPG_BIND(ctx);
     return batch_host<F64>(ctx, is_max, nb, (const F64 *)tgtf, (const F64 *)leq, m, cols, max_iter,
                            out_status, (F64 *)out_v, (F64 *)out_sol);
 }
@@ -406,8 +449,88 @@ int xpg_six_batch_rat32(xpg_ctx * ctx, int is_max, int nb, const xpg_rat32 * tgt
                         const xpg_rat32 * leq, int m, int cols, unsigned max_iter,
                         int32_t * out_status, xpg_rat32 * out_v, xpg_rat32 * out_sol)
 {
+    XPG_BIND(ctx);
     return batch_host<R32>(ctx, is_max, nb, (const R32 *)tgtf, (const R32 *)leq, m, cols, max_iter,
                            out_status, (R32 *)out_v, (R32 *)out_sol);
+}
+
+// ---- the same batches over several devices: one context + host thread per shard ------------------
+} // extern "C"
+namespace {
+// fn(ctx, lo, hi) runs shard [lo, hi) on its own context; the first error wins.
+template <class F> int run_sharded(int ndev, const int * devices, int nb, F fn)
+{
+    if (ndev <= 0 || nb < 0) return XPG_ERR_SHAPE;
+    std::vector<int> rcs((size_t)ndev, 0);
+    std::vector<std::thread> th;
+    const int base = nb / ndev, extra = nb % ndev;
+    for (int g = 0; g < ndev; g++) {
+        const int lo = g * base + (g < extra ? g : extra), hi = lo + base + (g < extra ? 1 : 0);
+        const int dev = devices ? devices[g] : g;
+        th.emplace_back([=, &rcs] {
+            xpg_ctx * c = 0;
+            int rc = xpg_create(&c, dev);
+            if (rc == 0 && hi > lo) rc = fn(c, lo, hi);
+            if (c) xpg_destroy(c);
+            rcs[(size_t)g] = rc;
+        });
+    }
+    for (auto & t : th) t.join();
+    for (int rc : rcs) if (rc) return rc;
+    return 0;
+}
+} // namespace
+extern "C" {
+
+int xpg_six_batch_f64_multi(int ndev, const int * devices, int is_max, int nb, const double * tgtf, const double * leq,
+                            int m, int cols, unsigned max_iter, int32_t * out_status, double * out_v, double * out_sol)
+{
+    if (!tgtf || !leq || m <= 0 || cols < 2 || !out_status || !out_v || !out_sol) return XPG_ERR_SHAPE;
+    return run_sharded(ndev, devices, nb, [=](xpg_ctx * c, int lo, int hi) {
+        return xpg_six_batch_f64(c, is_max, hi - lo, tgtf + (size_t)lo * cols, leq + (size_t)lo * m * cols, m, cols, max_iter,
+                                 out_status + lo, out_v + lo, out_sol + (size_t)lo * cols);
+    });
+}
+int xpg_six_batch_rat32_multi(int ndev, const int * devices, int is_max, int nb, const xpg_rat32 * tgtf,
+                              const xpg_rat32 * leq, int m, int cols, unsigned max_iter, int32_t * out_status,
+                              xpg_rat32 * out_v, xpg_rat32 * out_sol)
+{
+    if (!tgtf || !leq || m <= 0 || cols < 2 || !out_status || !out_v || !out_sol) return XPG_ERR_SHAPE;
+    return run_sharded(ndev, devices, nb, [=](xpg_ctx * c, int lo, int hi) {
+        return xpg_six_batch_rat32(c, is_max, hi - lo, tgtf + (size_t)lo * cols, leq + (size_t)lo * m * cols, m, cols,
+                                   max_iter, out_status + lo, out_v + lo, out_sol + (size_t)lo * cols);
+    });
+}
+int xpg_mip_batch_rat32_multi(int ndev, const int * devices, int nb, int is_max, int is_bin, const xpg_rat32 * tgtf,
+                              const xpg_rat32 * leq, int leq_rows, int cols, int32_t * out_status, xpg_rat32 * out_v,
+                              xpg_rat32 * out_sol, long long * out_nodes)
+{
+    if (!tgtf || !leq || leq_rows <= 0 || cols < 2 || !out_status || !out_v || !out_sol) return XPG_ERR_SHAPE;
+    std::atomic<long long> nodes(0);
+    const int rc = run_sharded(ndev, devices, nb, [=, &nodes](xpg_ctx * c, int lo, int hi) {
+        long long n = 0;
+        const int r = xpg_mip_batch_rat32(c, hi - lo, is_max, is_bin, tgtf + (size_t)lo * cols,
+                                          leq + (size_t)lo * leq_rows * cols, leq_rows, cols, out_status + lo, out_v + lo,
+                                          out_sol + (size_t)lo * cols, &n);
+        nodes += n;
+        return r;
+    });
+    if (out_nodes) *out_nodes = nodes.load();
+    return rc;
+}
+int xpg_dep_is_empty_batch_rat32_multi(int ndev, const int * devices, int nb, const xpg_rat32 * mats, int rows, int cols,
+                                       int32_t * out_empty, long long * out_nodes)
+{
+    if (!mats || rows <= 0 || cols < 2 || !out_empty) return XPG_ERR_SHAPE;
+    std::atomic<long long> nodes(0);
+    const int rc = run_sharded(ndev, devices, nb, [=, &nodes](xpg_ctx * c, int lo, int hi) {
+        long long n = 0;
+        const int r = xpg_dep_is_empty_batch_rat32(c, hi - lo, mats + (size_t)lo * rows * cols, rows, cols, out_empty + lo, &n);
+        nodes += n;
+        return r;
+    });
+    if (out_nodes) *out_nodes = nodes.load();
+    return rc;
 }
 
 // ---- MIP / has_solution -------------------------------------------------------------------------
@@ -415,6 +538,7 @@ int xpg_mip_maxm_rat32(xpg_ctx * ctx, const xpg_rat32 * tgtf, const xpg_rat32 * 
                        const xpg_rat32 * eq, int eq_rows, const xpg_rat32 * leq, int leq_rows, int cols,
                        int is_bin, const uint8_t * ind, xpg_rat32 * out_v, xpg_rat32 * out_sol)
 {
+    XPG_BIND(ctx);
     return mip_solve<R32>(ctx, 1, true, is_bin != 0, (const R32 *)tgtf, (const R32 *)vc, vc_rows, (const R32 *)eq,
                           eq_rows, (const R32 *)leq, leq_rows, cols, ind, (R32 *)out_v, (R32 *)out_sol, 0);
 }
@@ -422,6 +546,7 @@ int xpg_mip_minm_rat32(xpg_ctx * ctx, const xpg_rat32 * tgtf, const xpg_rat32 * 
                        const xpg_rat32 * eq, int eq_rows, const xpg_rat32 * leq, int leq_rows, int cols,
                        int is_bin, const uint8_t * ind, xpg_rat32 * out_v, xpg_rat32 * out_sol)
 {
+    XPG_BIND(ctx);
     return mip_solve<R32>(ctx, 1, false, is_bin != 0, (const R32 *)tgtf, (const R32 *)vc, vc_rows, (const R32 *)eq,
                           eq_rows, (const R32 *)leq, leq_rows, cols, ind, (R32 *)out_v, (R32 *)out_sol, 0);
 }
@@ -429,6 +554,7 @@ int xpg_mip_maxm_f64(xpg_ctx * ctx, const double * tgtf, const double * vc, int 
                      int eq_rows, const double * leq, int leq_rows, int cols, int is_bin, const uint8_t * ind,
                      double * out_v, double * out_sol)
 {
+    XPG_BIND(ctx);
     return mip_solve<F64>(ctx, 0, true, is_bin != 0, (const F64 *)tgtf, (const F64 *)vc, vc_rows, (const F64 *)eq,
                           eq_rows, (const F64 *)leq, leq_rows, cols, ind, (F64 *)out_v, (F64 *)out_sol, 0);
 }
@@ -436,6 +562,7 @@ int xpg_mip_minm_f64(xpg_ctx * ctx, const double * tgtf, const double * vc, int 
                      int eq_rows, const double * leq, int leq_rows, int cols, int is_bin, const uint8_t * ind,
                      double * out_v, double * out_sol)
 {
+    XPG_BIND(ctx);
     return mip_solve<F64>(ctx, 0, false, is_bin != 0, (const F64 *)tgtf, (const F64 *)vc, vc_rows, (const F64 *)eq,
                           eq_rows, (const F64 *)leq, leq_rows, cols, ind, (F64 *)out_v, (F64 *)out_sol, 0);
 }
@@ -443,6 +570,7 @@ int xpg_has_solution_rat32(xpg_ctx * ctx, const xpg_rat32 * leq, int leq_rows, c
                            const xpg_rat32 * vc, int vc_rows, int cols, int rhs_idx, int is_int_sol,
                            int is_unique_sol)
 {
+    XPG_BIND(ctx);
     return has_solution(ctx, (const R32 *)leq, leq_rows, (const R32 *)eq, eq_rows, (const R32 *)vc, vc_rows, cols,
                         rhs_idx, is_int_sol != 0, is_unique_sol != 0);
 }
@@ -451,12 +579,14 @@ int xpg_mip_batch_rat32(xpg_ctx * ctx, int nb, int is_max, int is_bin, const xpg
                         int leq_rows, int cols, int32_t * out_status, xpg_rat32 * out_v, xpg_rat32 * out_sol,
                         long long * out_nodes)
 {
+    XPG_BIND(ctx);
     return mip_batch<R32>(ctx, 1, nb, is_max != 0, is_bin != 0, (const R32 *)tgtf, (const R32 *)leq, leq_rows, cols,
                           out_status, (R32 *)out_v, (R32 *)out_sol, out_nodes);
 }
 int xpg_dep_is_empty_batch_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols,
                                  int32_t * out_empty, long long * out_nodes)
 {
+    XPG_BIND(ctx);
     long n = 0;
     int rc = dep_is_empty_batch(ctx, nb, (const R32 *)mats, rows, cols, out_empty, &n);
     if (out_nodes) *out_nodes = n;
@@ -466,29 +596,37 @@ int xpg_dep_is_empty_batch_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, 
 // ---- rational row elimination ---------------------------------------------------------------
 int xpg_lineq_reduce_batch_rat32(xpg_ctx * ctx, int nb, xpg_rat32 * mats, int rows, int cols, int rhs_idx,
                                  int is_intersect, int32_t * out_rows, int32_t * out_ok)
-{ return lineq_reduce_batch(ctx, nb, (R32 *)mats, rows, cols, rhs_idx, 1, is_intersect, out_rows, out_ok); }
+{
+    XPG_BIND(ctx); return lineq_reduce_batch(ctx, nb, (R32 *)mats, rows, cols, rhs_idx, 1, is_intersect, out_rows, out_ok); }
 int xpg_lineq_remove_iden_batch_rat32(xpg_ctx * ctx, int nb, xpg_rat32 * mats, int rows, int cols,
                                       int32_t * out_rows)
-{ return lineq_reduce_batch(ctx, nb, (R32 *)mats, rows, cols, 0, 0, 1, out_rows, 0); }
+{
+    XPG_BIND(ctx); return lineq_reduce_batch(ctx, nb, (R32 *)mats, rows, cols, 0, 0, 1, out_rows, 0); }
 int xpg_lineq_fme_batch_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols, int rhs_idx,
                               int u, int darkshadow, xpg_rat32 * outs, int cap_rows, int32_t * out_rows,
                               int32_t * out_ok)
 {
+    XPG_BIND(ctx);
     return lineq_fme_batch(ctx, nb, (const R32 *)mats, rows, cols, rhs_idx, u, darkshadow, (R32 *)outs, cap_rows,
                            out_rows, out_ok);
 }
 int xpg_lineq_calc_bound_batch_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols, int rhs_idx,
                                      int cap_rows, xpg_rat32 * bounds, int32_t * out_rows, int32_t * out_ok)
-{ return lineq_calc_bound_batch(ctx, nb, (const R32 *)mats, rows, cols, rhs_idx, cap_rows, (R32 *)bounds, out_rows, out_ok); }
+{
+    XPG_BIND(ctx); return lineq_calc_bound_batch(ctx, nb, (const R32 *)mats, rows, cols, rhs_idx, cap_rows, (R32 *)bounds, out_rows, out_ok); }
 int xpg_rat_rank_batch(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols, int32_t * out_rank)
-{ return out_rank ? gauss_batch(ctx, nb, (const R32 *)mats, rows, cols, 0, out_rank, 0, 0) : XPG_ERR_SHAPE; }
+{
+    XPG_BIND(ctx); return out_rank ? gauss_batch(ctx, nb, (const R32 *)mats, rows, cols, 0, out_rank, 0, 0) : XPG_ERR_SHAPE; }
 int xpg_rat_det_batch(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int n, xpg_rat32 * out_det)
-{ return out_det ? gauss_batch(ctx, nb, (const R32 *)mats, n, n, 1, 0, (R32 *)out_det, 0) : XPG_ERR_SHAPE; }
+{
+    XPG_BIND(ctx); return out_det ? gauss_batch(ctx, nb, (const R32 *)mats, n, n, 1, 0, (R32 *)out_det, 0) : XPG_ERR_SHAPE; }
 int xpg_rat_inv_batch(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int n, xpg_rat32 * out_inv, int32_t * out_ok)
-{ return (out_inv && out_ok) ? gauss_batch(ctx, nb, (const R32 *)mats, n, n, 2, out_ok, 0, (R32 *)out_inv) : XPG_ERR_SHAPE; }
+{
+    XPG_BIND(ctx); return (out_inv && out_ok) ? gauss_batch(ctx, nb, (const R32 *)mats, n, n, 2, out_ok, 0, (R32 *)out_inv) : XPG_ERR_SHAPE; }
 int xpg_rat_rank_basis_batch(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols, int is_unitarize,
                              int32_t * out_rank, xpg_rat32 * basis, int32_t * basis_rows)
 {
+    XPG_BIND(ctx);
     if (!out_rank || !basis || !basis_rows) return XPG_ERR_SHAPE;
     const int st = gauss_batch(ctx, nb, (const R32 *)mats, rows, cols, 3, out_rank, 0, (R32 *)basis, is_unitarize ? 1 : 0);
     if (st != 0) return st;
@@ -496,11 +634,14 @@ int xpg_rat_rank_basis_batch(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int 
     return 0;
 }
 int xpg_rat_null_batch(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols, xpg_rat32 * ns)
-{ return ns ? gauss_batch(ctx, nb, (const R32 *)mats, rows, cols, 4, 0, 0, (R32 *)ns) : XPG_ERR_SHAPE; }
+{
+    XPG_BIND(ctx); return ns ? gauss_batch(ctx, nb, (const R32 *)mats, rows, cols, 4, 0, 0, (R32 *)ns) : XPG_ERR_SHAPE; }
 int xpg_int_hnf_batch(xpg_ctx * ctx, int nb, const int32_t * mats, int rows, int cols, int32_t * h, int32_t * u,
                       int32_t * status)
-{ return int_hnf_batch(ctx, nb, mats, rows, cols, h, u, status); }
+{
+    XPG_BIND(ctx); return int_hnf_batch(ctx, nb, mats, rows, cols, h, u, status); }
 int xpg_int_gcd_batch(xpg_ctx * ctx, int nb, int32_t * mats, int rows, int cols)
-{ return int_gcd_batch(ctx, nb, mats, rows, cols); }
+{
+    XPG_BIND(ctx); return int_gcd_batch(ctx, nb, mats, rows, cols); }
 
 } // extern "C"

@@ -12,7 +12,12 @@ from .six import RAT, as_kind
 
 
 def _stack(mats):
-    a = as_kind(mats, RAT)
+    """One system [rows, cols, 2] or a stack [nb, rows, cols, 2] of (num, den) pairs. Integer systems
+    are converted explicitly by the caller (xpoly_amd.six.as_kind(a, RAT, ndim)), never guessed."""
+    a = np.asarray(mats)
+    if a.ndim not in (3, 4) or a.shape[-1] != 2 or not np.issubdtype(a.dtype, np.integer):
+        raise ValueError("Lineq takes (num, den) pairs [rows, cols, 2] or [nb, rows, cols, 2], got %s %s" % (a.dtype, a.shape))
+    a = as_kind(a, RAT, a.ndim - 1)
     if a.ndim == 3:
         a = a[None]
     return np.ascontiguousarray(a)

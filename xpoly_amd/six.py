@@ -19,14 +19,26 @@ F64, RAT = 0, 1
 SIX_SUCC, SIX_UNBOUND, SIX_NO_PRI_FEASIBLE_SOL, SIX_OPTIMAL_IS_INFEASIBLE, SIX_TIME_OUT = range(5)
 
 
-def as_kind(a, kind):
+def as_kind(a, kind, ndim):
+    """The array as the ABI wants it. `ndim` is the number of LOGICAL axes (1: a row such as tgtf,
+    2: a matrix, 3: a stack of matrices). A rational problem is given either as integers of exactly
+    that many axes (each becomes n/1) or as (num, den) pairs with ONE more, trailing axis of length 2
+    -- the in-memory layout of RMat. Nothing is inferred from the shape alone: an integer matrix that
+    happens to have two columns stays an integer matrix."""
     if a is None:
         return None
     if kind == F64:
-        return np.ascontiguousarray(a, dtype=np.float64)
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if a.ndim != ndim:
+            raise ValueError("expected %d axes, got shape %s" % (ndim, a.shape))
+        return a
     a = np.asarray(a)
-    if a.ndim >= 1 and a.shape[-1] == 2 and a.dtype == np.int32:
-        return np.ascontiguousarray(a)
+    if a.ndim == ndim + 1:
+        if a.shape[-1] != 2 or not np.issubdtype(a.dtype, np.integer):
+            raise ValueError("rational input must be integer (num, den) pairs [..., 2], got %s %s" % (a.dtype, a.shape))
+        return np.ascontiguousarray(a, dtype=np.int32)
+    if a.ndim != ndim:
+        raise ValueError("expected %d axes (integers) or %d (num/den pairs), got shape %s" % (ndim, ndim + 1, a.shape))
     out = np.empty(a.shape + (2,), dtype=np.int32)
     out[..., 0] = a
     out[..., 1] = 1
@@ -100,7 +112,7 @@ class Context:
     # ---- K1 ---------------------------------------------------------------------------
     def pivot(self, kind, tab, obj, rhs_idx, row, col):
         """SIX::pivot arithmetic (lpsol.h:1471-1501) on host arrays, in place."""
-        tab = as_kind(tab, kind); obj = as_kind(obj, kind)
+        tab = as_kind(tab, kind, 2); obj = as_kind(obj, kind, 1)
         m, W = tab.shape[0], tab.shape[1]
         fn = lib().xpg_pivot_f64 if kind == F64 else lib().xpg_pivot_rat32
         self.check(fn(self._h, vp(tab), C.c_int(m), C.c_int(W), vp(obj), C.c_int(rhs_idx),
@@ -114,7 +126,7 @@ class Context:
 
     # ---- batches --------------------------------------------------------------------------
     def six_batch(self, kind, is_max, tgtf, leq, max_iter=0xFFFFFFFF):
-        tgtf = as_kind(tgtf, kind); leq = as_kind(leq, kind)
+        tgtf = as_kind(tgtf, kind, 2); leq = as_kind(leq, kind, 3)
         nb, m, cols = leq.shape[0], leq.shape[1], leq.shape[2]
         status = np.zeros(nb, dtype=np.int32)
         v = empty_kind((nb,), kind)
@@ -133,6 +145,49 @@ class Context:
                       C.c_void_p(pivots_ptr) if pivots_ptr else None), "xpg_six_batch_dev")
 
 
+def _check_multi(rc, what):
+    if rc < 0:
+        raise XpgError("%s: %s" % (what, _capi.ERRORS.get(rc, rc)))
+
+
+def six_batch_multi(devices, kind, is_max, tgtf, leq, max_iter=0xFFFFFFFF):
+    """xpg_six_batch_*_multi: the batch cut into contiguous shards, one per entry of `devices`, each on a
+    context and host thread of its own inside the library; results land in these host arrays."""
+    tgtf = as_kind(tgtf, kind, 2); leq = as_kind(leq, kind, 3)
+    nb, m, cols = leq.shape[0], leq.shape[1], leq.shape[2]
+    status = np.zeros(nb, dtype=np.int32)
+    v = empty_kind((nb,), kind); sol = empty_kind((nb, cols), kind)
+    dev = (C.c_int * len(devices))(*devices)
+    fn = lib().xpg_six_batch_f64_multi if kind == F64 else lib().xpg_six_batch_rat32_multi
+    _check_multi(fn(C.c_int(len(devices)), dev, C.c_int(int(is_max)), C.c_int(nb), vp(tgtf), vp(leq), C.c_int(m),
+                    C.c_int(cols), C.c_uint(max_iter), vp(status), vp(v), vp(sol)), "xpg_six_batch_multi")
+    return status, v, sol
+
+
+def mip_batch_multi(devices, is_max, is_bin, tgtf, leq):
+    tgtf = as_kind(tgtf, RAT, 2); leq = as_kind(leq, RAT, 3)
+    nb, rows, cols = leq.shape[0], leq.shape[1], leq.shape[2]
+    st = np.zeros(nb, dtype=np.int32); v = empty_kind((nb,), RAT); sol = empty_kind((nb, cols), RAT)
+    nodes = C.c_longlong()
+    dev = (C.c_int * len(devices))(*devices)
+    _check_multi(lib().xpg_mip_batch_rat32_multi(C.c_int(len(devices)), dev, C.c_int(nb), C.c_int(int(is_max)),
+                                                 C.c_int(int(is_bin)), vp(tgtf), vp(leq), C.c_int(rows), C.c_int(cols),
+                                                 vp(st), vp(v), vp(sol), C.byref(nodes)), "xpg_mip_batch_rat32_multi")
+    return st, v, sol, nodes.value
+
+
+def dep_is_empty_batch_multi(devices, mats):
+    mats = as_kind(mats, RAT, 3)
+    nb, rows, cols = mats.shape[0], mats.shape[1], mats.shape[2]
+    out = np.zeros(nb, dtype=np.int32)
+    nodes = C.c_longlong()
+    dev = (C.c_int * len(devices))(*devices)
+    _check_multi(lib().xpg_dep_is_empty_batch_rat32_multi(C.c_int(len(devices)), dev, C.c_int(nb), vp(mats), C.c_int(rows),
+                                                          C.c_int(cols), vp(out), C.byref(nodes)),
+                 "xpg_dep_is_empty_batch_rat32_multi")
+    return out, nodes.value
+
+
 class DeviceLP:
     """xpg_lp: a slack-form LP living in HBM (tableau, objective row, basis)."""
 
@@ -141,11 +196,11 @@ class DeviceLP:
         if on_device:
             leq_p, tg_p = C.c_void_p(leq), C.c_void_p(tgtf)
         else:
-            leq = as_kind(leq, kind); tgtf = as_kind(tgtf, kind)
+            leq = as_kind(leq, kind, 2); tgtf = as_kind(tgtf, kind, 1)
             m, cols = leq.shape[0], leq.shape[1]
             leq_p, tg_p = vp(leq), vp(tgtf)
         self.m, self.cols = m, cols
-        vd = as_kind(vc_diag, kind); vr = as_kind(vc_rhs, kind)
+        vd = as_kind(vc_diag, kind, 1); vr = as_kind(vc_rhs, kind, 1)
         self._h = C.c_void_p()
         ctx.check(lib().xpg_lp_create(ctx._h, C.c_int(kind), leq_p, C.c_int(m), C.c_int(cols), tg_p,
                                       vp(vd), vp(vr), C.c_int(int(on_device)), C.byref(self._h)),
@@ -170,6 +225,12 @@ class DeviceLP:
         n = C.c_uint()
         self.ctx.check(lib().xpg_lp_pivots_done(self._h, C.byref(n)), "xpg_lp_pivots_done")
         return n.value
+
+    def counters(self):
+        """(sweeps of a full 16-pivot batch, sweeps of a shorter one) of the blocked loop since begin()."""
+        f, p = C.c_uint(), C.c_uint()
+        self.ctx.check(lib().xpg_lp_counters(self._h, C.byref(f), C.byref(p)), "xpg_lp_counters")
+        return f.value, p.value
 
     def shape(self):
         r, w, rhs = C.c_int(), C.c_int(), C.c_int()
@@ -216,12 +277,12 @@ class MIP:
 
     def _solve(self, is_max, tgtf, vc, eq, leq, is_bin, rational_indicator):
         k = self.kind
-        tgtf = as_kind(tgtf, k); vc = as_kind(vc, k)
+        tgtf = as_kind(tgtf, k, 1); vc = as_kind(vc, k, 2)
         cols = tgtf.shape[0]
         eq_rows = 0 if eq is None else len(eq)
         leq_rows = 0 if leq is None else len(leq)
-        eq_a = as_kind(eq, k) if eq_rows else None
-        leq_a = as_kind(leq, k) if leq_rows else None
+        eq_a = as_kind(eq, k, 2) if eq_rows else None
+        leq_a = as_kind(leq, k, 2) if leq_rows else None
         ind = None if rational_indicator is None else np.ascontiguousarray(rational_indicator, dtype=np.uint8)
         v = empty_kind((1,), k); sol = empty_kind((cols,), k)
         name = "xpg_mip_%s_%s" % ("maxm" if is_max else "minm", "f64" if k == F64 else "rat32")
@@ -242,7 +303,7 @@ class MIP:
 def mip_batch(ctx, is_max, is_bin, tgtf, leq):
     """nb independent rational MIPs (x >= 0, inequalities only) advanced in lock step.
     tgtf [nb, cols(,2)], leq [nb, rows, cols(,2)]. Returns (status[nb], v[nb,2], sol[nb,cols,2], nodes)."""
-    tgtf = as_kind(tgtf, RAT); leq = as_kind(leq, RAT)
+    tgtf = as_kind(tgtf, RAT, 2); leq = as_kind(leq, RAT, 3)
     nb, rows, cols = leq.shape[0], leq.shape[1], leq.shape[2]
     st = np.zeros(nb, dtype=np.int32); v = empty_kind((nb,), RAT); sol = empty_kind((nb, cols), RAT)
     nodes = C.c_longlong()
@@ -255,7 +316,7 @@ def mip_batch(ctx, is_max, is_bin, tgtf, leq):
 def dep_is_empty_batch(ctx, mats):
     """DepPoly::is_empty (src/eng/poly.cpp:530-573) for a stack of dependence polyhedra
     [nb, rows, cols(,2)] with the constant in the last column. Returns (empty[nb], nodes)."""
-    mats = as_kind(mats, RAT)
+    mats = as_kind(mats, RAT, 3)
     nb, rows, cols = mats.shape[0], mats.shape[1], mats.shape[2]
     out = np.zeros(nb, dtype=np.int32)
     nodes = C.c_longlong()
@@ -266,12 +327,12 @@ def dep_is_empty_batch(ctx, mats):
 
 def has_solution(ctx, leq, eq, vc, rhs_idx, is_int_sol, is_unique_sol):
     """Lineq::has_solution (src/com/linsys.cpp:830-906) on rational systems."""
-    vc = as_kind(vc, RAT)
+    vc = as_kind(vc, RAT, 2)
     cols = vc.shape[1]
     leq_rows = 0 if leq is None else len(leq)
     eq_rows = 0 if eq is None else len(eq)
-    leq_a = as_kind(leq, RAT) if leq_rows else None
-    eq_a = as_kind(eq, RAT) if eq_rows else None
+    leq_a = as_kind(leq, RAT, 2) if leq_rows else None
+    eq_a = as_kind(eq, RAT, 2) if eq_rows else None
     r = lib().xpg_has_solution_rat32(ctx._h, vp(leq_a), C.c_int(leq_rows), vp(eq_a), C.c_int(eq_rows), vp(vc),
                                      C.c_int(vc.shape[0]), C.c_int(cols), C.c_int(rhs_idx),
                                      C.c_int(int(is_int_sol)), C.c_int(int(is_unique_sol)))
@@ -293,12 +354,12 @@ class SIX:
 
     def _solve(self, is_max, tgtf, vc, eq, leq):
         k = self.kind
-        tgtf = as_kind(tgtf, k); vc = as_kind(vc, k)
+        tgtf = as_kind(tgtf, k, 1); vc = as_kind(vc, k, 2)
         cols = tgtf.shape[0]
         eq_rows = 0 if eq is None else len(eq)
         leq_rows = 0 if leq is None else len(leq)
-        eq_a = as_kind(eq, k) if eq_rows else None
-        leq_a = as_kind(leq, k) if leq_rows else None
+        eq_a = as_kind(eq, k, 2) if eq_rows else None
+        leq_a = as_kind(leq, k, 2) if leq_rows else None
         v = empty_kind((1,), k); sol = empty_kind((cols,), k)
         name = "xpg_six_%s_%s" % ("maxm" if is_max else "minm", "f64" if k == F64 else "rat32")
         st = getattr(lib(), name)(self.ctx._h, vp(tgtf), vp(vc), C.c_int(vc.shape[0]), vp(eq_a),
