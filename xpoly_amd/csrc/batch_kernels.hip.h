@@ -93,41 +93,6 @@ template <class S> __device__ __forceinline__ int sm_ratio(const Small<S> & P, i
 // per pivot instead of ten.
 enum { ACT_PIVOT = 0, ACT_OPT = 1, ACT_FINDPAIR = 2, ACT_CLOSE = 3 };
 
-// Wave-wide arg-min on the VALU: four DPP row_shr steps reduce each 16-lane row into its last
-// lane, four v_readlane pairs fetch the row results, the final combine is scalar. This
-// replaces six dependent ds_bpermute stages (LDS-latency each) in the selection chain.
-template <int CTRL> __device__ __forceinline__ int dpp_row_shr(int own)
-{ return __builtin_amdgcn_update_dpp(own, own, CTRL, 0xf, 0xf, false); }   // lanes without a source keep `own`
-
-template <class S, int CTRL> __device__ __forceinline__ Cand<S> dpp_step(Cand<S> c)
-{
-    int w[2];
-    __builtin_memcpy(w, &c.q, 8);
-    w[0] = dpp_row_shr<CTRL>(w[0]); w[1] = dpp_row_shr<CTRL>(w[1]);
-    Cand<S> t;
-    __builtin_memcpy(&t.q, w, 8);
-    t.idx = dpp_row_shr<CTRL>(c.idx);
-    return better(c, t);
-}
-template <class S> __device__ __forceinline__ Cand<S> read_lane(Cand<S> c, int lane)
-{
-    int w[2];
-    __builtin_memcpy(w, &c.q, 8);
-    w[0] = __builtin_amdgcn_readlane(w[0], lane); w[1] = __builtin_amdgcn_readlane(w[1], lane);
-    Cand<S> t;
-    __builtin_memcpy(&t.q, w, 8);
-    t.idx = __builtin_amdgcn_readlane(c.idx, lane);
-    return t;
-}
-template <class S> __device__ __forceinline__ Cand<S> wave_argmin(Cand<S> c)
-{
-    c = dpp_step<S, 0x111>(c);      // row_shr:1
-    c = dpp_step<S, 0x112>(c);      // row_shr:2
-    c = dpp_step<S, 0x114>(c);      // row_shr:4
-    c = dpp_step<S, 0x118>(c);      // row_shr:8 -> lanes 15, 31, 47, 63 hold their row's winner
-    return better(better(read_lane(c, 15), read_lane(c, 31)), better(read_lane(c, 47), read_lane(c, 63)));
-}
-
 // Pricing (lpsol.h:1054-1069) + ratio test (lpsol.h:553-663) + genPair by wave 0.
 // Results in sh_w[0..2] = action, entering column, leaving variable; the pivot element and
 // c_nv are parked in sh_c so that nobody re-reads them after the row has been rescaled.

@@ -56,6 +56,10 @@ namespace xpg {
 #define XPG_STAMP(st_, slot_) do { } while (0)
 #endif
 
+#ifdef XPG_STAMPS
+__device__ double g_dbg_rows[4][8192];                      // per row of the last pick: bc, bi, pair word, counter
+#endif
+
 __device__ __forceinline__ unsigned blk_epoch(int batch, int t) { return (((unsigned)batch << 5) | (unsigned)t) + 1u; }
 
 __device__ __forceinline__ unsigned long long shfl_u64(unsigned long long x, int src)
@@ -73,9 +77,9 @@ __device__ __forceinline__ BlkLook blk_lookahead(const LpView<F64> & v, unsigned
     unsigned long long key = 0;
     for (int k = lane; k < nparts; k += 64) {
         const int * P = v.blkP + (size_t)k * BLK_PART_INTS;
-        const bool ok = (unsigned)P[4] == want_epoch;
+        const bool ok = (unsigned)P[2] == want_epoch;       // layout: blk_part_store
         const int pn = P[0], pa = P[1];
-        const unsigned long long pk = ((unsigned long long)(unsigned)P[3] << 32) | (unsigned)P[2];
+        const unsigned long long pk = ((unsigned long long)(unsigned)P[5] << 32) | (unsigned)P[4];
         if (ok) { nf = min(nf, pn); any |= pa; key = pk > key ? pk : key; }
     }
     for (int o = 32; o > 0; o >>= 1) { nf = min(nf, __shfl_xor(nf, o)); any |= __shfl_xor(any, o); }
@@ -167,6 +171,9 @@ __device__ __forceinline__ bool blk_pick_body(const LpView<F64> & v, int batch, 
             }
         }
         K[(size_t)i * BLK_MAX + n] = -a;                                  // -a_i,nv (lpsol.h:1485)
+#ifdef XPG_STAMPS
+        if (i < 8192) { g_dbg_rows[0][i] = bc; g_dbg_rows[1][i] = (double)bi; g_dbg_rows[2][i] = (double)w; g_dbg_rows[3][i] = (double)cc; }
+#endif
         XPG_STAMP(st, 1);                               // round 2 (column gathers, E, pair word, counter) + replay
         if (le(F64(a), zero<F64>())) continue;                            // findPivotBV, lpsol.h:553-663
         if (((w >> (bi & 31)) & 1u) || cc >= lim) continue;
@@ -180,14 +187,15 @@ __device__ __forceinline__ bool blk_pick_body(const LpView<F64> & v, int batch, 
     XPG_STAMP(st, 3);                                   // arg-min
     const bool publisher = wbest.idx != INT_MAX ? (best.idx == wbest.idx) : (tid == 0);
     if (publisher) {
+        // six {data, tag} granules of 16 bytes (the layout the chain kernel polls, lp_chain.hip.h)
         unsigned long long * rec = v.blkR + (size_t)p * BLK_REC_WORDS;
-        rec[0] = to_bits(wbest.q);
-        rec[1] = to_bits(F64(best_a));
-        rec[2] = ((unsigned long long)(unsigned)wbest.idx << 32) | (unsigned)best_b;
-        rec[3] = ((unsigned long long)best_w << 32) | (unsigned)best_cc;
-        rec[4] = cnv_bits;
-        rec[5] = (unsigned long long)(unsigned)first;
-        rec[6] = (unsigned long long)blk_epoch(batch, t);
+        const unsigned long long tag = (unsigned long long)blk_epoch(batch, t);
+        rec[0] = to_bits(wbest.q); rec[1] = tag;
+        rec[2] = to_bits(F64(best_a)); rec[3] = tag;
+        rec[4] = ((unsigned long long)(unsigned)wbest.idx << 32) | (unsigned)best_b; rec[5] = tag;
+        rec[6] = ((unsigned long long)best_w << 32) | (unsigned)best_cc; rec[7] = tag;
+        rec[8] = cnv_bits; rec[9] = tag;
+        rec[10] = (unsigned long long)(unsigned)first; rec[11] = tag;
     }
     return true;
 }
@@ -283,8 +291,8 @@ __device__ __forceinline__ bool blk_prep_body(const LpView<F64> & v, int batch, 
         bool valid = false;
         if (lane < BLK_PICK_WGS) {
             const unsigned long long * rk = v.blkR + (size_t)lane * BLK_REC_WORDS;
-            w0 = rk[0]; w1 = rk[1]; w2 = rk[2]; w3 = rk[3]; w4 = rk[4]; w5 = rk[5];
-            valid = (unsigned)rk[6] == epoch;
+            w0 = rk[0]; w1 = rk[2]; w2 = rk[4]; w3 = rk[6]; w4 = rk[8]; w5 = rk[10];
+            valid = (unsigned)rk[11] == epoch;
         }
         const unsigned long long vmask = __ballot(valid);
         any_rec = vmask != 0;
@@ -384,8 +392,9 @@ __device__ __forceinline__ bool blk_prep_body(const LpView<F64> & v, int batch, 
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int k = 1; k < (int)(blockDim.x >> 6); k++) { nf = min(nf, sh_nf[k]); any |= sh_any[k]; key = sh_key[k] > key ? sh_key[k] : key; }
-        int * P = v.blkP + (size_t)p * BLK_PART_INTS;
-        P[0] = nf; P[1] = any; P[2] = (int)(unsigned)key; P[3] = (int)(unsigned)(key >> 32); P[4] = (int)epoch;
+        int * P = v.blkP + (size_t)p * BLK_PART_INTS;        // {nf, any, epoch, 0 | key} : the first 16 bytes are
+        P[0] = nf; P[1] = any; P[2] = (int)epoch; P[3] = 0;   // the granule the chain kernel polls
+        P[4] = (int)(unsigned)key; P[5] = (int)(unsigned)(key >> 32);
     }
     // -column from the generic pick's colbuf when it chose this pivot
     if (generic_pivot)
@@ -406,6 +415,15 @@ __device__ __forceinline__ bool blk_prep_body(const LpView<F64> & v, int batch, 
             st->blk.budget = budget - 1;
             if (bb != batch) { st->blk.batch = batch; st->blk.closed = 0; st->blk.generic = 0; }
             st->blk.r[n] = r; st->blk.n = n + 1;
+        }
+        // ticket of the chain kernel (stages 1.. of this batch in one launch): stage 0 staged a pivot, and
+        // the counters as they stand after it -- fields the chain itself never writes, so a late worker
+        // of that launch reads what the early ones read
+        if (t == 0) {
+            st->blk.ch_epoch = epoch;
+            st->blk.ch_budget = generic_pivot ? budget : budget - 1;
+            st->blk.ch_done = generic_pivot ? done : done + 1;
+            st->blk.ch_tp = generic_pivot ? tp : tp + 1;
         }
         // (from_generic and row are read by every workgroup of this launch in the generic case: they are
         // left alone here and cleared by the next batch's generic-pick launch, a single workgroup)

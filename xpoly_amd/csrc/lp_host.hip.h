@@ -13,6 +13,7 @@
 #include "../../include/xpoly_amd.h"
 #include "lp_kernels.hip.h"
 #include "lp_blocked.hip.h"
+#include "lp_chain.hip.h"
 
 struct xpg_ctx {
     int device;
@@ -26,6 +27,7 @@ struct xpg_ctx {
     int block_len;          // blocked loop (loop_mode 3): pivots staged per sweep, 1..16
     int loop_auto;          // XPG_LOOP unset: blocked loop where the sweep is what costs (large fp64 tableaux)
     int num_cus;            // compute units of the device
+    int chain;              // blocked loop: stages 1.. of a batch in ONE persistent launch (lp_chain.hip.h); XPG_CHAIN=0 turns it off
     // xpg_profile_begin/end: event pairs around each sweep launch
     std::vector<hipEvent_t> ev0, ev1;
     int prof_cap, prof_n, prof_stride, prof_seen;
@@ -125,8 +127,8 @@ template <> inline void launch_pipe_sweep<F64>(xpg_ctx * ctx, const LpView<F64> 
                            v, slot, colstride);
 }
 // One batch of the blocked loop: B x (pick, prep) -- the generic pick once after pick(0) -- and a sweep.
-template <class S> inline void launch_blk_batch(xpg_ctx *, const LpView<S> &, int, int) {}
-template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> & v, int batch, int B)
+template <class S> inline void launch_blk_batch(xpg_ctx *, const LpView<S> &, int, int, bool) {}
+template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> & v, int batch, int B, bool ref_pricing)
 {
     const int strips = (v.W + 511) / 512;
     // workgroup sizes of pick and prep: 64 = one wave per workgroup, no LDS round in the reductions
@@ -137,7 +139,19 @@ template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> &
     const int want_pick = (v.m + tp - 1) / tp;
     const int npick = want_pick < BLK_PICK_WGS ? want_pick : BLK_PICK_WGS;
     const dim3 gprep((v.W + tq - 1) / tq);
+    // Stages 1 .. B-1 in one persistent launch where every worker (one wave per 64 rows / 64 columns) can
+    // be resident at once -- they poll each other's records, so each needs a slot of its own; one per CU
+    // keeps that beyond doubt. Wider or taller tableaux, and the opt-in Dantzig pricing, take the
+    // launch-per-stage path.
+    const int cpick = (v.m + 63) / 64, cprep = (v.W + 63) / 64;
+    const bool chain = ctx->chain && ref_pricing && B > 1 && cpick <= ctx->num_cus && cprep <= ctx->num_cus &&
+                       cpick <= BLK_REC_MAX && cprep <= 256 &&
+                       tpb_prep == 64;             // stage 0's prep leaves one look-ahead partial per 64 columns, as the chain's workers do
     for (int t = 0; t < B; t++) {
+        if (t == 1 && chain) {
+            hipLaunchKernelGGL(k_blk_chain, dim3(cpick > cprep ? cpick : cprep), dim3(64), 0, ctx->stream, v, batch, 1, B, cpick, cprep);
+            break;
+        }
         hipLaunchKernelGGL(k_blk_pick, dim3(npick), dim3(tp), 0, ctx->stream, v, batch, t, (int)gprep.x);
         if (t == 0) hipLaunchKernelGGL(k_blk_pick_generic, dim3(1), dim3(1024), 0, ctx->stream, v, batch, (int)gprep.x);
         hipLaunchKernelGGL(k_blk_prep, gprep, dim3(tq), 0, ctx->stream, v, batch, t);
@@ -253,7 +267,7 @@ template <class S> struct Lp : LpBase {
         if ((rc = alloc((void **)&v.pickrec, (size_t)PICK_WORDS * 8))) return rc;
         if ((rc = alloc((void **)&v.blkK, (size_t)round_up(m, 16) * BLK_MAX * sizeof(S)))) return rc;
         if ((rc = alloc((void **)&v.blkE, (size_t)BLK_MAX * ld * sizeof(S)))) return rc;
-        if ((rc = alloc((void **)&v.blkR, (size_t)BLK_PICK_WGS * BLK_REC_WORDS * 8))) return rc;
+        if ((rc = alloc((void **)&v.blkR, (size_t)BLK_REC_MAX * BLK_REC_WORDS * 8))) return rc;
         if ((rc = alloc((void **)&v.blkP, (size_t)((ld + BLK_TPB_MIN - 1) / BLK_TPB_MIN + 2) * BLK_PART_INTS * 4))) return rc;
         if ((rc = alloc((void **)&v.trace, (size_t)v.trace_cap * 8))) return rc;
         if ((rc = alloc((void **)&d_leq, (size_t)m * cols * sizeof(S)))) return rc;
@@ -359,7 +373,7 @@ template <class S> struct Lp : LpBase {
             // the last batch of a budget that is not a multiple of B is enqueued at its own length, so its
             // sweep is the kernel specialised for that many stages (not the full-batch kernel's slow tail)
             const unsigned left = k - b * (unsigned)B;
-            launch_blk_batch(ctx, v, batch, left < (unsigned)B ? (int)left : B);
+            launch_blk_batch(ctx, v, batch, left < (unsigned)B ? (int)left : B, opt_pricing == 0);
             if ((b & 7) == 7) {                         // throttle: at most 2 x 8 batches in flight
                 hipEvent_t e = throttle[(b >> 3) & 1];
                 if ((b >> 3) >= 2) (void)hipEventSynchronize(e);

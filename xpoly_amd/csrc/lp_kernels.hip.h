@@ -78,13 +78,16 @@ struct LoopState {
         int want_generic;      // a fast pick found no row in its first pass: the next batch starts generic
         int la_from_state;     // the current look-ahead is next_first / anypos (left by reset or the generic
                                // pick), not the per-workgroup partials of the last prep
+        unsigned ch_epoch;     // chain kernel ticket: epoch of the stage-0 prep that staged this batch's first pivot
+        unsigned ch_budget, ch_done, ch_tp;   // budget / done / total_pivots after that stage
         unsigned sweeps_full;  // sweeps that applied a full batch of BLK_MAX pivots (xpg_lp_counters)
         unsigned sweeps_part;  // sweeps that applied fewer (budget ran out, or a pick closed the batch early)
         unsigned long long dbg[8];   // diagnostic builds (-DXPG_STAMPS): 100 MHz ticks between points of pick / prep
     } blk;
 };
-enum { BLK_MAX = 16, BLK_REC_WORDS = 8, BLK_PART_INTS = 8,
-       BLK_PICK_WGS = 64,      // pick workgroups (= records) at most: one lane of a wave combines each
+enum { BLK_MAX = 16, BLK_REC_WORDS = 16, BLK_PART_INTS = 8,
+       BLK_PICK_WGS = 64,      // pick workgroups (= records) of the launch-per-stage path: one lane of a wave combines each
+       BLK_REC_MAX = 256,      // records allocated: the chain kernel has one per 64 rows, up to 256 workers
        BLK_TPB_MIN = 64 };     // smallest workgroup of pick / prep: sizes the partial array
 enum { NF_UNKNOWN = -2 };
 typedef LoopState::PipeDesc PipeDesc;
@@ -155,6 +158,52 @@ __device__ inline int block_min_int(int v, int * sh)
     int r = sh[0];
     for (int k = 1; k < nw; k++) r = min(r, sh[k]);
     return r;
+}
+
+// Wave-wide arg-min on the VALU: four DPP row_shr steps reduce each 16-lane row into its last
+// lane, four v_readlane pairs fetch the row results, the final combine is scalar. This
+// replaces six dependent ds_bpermute stages (LDS-latency each) in the selection chain.
+template <int CTRL> __device__ __forceinline__ int dpp_row_shr(int own)
+{ return __builtin_amdgcn_update_dpp(own, own, CTRL, 0xf, 0xf, false); }   // lanes without a source keep `own`
+
+template <class S, int CTRL> __device__ __forceinline__ Cand<S> dpp_step(Cand<S> c)
+{
+    int w[2];
+    __builtin_memcpy(w, &c.q, 8);
+    w[0] = dpp_row_shr<CTRL>(w[0]); w[1] = dpp_row_shr<CTRL>(w[1]);
+    Cand<S> t;
+    __builtin_memcpy(&t.q, w, 8);
+    t.idx = dpp_row_shr<CTRL>(c.idx);
+    return better(c, t);
+}
+template <class S> __device__ __forceinline__ Cand<S> read_lane(Cand<S> c, int lane)
+{
+    int w[2];
+    __builtin_memcpy(w, &c.q, 8);
+    w[0] = __builtin_amdgcn_readlane(w[0], lane); w[1] = __builtin_amdgcn_readlane(w[1], lane);
+    Cand<S> t;
+    __builtin_memcpy(&t.q, w, 8);
+    t.idx = __builtin_amdgcn_readlane(c.idx, lane);
+    return t;
+}
+template <class S> __device__ __forceinline__ Cand<S> wave_argmin(Cand<S> c)
+{
+    c = dpp_step<S, 0x111>(c);      // row_shr:1
+    c = dpp_step<S, 0x112>(c);      // row_shr:2
+    c = dpp_step<S, 0x114>(c);      // row_shr:4
+    c = dpp_step<S, 0x118>(c);      // row_shr:8 -> lanes 15, 31, 47, 63 hold their row's winner
+    return better(better(read_lane(c, 15), read_lane(c, 31)), better(read_lane(c, 47), read_lane(c, 63)));
+}
+
+// Wave-wide integer minimum the same way.
+__device__ __forceinline__ int wave_min_int(int x)
+{
+    x = min(x, dpp_row_shr<0x111>(x));
+    x = min(x, dpp_row_shr<0x112>(x));
+    x = min(x, dpp_row_shr<0x114>(x));
+    x = min(x, dpp_row_shr<0x118>(x));
+    return min(min(__builtin_amdgcn_readlane(x, 15), __builtin_amdgcn_readlane(x, 31)),
+               min(__builtin_amdgcn_readlane(x, 47), __builtin_amdgcn_readlane(x, 63)));
 }
 
 template <class S> __device__ __forceinline__ bool ppt_seen(const LpView<S> & v, int nv, int b)
@@ -1021,9 +1070,11 @@ template <class S> __global__ void k_reset_loop(LpView<S> v, unsigned max_iter, 
         st->blk.budget = 0xFFFFFFFFu; st->blk.price_key = 0ull;
         st->blk.want_generic = 0; st->blk.la_from_state = 1; st->blk.la_epoch = 0u;
         st->blk.sweeps_full = 0u; st->blk.sweeps_part = 0u;
+        st->blk.ch_epoch = 0u; st->blk.ch_budget = 0u; st->blk.ch_done = 0u; st->blk.ch_tp = 0u;
         for (int k = 0; k < 8; k++) st->blk.dbg[k] = 0ull;
-        for (int k = 0; k < BLK_PICK_WGS; k++) v.blkR[(size_t)k * BLK_REC_WORDS + 6] = 0ull;       // record epochs
-        for (int k = 0; k < (v.ld + BLK_TPB_MIN - 1) / BLK_TPB_MIN + 1; k++) v.blkP[(size_t)k * BLK_PART_INTS + 4] = 0;  // partial epochs
+        for (int k = 0; k < BLK_REC_MAX; k++)                 // record tags
+            for (int q = 1; q < 12; q += 2) v.blkR[(size_t)k * BLK_REC_WORDS + q] = 0ull;
+        for (int k = 0; k < (v.ld + BLK_TPB_MIN - 1) / BLK_TPB_MIN + 1; k++) v.blkP[(size_t)k * BLK_PART_INTS + 2] = 0;  // partial epochs
         for (int k = 0; k < 2; k++) v.pickrec[PICK_CTR_OFF + 16 * k] = 0ull;   // arrival counters
         for (int k = 0; k < 2; k++) {                  // pipelined loop: iteration 0 has no pivot yet
             PipeDesc & D = st->pd[k];

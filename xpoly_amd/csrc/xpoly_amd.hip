@@ -56,6 +56,8 @@ int xpg_create(xpg_ctx ** out, int device)
     c->loop_mode = (lm && lm[0] == 's' && lm[1] == 'e') ? 1 : ((lm && lm[0] == 's' && lm[1] == 'p') ? 2 : 0);
     if (lm && lm[0] == 'b') c->loop_mode = 3;          // "block": B pivots per sweep (lp_blocked.hip.h)
     if (lm && lm[0] == 'p') c->loop_mode = 0;          // "pipe": always the pipelined loop
+    const char * ch = getenv("XPG_CHAIN");               // "0": launch-per-stage chain, for A/B runs
+    c->chain = ch ? atoi(ch) : 1;
     c->num_cus = 0;
     if (hipDeviceGetAttribute(&c->num_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) c->num_cus = 0;
     c->loop_auto = lm ? 0 : 1;                         // unset: blocked loop for large fp64 tableaux, else pipelined
@@ -360,6 +362,33 @@ int xpg_lp_debug(xpg_lp * lp, unsigned long long * out8)
     int rc = ((Lp<F64> *)lp->impl)->read_state(&hs);
     if (rc) return rc;
     for (int k = 0; k < 8; k++) out8[k] = hs.blk.dbg[k];
+    return 0;
+}
+// the staged rows / columns of the last batch: E[16][ld], K[m][16]; *ld receives the leading dimension
+int xpg_lp_debug_staged(xpg_lp * lp, double * E, double * K, int * ld)
+{
+    if (!lp || !lp->impl || lp->impl->kind != 0) return XPG_ERR_SHAPE;
+    Lp<F64> * p = (Lp<F64> *)lp->impl;
+    xpg_ctx * ctx = p->ctx;
+    if (ld) *ld = p->v.ld;
+    if (E) XPG_HIP(ctx, hipMemcpy(E, p->v.blkE, (size_t)BLK_MAX * p->v.ld * 8, hipMemcpyDeviceToHost));
+    if (K) XPG_HIP(ctx, hipMemcpy(K, p->v.blkK, (size_t)p->v.m * BLK_MAX * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+int xpg_lp_debug_counts(xpg_lp * lp, int * rowcnt, int * colcnt, int n)
+{
+    if (!lp || !lp->impl || lp->impl->kind != 0) return XPG_ERR_SHAPE;
+    Lp<F64> * p = (Lp<F64> *)lp->impl;
+    xpg_ctx * ctx = p->ctx;
+    XPG_HIP(ctx, hipMemcpy(rowcnt, p->v.rowcnt, (size_t)n * 4, hipMemcpyDeviceToHost));
+    XPG_HIP(ctx, hipMemcpy(colcnt, p->v.colcnt, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+int xpg_lp_debug_rows(xpg_lp * lp, double * out)              // [4][8192]
+{
+    if (!lp || !lp->impl) return XPG_ERR_SHAPE;
+    xpg_ctx * ctx = lp->impl->ctx;
+    XPG_HIP(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_rows), sizeof(double) * 4 * 8192));
     return 0;
 }
 #endif
