@@ -1,6 +1,7 @@
 """GPU diagnostic: where does the time of a pick / prep launch of the blocked loop go? Needs a library built
 with -DXPG_STAMPS (tools/run_stamps.sh builds tools/_build/libxpoly_stamps.so and points XPG_SO_PATH at it)."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -15,6 +16,12 @@ lp.begin(); lp.iterate(3840)
 lp.begin(); lp.iterate(3840)
 d = (C.c_ulonglong * 8)()
 lib().xpg_lp_debug(lp._h, d)
+if os.environ.get("XPG_CHAIN", "1") != "0":
+    names = ["partials seen -> records seen (pick segment)", "records seen -> partials seen (prep segment)"]
+    for k in range(2):
+        print("%-40s %6.2f us per chain stage" % (names[k], d[k] * 0.01 / (3840 * 15 / 16)))
+    print("(launch-path stage 0 stamps are mixed into slots 0-7 as well: 1/16 of the pivots)")
+    raise SystemExit
 names = ["pick: state+partials+pre", "pick: round 2 + replay", "pick: division", "pick: arg-min",
          "prep: state+records+pre", "prep: round 2 + replay + objective", "prep: pricing partial", "prep: commit"]
 for k in range(8):

@@ -77,9 +77,9 @@ __device__ __forceinline__ BlkLook blk_lookahead(const LpView<F64> & v, unsigned
     unsigned long long key = 0;
     for (int k = lane; k < nparts; k += 64) {
         const int * P = v.blkP + (size_t)k * BLK_PART_INTS;
-        const bool ok = (unsigned)P[2] == want_epoch;       // layout: blk_part_store
+        const bool ok = (unsigned)P[2] == want_epoch;       // layout: the partial store of blk_prep_body
         const int pn = P[0], pa = P[1];
-        const unsigned long long pk = ((unsigned long long)(unsigned)P[5] << 32) | (unsigned)P[4];
+        const unsigned long long pk = ((unsigned long long)(unsigned)P[17] << 32) | (unsigned)P[16];
         if (ok) { nf = min(nf, pn); any |= pa; key = pk > key ? pk : key; }
     }
     for (int o = 32; o > 0; o >>= 1) { nf = min(nf, __shfl_xor(nf, o)); any |= __shfl_xor(any, o); }
@@ -347,6 +347,7 @@ __device__ __forceinline__ bool blk_prep_body(const LpView<F64> & v, int batch, 
     const bool dantzig = pricing == 1;
     int nf = INT_MAX, any = 0;
     unsigned long long key = 0;
+    int my_j = -1; F64 my_e = zero<F64>(), my_o = zero<F64>();  // this thread's (last) column, its new e and objective entry
     for (int j = gid; j < W; j += gsz) {
         const bool pre = j == j_pre;                           // this thread's first column: loaded with the state
         double x = ((const double *)v.tab)[(size_t)r * ld + j];
@@ -376,6 +377,7 @@ __device__ __forceinline__ bool blk_prep_body(const LpView<F64> & v, int batch, 
         if (!generic_pivot && j < enter && in && !nv_old) oj = zero<F64>();
         const F64 o = add(tt, oj);                             // addRowToRow, :1501
         v.obj[j] = o;
+        my_j = j; my_e = e; my_o = o;
         XPG_STAMP(st, 5);                               // round 2 (pivot row gather, K row of r) + replay + objective
         if (nv_new && gt(o, zero<F64>())) {                    // look-ahead pricing of the next pivot
             any = 1;
@@ -390,11 +392,25 @@ __device__ __forceinline__ bool blk_prep_body(const LpView<F64> & v, int batch, 
     key = wave_max_u64(key);
     if ((threadIdx.x & 63) == 0) { sh_nf[threadIdx.x >> 6] = nf; sh_any[threadIdx.x >> 6] = any; sh_key[threadIdx.x >> 6] = key; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 1; k < (int)(blockDim.x >> 6); k++) { nf = min(nf, sh_nf[k]); any |= sh_any[k]; key = sh_key[k] > key ? sh_key[k] : key; }
-        int * P = v.blkP + (size_t)p * BLK_PART_INTS;        // {nf, any, epoch, 0 | key} : the first 16 bytes are
-        P[0] = nf; P[1] = any; P[2] = (int)epoch; P[3] = 0;   // the granule the chain kernel polls
-        P[4] = (int)(unsigned)key; P[5] = (int)(unsigned)(key >> 32);
+    for (int k = 0; k < (int)(blockDim.x >> 6); k++) { nf = min(nf, sh_nf[k]); any |= sh_any[k]; key = sh_key[k] > key ? sh_key[k] : key; }
+    // The partial, in the granule layout the chain kernel polls (lp_chain.hip.h): g0 {nf, any, epoch, 0},
+    // g1 {e_t[nf], epoch}, g2 {objective entry of nf, epoch}, g3 {e_t[rhs], epoch} (the workgroup that owns the
+    // constant column), then the Dantzig key. g1..g3 are what the chain's first stage needs fresh of this one.
+    {
+        int * P = v.blkP + (size_t)p * BLK_PART_INTS;
+        if (my_j >= 0 && my_j == nf) {
+            const unsigned long long eb_ = to_bits(my_e), ob_ = to_bits(my_o);
+            P[4] = (int)(unsigned)eb_; P[5] = (int)(unsigned)(eb_ >> 32); P[6] = (int)epoch; P[7] = 0;
+            P[8] = (int)(unsigned)ob_; P[9] = (int)(unsigned)(ob_ >> 32); P[10] = (int)epoch; P[11] = 0;
+        }
+        if (my_j == rhs) {
+            const unsigned long long eb_ = to_bits(my_e);
+            P[12] = (int)(unsigned)eb_; P[13] = (int)(unsigned)(eb_ >> 32); P[14] = (int)epoch; P[15] = 0;
+        }
+        if (threadIdx.x == 0) {
+            P[0] = nf; P[1] = any; P[2] = (int)epoch; P[3] = 0;
+            P[16] = (int)(unsigned)key; P[17] = (int)(unsigned)(key >> 32);
+        }
     }
     // -column from the generic pick's colbuf when it chose this pivot
     if (generic_pivot)

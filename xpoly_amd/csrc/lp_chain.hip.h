@@ -6,48 +6,57 @@
 // cold TLBs) -- and a launch boundary. The same chain step as a phase of a persistent launch costs
 // 2.2-2.8 us in the lab (tools/launch_lab.hip, rows D against B). This kernel is that persistent form.
 //
-// Workers are one-wave workgroups, one per 64 rows (pick role) and one per 64 columns (prep role);
-// worker w plays both roles while it has rows and columns. NOTHING is a barrier: every hand-off is a
-// data-tagged record that its consumers poll (MI355X_MICROARCH.md, "Valid forms": every byte of the
-// hand-off stored sc1 and drained by s_waitcnt vmcnt(0) before the tag granule; every load of it a
-// global sc1 load to registers).
-//   stage t, pick role:  poll the look-ahead partials of stage t-1 (16-byte granules {nf, any, epoch})
-//                        -> entering column `first`; replay that column and the constant column for
-//                        the lane's own row (its k_s[i] live in registers, e_s[first] / e_s[rhs] come
-//                        by one sc1 load per stage, lane s loads stage s); ratio test (lpsol.h:553-663);
-//                        DPP arg-min; -a_i,nv -> K (sc1); ONE lane publishes the worker's record:
-//                        six 16-byte granules {data, tag}
-//   stage t, prep role:  poll the <= 256 records (lane l polls record l, all six granules in one
-//                        round); combine (lowest row wins ties, lpsol.h:604-611); replay the pivot row
-//                        for the lane's own column (its e_s[j] live in registers, k_s[r] by one sc1
-//                        load, lane s loads stage s); scaled row -> E (sc1), objective row, look-ahead
-//                        pricing (lpsol.h:1054-1069); DPP min; ONE lane publishes the partial granule.
-//                        Lane 0 of worker 0 commits the pivot exactly as blk_prep_body does.
-// What each worker reads of the committed state at entry comes from fields this kernel never writes
-// (the ticket blk.ch_* left by stage 0's prep launch), so a worker that starts late sees what the early
-// ones saw. Basis words a stage needs (pair word, counters, nv[j], rowcnt[j]) are re-read every stage with
-// sc1 loads and only once the hand-off that orders them behind the previous stage's commit has been seen
-// (the partials for the pick role, the records for the prep role: a prep-only worker does not wait for
-// partials, so at the top of a stage the previous commit may still be in flight); the two entries the
-// committing lane rewrites DURING a stage (enter, leave) are the ones that stage does not read. The basic
-// variable of the lane's own row is kept in a register: every worker learns (row, entering) of each stage.
+// Workers are one-wave workgroups: worker w owns rows 64w .. 64w+63 (pick role, w < npick) and columns
+// 64w .. 64w+63 (prep role, w < nprep); one more worker, the committer, owns the basis arrays. There is
+// NO barrier and NO store drain on the path: every hand-off is a set of 16-byte granules {data, tag}, each
+// written by one sc1 store and polled by its consumers with sc1 loads (MI355X_MICROARCH.md, "Valid forms":
+// a granule needs no ordering), and whatever a stage needs FRESH from the stage before it travels inside
+// those granules:
+//   partial of prep worker w, stage t   g0 {lowest eligible column of its 64 (or INT_MAX), any c_j > 0}
+//                                       g1 {e_t[that column]}   g2 {objective entry of that column}
+//                                       g3 {e_t[rhs]}  (only the worker that owns the constant column)
+//   record of pick worker w, stage t    g0 {ratio key, row}: the ONLY granule everybody polls (one 16-byte load per
+//                                       record and lane; six were measured to cost 2.6 us per hand-off in L2
+//                                       contention: 129 workers x 64 records x 6 loads on 64 lines)
+//                                       g1 {pivot element, leaving}  g2 {pair word, counter, entering | 1 + last
+//                                       stage this row pivoted in}  g3 {c_nv}: fetched of the WINNER only, in the
+//                                       same round as the pivot row gather
+//   commit granule, stage t             written by the committer behind its own drain (off the path)
+// Everything else a stage reads from memory was stored at least one full stage earlier by a wave that has
+// since completed a poll (whose s_waitcnt vmcnt(0) also waits for that wave's own stores) and then published
+// a granule the reader has seen: e_s[first] for s <= t-2, k_s[r] for s <= t-1, and the basis words behind
+// the commit granule. Own data never leaves registers: a lane keeps k_s[i] of its row, e_s[j] of its
+// column, its objective entry, its row's basic variable, the replayed constant column of its row (ONE
+// update per stage: the constant column is the same column every stage) and the last stage its row
+// pivoted in (which replaces the list of pivot rows in both replays).
+//   stage t, pick role:  poll the partials of stage t-1 and the commit granule -> entering column `first`;
+//                        one round: the column gather, e_s[first] (lane s), the three fresh granules, pair
+//                        word, counter; replay (the sweep's own mul-then-add per stage), ratio test
+//                        (lpsol.h:553-663) as a 64-bit key whose unsigned order is better()'s, DPP min;
+//                        -a_i,nv -> K; the winning lane publishes the record
+//   stage t, prep role:  poll the records (lane l polls record l), combine; one round: the pivot row
+//                        gather, k_s[r] (lane s), nv[j], rowcnt[j]; replay, scaled row -> E, objective row,
+//                        look-ahead pricing (lpsol.h:1054-1069), DPP min; partial out
+//   committer:           polls the records like everyone, commits the pivot exactly as blk_prep_body does
+// What a worker reads of the committed state at entry comes from fields this launch never writes (the
+// ticket blk.ch_* left by stage 0's prep launch), so a worker that starts late sees what the early ones saw.
 // Anything but "fast pick found a row" ends the launch for every worker alike: the pick role publishes
-// a CLOSE record instead (budget spent, iteration limit, no eligible column), an empty first ratio pass
-// is seen by everyone in the records. The batch then has fewer than B staged pivots, the sweep applies
-// them, and the next batch starts with the launch-per-stage kernels, which own every rare branch.
+// CLOSE records instead (budget spent, iteration limit, no eligible column), an empty first ratio pass is
+// seen by everyone in the records. The batch then has fewer than B staged pivots, the sweep applies them,
+// and the next batch starts with the launch-per-stage kernels, which own every rare branch.
 // A poll that does not complete within ~0.5 s flags ST_CHAIN_STUCK (XPG_ERR_HIP for the caller).
 #pragma once
 #include "lp_blocked.hip.h"
 
 namespace xpg {
 
-enum { ST_CHAIN_STUCK = -1, CH_SPIN_LIMIT = 1 << 21, CH_CLOSE = 0x7FFFFFFF };
+enum { ST_CHAIN_STUCK = -1, CH_SPIN_LIMIT = 1 << 21, CH_CLOSE = 0x7FFFFFFF, CH_PART_BYTES = BLK_PART_INTS * 4 };
 typedef unsigned int ch_u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned long long ch_lo64(ch_u32x4 g) { return ((unsigned long long)g.y << 32) | g.x; }
-__device__ __forceinline__ unsigned long long ch_hi64(ch_u32x4 g) { return ((unsigned long long)g.w << 32) | g.z; }
 
-// all six granules of one record in one round (the asm block waits for its own loads)
+// all six granules of one record in one round (the asm block waits for its own loads -- and, vmcnt being one
+// counter, for every store this wave issued before)
 __device__ __forceinline__ void ch_load_record(const void * p, ch_u32x4 (&g)[6])
 {
     asm volatile("global_load_dwordx4 %0, %6, off sc1\n\t"
@@ -59,16 +68,30 @@ __device__ __forceinline__ void ch_load_record(const void * p, ch_u32x4 (&g)[6])
                  "s_waitcnt vmcnt(0)"
                  : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]) : "v"(p) : "memory");
 }
-// up to four partial granules (32 bytes apart in units of one partial) in one round
-__device__ __forceinline__ void ch_load_partials(const void * p0, const void * p1, const void * p2, const void * p3,
-                                                 ch_u32x4 (&g)[4])
+// four granules from four addresses in one round
+__device__ __forceinline__ void ch_load4(const void * p0, const void * p1, const void * p2, const void * p3,
+                                         ch_u32x4 & g0, ch_u32x4 & g1, ch_u32x4 & g2, ch_u32x4 & g3)
 {
     asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
                  "global_load_dwordx4 %1, %5, off sc1\n\t"
                  "global_load_dwordx4 %2, %6, off sc1\n\t"
                  "global_load_dwordx4 %3, %7, off sc1\n\t"
                  "s_waitcnt vmcnt(0)"
-                 : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+                 : "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&v"(g3) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+}
+__device__ __forceinline__ void ch_load3(const void * p0, const void * p1, const void * p2, ch_u32x4 & g0, ch_u32x4 & g1, ch_u32x4 & g2)
+{
+    asm volatile("global_load_dwordx4 %0, %3, off sc1\n\t"
+                 "global_load_dwordx4 %1, %4, off sc1\n\t"
+                 "global_load_dwordx4 %2, %5, off sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(g0), "=&v"(g1), "=&v"(g2) : "v"(p0), "v"(p1), "v"(p2) : "memory");
+}
+__device__ __forceinline__ ch_u32x4 ch_load1(const void * p)
+{
+    ch_u32x4 g;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g) : "v"(p) : "memory");
+    return g;
 }
 // One 16-byte granule {data, tag} by one store. The s_nop belongs to the store: a VMEM store of more than 8
 // bytes reads its data registers after issue, the hardware does not interlock a VALU write to them in the next
@@ -78,6 +101,12 @@ __device__ __forceinline__ void ch_store_granule(void * p, unsigned long long lo
 {
     ch_u32x4 g;
     g.x = (unsigned)lo; g.y = (unsigned)(lo >> 32); g.z = (unsigned)hi; g.w = (unsigned)(hi >> 32);
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 3" :: "v"(p), "v"(g) : "memory");
+}
+__device__ __forceinline__ void ch_store_granule3(void * p, unsigned x, unsigned y, unsigned z, unsigned tag)
+{
+    ch_u32x4 g;
+    g.x = x; g.y = y; g.z = z; g.w = tag;
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 3" :: "v"(p), "v"(g) : "memory");
 }
 __device__ __forceinline__ void ch_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -123,17 +152,149 @@ __device__ __forceinline__ unsigned long long ch_readlane_u64(unsigned long long
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), lane);
     return ((unsigned long long)hi << 32) | lo;
 }
+// The ratio as a key whose UNSIGNED order is the order better() puts ratios in: -0 and +0 are one value,
+// then the usual monotone map of IEEE doubles. ~0 is "no candidate".
+__device__ __forceinline__ unsigned long long ch_ratio_key(double q)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, q + 0.0);   // (-0) + (+0) = +0
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+template <int CTRL> __device__ __forceinline__ unsigned long long ch_min_step(unsigned long long x)
+{
+    const unsigned lo = (unsigned)dpp_row_shr<CTRL>((int)(unsigned)x), hi = (unsigned)dpp_row_shr<CTRL>((int)(unsigned)(x >> 32));
+    const unsigned long long t = ((unsigned long long)hi << 32) | lo;
+    return t < x ? t : x;
+}
+__device__ __forceinline__ unsigned long long ch_wave_min_u64(unsigned long long x)
+{
+    x = ch_min_step<0x111>(x); x = ch_min_step<0x112>(x); x = ch_min_step<0x114>(x); x = ch_min_step<0x118>(x);
+    const unsigned long long a = ch_readlane_u64(x, 15), b = ch_readlane_u64(x, 31), c = ch_readlane_u64(x, 47), d = ch_readlane_u64(x, 63);
+    const unsigned long long ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+}
 
-// npick = ceil(m / 64) <= 256 pick workers, nprep = ceil(W / 64) <= 256 prep workers; grid = max of the two.
+// The winner of a stage, as every worker derives it from the records.
+struct ChWinner { int r, enter, leave, qstar, cc; uint32_t w; double a; unsigned long long cnv; };
+enum { CH_CLOSE_ROW = 0x7FFFFFFE };
+
+// Poll g0 {key, row, tag} of the <= 256 records of stage `tag` (lane l polls l, l + 64, ...) and find the winner.
+// Returns the winner's record index (>= 0), -1 on CLOSE, -2 when the first ratio pass was empty everywhere, -3 on
+// a stuck poll; W.r is set.
+__device__ __forceinline__ int ch_poll_records(const unsigned long long * blkR, int npick, unsigned tag, int lane, ChWinner & W)
+{
+    const int nu = (npick + 63) >> 6;                           // records per lane, wave-uniform
+    const int k0 = lane, k1 = lane + 64, k2 = lane + 128, k3 = lane + 192;
+    // (a lane without a record of its own re-reads one it shares with another lane of the same line: no hot spot)
+    const char * base = (const char *)blkR;
+    const void * p0 = base + (size_t)(k0 < npick ? k0 : k0 % npick) * (BLK_REC_WORDS * 8);
+    const void * p1 = base + (size_t)(k1 < npick ? k1 : k0 % npick) * (BLK_REC_WORDS * 8);
+    const void * p2 = base + (size_t)(k2 < npick ? k2 : k0 % npick) * (BLK_REC_WORDS * 8);
+    const void * p3 = base + (size_t)(k3 < npick ? k3 : k0 % npick) * (BLK_REC_WORDS * 8);
+    ch_u32x4 g0, g1, g2, g3;
+    unsigned spins = 0;
+    for (;;) {
+        bool ok;
+        if (nu == 1) { g0 = ch_load1(p0); ok = g0.w == tag; }
+        else { ch_load4(p0, p1, p2, p3, g0, g1, g2, g3); ok = g0.w == tag && g1.w == tag && g2.w == tag && g3.w == tag; }
+        if (__all(ok)) break;
+        if (++spins > CH_SPIN_LIMIT) return -3;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    unsigned long long key = ~0ull; int row = INT_MAX, rec = 0;
+    if (k0 < npick) { key = ch_lo64(g0); row = (int)g0.z; rec = k0; }
+    if (nu > 1) {                                               // strict compares: the lower record (lower rows) wins ties
+        if (k1 < npick && ch_lo64(g1) < key) { key = ch_lo64(g1); row = (int)g1.z; rec = k1; }
+        if (k2 < npick && ch_lo64(g2) < key) { key = ch_lo64(g2); row = (int)g2.z; rec = k2; }
+        if (k3 < npick && ch_lo64(g3) < key) { key = ch_lo64(g3); row = (int)g3.z; rec = k3; }
+    }
+    // every pick worker takes the same fast / close decision, so record 0 tells which it was
+    if (__builtin_amdgcn_readfirstlane((int)g0.z) == CH_CLOSE_ROW) return -1;
+    const unsigned long long kmin = ch_wave_min_u64(key);
+    if (kmin == ~0ull) return -2;
+    // the lowest row among the records with the least ratio (lpsol.h:604-611)
+    const int myrow = key == kmin ? row : INT_MAX;
+    W.r = wave_min_int(myrow);
+    const unsigned long long hit = __ballot(myrow == W.r);
+    return __builtin_amdgcn_readlane(rec, __ffsll((long long)hit) - 1);
+}
+// g1..g3 of the winner's record (the asm block's wait also completes whatever loads the caller has in flight)
+__device__ __forceinline__ bool ch_load_winner(const unsigned long long * blkR, int widx, unsigned tag, ChWinner & W)
+{
+    const char * p = (const char *)blkR + (size_t)widx * (BLK_REC_WORDS * 8);
+    ch_u32x4 g1, g2, g3;
+    unsigned spins = 0;
+    for (;;) {
+        ch_load3(p + 16, p + 32, p + 48, g1, g2, g3);
+        if (__all(g1.w == tag && g2.w == tag && g3.w == tag)) break;     // (every lane loads the same granules)
+        if (++spins > CH_SPIN_LIMIT) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    W.a = __builtin_bit_cast(double, ch_lo64(g1)); W.leave = (int)g1.z;
+    W.w = g2.x; W.cc = (int)g2.y; W.enter = (int)(g2.z & 0xFFFFFFu); W.qstar = (int)(g2.z >> 24) - 1;
+    W.cnv = ch_lo64(g3);
+    return true;
+}
+
+// ---- the committer: one extra worker that owns the basis arrays --------------------------------------
+__device__ __forceinline__ void ch_commit_loop(const LpView<F64> & v, int batch, int t0, int B, int npick, int nprep,
+                                               unsigned budget, unsigned done, unsigned tp)
+{
+    LoopState * st = v.st;
+    const int lane = (int)threadIdx.x;
+    for (int t = t0; t < B; t++) {
+        const unsigned tag = blk_epoch(batch, t);
+        ChWinner g;
+        const int widx = ch_poll_records(v.blkR, npick, tag, lane, g);
+        if (widx == -3 || (widx >= 0 && !ch_load_winner(v.blkR, widx, tag, g))) { if (lane == 0) ch_st(&st->status, (int)ST_CHAIN_STUCK); return; }
+        if (widx < 0) {
+            // CLOSE with budget left, or an empty first ratio pass: the batch takes no more pivots (blk_pick_body /
+            // blk_prep_body set `closed` in the same cases); with the budget spent it just ends
+            if (lane == 0 && (widx == -2 || budget != 0)) st->blk.closed = 1;
+            return;
+        }
+        if (lane == 0) {
+            const int enter = g.enter, leave = g.leave, r = g.r;
+            if (!((g.w >> (leave & 31)) & 1u)) {                // genPair, lpsol.h:100-104
+                ch_st(&v.ppt[(size_t)enter * v.pw + (leave >> 5)], g.w | (1u << (leave & 31)));
+                __hip_atomic_fetch_add(&v.rowcnt[enter], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ch_st(&v.colcnt[leave], g.cc + 1);
+            }
+            ch_st(&v.nv[enter], (uint8_t)0); ch_st(&v.nv[leave], (uint8_t)1);          // lpsol.h:1504-1510
+            ch_st(&v.bv[enter], (uint8_t)1); ch_st(&v.bv[leave], (uint8_t)0);
+            ch_st(&v.eq2bv[r], enter); ch_st(&v.bv2eq[enter], r); ch_st(&v.bv2eq[leave], -1);
+            if ((int)tp < v.trace_cap) { v.trace[2 * tp] = enter; v.trace[2 * tp + 1] = leave; }
+            st->total_pivots = tp + 1;
+            st->done = done + 1;
+            st->blk.budget = budget - 1;
+            st->blk.r[t] = r; st->blk.n = t + 1;
+            st->blk.la_from_state = 0;
+            st->blk.la_epoch = tag;
+        }
+        ch_drain();                                             // the commit is out: the pick role of stage t+1 may read it
+        if (lane == 0)
+            ch_store_granule((char *)v.blkP + (size_t)nprep * CH_PART_BYTES, (unsigned long long)(unsigned)INT_MAX, (unsigned long long)tag);
+        tp += 1; done += 1; budget -= 1;
+    }
+}
+
+#ifdef XPG_STAMPS
+__device__ unsigned long long g_ch_ts[4][16][8];            // [worker class][stage][point]: raw 100 MHz stamps of the last batch
+#define CH_TS(pt_) do { if (lane == 0 && tsw >= 0) g_ch_ts[tsw][t][pt_] = wall_clock64(); } while (0)
+#else
+#define CH_TS(pt_) do { } while (0)
+#endif
+
+// npick = ceil(m / 64) pick workers, nprep = ceil(W / 64) <= 255 prep workers; grid = max of the two, + 1.
 __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int t0, int B, int npick, int nprep)
 {
     LoopState * st = v.st;
     const int w = (int)blockIdx.x, lane = (int)threadIdx.x;
-    const int m = v.m, W = v.W, rhs = v.rhs, ld = v.ld, lim = v.rhs - 1;
     // ---- the ticket: stage 0 of THIS batch staged a pivot (fields this launch never writes)
     if (st->blk.ch_epoch != blk_epoch(batch, t0 - 1) || st->status != ST_RUNNING || st->pricing != 0) return;
-    unsigned budget = st->blk.ch_budget, done = st->blk.ch_done, tp = st->blk.ch_tp;
+    unsigned budget = st->blk.ch_budget, done = st->blk.ch_done;
     const unsigned max_iter = st->max_iter;
+    if (w == (int)gridDim.x - 1) { ch_commit_loop(v, batch, t0, B, npick, nprep, budget, done, st->blk.ch_tp); return; }
+    const int m = v.m, W = v.W, rhs = v.rhs, ld = v.ld, lim = v.rhs - 1;
     const bool picker = w < npick, prepper = w < nprep;
     const int i = w * 64 + lane, j = w * 64 + lane;         // this lane's row (pick role) and column (prep role)
     const bool has_row = picker && i < m, has_col = prepper && j < W;
@@ -141,193 +302,174 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
     const double * __restrict__ tab = (const double *)v.tab;
     double * K = (double *)v.blkK;
     double * E = (double *)v.blkE;
-    // own data of earlier stages (written by previous launches): into registers once
+    const char * parts = (const char *)v.blkP;
+    const int wrhs = rhs >> 6;                              // the prep worker that owns the constant column
+    // ---- own data of the stages before t0 (written by previous launches): into registers once
     double kreg[BLK_MAX], ereg[BLK_MAX];
 #pragma unroll
     for (int s = 0; s < BLK_MAX; s++) {
         kreg[s] = (s < t0 && has_row) ? K[(size_t)ic * BLK_MAX + s] : 0.0;
         ereg[s] = (s < t0 && has_col) ? E[(size_t)s * ld + jc] : 0.0;
     }
-    int rs[BLK_MAX];                                        // pivot rows staged so far (wave-uniform)
-#pragma unroll
-    for (int s = 0; s < BLK_MAX; s++) rs[s] = s < t0 ? st->blk.r[s] : -1;
-    F64 oj = has_col ? v.obj[jc] : zero<F64>();            // this lane's objective entry: own data throughout
+    F64 oj = has_col ? v.obj[jc] : zero<F64>();            // this lane's objective entry
     int bi = v.eq2bv[ic];                                   // basic variable of this lane's row (stage 0's commit is in)
-    bool stuck = false;
+    int sstar = -1;                                         // last stage in which this lane's row was the pivot row
+    double bcur = tab[(size_t)ic * ld + rhs];               // this row's constant, replayed through the stages before t - 1
+    double klast = 0.0;                                     // k of stage t - 1 for this row
+    for (int s = 0; s < t0; s++) {
+        const int rs = st->blk.r[s];
+        if (rs == i) sstar = s;
+        const double ks = has_row ? K[(size_t)ic * BLK_MAX + s] : 0.0;
+        if (s + 1 < t0) {                                   // (t0 = 1: no step here; stage t0 - 1 is applied in the loop)
+            const double eb = E[(size_t)s * ld + rhs];
+            const double pb = ks * eb;
+            bcur = (rs == i) ? eb : (bcur + pb);
+        } else klast = ks;
+    }
+    int r_prev = st->blk.r[t0 - 1];                         // pivot row of stage t - 1 (for the constant's step)
+#ifdef XPG_STAMPS
+    const int tsw = w == 0 ? 0 : (w == npick - 1 ? 1 : (w == npick ? 2 : (w == nprep - 1 ? 3 : -1)));
+#endif
 
 #pragma unroll 1
     for (int t = t0; t < B; t++) {
         const unsigned want_part = blk_epoch(batch, t - 1), tag = blk_epoch(batch, t);
-        int first = -1;
+        CH_TS(0);
         // =========================== pick role =====================================================
         if (picker) {
-            // ---- poll the partials of stage t-1: <= 4 per lane
-            int nf = INT_MAX, any = 0;
+            // ---- poll the g0 granules of the partials of stage t-1 and the commit granule (slot nprep)
+            int nf = INT_MAX;
             {
-                const char * base = (const char *)v.blkP;
                 const int k0 = lane, k1 = lane + 64, k2 = lane + 128, k3 = lane + 192;
-                const void * p0 = base + (size_t)(k0 < nprep ? k0 : 0) * (BLK_PART_INTS * 4);
-                const void * p1 = base + (size_t)(k1 < nprep ? k1 : 0) * (BLK_PART_INTS * 4);
-                const void * p2 = base + (size_t)(k2 < nprep ? k2 : 0) * (BLK_PART_INTS * 4);
-                const void * p3 = base + (size_t)(k3 < nprep ? k3 : 0) * (BLK_PART_INTS * 4);
-                ch_u32x4 g[4];
+                const int kc = k0 <= nprep ? k0 : k0 % (nprep + 1);
+                const void * p0 = parts + (size_t)kc * CH_PART_BYTES;
+                const void * p1 = parts + (size_t)(k1 <= nprep ? k1 : kc) * CH_PART_BYTES;   // (no slot of its own: its first one again)
+                const void * p2 = parts + (size_t)(k2 <= nprep ? k2 : kc) * CH_PART_BYTES;
+                const void * p3 = parts + (size_t)(k3 <= nprep ? k3 : kc) * CH_PART_BYTES;
+                // (the commit of stage t0 - 1 was a launch of its own: no granule to wait for)
+                const bool x0 = kc == nprep && t == t0, x1 = (k1 <= nprep ? k1 : kc) == nprep && t == t0;
+                const bool x2 = (k2 <= nprep ? k2 : kc) == nprep && t == t0, x3 = (k3 <= nprep ? k3 : kc) == nprep && t == t0;
+                ch_u32x4 g0, g1, g2, g3;
                 unsigned spins = 0;
                 for (;;) {
-                    ch_load_partials(p0, p1, p2, p3, g);
-                    const bool ok = g[0].z == want_part && g[1].z == want_part && g[2].z == want_part && g[3].z == want_part;
+                    ch_load4(p0, p1, p2, p3, g0, g1, g2, g3);
+                    const bool ok = (g0.z == want_part || x0) && (g1.z == want_part || x1) && (g2.z == want_part || x2) && (g3.z == want_part || x3);
                     if (__all(ok)) break;
-                    if (++spins > CH_SPIN_LIMIT) { stuck = true; break; }
+                    if (++spins > CH_SPIN_LIMIT) { if (lane == 0) ch_st(&st->status, (int)ST_CHAIN_STUCK); return; }
                     __builtin_amdgcn_s_sleep(1);
                 }
-                if (stuck) break;
-                if (k0 < nprep) { nf = min(nf, (int)g[0].x); any |= (int)g[0].y; }
-                if (k1 < nprep) { nf = min(nf, (int)g[1].x); any |= (int)g[1].y; }
-                if (k2 < nprep) { nf = min(nf, (int)g[2].x); any |= (int)g[2].y; }
-                if (k3 < nprep) { nf = min(nf, (int)g[3].x); any |= (int)g[3].y; }
+                if (k0 < nprep) nf = min(nf, (int)g0.x);
+                if (k1 < nprep) nf = min(nf, (int)g1.x);
+                if (k2 < nprep) nf = min(nf, (int)g2.x);
+                if (k3 < nprep) nf = min(nf, (int)g3.x);
             }
-            first = wave_min_int(nf);
-            (void)any;
+            CH_TS(1);                                       // partials + commit granule seen
+            const int first = wave_min_int(nf);
             // the fast path of blk_pick_body, or the end of the batch for everyone
             const bool fast = first >= 0 && first < rhs && done < max_iter && budget != 0;
             unsigned long long * rec = v.blkR + (size_t)w * BLK_REC_WORDS;
             if (!fast) {
-                if (lane == 0) {
-                    // (budget spent: the launch-per-stage pick leaves the batch open; otherwise it closes it)
-                    if (w == 0 && budget != 0) ch_st(&st->blk.closed, 1);
-                    ch_drain();
-                    for (int q = 0; q < 6; q++) ch_store_granule(rec + 2 * q, q == 5 ? (unsigned long long)CH_CLOSE : 0ull, (unsigned long long)tag);
-                }
-                first = CH_CLOSE;
-            } else {
-                // ---- one round: the column gathers, e_s[first] / e_s[rhs] (lane s / lane 16+s), c_nv, pair word, counter
-                const double x0 = tab[(size_t)ic * ld + first], b0 = tab[(size_t)ic * ld + rhs];
-                double ev = 0.0;
-                if (lane < t) ev = ch_ld(&E[(size_t)lane * ld + first]);
-                else if (lane >= 16 && lane - 16 < t) ev = ch_ld(&E[(size_t)(lane - 16) * ld + rhs]);
-                const unsigned long long cnv_bits = to_bits(ch_ld(&v.obj[first]));
-                const uint32_t pw_word = ch_ld(&v.ppt[(size_t)first * v.pw + (bi >> 5)]);
-                const int cc = ch_ld(&v.colcnt[bi]);
-                double a = x0, bc = b0;
-#pragma unroll
-                for (int s = 0; s < BLK_MAX; s++) {
-                    if (s < t) {
-                        const double ec = ch_readlane_f64(ev, s), eb = ch_readlane_f64(ev, 16 + s);
-                        const double k = kreg[s];
-                        const double pa = k * ec, pb = k * eb;
-                        a = (i == rs[s]) ? ec : (a + pa);
-                        bc = (i == rs[s]) ? eb : (bc + pb);
-                    }
-                }
-#pragma unroll
-                for (int s = 0; s < BLK_MAX; s++) if (s == t) kreg[s] = -a;      // -a_i,nv (lpsol.h:1485)
-                if (has_row) ch_st(&K[(size_t)i * BLK_MAX + t], -a);
-#ifdef XPG_STAMPS
-                if (has_row && i < 8192) { g_dbg_rows[0][i] = bc; g_dbg_rows[1][i] = (double)bi; g_dbg_rows[2][i] = (double)pw_word; g_dbg_rows[3][i] = (double)cc; }
-#endif
-                // findPivotBV's first pass (lpsol.h:553-663)
-                Cand<F64> c; c.q = zero<F64>(); c.idx = INT_MAX;
-                if (has_row && !le(F64(a), zero<F64>()) && !((pw_word >> (bi & 31)) & 1u) && cc < lim) {
-                    c.q = div(F64(bc), F64(a)); c.idx = i;
-                }
-                const Cand<F64> best = wave_argmin(c);
-                const int bidx = __builtin_amdgcn_readfirstlane(best.idx);
-                const bool publisher = bidx != INT_MAX ? (i == bidx) : (lane == 0);
-                ch_drain();                                                       // the wave's K stores are out
-                if (publisher) {
-                    const unsigned long long tg = (unsigned long long)tag;
-                    ch_store_granule(rec + 0, to_bits(best.q), tg);
-                    ch_store_granule(rec + 2, to_bits(F64(a)), tg);
-                    ch_store_granule(rec + 4, ((unsigned long long)(unsigned)bidx << 32) | (unsigned)bi, tg);
-                    ch_store_granule(rec + 6, ((unsigned long long)pw_word << 32) | (unsigned)cc, tg);
-                    ch_store_granule(rec + 8, cnv_bits, tg);
-                    ch_store_granule(rec + 10, (unsigned long long)(unsigned)first, tg);
-                }
+                if (lane == 0) ch_store_granule3(rec, ~0u, ~0u, (unsigned)CH_CLOSE_ROW, tag);
+                return;
             }
-        }
-        // =========================== prep role (every worker reads the records: all must leave together) ====
-        Cand<F64> g; g.q = zero<F64>(); g.idx = INT_MAX;
-        double g_a = 0.0; int g_b = 0, g_cc = 0, enter = -1; uint32_t g_w = 0; unsigned long long g_cnv = 0;
-        {
-            Cand<F64> mine; mine.q = zero<F64>(); mine.idx = INT_MAX;
-            unsigned long long m_a = 0, m_ib = 0, m_wc = 0, m_cnv = 0, m_first = 0;
-            unsigned spins = 0;
-            for (int u = 0; u < 4; u++) {                   // <= 256 records, lane l polls l, l + 64, ...
-                const int k = lane + 64 * u;
-                if (64 * u >= npick) break;                 // wave-uniform
-                const void * p = v.blkR + (size_t)(k < npick ? k : 0) * BLK_REC_WORDS;
-                ch_u32x4 gr[6];
+            // ---- one round: the column gather; e_s[first] for s <= t-2 from memory (lane s); the three fresh
+            // granules of stage t-1 (lane 32: e[first], lane 33: c[first], lane 34: e[rhs]); pair word, counter
+            const double x0 = tab[(size_t)ic * ld + first];
+            double ev = 0.0;
+            if (lane + 1 < t) ev = ch_ld(&E[(size_t)lane * ld + first]);
+            const uint32_t pw_word = ch_ld(&v.ppt[(size_t)first * v.pw + (bi >> 5)]);
+            const int cc = ch_ld(&v.colcnt[bi]);
+            {
+                const bool fresh = lane >= 32 && lane <= 34;
+                const char * gp = parts + (size_t)(lane == 34 ? wrhs : (first >> 6)) * CH_PART_BYTES + (fresh ? 16 * (lane - 31) : 0);
+                unsigned spins = 0;
                 for (;;) {
-                    ch_load_record(p, gr);
-                    const bool ok = gr[0].z == tag && gr[1].z == tag && gr[2].z == tag && gr[3].z == tag && gr[4].z == tag && gr[5].z == tag;
-                    if (__all(ok)) break;
-                    if (++spins > CH_SPIN_LIMIT) { stuck = true; break; }
+                    const ch_u32x4 g = ch_load1(gp);
+                    if (__all(g.z == want_part || !fresh)) { if (fresh) ev = __builtin_bit_cast(double, ch_lo64(g)); break; }
+                    if (++spins > CH_SPIN_LIMIT) { if (lane == 0) ch_st(&st->status, (int)ST_CHAIN_STUCK); return; }
                     __builtin_amdgcn_s_sleep(1);
                 }
-                if (stuck) break;
-                if (k < npick) {
-                    const unsigned long long fw = ch_lo64(gr[5]);
-                    Cand<F64> c; c.q = from_bits<F64>(ch_lo64(gr[0])); c.idx = (int)(unsigned)(ch_lo64(gr[2]) >> 32);
-                    if ((unsigned)fw == (unsigned)CH_CLOSE) { c.idx = INT_MAX; m_first = fw; }
-                    else if (m_first != (unsigned long long)CH_CLOSE) m_first = fw;
-                    const Cand<F64> nb = better(mine, c);
-                    if (nb.idx != mine.idx) { m_a = ch_lo64(gr[1]); m_ib = ch_lo64(gr[2]); m_wc = ch_lo64(gr[3]); }
-                    m_cnv = ch_lo64(gr[4]);
-                    mine = nb;
+            }
+            CH_TS(2);                                       // gather round issued, fresh granules in
+            const double ec_new = ch_readlane_f64(ev, 32), eb_new = ch_readlane_f64(ev, 34);
+            const unsigned long long cnv_bits = __builtin_bit_cast(unsigned long long, ch_readlane_f64(ev, 33));
+            // the constant column: ONE step, stage t-1 (the arithmetic of every other cell of the sweep)
+            {
+                const double pb = klast * eb_new;
+                bcur = (i == r_prev) ? eb_new : (bcur + pb);
+            }
+            // the entering column through the stages 0 .. t-1
+            double a = x0;
+#pragma unroll
+            for (int s = 0; s < BLK_MAX; s++) {
+                if (s < t) {
+                    const double ec = (s + 1 < t) ? ch_readlane_f64(ev, s) : ec_new;
+                    const double pa = kreg[s] * ec;
+                    a = (s == sstar) ? ec : (a + pa);
                 }
             }
-            if (stuck) break;
-            // every pick worker takes the same fast / close decision, so any record tells which it was
-            const unsigned f0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)m_first);
-            if (f0 == (unsigned)CH_CLOSE) break;
-            enter = (int)f0;
-            g = wave_argmin(mine);
-            const int gi = __builtin_amdgcn_readfirstlane(g.idx);
-            if (gi == INT_MAX) {
-                // first ratio pass empty: the second pass / disableNV are the generic pick's (next batch)
-                if (w == 0 && lane == 0) ch_st(&st->blk.closed, 1);
-                break;
-            }
-            const unsigned long long hit = __ballot(mine.idx == gi);
-            const int src = __ffsll((long long)hit) - 1;
-            g.idx = gi; g.q = from_bits<F64>(ch_readlane_u64(to_bits(g.q), 0));
-            g_a = from_bits<F64>(ch_readlane_u64(m_a, src)).v;
-            const unsigned long long ib = ch_readlane_u64(m_ib, src), wc = ch_readlane_u64(m_wc, src);
-            g_b = (int)(unsigned)ib; g_w = (uint32_t)(wc >> 32); g_cc = (int)(unsigned)wc;
-            g_cnv = ch_readlane_u64(m_cnv, 0);
-        }
-        const int r = g.idx, leave = g_b, n = t;
+            klast = -a;                                                           // -a_i,nv (lpsol.h:1485)
 #pragma unroll
-        for (int s = 0; s < BLK_MAX; s++) if (s == t) rs[s] = r;
-        if (i == r) bi = enter;                             // lpsol.h:1508, as every later pick of this launch sees it
+            for (int s = 0; s < BLK_MAX; s++) if (s == t) kreg[s] = klast;
+            if (has_row) ch_st(&K[(size_t)i * BLK_MAX + t], klast);
+            // findPivotBV's first pass (lpsol.h:553-663)
+            unsigned long long key = ~0ull;
+            if (has_row && !le(F64(a), zero<F64>()) && !((pw_word >> (bi & 31)) & 1u) && cc < lim) key = ch_ratio_key(bcur / a);
+            const unsigned long long kmin = ch_wave_min_u64(key);
+            const unsigned long long hit = __ballot(key == kmin);
+            const bool publisher = kmin != ~0ull ? (lane == __ffsll((long long)hit) - 1) : (lane == 0);
+            if (publisher) {
+                const unsigned long long ab = to_bits(F64(a));
+                ch_store_granule3(rec + 2, (unsigned)ab, (unsigned)(ab >> 32), (unsigned)bi, tag);
+                ch_store_granule3(rec + 4, pw_word, (unsigned)cc, (unsigned)first | ((unsigned)(sstar + 1) << 24), tag);
+                ch_store_granule3(rec + 6, (unsigned)cnv_bits, (unsigned)(cnv_bits >> 32), 0u, tag);
+                ch_store_granule3(rec + 0, (unsigned)kmin, (unsigned)(kmin >> 32), (unsigned)(kmin != ~0ull ? i : INT_MAX), tag);
+            }
+            CH_TS(3);                                       // record issued
+        }
+        // =========================== every worker reads the records: all leave together ======================
+        ChWinner g;
+        const int widx = ch_poll_records(v.blkR, npick, tag, lane, g);
+        if (widx == -3) { if (lane == 0) ch_st(&st->status, (int)ST_CHAIN_STUCK); return; }
+        if (widx < 0) return;                               // CLOSE / empty first pass: the committer records it
+        CH_TS(4);                                           // records seen and combined
+        const int r = g.r;
+        r_prev = r;
+        // =========================== prep role =====================================================
+        // ---- one round: the pivot row gather, k_q[r] (lane q), this column's basis words (the previous stage's
+        // commit is behind the records just read), and the rest of the winner's record (whose wait completes the
+        // loads before it as well)
+        double x0 = 0.0, kv = 0.0; int nvj = 0, rcj0 = INT_MAX;
         if (prepper) {
-            // ---- one round: the pivot row gather, k_q[r] (lane q), this column's basis words (the previous
-            // stage's commit is behind the records just read), the committing lane's counter
-            const double x0 = tab[(size_t)r * ld + jc];
-            const int nvj = has_col && j < rhs ? (int)ch_ld(&v.nv[jc]) : 0;
-            const int rcj0 = has_col && j < rhs ? ch_ld(&v.rowcnt[jc]) : INT_MAX;
-            double kv = 0.0;
+            x0 = tab[(size_t)r * ld + jc];
+            if (has_col && j < rhs) { nvj = (int)ch_ld(&v.nv[jc]); rcj0 = ch_ld(&v.rowcnt[jc]); }
             if (lane < t) kv = ch_ld(&K[(size_t)r * BLK_MAX + lane]);
-            int rc_enter = 0;
-            if (w == 0 && lane == 0) rc_enter = ch_ld(&v.rowcnt[enter]);
-            const F64 sc = div(one<F64>(), F64(g_a));       // 1/(eq.get(eqnum, nv)), lpsol.h:1471
+        }
+        if (!ch_load_winner(v.blkR, widx, tag, g)) { if (lane == 0) ch_st(&st->status, (int)ST_CHAIN_STUCK); return; }
+        const int enter = g.enter, leave = g.leave;
+        if (i == r) { bi = enter; sstar = t; }              // lpsol.h:1508, as every later pick of this launch sees it
+        if (prepper) {
+            const F64 sc = div(one<F64>(), F64(g.a));       // 1/(eq.get(eqnum, nv)), lpsol.h:1471
             const int smode = scale_mode(sc);
-            const F64 cnv = from_bits<F64>(g_cnv);
+            const F64 cnv = from_bits<F64>(g.cnv);
             const int cmode = scale_mode(cnv);
+            const int qstar = g.qstar;                      // the last stage before t in which row r was the pivot row
             double x = x0;
 #pragma unroll
             for (int q = 0; q < BLK_MAX; q++) {             // the pivot row as the pending sweeps would leave it
                 if (q < t) {
                     const double kq = ch_readlane_f64(kv, q);
                     const double pr = kq * ereg[q];
-                    x = (r == rs[q]) ? ereg[q] : (x + pr);
+                    x = (q == qstar) ? ereg[q] : (x + pr);
                 }
             }
             const F64 e = scaled(F64(x), sc, smode);
+            CH_TS(5);                                       // row gather in, replayed, scaled
 #pragma unroll
             for (int q = 0; q < BLK_MAX; q++) if (q == t) ereg[q] = e.v;
             int nf = INT_MAX, any = 0;
             if (has_col) {
-                ch_st(&E[(size_t)n * ld + j], e.v);
+                ch_st(&E[(size_t)t * ld + j], e.v);
                 F64 tt = mul(e, minus_one<F64>());          // nvexp.mul(-1), lpsol.h:1496
                 if (j >= rhs) tt = neg(tt);                 // :1497-1499
                 tt = scaled(tt, cnv, cmode);                // nvexp.mul(tgtf(nv)), :1500
@@ -338,37 +480,24 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
                 const int rcj = (in && j != enter) ? rcj0 : INT_MAX;
                 if (j < enter && in && !nv_old) oj = zero<F64>();     // lpsol.h:1055-1060
                 oj = add(tt, oj);                           // addRowToRow, :1501
-                ch_st(&v.obj[j], oj);
+                v.obj[j] = oj;                              // (read again only by later launches)
                 if (nv_new && gt(oj, zero<F64>())) { any = 1; if (rcj < lim) nf = j; }
             }
             nf = wave_min_int(nf);
             any = __ballot(any != 0) != 0ull ? 1 : 0;
-            // ---- worker 0, lane 0 commits the pivot (as blk_prep_body)
-            if (w == 0 && lane == 0) {
-                if (!((g_w >> (leave & 31)) & 1u)) {        // genPair, lpsol.h:100-104
-                    ch_st(&v.ppt[(size_t)enter * v.pw + (leave >> 5)], g_w | (1u << (leave & 31)));
-                    ch_st(&v.rowcnt[enter], rc_enter + 1); ch_st(&v.colcnt[leave], g_cc + 1);
-                }
-                ch_st(&v.nv[enter], (uint8_t)0); ch_st(&v.nv[leave], (uint8_t)1);      // lpsol.h:1504-1510
-                ch_st(&v.bv[enter], (uint8_t)1); ch_st(&v.bv[leave], (uint8_t)0);
-                ch_st(&v.eq2bv[r], enter); ch_st(&v.bv2eq[enter], r); ch_st(&v.bv2eq[leave], -1);
-                if ((int)tp < v.trace_cap) { v.trace[2 * tp] = enter; v.trace[2 * tp + 1] = leave; }
-                st->total_pivots = tp + 1;
-                st->done = done + 1;
-                st->blk.budget = budget - 1;
-                st->blk.r[n] = r; st->blk.n = n + 1;
-                st->blk.la_from_state = 0;
-                st->blk.la_epoch = tag;
+            // ---- the partial: the lane that owns the worker's candidate column publishes what the next pick needs
+            // fresh of it, the lane that owns the constant column its new e, lane 0 the candidate itself
+            char * P = (char *)v.blkP + (size_t)w * CH_PART_BYTES;
+            if (has_col && j == nf) {
+                ch_store_granule(P + 16, to_bits(e), (unsigned long long)tag);
+                ch_store_granule(P + 32, to_bits(oj), (unsigned long long)tag);
             }
-            ch_drain();                                     // this wave's E / obj (and the commit) are out
-            if (lane == 0) {
-                int * P = v.blkP + (size_t)w * BLK_PART_INTS;
-                ch_store_granule(P, ((unsigned long long)(unsigned)any << 32) | (unsigned)nf, (unsigned long long)tag);
-            }
+            if (has_col && j == rhs) ch_store_granule(P + 48, to_bits(e), (unsigned long long)tag);
+            if (lane == 0) ch_store_granule(P, ((unsigned long long)(unsigned)any << 32) | (unsigned)nf, (unsigned long long)tag);
+            CH_TS(6);                                       // partial issued
         }
-        tp += 1; done += 1; budget -= 1;
+        done += 1; budget -= 1;
     }
-    if (stuck && lane == 0) ch_st(&st->status, (int)ST_CHAIN_STUCK);
 }
 
 } // namespace xpg

@@ -144,12 +144,12 @@ template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> &
     // keeps that beyond doubt. Wider or taller tableaux, and the opt-in Dantzig pricing, take the
     // launch-per-stage path.
     const int cpick = (v.m + 63) / 64, cprep = (v.W + 63) / 64;
-    const bool chain = ctx->chain && ref_pricing && B > 1 && cpick <= ctx->num_cus && cprep <= ctx->num_cus &&
-                       cpick <= BLK_REC_MAX && cprep <= 256 &&
+    const bool chain = ctx->chain && ref_pricing && B > 1 && cpick < ctx->num_cus && cprep < ctx->num_cus &&
+                       cpick <= BLK_REC_MAX && cprep <= 255 &&
                        tpb_prep == 64;             // stage 0's prep leaves one look-ahead partial per 64 columns, as the chain's workers do
     for (int t = 0; t < B; t++) {
         if (t == 1 && chain) {
-            hipLaunchKernelGGL(k_blk_chain, dim3(cpick > cprep ? cpick : cprep), dim3(64), 0, ctx->stream, v, batch, 1, B, cpick, cprep);
+            hipLaunchKernelGGL(k_blk_chain, dim3((cpick > cprep ? cpick : cprep) + 1), dim3(64), 0, ctx->stream, v, batch, 1, B, cpick, cprep);
             break;
         }
         hipLaunchKernelGGL(k_blk_pick, dim3(npick), dim3(tp), 0, ctx->stream, v, batch, t, (int)gprep.x);
@@ -268,7 +268,7 @@ template <class S> struct Lp : LpBase {
         if ((rc = alloc((void **)&v.blkK, (size_t)round_up(m, 16) * BLK_MAX * sizeof(S)))) return rc;
         if ((rc = alloc((void **)&v.blkE, (size_t)BLK_MAX * ld * sizeof(S)))) return rc;
         if ((rc = alloc((void **)&v.blkR, (size_t)BLK_REC_MAX * BLK_REC_WORDS * 8))) return rc;
-        if ((rc = alloc((void **)&v.blkP, (size_t)((ld + BLK_TPB_MIN - 1) / BLK_TPB_MIN + 2) * BLK_PART_INTS * 4))) return rc;
+        if ((rc = alloc((void **)&v.blkP, (size_t)((ld + BLK_TPB_MIN - 1) / BLK_TPB_MIN + 3) * BLK_PART_INTS * 4))) return rc;
         if ((rc = alloc((void **)&v.trace, (size_t)v.trace_cap * 8))) return rc;
         if ((rc = alloc((void **)&d_leq, (size_t)m * cols * sizeof(S)))) return rc;
         if ((rc = alloc((void **)&d_tgtf, (size_t)cols * sizeof(S)))) return rc;

@@ -85,7 +85,7 @@ struct LoopState {
         unsigned long long dbg[8];   // diagnostic builds (-DXPG_STAMPS): 100 MHz ticks between points of pick / prep
     } blk;
 };
-enum { BLK_MAX = 16, BLK_REC_WORDS = 16, BLK_PART_INTS = 8,
+enum { BLK_MAX = 16, BLK_REC_WORDS = 16, BLK_PART_INTS = 20,
        BLK_PICK_WGS = 64,      // pick workgroups (= records) of the launch-per-stage path: one lane of a wave combines each
        BLK_REC_MAX = 256,      // records allocated: the chain kernel has one per 64 rows, up to 256 workers
        BLK_TPB_MIN = 64 };     // smallest workgroup of pick / prep: sizes the partial array
@@ -1074,7 +1074,8 @@ template <class S> __global__ void k_reset_loop(LpView<S> v, unsigned max_iter, 
         for (int k = 0; k < 8; k++) st->blk.dbg[k] = 0ull;
         for (int k = 0; k < BLK_REC_MAX; k++)                 // record tags
             for (int q = 1; q < 12; q += 2) v.blkR[(size_t)k * BLK_REC_WORDS + q] = 0ull;
-        for (int k = 0; k < (v.ld + BLK_TPB_MIN - 1) / BLK_TPB_MIN + 1; k++) v.blkP[(size_t)k * BLK_PART_INTS + 2] = 0;  // partial epochs
+        for (int k = 0; k < (v.ld + BLK_TPB_MIN - 1) / BLK_TPB_MIN + 2; k++)                      // partial epochs (four granules each)
+            for (int q = 2; q < 16; q += 4) v.blkP[(size_t)k * BLK_PART_INTS + q] = 0;
         for (int k = 0; k < 2; k++) v.pickrec[PICK_CTR_OFF + 16 * k] = 0ull;   // arrival counters
         for (int k = 0; k < 2; k++) {                  // pipelined loop: iteration 0 has no pivot yet
             PipeDesc & D = st->pd[k];

@@ -384,6 +384,13 @@ int xpg_lp_debug_counts(xpg_lp * lp, int * rowcnt, int * colcnt, int n)
     XPG_HIP(ctx, hipMemcpy(colcnt, p->v.colcnt, (size_t)n * 4, hipMemcpyDeviceToHost));
     return 0;
 }
+int xpg_lp_debug_chain_ts(xpg_lp * lp, unsigned long long * out)   // [4][16][8]
+{
+    if (!lp || !lp->impl) return XPG_ERR_SHAPE;
+    xpg_ctx * ctx = lp->impl->ctx;
+    XPG_HIP(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ch_ts), sizeof(unsigned long long) * 4 * 16 * 8));
+    return 0;
+}
 int xpg_lp_debug_rows(xpg_lp * lp, double * out)              // [4][8192]
 {
     if (!lp || !lp->impl) return XPG_ERR_SHAPE;
