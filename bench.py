@@ -104,31 +104,70 @@ def cpu_reference_pivots(leq, tgtf):
                        "(t[K=3]-t[K=1])/2 = %.3f s/pivot; set-up %.1f s per call" % (per, ts[1] - per))
 
 
-def cpu_per_core(fn_one, n_items, budget_s, what):
-    """One worker thread per host core (ctypes releases the GIL inside the oracle), each solving a
-    disjoint slice of the items for about budget_s. Returns items/s over all cores."""
-    import threading
-    cores = host_cores()
-    counts = [0] * cores
+_POOL_STATE = {}
+
+
+def _pool_worker(args):
+    """One process per host core: solves its own slice of the problems, cyclically, for budget_s seconds."""
+    kind, w, cores, budget_s = args
+    from oracle.checker import RAT, Port
+    port = Port()
+    st = _POOL_STATE
+    n, i = 0, w
     t_end = time.perf_counter() + budget_s
+    while time.perf_counter() < t_end:
+        if kind == "lp":
+            port.six_solve(0, True, st["tg"][i], st["vc"], None, st["leq"][i])
+        else:
+            port.mip_solve(RAT, True, True, st["tg"][i], st["vc"], None, st["leq"][i])
+        n += 1
+        i += cores
+        if i >= len(st["leq"]):
+            i = w % len(st["leq"])
+    return n
 
-    def work(w):
-        i = w
-        while i < n_items and time.perf_counter() < t_end:
-            fn_one(i)
-            counts[w] += 1
-            i += cores
 
+def cpu_per_core(kind, tg, vc, leq, budget_s, what):
+    """The oracle on every host core at once: one PROCESS per core (forked before this process touches the
+    GPU), each solving a disjoint slice for budget_s seconds. Returns items/s over all cores."""
+    import multiprocessing as mp
+    cores = host_cores()
+    _POOL_STATE.update(tg=tg, vc=vc, leq=leq)
     t0 = time.perf_counter()
-    th = [threading.Thread(target=work, args=(w,)) for w in range(cores)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
+    with mp.get_context("fork").Pool(cores) as pool:
+        counts = pool.map(_pool_worker, [(kind, w, cores, budget_s) for w in range(cores)], chunksize=1)
     dt = time.perf_counter() - t0
     n = sum(counts)
-    return dict(value=round(n / dt, 2), cores=cores, kind="port",
-                sample="%d %s through the oracle, one thread per host core (%d), %.1f s" % (n, what, cores, dt))
+    return dict(value=round(n / budget_s, 2), cores=cores, kind="port",
+                sample="%d %s through the oracle, one process per host core (%d), %.1f s each (%.1f s wall incl. fork)"
+                       % (n, what, cores, budget_s, dt))
+
+
+def cpu_baselines(legs, no_ref):
+    """Every CPU figure of the run, taken BEFORE anything touches the GPU (the per-core legs fork)."""
+    from oracle.checker import Port
+    from tools import gen
+    port = Port()
+    cpu = {}
+    if "pivots" in legs:
+        cpu = cpu_baseline_pivots(8.0)
+        if not no_ref:
+            leq, tgtf = gen.hard_lp_f64(M, NVARS)
+            cpu["reference"] = cpu_reference_pivots(leq, tgtf)
+            del leq
+    if "batched" in legs:
+        leq_b, tg_b = gen.small_lp_batch_f64(2048, BATCH_M, BATCH_COLS, 1, seed=gen.XS_SEED + 1001)
+        r = cpu_per_core("lp", tg_b, gen.vc_nonneg(BATCH_COLS - 1), leq_b, 6.0, "dep-test-like LPs (32x64, SIX::maxm)")
+        r["unit"] = "LPs/s"
+        cpu["batched"] = r
+    if "rational" in legs:
+        cpu["rational"] = cpu_rational(port, gen)
+    if "mip" in legs:
+        leq_m, tg_m = gen.knapsack_batch_rat(MIP_NB, MIP_NV)
+        r = cpu_per_core("mip", tg_m, gen.to_rat(gen.vc_nonneg(MIP_NV, False)), leq_m, 4.0, "0-1 knapsack MIPs (%d vars)" % MIP_NV)
+        r["unit"] = "MIPs/s"
+        cpu["mip"] = r
+    return cpu
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -174,9 +213,13 @@ def main():
     if world != a.gpus:
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
 
+    stub = a.stub_solver
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not stub:
+        cpu = cpu_baselines(legs, a.no_ref_baseline)     # forks: before torch / HIP are initialised in this process
+
     import torch
     from xpoly_amd.shard import gather_records, pack_records, shard_range
-    stub = a.stub_solver
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -223,7 +266,6 @@ def main():
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
     if stub:
         out["stub_solver"] = True
-    cpu = None
 
     # ---- leg 1: pivots/s on the 4096 x 8192 tableau (one replica per rank) -------------------------
     leq = tgtf = None
@@ -412,27 +454,6 @@ def main():
         if "mip" in legs:
             out["mip"] = leg_mip(ctx, xpoly_amd, gen)
 
-    # ---- CPU baselines (rank 0, N = 1 only) --------------------------------------------------------
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and not stub:
-        from oracle.checker import Port
-        port = Port()
-        if "pivots" in legs:
-            cpu = cpu_baseline_pivots()
-            if not a.no_ref_baseline:
-                cpu["reference"] = cpu_reference_pivots(leq, tgtf)
-        else:
-            cpu = {}
-        if b_leq is not None:
-            vc = gen.vc_nonneg(BATCH_COLS - 1)
-            d_leq_f, d_tg_f = gen.small_lp_batch_f64(2048, BATCH_M, BATCH_COLS, 1, seed=gen.XS_SEED + 1001)
-            r = cpu_per_core(lambda i: port.six_solve(0, True, d_tg_f[i], vc, None, d_leq_f[i]), 2048, 6.0,
-                             "dep-test-like LPs (32x64, SIX::maxm)")
-            r["unit"] = "LPs/s"
-            cpu["batched"] = r
-        if "rational" in out:
-            cpu["rational"] = cpu_rational(port, gen)
-        if "mip" in out:
-            cpu["mip"] = cpu_mip(port, gen)
     if rank == 0:
         out["cpu_baseline"] = cpu
         print(json.dumps(out))
@@ -538,16 +559,6 @@ def leg_mip(ctx, xpoly_amd, gen):
                 nodes_per_problem=round(nodes / MIP_NB, 2), wall_ms=round(dt * 1e3, 2),
                 status_hist=np.bincount(np.clip(st, 0, 4), minlength=5).tolist(), dtype="int32 num/den",
                 sample="xpg_mip_batch_rat32, host arrays in and out (PCIe included)")
-
-
-def cpu_mip(port, gen):
-    from oracle.checker import RAT
-    leq, tgtf = gen.knapsack_batch_rat(MIP_NB, MIP_NV)
-    vc = gen.to_rat(gen.vc_nonneg(MIP_NV, False))
-    r = cpu_per_core(lambda i: port.mip_solve(RAT, True, True, tgtf[i], vc, None, leq[i]), MIP_NB, 6.0,
-                     "0-1 knapsack MIPs (%d vars)" % MIP_NV)
-    r["unit"] = "MIPs/s"
-    return r
 
 
 if __name__ == "__main__":

@@ -252,3 +252,39 @@ def test_live_reference_agrees_with_port(ref, port):
             assert r[0] == o[0] and same(r[1], o[1])
             if r[0] == 0:
                 assert same(r[2], o[2])
+
+
+# ---- the fixtures at the BASELINE shapes (tests/golden/g8_large.json, tools/gen_golden_large.py) -------------
+def _checksum(a):
+    import zlib
+    a = np.ascontiguousarray(a)
+    v = a.view(np.uint64).reshape(-1) if a.dtype.itemsize == 8 else a.view(np.uint32).reshape(-1).astype(np.uint64)
+    return dict(crc32="%08x" % (zlib.crc32(a.tobytes()) & 0xFFFFFFFF), sum="%016x" % int(v.sum(dtype=np.uint64)),
+                xor="%016x" % int(np.bitwise_xor.reduce(v)))
+
+
+def test_g8_large_pins_the_oracle_at_the_baseline_shapes(port):
+    """The restatement against what the real reference returned at 32 x 64 (64 LPs per family here, all 256 on
+    the GPU side), at the rational 1024 x 2048 tableau (K = 8) and at the 4096 x 12289 tableau (K = 16)."""
+    import zlib
+    g = json.load(open(os.path.join(GOLD, "g8_large.json")))
+    vc = gen.vc_nonneg(63)
+    for rec in g["g3_large"]:
+        leq, tg = gen.small_lp_batch_f64(256, 32, 64, rec["family"], seed=gen.XS_SEED + rec["seed_offset"])
+        for b in range(0, 256, 4):
+            want = rec["records"][b]
+            st, v, sol = port.six_solve(F64, True, tg[b], vc, None, leq[b])
+            assert st == want["status"] and float(v).hex() == want["v"], (rec["family"], b)
+            if st == 0:
+                assert "%08x" % (zlib.crc32(np.ascontiguousarray(sol).tobytes()) & 0xFFFFFFFF) == want["sol_crc32"]
+    rec = g["g4_large"][0]
+    leq, tgtf = gen.int_lp_rat(1024, 1023)
+    r = port.two_stage(RAT, leq, tgtf, rec["K"])
+    assert r["status"] == rec["status"] and _checksum(r["tab"]) == rec["tab"] and _checksum(r["tgtf"]) == rec["tgtf"]
+    assert _checksum(r["eq2bv"].astype(np.int32)) == rec["eq2bv"]
+    rec = g["g2_large"][0]
+    leq, tgtf = gen.dense_lp_f64(4096, 8192)
+    r = port.two_stage(F64, leq, tgtf, rec["K"])
+    assert list(r["tab"].shape) == rec["tab_shape"] and r["status"] == rec["status"]
+    assert _checksum(r["tab"]) == rec["tab"] and _checksum(r["tgtf"]) == rec["tgtf"]
+    assert _checksum(r["eq2bv"].astype(np.int32)) == rec["eq2bv"]
