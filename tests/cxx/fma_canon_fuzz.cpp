@@ -1,0 +1,53 @@
+// CPU check of xpg::fma_canon (xpoly_amd/csrc/scalar.hip.h): the fused a + k*e of the rational sweep must equal
+// add(a, mul(k, e)) -- the reference's two operations (src/com/rational.cpp:273-310, :363-397) -- bit for bit
+// on canonical operands, including the magnitudes that trigger the float32 `appro` rescue.
+// Build: hipcc -O2 -ffp-contract=off -o tests/cxx/fma_canon_fuzz tests/cxx/fma_canon_fuzz.cpp   (host code only)
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include "../../xpoly_amd/csrc/scalar.hip.h"
+
+using namespace xpg;
+
+static uint64_t s = 88172645463325252ull;
+static uint64_t rnd() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; }
+
+// a canonical rational whose size class is drawn first (small integers ... near the appro threshold)
+static R32 draw()
+{
+    static const int64_t caps[] = { 4, 10, 100, 10000, 1000000, 0x1fffffff, 0x7ffffffe };
+    for (;;) {
+        const int64_t cn = caps[rnd() % 7], cd = caps[rnd() % 7];
+        int64_t n = (int64_t)(rnd() % (uint64_t)(2 * cn + 1)) - cn, d = 1 + (int64_t)(rnd() % (uint64_t)cd);
+        if (rnd() % 5 == 0) d = 1;
+        R32 r((int32_t)n, (int32_t)d);
+        reduce(r);
+        if (canonical(r)) return r;
+    }
+}
+
+int main(int argc, char ** argv)
+{
+    const long N = argc > 1 ? atol(argv[1]) : 3000000;
+    long appro_like = 0, zeros = 0;
+    for (long it = 0; it < N; it++) {
+        const R32 a = draw(), k = draw(), e = draw();
+        const R32 want = add(a, mul(k, e));
+        const R32 got = fma_canon(a, k, e);
+        if (want.num != got.num || want.den != got.den) {
+            printf("MISMATCH a=%d/%d k=%d/%d e=%d/%d want=%d/%d got=%d/%d\n", a.num, a.den, k.num, k.den, e.num, e.den,
+                   want.num, want.den, got.num, got.den);
+            return 1;
+        }
+        const R32 m1 = mul(k, e), m2 = mul_canon(k, e), a1 = add(a, k), a2 = add_canon(a, k);
+        if (m1.num != m2.num || m1.den != m2.den || a1.num != a2.num || a1.den != a2.den) {
+            printf("MISMATCH mul/add_canon a=%d/%d k=%d/%d e=%d/%d\n", a.num, a.den, k.num, k.den, e.num, e.den);
+            return 1;
+        }
+        if (!canonical(got)) { printf("result not canonical: %d/%d\n", got.num, got.den); return 1; }
+        if (want.den == 1000000 || want.den == 100000 || want.den == 10000 || want.den == 1000) appro_like++;
+        if (want.num == 0) zeros++;
+    }
+    printf("fma_canon == add(mul) on %ld canonical triples (%ld results with an appro denominator, %ld zeros)\n", N, appro_like, zeros);
+    return 0;
+}

@@ -69,3 +69,14 @@ def test_header_is_plain_c99_and_links():
                            "-Wl,-rpath," + os.path.join(ROOT, "xpoly_amd")])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_fma_canon_equals_the_two_reference_operations():
+    """The rational sweep's fused a + k*e (scalar.hip.h, fma_canon / mul_canon / add_canon) against add(a, mul(k, e)),
+    the reference's two operations (src/com/rational.cpp:273-310, :363-397), on 2 M canonical triples that include
+    the float32 `appro` rescue: host code only, no GPU."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cxx", "fma_canon_fuzz")
+    subprocess.check_call(["hipcc", "-O2", "-ffp-contract=off", "-w", "-o", exe, os.path.join(ROOT, "tests", "cxx", "fma_canon_fuzz.cpp")])
+    r = subprocess.run([exe, "2000000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "fma_canon == add(mul)" in r.stdout, r.stdout + r.stderr

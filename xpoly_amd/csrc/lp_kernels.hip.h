@@ -40,6 +40,8 @@ struct LoopState {
     int infeasible;        // set by the feasibility kernels
     unsigned total_pivots; // over the handle's lifetime (trace index)
     int aux;               // scratch result for phase-1 helper kernels
+    int noncanon;          // rational LP: some input entry is not in lowest terms with den > 0 (k_build); the sweep then
+                           // keeps to the reference's two generic operations per cell (no fma_canon, no zero-column skip)
     // look-ahead pricing, filled by k_prep's atomics after the objective update:
     int next_first;        // lowest eligible entering column of the next iteration
                            // (INT_MAX: none, NF_UNKNOWN: not computed)
@@ -458,11 +460,20 @@ template <class S> __global__ __launch_bounds__(1024) void k_pick(LpView<S> v)
 // LoopState (lpsol.h:1468-1474, :1485, :1496-1510). Reads the tableau only.
 // guarded: only while the loop is running; counted: the pivot counts towards 'cnt'
 // (the forced pivots of phase 1 are neither, lpsol.h:906-908, :939).
+// canonical-operand forms of the rational operations (scalar.hip.h), selected where every operand is known canonical
+template <class S> __device__ __forceinline__ S mul_c(S a, S b, bool) { return mul(a, b); }
+template <> __device__ __forceinline__ R32 mul_c<R32>(R32 a, R32 b, bool canon) { return canon ? mul_canon(a, b) : mul(a, b); }
+template <class S> __device__ __forceinline__ S add_c(S a, S b, bool) { return add(a, b); }
+template <> __device__ __forceinline__ R32 add_c<R32>(R32 a, R32 b, bool canon) { return canon ? add_canon(a, b) : add(a, b); }
+template <class S> __device__ __forceinline__ S scaled_c(S cell, S x, int mode, bool canon)
+{ return mode == SCALE_KEEP ? cell : (mode == SCALE_ZERO ? zero<S>() : mul_c(cell, x, canon)); }
+
 template <class S> __global__ __launch_bounds__(256)
 void k_prep(LpView<S> v, int guarded, int counted, int bookkeeping, int lookahead)
 {
     LoopState * st = v.st;
     if ((guarded && st->status != ST_RUNNING) || st->row < 0) return;
+    const bool canon = guarded && !is_f64<S>::value && st->noncanon == 0;
     const int r = st->row, c = st->col;
     const S s = div(one<S>(), from_bits<S>(st->piv_bits));   // 1/(eq.get(eqnum, nv)), :1471
     const int smode = scale_mode(s);
@@ -472,12 +483,12 @@ void k_prep(LpView<S> v, int guarded, int counted, int bookkeeping, int lookahea
     const int lim = v.rhs - 1;
     int nf = INT_MAX, any = 0;
     for (int j = gid; j < v.W; j += gsz) {
-        S e = scaled(v.tab[(size_t)r * v.ld + j], s, smode);
+        S e = scaled_c(v.tab[(size_t)r * v.ld + j], s, smode, canon);
         v.rowbuf[j] = e;
-        S t = mul(e, minus_one<S>());                          // nvexp.mul(-1), :1496
+        S t = mul_c(e, minus_one<S>(), canon);                 // nvexp.mul(-1), :1496
         if (j >= v.rhs) t = neg(t);                            // :1497-1499
-        t = scaled(t, cnv, cmode);                             // nvexp.mul(tgtf(nv)), :1500
-        const S o = add(t, v.obj[j]);                          // addRowToRow, :1501
+        t = scaled_c(t, cnv, cmode, canon);                    // nvexp.mul(tgtf(nv)), :1500
+        const S o = add_c(t, v.obj[j], canon);                 // addRowToRow, :1501
         v.obj[j] = o;
         // look-ahead pricing of the next iteration (basis already swapped by k_pick)
         if (lookahead && j < v.rhs && v.nv[j] && gt(o, zero<S>())) {
@@ -530,6 +541,42 @@ void k_update(LpView<S> v, int guarded)
         if (i >= v.m) break;
         S * p = v.tab + (size_t)i * v.ld + j;
         const S o = (i == r) ? e : add(*p, mul(v.colbuf[i], e));
+        *p = o;
+        if (ex_col) v.nextcol[i] = o;
+        if (ex_b) v.bcol[i] = o;
+    }
+}
+
+// K1, rational: integer-ALU bound (Euclid loops), not HBM. Two things make it cheaper without changing a bit
+// (scalar.hip.h, fma_canon): while every cell is canonical -- always, unless the caller's input held fractions
+// not in lowest terms (LoopState::noncanon) -- a + k*e is one fused operation on 32-bit gcds, and a column whose
+// scaled pivot-row entry is 0 is left alone altogether (a + k*0 = a exactly; in the first pivots of a slack-form
+// LP that is about half the columns: the slack columns of rows that have not pivoted yet).
+template <int ROWS> __global__ __launch_bounds__(256)
+void k_update_r32(LpView<R32> v, int guarded)
+{
+    const LoopState * st = v.st;
+    if ((guarded && st->status != ST_RUNNING) || st->row < 0) return;
+    const int r = st->row;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= v.W) return;
+    const int xcol = guarded ? st->next_first : -1;
+    const bool ex_col = guarded && j == xcol, ex_b = guarded && j == v.rhs;
+    if (guarded && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        v.st->cached_col = (xcol >= 0 && xcol < v.W) ? xcol : -1; v.st->bcol_valid = 1;
+    }
+    const bool canon = guarded && st->noncanon == 0;          // (one-shot pivots on a caller's tableau: generic)
+    const R32 e = v.rowbuf[j];
+    const int i0 = blockIdx.y * ROWS;
+    if (canon && e.num == 0 && !ex_col && !ex_b) {
+        if (r >= i0 && r < i0 + ROWS) v.tab[(size_t)r * v.ld + j] = e;      // the pivot row's own cell := e
+        return;
+    }
+    for (int ii = 0; ii < ROWS; ii++) {
+        const int i = i0 + ii;
+        if (i >= v.m) break;
+        R32 * p = v.tab + (size_t)i * v.ld + j;
+        const R32 o = (i == r) ? e : (canon ? fma_canon(*p, v.colbuf[i], e) : add(*p, mul(v.colbuf[i], e)));
         *p = o;
         if (ex_col) v.nextcol[i] = o;
         if (ex_b) v.bcol[i] = o;
@@ -1020,6 +1067,8 @@ template <class S> __global__ void k_finish(LpView<S> v, S * maxv)
 
 // ---- slack-form construction (SIX::slack, lpsol.h:1406-1433; the xa column
 // of constructBasicFeasibleSolution, lpsol.h:860-868) straight into HBM.
+__device__ __forceinline__ bool is_canonical_cell(F64) { return true; }
+__device__ __forceinline__ bool is_canonical_cell(R32 a) { return canonical(a); }
 template <class S> __global__ void k_build(LpView<S> v, const S * leq, const S * tgtf,
                                            int n, int with_xa)
 {
@@ -1036,11 +1085,13 @@ template <class S> __global__ void k_build(LpView<S> v, const S * leq, const S *
             else if (j == v.rhs) val = leq[(size_t)i * cols + n];
             else if (j - first_slack == i) val = one<S>();
             v.tab[(size_t)i * v.ld + j] = val;
+            if (!is_canonical_cell(val)) v.st->noncanon = 1;
         } else {
             if (with_xa) { if (j == n) val = minus_one<S>(); }
             else if (j < n) val = tgtf[j];
             else if (j == v.rhs) val = tgtf[n];
             v.obj[j] = val;
+            if (!is_canonical_cell(val)) v.st->noncanon = 1;
         }
     }
 }

@@ -145,6 +145,99 @@ XPG_HD R32 add(R32 a, R32 b)   // rational.cpp:363-397
     return squeeze(n, (long long)a.den * (long long)b.den);
 }
 XPG_HD R32 neg(R32 a) { return R32(-a.num, a.den); }
+
+// ---- a + k*e for CANONICAL operands ------------------------------------------------------------------
+// "Canonical" = in lowest terms with den > 0, below the appro threshold: what squeeze() returns, and a fixed
+// point of it -- so every tableau cell is canonical once it has been through one operation, and from the start
+// when the input is (xpg::canonical below; the sweep takes this path only then).
+// fma_canon(a, k, e) == add(a, mul(k, e)) bit for bit (tests/cxx/fma_canon_fuzz.cpp), with four 32-bit Euclid
+// loops in place of two 64-bit ones and their 64-bit divisions:
+//   * k*e: gcd(k.num, k.den) = gcd(e.num, e.den) = 1, so cancelling gcd(|k.num|, e.den) and gcd(|e.num|, k.den)
+//     crosswise leaves the product in lowest terms -- the pair reduce64 (rational.cpp:163-185) arrives at;
+//   * a + p with g = gcd(a.den, p.den), A = a.den/g, P = p.den/g: n' = a.num*P + p.num*A is coprime to A and to P,
+//     so gcd(n', A*P*g) = gcd(n' mod g, g);
+//   * the zero cases: k*0 = 0/1 (rational.cpp:276-281) and a + 0/1 = squeeze(a.num, a.den) = a.
+// The tail of squeeze (second-reduce and appro thresholds, rational.cpp:294-309) is applied to the same
+// lowest-terms pair the reference applies it to.
+// Binary gcd (the value is the Euclidean one; ~7 instructions per step against ~30 for a 32-bit remainder on
+// gfx950, and the step counts of the lanes of a wave lie closer together).
+XPG_HD uint32_t gcd32(uint32_t x, uint32_t y)
+{
+    if (x == 0) return y;
+    if (y == 0) return x;
+    const int sh = __builtin_ctz(x | y);
+    x >>= __builtin_ctz(x);
+    do {
+        y >>= __builtin_ctz(y);
+        const uint32_t lo = x < y ? x : y, hi = x < y ? y : x;
+        x = lo; y = hi - lo;
+    } while (y != 0);
+    return x << sh;
+}
+XPG_HD bool canonical(R32 a)
+{
+    if (a.den <= 0) return false;
+    if (a.num == 0) return a.den == 1;
+    const uint32_t mag = a.num < 0 ? (uint32_t)(-(long long)a.num) : (uint32_t)a.num;
+    return gcd32(mag, (uint32_t)a.den) == 1 && mag < 0x7fffFFFFu && a.den < 0x7fffFFFF;
+}
+XPG_HD R32 squeeze_lowest(long long n, long long d)            // squeeze() for a pair already in lowest terms, d > 0
+{
+    const long long imax = 0x7fffFFFFLL;
+    long long mag = n >= 0 ? n : -n;
+    if (mag >= (imax >> 2) || d >= (imax >> 2)) {
+        if (mag >= imax || d >= imax) appro64(mag, d);
+    }
+    return R32((int32_t)(n < 0 ? -mag : mag), (int32_t)d);
+}
+XPG_HD R32 mul_canon(R32 a, R32 b)                             // == mul(a, b) for canonical a, b
+{
+    if (a.num == 0 || b.num == 0) return R32(0, 1);
+    const uint32_t an = a.num < 0 ? (uint32_t)(-(long long)a.num) : (uint32_t)a.num;
+    const uint32_t bn = b.num < 0 ? (uint32_t)(-(long long)b.num) : (uint32_t)b.num;
+    const uint32_t g1 = gcd32(an, (uint32_t)b.den), g2 = gcd32(bn, (uint32_t)a.den);
+    const long long mag = (long long)(an / g1) * (long long)(bn / g2);
+    const long long den = (long long)((uint32_t)a.den / g2) * (long long)((uint32_t)b.den / g1);
+    return squeeze_lowest(((a.num < 0) != (b.num < 0)) ? -mag : mag, den);
+}
+XPG_HD R32 add_canon(R32 a, R32 p)                             // == add(a, p) for canonical a, p
+{
+    if (p.num == 0) return a;
+    if (a.num == 0) return p;
+    const uint32_t g = gcd32((uint32_t)a.den, (uint32_t)p.den);
+    const uint32_t A = (uint32_t)a.den / g, P = (uint32_t)p.den / g;
+    long long n = (long long)a.num * (long long)P + (long long)p.num * (long long)A;
+    if (n == 0) return R32(0, 1);
+    long long d = (long long)A * (long long)p.den;
+    if (g != 1) {
+        const unsigned long long nm = n < 0 ? (unsigned long long)(-n) : (unsigned long long)n;
+        const uint32_t h = gcd32((uint32_t)(nm % g), g);
+        if (h != 1) { n /= (long long)h; d /= (long long)h; }
+    }
+    return squeeze_lowest(n, d);
+}
+XPG_HD R32 fma_canon(R32 a, R32 k, R32 e)
+{
+    if (k.num == 0 || e.num == 0) return a;
+    const uint32_t kn = k.num < 0 ? (uint32_t)(-(long long)k.num) : (uint32_t)k.num;
+    const uint32_t en = e.num < 0 ? (uint32_t)(-(long long)e.num) : (uint32_t)e.num;
+    const uint32_t g1 = gcd32(kn, (uint32_t)e.den), g2 = gcd32(en, (uint32_t)k.den);
+    const long long pmag = (long long)(kn / g1) * (long long)(en / g2);
+    const long long pden = (long long)((uint32_t)k.den / g2) * (long long)((uint32_t)e.den / g1);
+    const R32 p = squeeze_lowest(((k.num < 0) != (e.num < 0)) ? -pmag : pmag, pden);
+    if (p.num == 0) return a;                                  // (appro can return 0/1)
+    const uint32_t g = gcd32((uint32_t)a.den, (uint32_t)p.den);
+    const uint32_t A = (uint32_t)a.den / g, P = (uint32_t)p.den / g;
+    long long n = (long long)a.num * (long long)P + (long long)p.num * (long long)A;
+    if (n == 0) return R32(0, 1);
+    long long d = (long long)A * (long long)p.den;
+    if (g != 1) {
+        const unsigned long long nm = n < 0 ? (unsigned long long)(-n) : (unsigned long long)n;
+        const uint32_t h = gcd32((uint32_t)(nm % g), g);
+        if (h != 1) { n /= (long long)h; d /= (long long)h; }
+    }
+    return squeeze_lowest(n, d);
+}
 XPG_HD R32 sub(R32 a, R32 b) { return add(a, neg(b)); }
 XPG_HD bool eq(R32 a, R32 b) { return a.num == b.num && a.den == b.den; }   // rational.h:80-83
 XPG_HD bool ne(R32 a, R32 b) { return a.num != b.num || a.den != b.den; }
