@@ -227,6 +227,15 @@ int xpg_mip_batch_rat32(xpg_ctx * ctx, int nb, int is_max, int is_bin, const xpg
 int xpg_dep_is_empty_batch_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols,
                                  int32_t * out_empty, long long * out_nodes);
 
+/* The same with the two arguments of the reference spelled out: the constant is column rhs_idx and the columns
+ * after it are constant symbols, which Lineq::move2var (src/com/linsys.cpp:1177-1200) first turns into variables
+ * (i + j <= 1 + M + N  ->  i + j - M - N <= 1, poly.cpp:536-548); vc [rhs_idx][rhs_idx + 1] are the caller's
+ * variable constraints (NULL: -x_i <= 0, poly.cpp:559-567).  With symbols the reference hands has_solution a
+ * matrix with several constant columns, which SIX::verify only ASSERTs (lpsol.h:1526-1552): systems that
+ * Lineq::reduce does not decide then get XPG_ERR_REF_UNDEFINED in out_empty. */
+int xpg_dep_is_empty_batch_ex_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols,
+                                    int rhs_idx, const xpg_rat32 * vc, int32_t * out_empty,
+                                    long long * out_nodes);
 /* Multi-device forms of the two batches above (sharding and devices[] as xpg_six_batch_*_multi;
  * out_nodes receives the sum over the shards). */
 int xpg_mip_batch_rat32_multi(int ndev, const int * devices, int nb, int is_max, int is_bin,
@@ -252,6 +261,11 @@ int xpg_lineq_reduce_batch_rat32(xpg_ctx * ctx, int nb, xpg_rat32 * mats, int ro
                                  int rhs_idx, int is_intersect, int32_t * out_rows, int32_t * out_ok);
 int xpg_lineq_remove_iden_batch_rat32(xpg_ctx * ctx, int nb, xpg_rat32 * mats, int rows, int cols,
                                       int32_t * out_rows);
+/* Lineq::move2var, src/com/linsys.cpp:1177-1200, in place on every system: columns first_sym..last_sym (constant
+ * symbols, behind the constant column rhs_idx) are multiplied by -1 and moved in front of column rhs_idx.  A
+ * reshaping of the host arrays (no kernel); the multiplication is the reference's Rational '*'. */
+int xpg_lineq_move2var_batch_rat32(xpg_ctx * ctx, int nb, xpg_rat32 * mats, int rows, int cols, int rhs_idx,
+                                   int first_sym, int last_sym);
 int xpg_lineq_fme_batch_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols,
                               int rhs_idx, int u, int darkshadow, xpg_rat32 * outs, int cap_rows,
                               int32_t * out_rows, int32_t * out_ok);

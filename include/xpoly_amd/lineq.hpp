@@ -1,0 +1,123 @@
+// C++ adapter: a class with the names and signatures of xpoly's Lineq (src/com/linsys.h:61-186) for the
+// members that sit on the hot path -- reduce, fme, has_solution, calcBound, move2var, removeIdenRow -- on top of
+// the C ABI in ../xpoly_amd.h, so that call sites such as
+//
+//     Lineq lin(NULL);                                      // src/eng/poly.cpp:537
+//     if (!lin.reduce(*coeff, coeff->get_col_size() - 1, true)) return true;
+//     return !lin.has_solution(*coeff, eq, lvc, rhs_idx, true, true);   // src/eng/poly.cpp:571, linsys.cpp:830
+//
+// compile unchanged against `xpoly_amd::Lineq<RMat>` and run on the GPU. Each member is the batch entry point
+// with a batch of one (the batch forms in xpoly_amd.h are what a caller with a SCoP's worth of polyhedra
+// should use). Header only; relies on the Matrix<Rational> contract only: get_row_size(), get_col_size(),
+// get_matrix() (row-major {int32 num; int32 den}, matt.h:152-156, rational.h:66-67), size(), reinit(r, c).
+#ifndef XPOLY_AMD_LINEQ_HPP
+#define XPOLY_AMD_LINEQ_HPP
+
+#include <cstring>
+#include <vector>
+#include "../xpoly_amd.h"
+#include "six.hpp"
+
+namespace xpoly_amd {
+
+template <class RMatT> class Lineq {
+    xpg_ctx * m_ctx;
+    RMatT * m_coeff;                 // linsys.h:64-70
+    int m_rhs_idx;
+    xpg_ctx * ctx() { return m_ctx ? m_ctx : detail::shared_context(); }
+    static void put(RMatT & m, const std::vector<xpg_rat32> & a, int rows, int cols)
+    {
+        m.reinit(rows, cols);
+        if (rows * cols) std::memcpy((void *)m.get_matrix(), (const void *)a.data(), sizeof(xpg_rat32) * (size_t)rows * cols);
+    }
+public:
+    explicit Lineq(RMatT * m, int rhs_idx = -1, xpg_ctx * c = 0) : m_ctx(c), m_coeff(m), m_rhs_idx(rhs_idx)
+    { if (m && rhs_idx == -1) m_rhs_idx = (int)m->get_col_size() - 1; }
+    void set_param(RMatT * m, int rhs_idx = -1)             // linsys.cpp:117-131
+    { m_coeff = m; m_rhs_idx = (m && rhs_idx == -1) ? (int)m->get_col_size() - 1 : rhs_idx; }
+
+    // Lineq::reduce, linsys.cpp:359-626: in place; false = the system is inconsistent.
+    bool reduce(RMatT & m, unsigned rhs_idx, bool is_intersect)
+    {
+        const int rows = (int)m.get_row_size(), cols = (int)m.get_col_size();
+        if (rows == 0) return true;
+        std::vector<xpg_rat32> a((size_t)rows * cols);
+        std::memcpy((void *)a.data(), (const void *)m.get_matrix(), sizeof(xpg_rat32) * a.size());
+        int32_t kept = 0, ok = 0;
+        if (xpg_lineq_reduce_batch_rat32(ctx(), 1, a.data(), rows, cols, (int)rhs_idx, is_intersect ? 1 : 0, &kept, &ok) != 0) return false;
+        put(m, a, kept, cols);
+        return ok != 0;
+    }
+    // Lineq::removeIdenRow, linsys.cpp:1209-1268
+    void removeIdenRow(RMatT & m)
+    {
+        const int rows = (int)m.get_row_size(), cols = (int)m.get_col_size();
+        if (rows == 0) return;
+        std::vector<xpg_rat32> a((size_t)rows * cols);
+        std::memcpy((void *)a.data(), (const void *)m.get_matrix(), sizeof(xpg_rat32) * a.size());
+        int32_t kept = 0;
+        if (xpg_lineq_remove_iden_batch_rat32(ctx(), 1, a.data(), rows, cols, &kept) == 0) put(m, a, kept, cols);
+    }
+    // Lineq::move2var, linsys.cpp:1177-1200
+    void move2var(RMatT & ieq, unsigned rhs_idx, unsigned first_sym, unsigned last_sym, unsigned * first_var_idx, unsigned * last_var_idx)
+    {
+        xpg_lineq_move2var_batch_rat32(ctx(), 1, (xpg_rat32 *)ieq.get_matrix(), (int)ieq.get_row_size(), (int)ieq.get_col_size(),
+                                       (int)rhs_idx, (int)first_sym, (int)last_sym);
+        if (first_var_idx) *first_var_idx = rhs_idx;
+        if (last_var_idx) *last_var_idx = rhs_idx + (last_sym - first_sym);
+    }
+    // Lineq::fme on the system given to the constructor / set_param, linsys.cpp:656-774
+    bool fme(unsigned u, RMatT & res, bool darkshadow = false)
+    {
+        const int rows = (int)m_coeff->get_row_size(), cols = (int)m_coeff->get_col_size();
+        int cap = rows * rows / 4 + rows + 1;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            std::vector<xpg_rat32> out((size_t)cap * cols);
+            int32_t orows = 0, ok = 0;
+            if (xpg_lineq_fme_batch_rat32(ctx(), 1, (const xpg_rat32 *)m_coeff->get_matrix(), rows, cols, m_rhs_idx, (int)u,
+                                          darkshadow ? 1 : 0, out.data(), cap, &orows, &ok) != 0) return false;
+            if (orows < 0) { cap = -orows; continue; }
+            put(res, out, orows, cols);
+            return ok != 0;
+        }
+        return false;
+    }
+    // Lineq::has_solution, linsys.cpp:830-906
+    bool has_solution(RMatT const & leq, RMatT const & eq, RMatT & vc, unsigned rhs_idx, bool is_int_sol, bool is_unique_sol)
+    {
+        if (leq.size() == 0 && eq.size() == 0) return false;
+        const int cols = leq.size() ? (int)leq.get_col_size() : (int)eq.get_col_size();
+        const int r = xpg_has_solution_rat32(ctx(), (const xpg_rat32 *)detail::data_of(leq), leq.size() ? (int)leq.get_row_size() : 0,
+                                             (const xpg_rat32 *)detail::data_of(eq), eq.size() ? (int)eq.get_row_size() : 0,
+                                             (const xpg_rat32 *)detail::data_of(vc), (int)vc.get_row_size(), cols, (int)rhs_idx,
+                                             is_int_sol ? 1 : 0, is_unique_sol ? 1 : 0);
+        return r == 1;
+    }
+    // Lineq::calcBound, linsys.cpp:1047-1078: limits[j] receives the bounds of variable j (every other variable
+    // eliminated). `limits` is anything with push_back / append_tail of RMatT* -- here a std::vector<RMatT> out
+    // parameter keeps ownership simple.
+    bool calcBound(std::vector<RMatT> & limits)
+    {
+        const int rows = (int)m_coeff->get_row_size(), cols = (int)m_coeff->get_col_size(), nv = m_rhs_idx;
+        int cap = 4 * rows + 16;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            std::vector<xpg_rat32> out((size_t)nv * cap * cols);
+            std::vector<int32_t> orows((size_t)nv);
+            int32_t ok = 0;
+            if (xpg_lineq_calc_bound_batch_rat32(ctx(), 1, (const xpg_rat32 *)m_coeff->get_matrix(), rows, cols, nv, cap, out.data(),
+                                                 orows.data(), &ok) != 0) return false;
+            if (ok < 0) { cap = -ok; continue; }
+            if (ok == 0) return false;
+            limits.resize((size_t)nv);
+            for (int j = 0; j < nv; j++) {
+                std::vector<xpg_rat32> one(out.begin() + (size_t)j * cap * cols, out.begin() + (size_t)j * cap * cols + (size_t)orows[(size_t)j] * cols);
+                put(limits[(size_t)j], one, orows[(size_t)j], cols);
+            }
+            return true;
+        }
+        return false;
+    }
+};
+
+} // namespace xpoly_amd
+#endif

@@ -59,6 +59,59 @@ public:
     unsigned minm(T & minv, Mat & res, Mat const & tgtf, Mat & vc, Mat const & eq, Mat const & leq, int rhs_idx = -1)
     { return solve(false, minv, res, tgtf, vc, eq, leq, rhs_idx); }
 
+    // SIX::TwoStageMethod, lpsol.h:291-301 / :1907-1930 -- same in/out arguments: newleq comes in as the
+    // inequalities (A | b) of an x >= 0 problem and goes out as the slack tableau after at most max_iter pivots,
+    // newtgtf as its objective row, newvc grown to the slack variables, the basis in the four vectors (anything
+    // with set(i, v): Vector<bool> / Vector<INT>, sstl.h), new_rhs_idx the constant column of the tableau.
+    // The tableau stays in HBM for the whole solve (xpg_lp_*); it is downloaded once at the end.
+    template <class VecB, class VecI>
+    unsigned TwoStageMethod(Mat & newleq, Mat & newvc, Mat & newtgtf, Mat & slack_sol, T & maxv, VecB & nvset, VecB & bvset,
+                            VecI & bv2eqmap, VecI & eq2bvmap, int & new_rhs_idx)
+    {
+        const int kind = scalar_kind<T>::value;
+        xpg_ctx * ctx = m_ctx ? m_ctx : detail::shared_context();
+        if (!ctx) return (unsigned)XPG_ERR_NO_DEVICE;
+        const int m = (int)newleq.get_row_size(), cols = (int)newleq.get_col_size(), n0 = cols - 1;
+        if (kind < 0 || new_rhs_idx != n0 || (int)newvc.get_row_size() != n0 || (int)newvc.get_col_size() != cols ||
+            (int)newtgtf.get_col_size() != cols)
+            return (unsigned)XPG_ERR_SHAPE;
+        std::vector<T> vcd((size_t)n0), vcr((size_t)n0);          // the only cells of vc the solver reads (lpsol.h:798-802)
+        for (int i = 0; i < n0; i++) { vcd[(size_t)i] = newvc.get(i, i); vcr[(size_t)i] = newvc.get(i, n0); }
+        xpg_lp * lp = 0;
+        int st = xpg_lp_create(ctx, kind, detail::data_of(newleq), m, cols, detail::data_of(newtgtf), vcd.data(), vcr.data(), 0, &lp);
+        if (st != 0) return (unsigned)st;
+        st = xpg_lp_two_stage(lp, m_max_iter);
+        int rows = 0, W = 0, rhs = 0;
+        if (st >= 0 && xpg_lp_shape(lp, &rows, &W, &rhs) == 0 && st != XPG_SIX_NO_PRI_FEASIBLE_SOL) {
+            std::vector<unsigned char> nv((size_t)rhs), bv((size_t)rhs);
+            std::vector<int32_t> b2e((size_t)rhs), e2b((size_t)rows);
+            newleq.reinit(rows, W); newtgtf.reinit(1, W); slack_sol.reinit(1, W);
+            T mv; std::memset((void *)&mv, 0, sizeof(T));
+            const int rc = xpg_lp_read(lp, (void *)newleq.get_matrix(), (void *)newtgtf.get_matrix(), nv.data(), bv.data(),
+                                       b2e.data(), e2b.data(), (void *)&mv, (void *)slack_sol.get_matrix());
+            if (rc != 0) st = rc;
+            for (int i = 0; i < rhs; i++) { nvset.set(i, nv[(size_t)i] != 0); bvset.set(i, bv[(size_t)i] != 0); bv2eqmap.set(i, b2e[(size_t)i]); }
+            for (int i = 0; i < rows; i++) eq2bvmap.set(i, e2b[(size_t)i]);
+            // vc as SIX::slack leaves it (lpsol.h:1422-1431): the caller's rows widened, -x_s <= 0 for every slack
+            Mat grown; grown.reinit(rhs, W);
+            T zero_; std::memset((void *)&zero_, 0, sizeof(T));
+            if (kind == 1) { int32_t z[2] = {0, 1}; std::memcpy((void *)&zero_, z, 8); }
+            T neg1 = zero_;
+            if (kind == 0) { const double d = -1.0; std::memcpy((void *)&neg1, &d, 8); } else { int32_t q[2] = {-1, 1}; std::memcpy((void *)&neg1, q, 8); }
+            for (int i = 0; i < rhs; i++)
+                for (int j = 0; j < W; j++) grown.set(i, j, zero_);
+            for (int i = 0; i < rhs; i++) {
+                grown.set(i, i, i < n0 ? vcd[(size_t)i] : neg1);
+                if (i < n0) grown.set(i, rhs, vcr[(size_t)i]);
+            }
+            newvc = grown;
+            maxv = mv;
+            new_rhs_idx = rhs;
+        }
+        xpg_lp_destroy(lp);
+        return (unsigned)st;
+    }
+
 private:
     unsigned solve(bool is_max, T & v, Mat & res, Mat const & tgtf, Mat & vc, Mat const & eq, Mat const & leq, int rhs_idx)
     {

@@ -195,6 +195,13 @@ class _Lib:
         res = mat.reshape(-1)[: r * c * 2].reshape(r, c, 2).copy()
         return ok, res
 
+    def move2var(self, mat, rhs_idx, first_sym, last_sym):
+        """Lineq::move2var (linsys.cpp:1177-1200)."""
+        mat = as_kind(mat, RAT, 2).copy()
+        self._f("move2var")(_vp(mat), C.c_int(mat.shape[0]), C.c_int(mat.shape[1]), C.c_int(rhs_idx),
+                            C.c_int(first_sym), C.c_int(last_sym))
+        return mat
+
     def remove_iden_row(self, mat):
         mat = as_kind(mat, RAT, 2).copy()
         rows, cols = mat.shape[0], mat.shape[1]

@@ -24,8 +24,10 @@
 #include "sbs.h"
 #include "sgraph.h"
 #include "lpsol.h"
+#include "linsys.h"
 
 #include "xpoly_amd/six.hpp"
+#include "xpoly_amd/lineq.hpp"
 
 namespace xpoly_amd {
 template <> struct scalar_kind<xcom::Float> { static const int value = 0; };
@@ -125,6 +127,77 @@ int main()
         if (!mis && a == IP_SUCC)
             mis = memcmp(s_ref.get_matrix(), s_gpu.get_matrix(), sizeof(Rational) * s_ref.get_col_size()) != 0;
         if (mis) printf("MISMATCH MIP %s: reference status %u, xpoly_amd status %u\n", is_bin ? "0-1" : "integer", a, b);
+        bad += mis; n++;
+    }
+    // ---- SIX::TwoStageMethod (lpsol.h:291-301) with the reference's own Vector<bool> / Vector<INT> in/outs
+    for (int it = 0; it < 24; it++) {
+        int m = irand(2, 7), nv = irand(2, 7);
+        for (int flavour = 0; flavour < 2; flavour++) {
+            unsigned K = it % 3 == 0 ? 2u : 0xFFFFFFFFu;
+            if (flavour == 0) {
+                RMat l1(m, nv + 1), t1(1, nv + 1), v1(nv, nv + 1), l2, t2, v2, s1, s2;
+                for (int i = 0; i < m; i++) for (int j = 0; j <= nv; j++) l1.setr(i, j, j < nv ? irand(0, 6) : irand(3, 20), 1);
+                for (int j = 0; j < nv; j++) { t1.setr(0, j, irand(1, 6), 1); v1.setr(j, j, -1, 1); }
+                l2 = l1; t2 = t1; v2 = v1;
+                Rational mv1, mv2; Vector<bool> n1, b1, n2, b2; Vector<INT> be1, eb1, be2, eb2; INT r1 = nv, r2 = nv;
+                xcom::SIX<RMat, Rational> ref; ref.set_param(0, K);
+                xpoly_amd::SIX<RMat, Rational> gpu; gpu.set_param(0, K);
+                UINT a = ref.TwoStageMethod(l1, v1, t1, s1, mv1, n1, b1, be1, eb1, r1);
+                UINT b = gpu.TwoStageMethod(l2, v2, t2, s2, mv2, n2, b2, be2, eb2, r2);
+                int mis = a != b || r1 != r2 || l1.get_row_size() != l2.get_row_size() || l1.get_col_size() != l2.get_col_size();
+                if (!mis) mis = memcmp(l1.get_matrix(), l2.get_matrix(), sizeof(Rational) * l1.size()) != 0 ||
+                                memcmp(t1.get_matrix(), t2.get_matrix(), sizeof(Rational) * t1.size()) != 0;
+                for (INT i = 0; !mis && i < r1; i++) mis = n1.get(i) != n2.get(i) || b1.get(i) != b2.get(i) || be1.get(i) != be2.get(i);
+                for (UINT i = 0; !mis && i < l1.get_row_size(); i++) mis = eb1.get(i) != eb2.get(i);
+                if (!mis && a == SIX_SUCC) mis = memcmp(&mv1, &mv2, sizeof(Rational)) != 0;
+                if (mis) printf("MISMATCH TwoStageMethod rational: reference status %u, xpoly_amd status %u\n", a, b);
+                bad += mis; n++;
+            } else {
+                FloatMat l1(m, nv + 1), t1(1, nv + 1), v1(nv, nv + 1), l2, t2, v2, s1, s2;
+                for (int i = 0; i < m; i++) for (int j = 0; j <= nv; j++) l1.set(i, j, Float((double)(j < nv ? irand(0, 6) : irand(3, 20))));
+                for (int j = 0; j < nv; j++) { t1.set(0, j, Float((double)irand(1, 6))); v1.set(j, j, Float(-1.0)); }
+                l2 = l1; t2 = t1; v2 = v1;
+                Float mv1, mv2; Vector<bool> n1, b1, n2, b2; Vector<INT> be1, eb1, be2, eb2; INT r1 = nv, r2 = nv;
+                xcom::SIX<FloatMat, Float> ref; ref.set_param(0, K);
+                xpoly_amd::SIX<FloatMat, Float> gpu; gpu.set_param(0, K);
+                UINT a = ref.TwoStageMethod(l1, v1, t1, s1, mv1, n1, b1, be1, eb1, r1);
+                UINT b = gpu.TwoStageMethod(l2, v2, t2, s2, mv2, n2, b2, be2, eb2, r2);
+                int mis = a != b || r1 != r2 || l1.get_col_size() != l2.get_col_size();
+                if (!mis) mis = memcmp(l1.get_matrix(), l2.get_matrix(), sizeof(Float) * l1.size()) != 0 ||
+                                memcmp(t1.get_matrix(), t2.get_matrix(), sizeof(Float) * t1.size()) != 0;
+                for (UINT i = 0; !mis && i < l1.get_row_size(); i++) mis = eb1.get(i) != eb2.get(i);
+                if (mis) printf("MISMATCH TwoStageMethod float: reference status %u, xpoly_amd status %u\n", a, b);
+                bad += mis; n++;
+            }
+        }
+    }
+    // ---- the Lineq call sites of the dependence test (src/eng/poly.cpp:530-573, src/com/linsys.cpp:884) through
+    // xcom::Lineq and xpoly_amd::Lineq<RMat>: reduce, has_solution, fme
+    for (int it = 0; it < 40; it++) {
+        int rows = irand(2, 9), nv = irand(1, 4);
+        RMat sys1(rows, nv + 1), sys2, vc(nv, nv + 1), eq;
+        for (int i = 0; i < rows; i++) for (int j = 0; j <= nv; j++) sys1.setr(i, j, j < nv ? irand(-3, 3) : irand(-4, 9), 1);
+        for (int j = 0; j < nv; j++) vc.setr(j, j, -1, 1);
+        sys2 = sys1;
+        xcom::Lineq ref(NULL);
+        xpoly_amd::Lineq<RMat> gpu(NULL);
+        bool ra = ref.reduce(sys1, nv, true), rb = gpu.reduce(sys2, nv, true);
+        int mis = ra != rb || sys1.get_row_size() != sys2.get_row_size() ||
+                  (sys1.size() && memcmp(sys1.get_matrix(), sys2.get_matrix(), sizeof(Rational) * sys1.size()) != 0);
+        if (!mis && ra && sys1.get_row_size() > 0 && sys1.get_row_size() <= sys1.get_col_size()) {
+            // (more rows than columns: convertEq2Ineq is out of bounds in the reference, lpsol.h:1232)
+            RMat vc2 = vc;
+            bool ha = ref.has_solution(sys1, eq, vc, nv, true, true), hb = gpu.has_solution(sys2, eq, vc2, nv, true, true);
+            mis = ha != hb;
+        }
+        if (!mis && ra && sys1.get_row_size() > 1) {
+            RMat f1, f2;
+            xcom::Lineq r2(&sys1, nv); xpoly_amd::Lineq<RMat> g2(&sys2, nv);
+            bool fa = r2.fme(0, f1, false), fb = g2.fme(0, f2, false);
+            mis = fa != fb || f1.get_row_size() != f2.get_row_size() ||
+                  (f1.size() && memcmp(f1.get_matrix(), f2.get_matrix(), sizeof(Rational) * f1.size()) != 0);
+        }
+        if (mis) printf("MISMATCH Lineq adapter on system %d\n", it);
         bad += mis; n++;
     }
     printf("dropin_demo: %d solves through xcom::SIX / MIP and xpoly_amd::SIX / MIP on the reference's own matrix types, "

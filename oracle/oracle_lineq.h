@@ -41,6 +41,23 @@ inline int cmp_const_rows(const RM & m, int rhs, int r1, int r2)
     return CST_UNK;
 }
 
+// Lineq::move2var (linsys.cpp:1177-1200): columns first_sym..last_sym are taken out, multiplied by -1 with the
+// scalar's own '*' (Matrix::mul, matt.h:1331-1348: so a coefficient such as 2/4 comes back as -1/2) and put
+// back in front of column rhs_idx, in their order.
+inline void move2var(RM & m, int rhs_idx, int first_sym, int last_sym)
+{
+    const int rows = m.r, cols = m.c;
+    RM out(rows, cols);
+    for (int i = 0; i < rows; i++) {
+        int c = 0;
+        for (int j = 0; j < rhs_idx; j++) out.at(i, c++) = m.at(i, j);
+        for (int j = first_sym; j <= last_sym; j++) out.at(i, c++) = mul(m.at(i, j), R32(-1, 1));
+        for (int j = rhs_idx; j < cols; j++)
+            if (j < first_sym || j > last_sym) out.at(i, c++) = m.at(i, j);
+    }
+    m = out;
+}
+
 // Lineq::removeIdenRow (linsys.cpp:1209-1268): drop later duplicates of a row;
 // row sums are a prefilter, equality is field-wise.
 inline void remove_iden_rows(RM & m)

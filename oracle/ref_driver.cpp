@@ -301,6 +301,17 @@ void ref_remove_iden_row(void * inout, int rows, int cols, int * out_rows)
     if (m.size() > 0) store(m, inout);
 }
 
+// Lineq::move2var (linsys.cpp:1177-1200): constant symbols first_sym..last_sym become variables in front of the
+// constant column rhs_idx. In place (the shape does not change).
+void ref_move2var(void * inout, int rows, int cols, int rhs_idx, int first_sym, int last_sym)
+{
+    RMat m;
+    load(m, inout, rows, cols);
+    Lineq lin(NULL);
+    lin.move2var(m, (UINT)rhs_idx, (UINT)first_sym, (UINT)last_sym, NULL, NULL);
+    store(m, inout);
+}
+
 // Lineq::has_solution (linsys.cpp:830).
 int ref_has_solution(const void * leq, int leq_rows, const void * eq,
                      int eq_rows, const void * vc, int vc_rows, int cols,

@@ -215,3 +215,36 @@ def test_batched_gauss_match_oracle(lq, port, n):
     rk = lq.rank(rect)
     for b in range(nb):
         assert rk[b] == port.rat_rank(rect[b])
+
+
+def test_move2var_and_dep_is_empty_with_symbols_and_vc(ctx, lq, port):
+    """N1 in full (SURVEY 8f): Lineq::move2var (linsys.cpp:1177-1200) and DepPoly::is_empty(keepit, vc)
+    (poly.cpp:530-573) with constant symbols and caller-supplied variable constraints, against golden G9 --
+    generated from the real reference's move2var / reduce / has_solution -- and against the oracle."""
+    import json
+    from xpoly_amd.six import dep_is_empty_batch
+    g = json.load(open(os.path.join(GOLD, "g9_dep.json")))
+    for c in g["move2var"]:
+        mat = dec(c["mat"]["data"], c["mat"]["shape"])
+        got = lq.move2var(mat, c["rhs"], c["first"], c["last"])[0]
+        assert np.array_equal(got, dec(c["out"]["data"], c["out"]["shape"]))
+        assert np.array_equal(got, port.move2var(mat, c["rhs"], c["first"], c["last"]))
+    seen = set()
+    for c in g["is_empty"]:
+        mat = dec(c["mat"]["data"], c["mat"]["shape"])
+        vc = None if c["vc"] is None else dec(c["vc"]["data"], c["vc"]["shape"])
+        empty, _ = dep_is_empty_batch(ctx, mat[None], rhs_idx=c["rhs"], vc=vc)
+        assert empty[0] == c["empty"], (c["rhs"], mat[..., 0].tolist(), empty[0], c["empty"])
+        seen.add(c["empty"])
+    assert {0, 1, -7} <= seen
+    # a batch of one shape with symbols, against the oracle composition
+    rng = np.random.default_rng(99)
+    nv, ns, rows = 3, 2, 9
+    mats = np.stack([gen.random_system(rng, rows, nv + ns) for _ in range(48)])
+    mats[..., 1] = 1
+    empty, _ = dep_is_empty_batch(ctx, mats, rhs_idx=nv)
+    for b in range(48):
+        moved = port.move2var(mats[b], nv, nv + 1, nv + ns)
+        ok, res = port.reduce(moved, nv + ns, True)
+        want = 1 if not ok else (0 if res.shape[0] == 0 else -7)
+        assert empty[b] == want, b

@@ -273,3 +273,32 @@ def test_dropin_demo_with_reference_types():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "0 mismatches" in r.stdout
+
+
+def test_rational_device_loop_with_fractions_not_in_lowest_terms(ctx, port):
+    """The HBM-resident rational loop takes its fused canonical sweep only while every input entry is in lowest
+    terms; inputs such as 2/4 or 6/3 stay as given until an operation touches them (rational.cpp never reduces on
+    construction), so those LPs must run the reference's two generic operations per cell -- and match the oracle
+    bit for bit either way."""
+    import xpoly_amd
+    rng = np.random.default_rng(314)
+    six = xpoly_amd.SIX(ctx, RAT)
+    checked = 0
+    for it in range(12):
+        m, nv = int(rng.integers(3, 10)), int(rng.integers(3, 10))
+        A = rng.integers(1, 7, size=(m, nv)); b = rng.integers(nv, 4 * nv, size=m); c = rng.integers(1, 6, size=nv)
+        leq = gen.to_rat(np.concatenate([A, b[:, None]], axis=1).astype(np.int32))
+        tg = gen.to_rat(np.concatenate([c, [0]]).astype(np.int32))
+        if it % 2 == 0:                                   # scale some entries by k/k: same value, not in lowest terms
+            for _ in range(m):
+                i, j, k = int(rng.integers(0, m)), int(rng.integers(0, nv + 1)), int(rng.integers(2, 5))
+                leq[i, j] = (leq[i, j, 0] * k, leq[i, j, 1] * k)
+        for K in (1, 3, 0xFFFFFFFF):
+            want = port.two_stage(RAT, leq, tg, K)
+            six.set_param(0, K)
+            got = six.TwoStageMethod(leq, tg)
+            assert got["status"] == want["status"], (it, K)
+            for k in ("tab", "tgtf", "nvset", "bvset", "bv2eq", "eq2bv"):
+                assert np.array_equal(got[k], want[k]), (it, K, k)
+            checked += 1
+    assert checked == 36

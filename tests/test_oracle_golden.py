@@ -288,3 +288,11 @@ def test_g8_large_pins_the_oracle_at_the_baseline_shapes(port):
     assert list(r["tab"].shape) == rec["tab_shape"] and r["status"] == rec["status"]
     assert _checksum(r["tab"]) == rec["tab"] and _checksum(r["tgtf"]) == rec["tgtf"]
     assert _checksum(r["eq2bv"].astype(np.int32)) == rec["eq2bv"]
+
+
+def test_g9_move2var_pins_the_oracle(port):
+    g = json.load(open(os.path.join(GOLD, "g9_dep.json")))
+    for c in g["move2var"]:
+        mat = np.array(c["mat"]["data"], dtype=np.int32).reshape(c["mat"]["shape"])
+        want = np.array(c["out"]["data"], dtype=np.int32).reshape(c["out"]["shape"])
+        assert np.array_equal(port.move2var(mat, c["rhs"], c["first"], c["last"]), want)

@@ -307,27 +307,55 @@ inline int has_solution(xpg_ctx * ctx, const R32 * leq, int leq_rows, const R32 
     return 0;
 }
 
-// DepPoly::is_empty(keepit, vc = NULL) (src/eng/poly.cpp:530-573) for a batch of dependence
-// polyhedra without constant symbols (rhs_idx == cols - 1): Lineq::reduce as the cheap
-// pre-filter, then Lineq::has_solution(is_int_sol = true, is_unique_sol = true) with x >= 0,
-// i.e. MIP::maxm and, failing that, MIP::minm. All systems advance together: one
-// wave-per-system reduce launch, then rounds of batched node LPs.
-inline int dep_is_empty_batch(xpg_ctx * ctx, int nb, const R32 * mats, int rows, int cols, int32_t * out_empty,
-                              long * out_nodes)
+// Lineq::move2var (src/com/linsys.cpp:1177-1200) for one system: the constant symbols first_sym..last_sym become
+// variables in front of the constant column rhs_idx -- taken out, multiplied by -1 with the scalar's own '*'
+// (Matrix::mul, matt.h:1331-1348: 2/4 comes back as -1/2) and inserted before column rhs_idx. Shape unchanged.
+inline void move2var_one(const R32 * in, R32 * out, int rows, int cols, int rhs_idx, int first_sym, int last_sym)
 {
-    if (!ctx || nb < 0 || !mats || rows <= 0 || cols < 2 || !out_empty) return XPG_ERR_SHAPE;
+    for (int i = 0; i < rows; i++) {
+        const R32 * src = in + (size_t)i * cols;
+        R32 * dst = out + (size_t)i * cols;
+        int c = 0;
+        for (int j = 0; j < rhs_idx; j++) dst[c++] = src[j];
+        for (int j = first_sym; j <= last_sym; j++) dst[c++] = mul(src[j], R32(-1, 1));
+        for (int j = rhs_idx; j < cols; j++)
+            if (j < first_sym || j > last_sym) dst[c++] = src[j];
+    }
+}
+
+// DepPoly::is_empty(keepit, vc) (src/eng/poly.cpp:530-573) for nb dependence polyhedra of one shape: the constant
+// is column rhs_idx, columns after it are constant symbols. move2var (when there are symbols) -> Lineq::reduce at
+// the last column -> inconsistent: empty; no row left: not empty; else Lineq::has_solution(int, unique) with the
+// caller's variable constraints vc [rhs_idx][rhs_idx + 1] (NULL: -x_i <= 0, poly.cpp:563-567).
+// With symbols that last step is undefined in the reference: has_solution is handed rhs_idx = the number of
+// variables while the matrix has grown by the symbols, which SIX::verify (lpsol.h:1526-1552, "No yet support const
+// term with multi-columns") only ASSERTs in debug builds -- those systems get XPG_ERR_REF_UNDEFINED, the ones
+// reduce decides get their answer.
+inline int dep_is_empty_batch(xpg_ctx * ctx, int nb, const R32 * mats, int rows, int cols, int rhs_idx, const R32 * vc_in,
+                              int32_t * out_empty, long * out_nodes)
+{
+    if (!ctx || nb < 0 || !mats || rows <= 0 || cols < 2 || !out_empty || rhs_idx < 1 || rhs_idx > cols - 1) return XPG_ERR_SHAPE;
     if (nb == 0) return 0;
-    const int rhs = cols - 1;
-    std::vector<R32> work(mats, mats + (size_t)nb * rows * cols);
+    const int last = cols - 1, nsym = last - rhs_idx;
+    std::vector<R32> work((size_t)nb * rows * cols);
+    if (nsym > 0) {
+        for (int b = 0; b < nb; b++)
+            move2var_one(mats + (size_t)b * rows * cols, work.data() + (size_t)b * rows * cols, rows, cols, rhs_idx, rhs_idx + 1, last);
+    } else {
+        work.assign(mats, mats + (size_t)nb * rows * cols);
+    }
     std::vector<int32_t> kept(nb), ok(nb);
-    int rc = lineq_reduce_batch(ctx, nb, work.data(), rows, cols, rhs, 1, 1, kept.data(), ok.data());
+    int rc = lineq_reduce_batch(ctx, nb, work.data(), rows, cols, last, 1, 1, kept.data(), ok.data());
     if (rc) return rc;
-    std::vector<R32> vc((size_t)rhs * cols, R32(0, 1));
-    for (int i = 0; i < rhs; i++) vc[(size_t)i * cols + i] = R32(-1, 1);
+    const int nv = rhs_idx;
+    std::vector<R32> vc((size_t)nv * (nv + 1), R32(0, 1));
+    if (vc_in) vc.assign(vc_in, vc_in + (size_t)nv * (nv + 1));
+    else for (int i = 0; i < nv; i++) vc[(size_t)i * (nv + 1) + i] = R32(-1, 1);
     std::vector<int> open;                       // systems still undecided
     for (int b = 0; b < nb; b++) {
         if (!ok[b]) out_empty[b] = 1;            // inconsistent bounds: empty (poly.cpp:550-552)
         else if (kept[b] == 0) out_empty[b] = 0; // only redundant constraints: conservatively non-empty (:553-557)
+        else if (nsym > 0) out_empty[b] = XPG_ERR_REF_UNDEFINED;
         else { out_empty[b] = 1; open.push_back(b); }
     }
     long nodes = 0;
@@ -336,8 +364,8 @@ inline int dep_is_empty_batch(xpg_ctx * ctx, int nb, const R32 * mats, int rows,
         for (size_t t = 0; t < open.size(); t++) {
             const int b = open[t];
             const R32 * leq = work.data() + (size_t)b * rows * cols;
-            const std::vector<R32> tgtf = feasibility_objective(leq, kept[b], (const R32 *)0, 0, cols, rhs);
-            tasks[t].start(make_problem<R32>(tgtf.data(), vc.data(), rhs, (const R32 *)0, 0, leq, kept[b], cols),
+            const std::vector<R32> tgtf = feasibility_objective(leq, kept[b], (const R32 *)0, 0, cols, last);
+            tasks[t].start(make_problem<R32>(tgtf.data(), vc.data(), nv, (const R32 *)0, 0, leq, kept[b], cols),
                            pass == 0, false, (const uint8_t *)0);
         }
         rc = run_mip_tasks<R32>(ctx, 1, tasks);

@@ -624,9 +624,32 @@ int xpg_dep_is_empty_batch_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, 
 {
     XPG_BIND(ctx);
     long n = 0;
-    int rc = dep_is_empty_batch(ctx, nb, (const R32 *)mats, rows, cols, out_empty, &n);
+    int rc = dep_is_empty_batch(ctx, nb, (const R32 *)mats, rows, cols, cols - 1, (const R32 *)0, out_empty, &n);
     if (out_nodes) *out_nodes = n;
     return rc;
+}
+int xpg_dep_is_empty_batch_ex_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols, int rhs_idx,
+                                    const xpg_rat32 * vc, int32_t * out_empty, long long * out_nodes)
+{
+    XPG_BIND(ctx);
+    long n = 0;
+    int rc = dep_is_empty_batch(ctx, nb, (const R32 *)mats, rows, cols, rhs_idx, (const R32 *)vc, out_empty, &n);
+    if (out_nodes) *out_nodes = n;
+    return rc;
+}
+int xpg_lineq_move2var_batch_rat32(xpg_ctx * ctx, int nb, xpg_rat32 * mats, int rows, int cols, int rhs_idx,
+                                   int first_sym, int last_sym)
+{
+    if (!ctx || nb < 0 || !mats || rows <= 0 || cols < 2 || rhs_idx < 0 || first_sym <= rhs_idx || last_sym < first_sym ||
+        last_sym >= cols)
+        return XPG_ERR_SHAPE;                           // the reference's ASSERT (linsys.cpp:1185-1188)
+    std::vector<R32> tmp((size_t)rows * cols);
+    for (int b = 0; b < nb; b++) {
+        R32 * m = (R32 *)mats + (size_t)b * rows * cols;
+        move2var_one(m, tmp.data(), rows, cols, rhs_idx, first_sym, last_sym);
+        memcpy(m, tmp.data(), sizeof(R32) * (size_t)rows * cols);
+    }
+    return 0;
 }
 
 // ---- rational row elimination ---------------------------------------------------------------

@@ -37,6 +37,15 @@ class Lineq:
                        "xpg_lineq_reduce_batch_rat32")
         return ok, [a[b, : out_rows[b]].copy() for b in range(nb)]
 
+    def move2var(self, mats, rhs_idx, first_sym, last_sym):
+        """Lineq::move2var (linsys.cpp:1177-1200): constant symbols become variables in front of the constant."""
+        a = _stack(mats).copy()
+        nb, rows, cols = a.shape[:3]
+        self.ctx.check(lib().xpg_lineq_move2var_batch_rat32(self.ctx._h, C.c_int(nb), vp(a), C.c_int(rows), C.c_int(cols),
+                                                            C.c_int(rhs_idx), C.c_int(first_sym), C.c_int(last_sym)),
+                       "xpg_lineq_move2var_batch_rat32")
+        return a
+
     def removeIdenRow(self, mats):
         """Lineq::removeIdenRow (linsys.cpp:1209-1268)."""
         a = _stack(mats).copy()

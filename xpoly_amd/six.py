@@ -313,15 +313,20 @@ def mip_batch(ctx, is_max, is_bin, tgtf, leq):
     return st, v, sol, nodes.value
 
 
-def dep_is_empty_batch(ctx, mats):
-    """DepPoly::is_empty (src/eng/poly.cpp:530-573) for a stack of dependence polyhedra
-    [nb, rows, cols(,2)] with the constant in the last column. Returns (empty[nb], nodes)."""
+def dep_is_empty_batch(ctx, mats, rhs_idx=None, vc=None):
+    """DepPoly::is_empty(keepit, vc) (src/eng/poly.cpp:530-573) for a stack of dependence polyhedra
+    [nb, rows, cols(,2)]: the constant is column rhs_idx (default: the last), the columns behind it are constant
+    symbols (moved to the variables first, Lineq::move2var); vc [rhs_idx, rhs_idx + 1] are the caller's variable
+    constraints (default -x_i <= 0). Returns (empty[nb], nodes); -7 where the reference is undefined."""
     mats = as_kind(mats, RAT, 3)
     nb, rows, cols = mats.shape[0], mats.shape[1], mats.shape[2]
+    rhs_idx = cols - 1 if rhs_idx is None else rhs_idx
+    vc_a = None if vc is None else as_kind(vc, RAT, 2)
     out = np.zeros(nb, dtype=np.int32)
     nodes = C.c_longlong()
-    ctx.check(lib().xpg_dep_is_empty_batch_rat32(ctx._h, C.c_int(nb), vp(mats), C.c_int(rows), C.c_int(cols),
-                                                 vp(out), C.byref(nodes)), "xpg_dep_is_empty_batch_rat32")
+    ctx.check(lib().xpg_dep_is_empty_batch_ex_rat32(ctx._h, C.c_int(nb), vp(mats), C.c_int(rows), C.c_int(cols),
+                                                    C.c_int(rhs_idx), vp(vc_a), vp(out), C.byref(nodes)),
+              "xpg_dep_is_empty_batch_ex_rat32")
     return out, nodes.value
 
 
