@@ -38,7 +38,7 @@ def main():
     read_b = fe[kf]["avg_kb"] * 1024 * 2
     write_b = wr[kw]["avg_kb"] * 1024
     res = dict(
-        command_fetch="rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-ref-baseline --no-batched",
+        command_fetch="rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 3 --warmup 1 --legs pivots --no-cpu-baseline",
         command_write="same with --pmc WRITE_SIZE (separate pass: both do not fit one TCC pass)",
         note="counters are KiB; FETCH_SIZE doubled per the gfx950 correction (16-B-per-lane streaming reads are tallied at half); WRITE_SIZE exact; averages include the one priming launch per solve that sweeps nothing",
         kernel=kf, fetch_size_kib_raw=fe[kf]["avg_kb"], write_size_kib=wr[kw]["avg_kb"],

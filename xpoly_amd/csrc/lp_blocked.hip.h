@@ -542,7 +542,7 @@ void blk_sweep_body(double * __restrict__ tab, int m, int W, int ld, const doubl
 //    s+1.. applied to it with the same two roundings per stage), and e is still in registers.
 template <int ROWS, int U> __global__ __launch_bounds__(256)
 void k_blk_sweep_full(double * __restrict__ tab, int m, int W, int ld, const double * __restrict__ E,
-                      const double * __restrict__ K, LoopState * __restrict__ st, int batch)
+                      const double * __restrict__ K, LoopState * __restrict__ st, int batch, int only_full)
 {
     constexpr int NB = BLK_MAX;
     static_assert(ROWS % (2 * U) == 0, "a row block holds whole ping-pong pairs");
@@ -559,6 +559,9 @@ void k_blk_sweep_full(double * __restrict__ tab, int m, int W, int ld, const dou
     const int status = st->status;
     const int n = (st->blk.batch == batch) ? st->blk.n : 0;
     if (status != ST_RUNNING || n == 0 || j >= W) return;
+    // only_full: a second launch (k_blk_sweep, the stage count as a template switch) follows for the batches that
+    // closed early -- the host turns that on for LPs that close batches often (Lp::queue_blocked)
+    if (only_full && n != NB) return;
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {     // xpg_lp_counters
         if (n == NB) st->blk.sweeps_full += 1u; else st->blk.sweeps_part += 1u;
     }
@@ -663,11 +666,12 @@ void k_blk_sweep_full(double * __restrict__ tab, int m, int W, int ld, const dou
 // The batch length as a template switch (block lengths below 16, and the A/B switch XPG_BLK_ROWS=1).
 template <int ROWS, int UNROLL, int BCAP> __global__ __launch_bounds__(256)
 void k_blk_sweep(double * __restrict__ tab, int m, int W, int ld, const double * __restrict__ E,
-                 const double * __restrict__ K, LoopState * __restrict__ st, int batch)
+                 const double * __restrict__ K, LoopState * __restrict__ st, int batch, int skip_full)
 {
     const int status = st->status;
     const int n = (st->blk.batch == batch) ? st->blk.n : 0;
     if (status != ST_RUNNING || n == 0) return;
+    if (skip_full && n == BLK_MAX) return;              // the full-batch kernel launched just before did this one
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {     // xpg_lp_counters
         if (n == BLK_MAX) st->blk.sweeps_full += 1u; else st->blk.sweeps_part += 1u;
     }

@@ -127,8 +127,8 @@ template <> inline void launch_pipe_sweep<F64>(xpg_ctx * ctx, const LpView<F64> 
                            v, slot, colstride);
 }
 // One batch of the blocked loop: B x (pick, prep) -- the generic pick once after pick(0) -- and a sweep.
-template <class S> inline void launch_blk_batch(xpg_ctx *, const LpView<S> &, int, int, bool) {}
-template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> & v, int batch, int B, bool ref_pricing)
+template <class S> inline void launch_blk_batch(xpg_ctx *, const LpView<S> &, int, int, bool, bool) {}
+template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> & v, int batch, int B, bool ref_pricing, bool closes_often)
 {
     const int strips = (v.W + 511) / 512;
     // workgroup sizes of pick and prep: 64 = one wave per workgroup, no LDS round in the reductions
@@ -164,17 +164,24 @@ template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> &
 #define XPG_BLK_LAUNCH(ROWS_, UNR_, CAP_)                                                                                 \
     hipExtLaunchKernelGGL((k_blk_sweep<ROWS_, UNR_, CAP_>), dim3(strips, (v.m + ROWS_ - 1) / ROWS_), dim3(256), 0,        \
                           ctx->stream, e0, e1, 0, (double *)v.tab, v.m, v.W, v.ld, (const double *)v.blkE,                \
-                          (const double *)v.blkK, v.st, batch)
+                          (const double *)v.blkK, v.st, batch, 0)
 #define XPG_BLK_FULL(ROWS_, UNR_)                                                                                         \
     hipExtLaunchKernelGGL((k_blk_sweep_full<ROWS_, UNR_>), dim3(strips, (v.m + ROWS_ - 1) / ROWS_), dim3(256), 0,         \
                           ctx->stream, e0, e1, 0, (double *)v.tab, v.m, v.W, v.ld, (const double *)v.blkE,                \
-                          (const double *)v.blkK, v.st, batch)
+                          (const double *)v.blkK, v.st, batch, closes_often ? 1 : 0)
     if (B <= 8) XPG_BLK_LAUNCH(32, 8, 8);
     else if (B < BLK_MAX || rows_env == 1) XPG_BLK_LAUNCH(32, 4, 16);
     else if (rows_env == 324) XPG_BLK_FULL(32, 4);
     else if (rows_env == 162) XPG_BLK_FULL(16, 2);
     else if (rows_env == 82) XPG_BLK_FULL(8, 2);
     else XPG_BLK_FULL(16, 4);                           // the default: full batches of 16
+    // An LP whose batches often close early (a rare branch of solveSlackForm met with pivots staged: 34-44 % of
+    // the sweeps on whole solves of 300 x 300 and 1024 x 1500 LPs, 1 of 261 on the bench LP,
+    // tools/probe_partial_batches.py) gets a second launch with the stage count as a template switch for those
+    // batches; the full-batch kernel above then leaves them alone.
+    if (closes_often && B == BLK_MAX && rows_env != 1)
+        hipLaunchKernelGGL((k_blk_sweep<32, 4, 16>), dim3(strips, (v.m + 31) / 32), dim3(256), 0, ctx->stream, (double *)v.tab,
+                           v.m, v.W, v.ld, (const double *)v.blkE, (const double *)v.blkK, v.st, batch, 1);
 #undef XPG_BLK_LAUNCH
 #undef XPG_BLK_FULL
     if (timed) ctx->prof_n++;
@@ -210,6 +217,7 @@ template <class S> struct Lp : LpBase {
     unsigned pipe_t = 0;    // pipelined loop: iteration counter since reset_loop (slot = pipe_t & 1)
     bool pipe_primed = false;
     int blk_batch = 0;      // blocked loop: id of the next batch since reset_loop
+    bool closes_often = false;   // blocked loop: >= 5 % of this solve's sweeps so far were of a batch closed early
     int colstride = 0;      // elements per colbuf half
     int opt_pricing = 0;    // xpg_lp_set_options: 0 the reference's rule, 1 Dantzig (non-parity)
     double opt_feas_tol = 0.0;
@@ -302,6 +310,7 @@ template <class S> struct Lp : LpBase {
     {
         XPG_HIP(ctx, hipMemcpyAsync(out, v.st, sizeof(LoopState), hipMemcpyDeviceToHost, ctx->stream));
         XPG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        closes_often = out->blk.sweeps_part >= 8 && out->blk.sweeps_part * 20u >= out->blk.sweeps_full + out->blk.sweeps_part;
         return 0;
     }
 
@@ -316,7 +325,7 @@ template <class S> struct Lp : LpBase {
     {
         hipLaunchKernelGGL((k_reset_loop<S>), dim3(1024), dim3(256), 0, ctx->stream, v, max_iter, opt_pricing,
                            opt_feas_tol);
-        pipe_t = 0; pipe_primed = false; blk_batch = 0;
+        pipe_t = 0; pipe_primed = false; blk_batch = 0; closes_often = false;
     }
     void queue_pivot(int guarded, int counted)
     {
@@ -376,7 +385,7 @@ template <class S> struct Lp : LpBase {
             // the last batch of a budget that is not a multiple of B is enqueued at its own length, so its
             // sweep is the kernel specialised for that many stages (not the full-batch kernel's slow tail)
             const unsigned left = k - b * (unsigned)B;
-            launch_blk_batch(ctx, v, batch, left < (unsigned)B ? (int)left : B, opt_pricing == 0);
+            launch_blk_batch(ctx, v, batch, left < (unsigned)B ? (int)left : B, opt_pricing == 0, closes_often);
             if ((b & 7) == 7) {                         // throttle: at most 2 x 8 batches in flight
                 hipEvent_t e = throttle[(b >> 3) & 1];
                 if ((b >> 3) >= 2) (void)hipEventSynchronize(e);
@@ -396,7 +405,7 @@ template <class S> struct Lp : LpBase {
             int rc = read_state(&hs);
             if (rc) return rc;
             if (hs.status != ST_RUNNING) break;
-            if (chunk < 256) chunk *= 2;
+            if (chunk < 1024) chunk *= 2;                // (queued launches behind a final status are no-ops)
         }
         return finish(hs.status);
     }
