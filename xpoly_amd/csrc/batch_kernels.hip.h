@@ -577,6 +577,8 @@ int batch_dev(xpg_ctx * ctx, int is_max, int nb, const S * tgtf, const S * leq, 
     return 0;
 }
 
+// Host-array form: staged through a grow-only scratch area the context owns (one hipMalloc per growth instead of
+// five hipMalloc / hipFree pairs per call: the MIP controller makes a call per lock-step round).
 template <class S>
 int batch_host(xpg_ctx * ctx, int is_max, int nb, const S * tgtf, const S * leq, int m, int cols,
                unsigned max_iter, int32_t * out_status, S * out_v, S * out_sol, int raw_sol = 0)
@@ -584,14 +586,23 @@ int batch_host(xpg_ctx * ctx, int is_max, int nb, const S * tgtf, const S * leq,
     if (!ctx || nb < 0 || m <= 0 || cols < 2) return XPG_ERR_SHAPE;
     if (nb == 0) return 0;
     const size_t bl = (size_t)nb * m * cols * 8, bt = (size_t)nb * cols * 8;
-    S * d_leq = 0; S * d_tgtf = 0; S * d_v = 0; S * d_sol = 0; int32_t * d_st = 0;
-    hipError_t e = hipMalloc((void **)&d_leq, bl);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_tgtf, bt);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_v, (size_t)nb * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_sol, bt);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_st, (size_t)nb * 4);
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t need = up(bl) + 2 * up(bt) + up((size_t)nb * 8) + up((size_t)nb * 4);
+    if (need > ctx->stage_cap) {
+        if (ctx->stage) (void)hipFree(ctx->stage);
+        ctx->stage = 0; ctx->stage_cap = 0;
+        const size_t cap = need + need / 2;
+        if (hipMalloc(&ctx->stage, cap) != hipSuccess) { ctx->err = "hipMalloc(batch staging)"; return XPG_ERR_ALLOC; }
+        ctx->stage_cap = cap;
+    }
+    char * p = (char *)ctx->stage;
+    S * d_leq = (S *)p; p += up(bl);
+    S * d_tgtf = (S *)p; p += up(bt);
+    S * d_sol = (S *)p; p += up(bt);
+    S * d_v = (S *)p; p += up((size_t)nb * 8);
+    int32_t * d_st = (int32_t *)p;
     int rc = 0;
-    if (e == hipSuccess) e = hipMemcpyAsync(d_leq, leq, bl, hipMemcpyHostToDevice, ctx->stream);
+    hipError_t e = hipMemcpyAsync(d_leq, leq, bl, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_tgtf, tgtf, bt, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_sol, out_sol, bt, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) rc = batch_dev<S>(ctx, is_max, nb, d_tgtf, d_leq, m, cols, max_iter, d_st, d_v, d_sol, 0, raw_sol);
@@ -599,7 +610,6 @@ int batch_host(xpg_ctx * ctx, int is_max, int nb, const S * tgtf, const S * leq,
     if (e == hipSuccess && rc == 0) e = hipMemcpyAsync(out_v, d_v, (size_t)nb * 8, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && rc == 0) e = hipMemcpyAsync(out_sol, d_sol, bt, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_leq); (void)hipFree(d_tgtf); (void)hipFree(d_v); (void)hipFree(d_sol); (void)hipFree(d_st);
     if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return XPG_ERR_HIP; }
     return rc;
 }
