@@ -91,7 +91,7 @@ template <class S> __device__ __forceinline__ int sm_ratio(const Small<S> & P, i
 // Wave 0 alone does the selection with wave-level primitives (ballot / shuffles, no
 // workgroup barrier); the other waves join for the staging and the sweep. Three barriers
 // per pivot instead of ten.
-enum { ACT_PIVOT = 0, ACT_OPT = 1, ACT_FINDPAIR = 2, ACT_CLOSE = 3 };
+enum { ACT_PIVOT = 0, ACT_OPT = 1, ACT_FINDPAIR = 2, ACT_CLOSE = 3, ACT_TIMEOUT = 4 };
 
 // Pricing (lpsol.h:1054-1069) + ratio test (lpsol.h:553-663) + genPair by wave 0.
 // Results in sh_w[0..2] = action, entering column, leaving variable; the pivot element and
@@ -206,6 +206,226 @@ template <class S> __device__ __forceinline__ void sm_pivot_fast(Small<S> & P, i
     __syncthreads();
 }
 
+// SIX::findPivotBV (lpsol.h:553-663) for column nv by one wavefront (R <= 64, lane = row): both passes, DPP
+// arg-min, no workgroup barrier. Returns the pivot row or INT_MAX; b / w / cc are this lane's basic variable, pair
+// word and counter (the caller fetches the winner's by v_readlane).
+template <class S> __device__ __forceinline__ int sm_ratio_wave(const Small<S> & P, int nv, int lane, int & b, uint32_t & w, int & cc, S & a)
+{
+    const int lim = P.rhs - 1, R = P.R, li = lane < R ? lane : 0;
+    a = P.tab[li * P.ld + nv];
+    const S bc = P.tab[li * P.ld + P.rhs];
+    b = P.eq2bv[li];
+    w = P.ppt[nv * P.pw + (b >> 5)];
+    cc = P.colcnt[b];
+    const bool open = lane < R && !((w >> (b & 31)) & 1u) && cc < lim;
+    const bool nonzero = open && !eq(a, zero<S>());
+    Cand<S> c; c.q = nonzero ? div(bc, a) : zero<S>();
+    c.idx = (nonzero && !le(a, zero<S>())) ? lane : INT_MAX;
+    Cand<S> best = wave_argmin(c);
+    if (best.idx == INT_MAX) {                                  // relaxed second pass: a != 0
+        c.idx = nonzero ? lane : INT_MAX;
+        best = wave_argmin(c);
+    }
+    return __builtin_amdgcn_readfirstlane(best.idx);
+}
+
+// SIX::findPivotNVandBVPair (lpsol.h:671-773) by wave 0 alone: candidates 64 per ballot in ascending order, positive
+// reduced costs first, then zero ones; each tried with the wave-level ratio test. On success the pivot is staged
+// exactly as sm_select_wave0 stages one (sh_w, parked pivot element and c_nv, pair table); else sh_w[0] = -1.
+template <class S> __device__ __forceinline__ void sm_findpair_wave0(Small<S> & P)
+{
+    const int lane = threadIdx.x, rhs = P.rhs, lim = rhs - 1;
+    for (int pass = 0; pass < 2; pass++)
+        for (int base = 0; base < rhs; base += 64) {
+            const int i = base + lane;
+            bool take = false;
+            if (i < rhs && !P.bv[i] && P.rowcnt[i] < lim) {
+                const S c = P.obj[i];
+                take = gt(c, zero<S>()) ? true : (eq(c, zero<S>()) ? pass == 1 : false);
+            }
+            unsigned long long mask = __ballot(take);
+            while (mask) {
+                const int cand = base + __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                int b, cc; uint32_t w; S a;
+                const int row = sm_ratio_wave(P, cand, lane, b, w, cc, a);
+                if (row == INT_MAX) continue;
+                const int leave = __builtin_amdgcn_readlane(b, row);
+                const uint32_t wv = (uint32_t)__builtin_amdgcn_readlane((int)w, row);
+                const int ccv = __builtin_amdgcn_readlane(cc, row);
+                Cand<S> pa; pa.q = a; pa.idx = 0;
+                const S piv = read_lane(pa, row).q;
+                if (lane == 0) {
+                    P.sh_w[0] = ACT_PIVOT; P.sh_w[1] = cand; P.sh_w[2] = leave; P.sh_w[3] = row;
+                    if (!((wv >> (leave & 31)) & 1u)) {        // genPair (a candidate row was not yet paired: always taken)
+                        P.ppt[cand * P.pw + (leave >> 5)] = wv | (1u << (leave & 31));
+                        P.rowcnt[cand] += 1; P.colcnt[leave] = ccv + 1;
+                    }
+                    S * pk = (S *)P.sh_c;
+                    pk[0] = piv;
+                    pk[1] = P.obj[cand];
+                }
+                return;
+            }
+        }
+    if (lane == 0) P.sh_w[0] = -1;
+}
+
+// ---- the overlapped fast loop (two or more wavefronts per LP, rhs <= 127 variables, R <= 64 rows) ----------
+// One pivot used to be: wave 0 selects (pricing, ratio test: a chain of ~30 dependent LDS round trips) while the
+// other waves wait -> barrier -> everybody stages (scaled row, -column, objective row) -> barrier -> everybody
+// sweeps -> barrier. PMC at 5 LPs per CU: 1 194 VALU + 770 SALU + 287 LDS wave-instructions per pivot in 21.8 k
+// cycles -- 27 % issue utilisation: the chain, not the arithmetic, sets the rate. Here the selection of pivot t+1
+// runs UNDER the sweep of pivot t, as the pipelined large-tableau loop does it (lp_kernels.hip.h):
+//   stage A   wave 0: objective row of pivot t (two columns per lane; it rescales its pivot-row entries itself) and
+//                     the pricing of pivot t+1 on the basis as it will be after the swap (lpsol.h:1054-1069, with
+//                     the zeroing of :1055-1060) -> the entering column `first` is known BEFORE the sweep starts;
+//             others: scaled pivot row -> e, -column -> k
+//   barrier
+//   stage C   wave 0: basis swap of pivot t; the two columns the next choice needs -- `first` and the constant
+//                     column -- updated for its rows with the sweep's own add(a, mul(k, e)); ratio test
+//                     (lpsol.h:553-663) on those fresh values, pair-table upkeep -> pivot t+1;
+//             others: the sweep of every other column (row r := e)
+//   barrier
+// Two barriers per pivot, and the longest dependent chain of a pivot is max(selection, sweep) instead of their sum.
+// Anything but "pivot chosen" leaves the loop with the tableau fully swept and the basis consistent, and the
+// generic code of sm_solve takes over exactly as it did behind sm_select_wave0.
+template <class S> __device__ __forceinline__ int sm_fast_loop(Small<S> & P, unsigned max_iter, unsigned & done, bool preselected)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool w0 = tid < 64;
+    const int st = tid - 64, nsw = (int)blockDim.x - 64;       // sweeper index / count
+    const int nswaves = nsw >> 6, swave = st >> 6;
+    const int rhs = P.rhs, lim = rhs - 1, R = P.R, W = P.W, ld = P.ld;
+    if (!preselected) {                                         // the first pivot: nothing to overlap with
+        if (w0) sm_select_wave0(P);
+        __syncthreads();
+    }
+    for (;;) {
+        const int action = P.sh_w[0];
+        if (action != ACT_PIVOT) return action;
+        const int enter = P.sh_w[1], leave = P.sh_w[2], r = P.sh_w[3];
+        const S * park = (const S *)P.sh_c;
+        const S piv = park[0], cnv = park[1];
+        const S s = div(one<S>(), piv);
+        const int smode = scale_mode(s), cmode = scale_mode(cnv);
+        const bool last = done + 1 >= max_iter;                 // while (cnt < m_max_iter), lpsol.h:1039: no pricing after the last pivot
+        // ---- stage A
+        S o0 = zero<S>(), o1 = zero<S>(); int rc0 = 0, rc1 = 0;
+        if (w0) {
+            const int j0 = lane, j1 = lane + 64;
+            const bool in0 = j0 < W, in1 = j1 < W;
+            const int q0 = in0 ? j0 : 0, q1 = in1 ? j1 : 0;
+            const S t0 = P.tab[r * ld + q0], t1 = P.tab[r * ld + q1];
+            const S ob0 = P.obj[q0], ob1 = P.obj[q1];
+            const int nvm0 = P.nv[q0 < rhs ? q0 : 0], nvm1 = P.nv[q1 < rhs ? q1 : 0];
+            rc0 = P.rowcnt[q0 < rhs ? q0 : 0]; rc1 = P.rowcnt[q1 < rhs ? q1 : 0];
+            S x0 = mul(scaled(t0, s, smode), minus_one<S>()), x1 = mul(scaled(t1, s, smode), minus_one<S>());   // nvexp.mul(-1), lpsol.h:1496
+            if (j0 >= rhs) x0 = neg(x0);                        // :1497-1499
+            if (j1 >= rhs) x1 = neg(x1);
+            o0 = add(scaled(x0, cnv, cmode), ob0);              // :1500-1501
+            o1 = add(scaled(x1, cnv, cmode), ob1);
+            int first = INT_MAX; bool anyc = false;
+            if (!last) {
+                // basis after this pivot's swap
+                const bool nb0 = in0 && j0 < rhs && (j0 == enter ? false : (j0 == leave ? true : nvm0 != 0));
+                const bool nb1 = in1 && j1 < rhs && (j1 == enter ? false : (j1 == leave ? true : nvm1 != 0));
+                const bool c0 = nb0 && gt(o0, zero<S>()), c1 = nb1 && gt(o1, zero<S>());
+                const bool e0 = c0 && rc0 < lim, e1 = c1 && rc1 < lim;
+                const unsigned long long m0 = __ballot(e0), m1 = __ballot(e1);
+                anyc = __ballot(c0 || c1) != 0ull;
+                first = m0 ? __ffsll((long long)m0) - 1 : (m1 ? 64 + __ffsll((long long)m1) - 1 : INT_MAX);
+                const int stop = first == INT_MAX ? rhs : first;
+                if (in0 && j0 < stop && j0 < rhs && !nb0) o0 = zero<S>();     // lpsol.h:1055-1060
+                if (in1 && j1 < stop && j1 < rhs && !nb1) o1 = zero<S>();
+            }
+            if (in0) P.obj[j0] = o0;
+            if (in1) P.obj[j1] = o1;
+            if (lane == 0) { P.sh_w[5] = first; P.sh_w[6] = anyc ? 1 : 0; }
+        } else {
+            for (int j = st; j < W; j += nsw) P.e[j] = scaled(P.tab[r * ld + j], s, smode);
+            for (int i = st; i < R; i += nsw) P.k[i] = i != r ? neg(P.tab[i * ld + enter]) : zero<S>();
+        }
+        __syncthreads();
+        const int first = P.sh_w[5];
+        const bool have_first = first != INT_MAX;
+        // ---- stage C
+        if (w0) {
+            if (lane == 0) {                                    // lpsol.h:1504-1510
+                P.nv[enter] = 0; P.nv[leave] = 1; P.bv[enter] = 1; P.bv[leave] = 0;
+                P.eq2bv[r] = enter; P.bv2eq[enter] = r; P.bv2eq[leave] = -1;
+            }
+            const int li = lane < R ? lane : 0;
+            const int fc = have_first ? first : rhs;
+            const S kb = P.k[li], ef = P.e[fc], eb = P.e[rhs];
+            const S a_old = P.tab[li * ld + fc], b_old = P.tab[li * ld + rhs];
+            const int b = P.eq2bv[li];
+            const S a = li == r ? ef : add(a_old, mul(kb, ef));
+            const S bc = li == r ? eb : add(b_old, mul(kb, eb));
+            if (lane < R) { if (have_first) P.tab[li * ld + fc] = a; P.tab[li * ld + rhs] = bc; }
+            if (last) {
+                if (lane == 0) P.sh_w[0] = ACT_TIMEOUT;
+            } else if (!have_first) {
+                if (lane == 0) { P.sh_w[0] = P.sh_w[6] ? ACT_FINDPAIR : ACT_OPT; P.sh_w[1] = first; P.sh_w[2] = -1; P.sh_w[3] = -1; }
+            } else {
+                // ratio test (lpsol.h:553-663) on the fresh column, exactly as sm_select_wave0
+                const uint32_t w = P.ppt[first * P.pw + (b >> 5)];
+                const int cc = P.colcnt[b];
+                const bool open = lane < R && !((w >> (b & 31)) & 1u) && cc < lim;
+                const bool nonzero = open && !eq(a, zero<S>());
+                Cand<S> c; c.q = nonzero ? div(bc, a) : zero<S>();
+                c.idx = (nonzero && !le(a, zero<S>())) ? lane : INT_MAX;
+                Cand<S> best = wave_argmin(c);
+                if (best.idx == INT_MAX) {                      // relaxed second pass: a != 0
+                    c.idx = nonzero ? lane : INT_MAX;
+                    best = wave_argmin(c);
+                }
+                const int row = __builtin_amdgcn_readfirstlane(best.idx);
+                if (row == INT_MAX) {
+                    if (lane == 0) { P.sh_w[0] = ACT_CLOSE; P.sh_w[1] = first; P.sh_w[2] = -1; P.sh_w[3] = -1; }
+                } else {
+                    const int nleave = __builtin_amdgcn_readlane(b, row);
+                    const uint32_t wv = (uint32_t)__builtin_amdgcn_readlane((int)w, row);
+                    const int ccv = __builtin_amdgcn_readlane(cc, row);
+                    Cand<S> pa; pa.q = a; pa.idx = 0;
+                    Cand<S> po0; po0.q = o0; po0.idx = rc0;
+                    Cand<S> po1; po1.q = o1; po1.idx = rc1;
+                    const S npiv = read_lane(pa, row).q;
+                    const Cand<S> pf = first < 64 ? read_lane(po0, first) : read_lane(po1, first - 64);
+                    if (lane == 0) {
+                        P.sh_w[0] = ACT_PIVOT; P.sh_w[1] = first; P.sh_w[2] = nleave; P.sh_w[3] = row;
+                        P.ppt[first * P.pw + (nleave >> 5)] = wv | (1u << (nleave & 31));      // genPair, lpsol.h:100-104
+                        P.rowcnt[first] = pf.idx + 1; P.colcnt[nleave] = ccv + 1;
+                        S * pk = (S *)P.sh_c;
+                        pk[0] = npiv;
+                        pk[1] = pf.q;
+                    }
+                }
+            }
+        } else {
+            // the sweep: wave w of the sweepers takes rows w, w + nswaves, ...; a lane owns columns lane and lane + 64
+            for (int j = st & 63; j < W; j += 64) {
+                if (j == rhs || (have_first && j == first)) continue;
+                const S ej = P.e[j];
+                for (int i0 = swave; i0 < R; i0 += 4 * nswaves) {
+                    const int last_i = R - 1;
+                    const int i1 = i0 + nswaves, i2 = i0 + 2 * nswaves, i3 = i0 + 3 * nswaves;
+                    const S a0 = P.tab[min(i0, last_i) * ld + j], a1 = P.tab[min(i1, last_i) * ld + j];
+                    const S a2 = P.tab[min(i2, last_i) * ld + j], a3 = P.tab[min(i3, last_i) * ld + j];
+                    const S k0 = P.k[min(i0, last_i)], k1 = P.k[min(i1, last_i)], k2 = P.k[min(i2, last_i)], k3 = P.k[min(i3, last_i)];
+                    P.tab[i0 * ld + j] = i0 == r ? ej : add(a0, mul(k0, ej));
+                    if (i1 <= last_i) P.tab[i1 * ld + j] = i1 == r ? ej : add(a1, mul(k1, ej));
+                    if (i2 <= last_i) P.tab[i2 * ld + j] = i2 == r ? ej : add(a2, mul(k2, ej));
+                    if (i3 <= last_i) P.tab[i3 * ld + j] = i3 == r ? ej : add(a3, mul(k3, ej));
+                }
+            }
+        }
+        P.pivots++;
+        done++;
+        __syncthreads();
+    }
+}
+
 // SIX::solveSlackForm (lpsol.h:1008-1191) incl. is_feasible (lpsol.h:784-822,
 // vc = "-x_i <= 0" for every variable). Returns a SIX_* status; maxv on success.
 template <class S> __device__ __forceinline__ int sm_solve(Small<S> & P, unsigned max_iter, S & maxv)
@@ -217,8 +437,16 @@ template <class S> __device__ __forceinline__ int sm_solve(Small<S> & P, unsigne
     __syncthreads();
     unsigned done = 0;
     const bool fast = rhs <= 128 && P.R <= 64;
+    const bool overlapped = fast && rhs <= 127 && blockDim.x >= 128;
+    bool preselected = false;                                   // the generic code below has staged a pivot in sh_w
     while (done < max_iter) {
-        if (fast) {
+        if (overlapped) {
+            const int action = sm_fast_loop(P, max_iter, done, preselected);
+            preselected = false;
+            if (action == ACT_TIMEOUT) return 4;
+            // rare outcomes fall through to the generic code below, which redoes the (idempotent) pricing scan
+            __syncthreads();
+        } else if (fast) {
             if (threadIdx.x < 64) sm_select_wave0(P);
             __syncthreads();
             const int action = P.sh_w[0];
@@ -276,16 +504,36 @@ template <class S> __device__ __forceinline__ int sm_solve(Small<S> & P, unsigne
                 maxv = P.obj[rhs];
                 return 0;
             }
-            for (int pass = 0; pass < 2 && enter < 0; pass++)           // lpsol.h:671-773
-                for (int i = 0; i < rhs; i++) {
-                    if (P.bv[i] || P.rowcnt[i] >= lim) continue;
-                    const S c = P.obj[i];
-                    const bool take = gt(c, zero<S>()) ? true : (eq(c, zero<S>()) ? pass == 1 : false);
-                    if (!take) continue;
-                    const int b = sm_ratio(P, i);
-                    if (b < 0) continue;
-                    enter = i; leave = b;
-                    break;
+            if (overlapped) {
+                // by wave 0 with wave-level ratio tests, the chosen pivot staged for the fast loop
+                if (threadIdx.x < 64) sm_findpair_wave0(P);
+                __syncthreads();
+                if (P.sh_w[0] != ACT_PIVOT) return 1;
+                preselected = true;
+                continue;
+            }
+            // SIX::findPivotNVandBVPair (lpsol.h:671-773): columns in ascending order, positive reduced costs first,
+            // then zero ones; the first whose ratio test finds a row. The scan is 64 columns per ballot (every wave
+            // computes the same masks from the same LDS words, so no barrier is needed) instead of one column per
+            // dependent LDS round: on dependence-test-like LPs most pivots come from here -- the pair table has
+            // exhausted every positive column -- and the serial scan alone was ~190 rounds per pivot.
+            for (int pass = 0; pass < 2 && enter < 0; pass++)
+                for (int base = 0; base < rhs && enter < 0; base += 64) {
+                    const int i = base + (int)(threadIdx.x & 63);
+                    bool take = false;
+                    if (i < rhs && !P.bv[i] && P.rowcnt[i] < lim) {
+                        const S c = P.obj[i];
+                        take = gt(c, zero<S>()) ? true : (eq(c, zero<S>()) ? pass == 1 : false);
+                    }
+                    unsigned long long mask = __ballot(take);
+                    while (mask) {
+                        const int cand = base + __ffsll((long long)mask) - 1;
+                        mask &= mask - 1;
+                        const int b = sm_ratio(P, cand);
+                        if (b < 0) continue;
+                        enter = cand; leave = b;
+                        break;
+                    }
                 }
             if (enter < 0) return 1;
         } else {
@@ -568,7 +816,11 @@ int batch_dev(xpg_ctx * ctx, int is_max, int nb, const S * tgtf, const S * leq, 
     if (const char * c = getenv("XPG_BATCH_COUNT_CLOSES")) { if (c[0] == '1') raw_sol |= 2; }   // profiling aid
     if (const char * t = getenv("XPG_BATCH_THREADS")) { const int v = atoi(t); if (v >= 64 && v <= 256 && v % 64 == 0) threads = v; }
     const int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
-    int grid = 256 * (per_cu > 16 ? 16 : per_cu) * 4;
+    // One workgroup per LP up to 64 per CU-slot: the hardware's dispatcher then balances LPs of very different
+    // lengths (the dependence-test family mixes phase-1 failures of a few dozen pivots with runs of thousands)
+    // better than a fixed grid-stride assignment does.
+    int grid = 256 * (per_cu > 16 ? 16 : per_cu) * 64;
+    if (const char * g = getenv("XPG_BATCH_GRID_X")) { const int v = atoi(g); if (v >= 1) grid = 256 * (per_cu > 16 ? 16 : per_cu) * v; }
     if (grid > nb) grid = nb;
     XPG_HIP(ctx, hipFuncSetAttribute((const void *)k_batch<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((k_batch<S>), dim3(grid), dim3(threads), lds, ctx->stream, nb, tgtf, leq, m, cols,
