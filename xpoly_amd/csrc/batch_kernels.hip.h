@@ -91,7 +91,7 @@ template <class S> __device__ __forceinline__ int sm_ratio(const Small<S> & P, i
 // Wave 0 alone does the selection with wave-level primitives (ballot / shuffles, no
 // workgroup barrier); the other waves join for the staging and the sweep. Three barriers
 // per pivot instead of ten.
-enum { ACT_PIVOT = 0, ACT_OPT = 1, ACT_FINDPAIR = 2, ACT_CLOSE = 3, ACT_TIMEOUT = 4 };
+enum { ACT_PIVOT = 0, ACT_OPT = 1, ACT_FINDPAIR = 2, ACT_CLOSE = 3, ACT_TIMEOUT = 4, ACT_UNBOUND = 5 };
 
 // Pricing (lpsol.h:1054-1069) + ratio test (lpsol.h:553-663) + genPair by wave 0.
 // Results in sh_w[0..2] = action, entering column, leaving variable; the pivot element and
@@ -289,7 +289,8 @@ template <class S> __device__ __forceinline__ void sm_findpair_wave0(Small<S> & 
 //   barrier
 // Two barriers per pivot, and the longest dependent chain of a pivot is max(selection, sweep) instead of their sum.
 // Anything but "pivot chosen" leaves the loop with the tableau fully swept and the basis consistent, and the
-// generic code of sm_solve takes over exactly as it did behind sm_select_wave0.
+// generic code of sm_solve takes over exactly as it did behind sm_select_wave0. (Rotating the selecting wave over
+// the SIMDs with the workgroup index was tried: no difference.)
 template <class S> __device__ __forceinline__ int sm_fast_loop(Small<S> & P, unsigned max_iter, unsigned & done, bool preselected)
 {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -302,7 +303,15 @@ template <class S> __device__ __forceinline__ int sm_fast_loop(Small<S> & P, uns
         __syncthreads();
     }
     for (;;) {
-        const int action = P.sh_w[0];
+        int action = P.sh_w[0];
+        if (action == ACT_FINDPAIR) {
+            // every positive column is exhausted: findPivotNVandBVPair right here, on the tableau the barrier above
+            // has just completed (the basic objective entries were zeroed by stage A's pricing: stop = rhs)
+            __syncthreads();                                    // everybody has read sh_w[0]
+            if (w0) sm_findpair_wave0(P);
+            __syncthreads();
+            action = P.sh_w[0] == ACT_PIVOT ? ACT_PIVOT : ACT_UNBOUND;
+        }
         if (action != ACT_PIVOT) return action;
         const int enter = P.sh_w[1], leave = P.sh_w[2], r = P.sh_w[3];
         const S * park = (const S *)P.sh_c;
@@ -444,6 +453,7 @@ template <class S> __device__ __forceinline__ int sm_solve(Small<S> & P, unsigne
             const int action = sm_fast_loop(P, max_iter, done, preselected);
             preselected = false;
             if (action == ACT_TIMEOUT) return 4;
+            if (action == ACT_UNBOUND) return 1;                // SIX_UNBOUND, lpsol.h:1138-1142
             // rare outcomes fall through to the generic code below, which redoes the (idempotent) pricing scan
             __syncthreads();
         } else if (fast) {
