@@ -413,6 +413,8 @@ template <class S> __device__ __forceinline__ int sm_fast_loop(Small<S> & P, uns
             }
         } else {
             // the sweep: wave w of the sweepers takes rows w, w + nswaves, ...; a lane owns columns lane and lane + 64
+            // (row pairs through ds_read2 with -a_i,nv fetched by v_readlane instead of an LDS read per row were
+            // tried: 5 % slower -- the sweep is not what the LDS pipe is short of)
             for (int j = st & 63; j < W; j += 64) {
                 if (j == rhs || (have_first && j == first)) continue;
                 const S ej = P.e[j];
