@@ -50,6 +50,7 @@ BATCH_PER_GPU = 8192                       # 65 536 LPs over 8 GPUs (BASELINE.js
 BATCH_M, BATCH_COLS = 32, 64
 PREWARM_SECONDS = 0.5
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "round2_pmc_hbm_traffic.json")
+PMC_BATCH = os.path.join(ROOT, "profiles", "round2_pmc_batch_issue.json")
 LEGS = ("pivots", "batched", "cfg2b", "rational", "mip")
 
 
@@ -423,6 +424,18 @@ def main():
                        collective=("one all_gather_into_tensor of (status,v,sol) records over %s, world size %d"
                                    % ("RCCL" if a.backend == "nccl" else a.backend, world)) if dist else "none (1 GPU)",
                        families=fams)
+        if os.path.exists(PMC_BATCH):                   # measured with rocprofv3 --pmc, not in this run
+            pb = json.load(open(PMC_BATCH))
+            batched["issue_rate"] = dict(
+                bound="instruction issue + dependent LDS rounds of the selection chain (HBM sees 16 KiB in / 0.5 KiB out per LP)",
+                dep_test_like=dict(valu_busy_percent=pb.get("dep_test_like_busy_percent", {}).get("VALUBusy"),
+                                   salu_busy_percent=pb.get("dep_test_like_busy_percent", {}).get("SALUBusy"),
+                                   wave_instructions_per_pivot=pb.get("dep_test_like_per_pivot")),
+                dense_positive=dict(valu_busy_percent=pb.get("dense_busy_percent", {}).get("VALUBusy"),
+                                    salu_busy_percent=pb.get("dense_busy_percent", {}).get("SALUBusy"),
+                                    wave_instructions_per_pivot=pb.get("dense_per_pivot")),
+                source="profiles/round2_pmc_batch_issue.json (rocprofv3 --pmc VALUBusy / SALUBusy / SQ_INSTS_* on "
+                       "tools/probe_batch.py; not collected in this run)")
         if world == 1 and not stub:
             # N = 1 reference point for STRONG scaling: the whole 65 536-LP batch of cfg 3 on one GPU
             full_n = BATCH_PER_GPU * 8
