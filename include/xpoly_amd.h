@@ -207,6 +207,15 @@ int xpg_mip_maxm_f64(xpg_ctx * ctx, const double * tgtf, const double * vc, int 
 int xpg_mip_minm_f64(xpg_ctx * ctx, const double * tgtf, const double * vc, int vc_rows,
                      const double * eq, int eq_rows, const double * leq, int leq_rows, int cols,
                      int is_bin, const uint8_t * rational_indicator, double * out_v, double * out_sol);
+/* OPT-IN, NON-PARITY: branch and bound that re-optimises every node from its parent's final
+ * tableau with the dual simplex instead of the fresh SIX per node of src/com/lpsol.h:2440-2448.  fp64; maximise (or
+ * minimise) tgtf . x subject to leq (A | b), x >= 0 and integral (0/1 bounds are rows of leq, as for the parity MIP).
+ * The tableau stays in HBM for the whole tree; a child is its parent's solved state plus one bound row.  Best
+ * incumbent, bounding by the relaxation, floor child first -- a different (sane) walk from the reference's, so its
+ * answers are checked against the optimum itself (tests/test_gpu_warm_mip.py: scipy / HiGHS), not against
+ * MIP::RecusivePart.  out_stats (may be NULL): nodes, dual pivots over all nodes, primal pivots of the root, depth. */
+int xpg_mip_warm_f64(xpg_ctx * ctx, int is_max, const double * tgtf, const double * leq, int leq_rows,
+                     int cols, int is_bin, double * out_v, double * out_sol, long long * out_stats);
 /* Lineq::has_solution(leq, eq, vc, rhs_idx, is_int_sol, is_unique_sol),
  * src/com/linsys.cpp:830-906.  Returns 1 / 0, or XPG_ERR_*. */
 int xpg_has_solution_rat32(xpg_ctx * ctx, const xpg_rat32 * leq, int leq_rows, const xpg_rat32 * eq,

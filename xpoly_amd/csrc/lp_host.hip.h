@@ -212,6 +212,7 @@ template <class S> struct Lp : LpBase {
     S * d_maxv;
     std::vector<void *> owned;
     size_t tab_elems;
+    int row_cap = 0;        // rows the tableau has room for (m + extra)
     bool began;
     int final_status;
     hipEvent_t throttle[2] = {nullptr, nullptr};
@@ -246,38 +247,41 @@ template <class S> struct Lp : LpBase {
         for (hipEvent_t e : throttle) if (e) (void)hipEventDestroy(e);
     }
 
+    // `extra`: rows (and their slack columns) that may be appended later (warm-started branch and bound, warm_mip.hip.h)
     int create(const void * leq, int m_, int cols, const void * tgtf, const void * vcd,
-               const void * vcr, int on_dev)
+               const void * vcr, int on_dev, int extra = 0)
     {
         m = m_; n0 = cols - 1; began = false; final_status = XPG_RUNNING;
-        const int Wmax = n0 + 1 + m + 1;            // with the phase-1 column
+        const int mcap = m + extra;
+        const int Wmax = n0 + 1 + mcap + 1;         // with the phase-1 column
         const int ld = round_up(Wmax, 16);
         const int nmax = Wmax - 1;
         v.m = m; v.ld = ld; v.W = 0; v.rhs = 0;
         v.pw = (nmax + 31) / 32;
         v.trace_cap = 1 << 16;
-        tab_elems = (size_t)m * ld;
+        tab_elems = (size_t)mcap * ld;
+        row_cap = mcap;
         int rc;
         if ((rc = alloc((void **)&v.tab, tab_elems * sizeof(S)))) return rc;
         if ((rc = alloc((void **)&v.obj, (size_t)ld * sizeof(S)))) return rc;
         if ((rc = alloc((void **)&v.rowbuf, (size_t)ld * sizeof(S)))) return rc;
-        colstride = round_up(m, 16);                // two halves: the pipelined loop double-buffers -column
+        colstride = round_up(mcap, 16);             // two halves: the pipelined loop double-buffers -column
         if ((rc = alloc((void **)&v.colbuf, (size_t)2 * colstride * sizeof(S)))) return rc;
         if ((rc = alloc((void **)&v.x, (size_t)ld * sizeof(S)))) return rc;
-        if ((rc = alloc((void **)&v.nextcol, (size_t)round_up(m, 16) * sizeof(S)))) return rc;
-        if ((rc = alloc((void **)&v.bcol, (size_t)round_up(m, 16) * sizeof(S)))) return rc;
+        if ((rc = alloc((void **)&v.nextcol, (size_t)round_up(mcap, 16) * sizeof(S)))) return rc;
+        if ((rc = alloc((void **)&v.bcol, (size_t)round_up(mcap, 16) * sizeof(S)))) return rc;
         if ((rc = alloc((void **)&v.vcd, (size_t)ld * sizeof(S)))) return rc;
         if ((rc = alloc((void **)&v.vcr, (size_t)ld * sizeof(S)))) return rc;
         if ((rc = alloc((void **)&v.nv, ld))) return rc;
         if ((rc = alloc((void **)&v.bv, ld))) return rc;
         if ((rc = alloc((void **)&v.bv2eq, (size_t)ld * 4))) return rc;
-        if ((rc = alloc((void **)&v.eq2bv, (size_t)round_up(m, 16) * 4))) return rc;
+        if ((rc = alloc((void **)&v.eq2bv, (size_t)round_up(mcap, 16) * 4))) return rc;
         if ((rc = alloc((void **)&v.rowcnt, (size_t)ld * 4))) return rc;
         if ((rc = alloc((void **)&v.colcnt, (size_t)ld * 4))) return rc;
         if ((rc = alloc((void **)&v.ppt, (size_t)nmax * v.pw * 4))) return rc;
         if ((rc = alloc((void **)&v.st, sizeof(LoopState)))) return rc;
         if ((rc = alloc((void **)&v.pickrec, (size_t)PICK_WORDS * 8))) return rc;
-        if ((rc = alloc((void **)&v.blkK, (size_t)round_up(m, 16) * BLK_MAX * sizeof(S)))) return rc;
+        if ((rc = alloc((void **)&v.blkK, (size_t)round_up(mcap, 16) * BLK_MAX * sizeof(S)))) return rc;
         if ((rc = alloc((void **)&v.blkE, (size_t)BLK_MAX * ld * sizeof(S)))) return rc;
         if ((rc = alloc((void **)&v.blkR, (size_t)BLK_REC_MAX * BLK_REC_WORDS * 8))) return rc;
         if ((rc = alloc((void **)&v.blkP, (size_t)((ld + BLK_TPB_MIN - 1) / BLK_TPB_MIN + 3) * BLK_PART_INTS * 4))) return rc;

@@ -17,6 +17,7 @@
 #include "batch_kernels.hip.h"
 #include "lineq_host.hip.h"
 #include "mip_host.hip.h"
+#include "warm_mip.hip.h"
 
 using namespace xpg;
 
@@ -611,6 +612,23 @@ int xpg_has_solution_rat32(xpg_ctx * ctx, const xpg_rat32 * leq, int leq_rows, c
     XPG_BIND(ctx);
     return has_solution(ctx, (const R32 *)leq, leq_rows, (const R32 *)eq, eq_rows, (const R32 *)vc, vc_rows, cols,
                         rhs_idx, is_int_sol != 0, is_unique_sol != 0);
+}
+
+int xpg_mip_warm_f64(xpg_ctx * ctx, int is_max, const double * tgtf, const double * leq, int leq_rows, int cols, int is_bin,
+                     double * out_v, double * out_sol, long long * out_stats)
+{
+    XPG_BIND(ctx);
+    if (!ctx || !tgtf || !leq || leq_rows <= 0 || cols < 2 || !out_v) return XPG_ERR_SHAPE;
+    std::vector<double> obj(tgtf, tgtf + cols);
+    if (!is_max) for (int j = 0; j < cols; j++) obj[(size_t)j] = -obj[(size_t)j];       // min c.x = -max (-c).x
+    WarmMip W(ctx);
+    WarmStats S;
+    double v = 0.0;
+    const int st = W.solve(obj.data(), leq, leq_rows, cols, is_bin != 0, &v, out_sol, S);
+    if (out_stats) { out_stats[0] = S.nodes; out_stats[1] = S.dual_pivots; out_stats[2] = S.root_pivots; out_stats[3] = S.max_depth; }
+    if (st == XPG_IP_SUCC) *out_v = is_max ? v : -v;
+    else *out_v = 0.0;
+    return st;
 }
 
 int xpg_mip_batch_rat32(xpg_ctx * ctx, int nb, int is_max, int is_bin, const xpg_rat32 * tgtf, const xpg_rat32 * leq,

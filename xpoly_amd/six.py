@@ -300,6 +300,18 @@ class MIP:
         return self._solve(False, tgtf, vc, eq, leq, is_bin, rational_indicator)
 
 
+def mip_warm(ctx, is_max, tgtf, leq, is_bin=False):
+    """OPT-IN, NON-PARITY (xpg_mip_warm_f64): fp64 branch and bound warm-started from the parent's tableau by the dual
+    simplex. Returns (status, v, sol, dict(nodes, dual_pivots, root_pivots, max_depth))."""
+    tgtf = as_kind(tgtf, F64, 1); leq = as_kind(leq, F64, 2)
+    rows, cols = leq.shape
+    v = C.c_double(); sol = np.zeros(cols); stats = (C.c_longlong * 4)()
+    st = lib().xpg_mip_warm_f64(ctx._h, C.c_int(int(is_max)), vp(tgtf), vp(leq), C.c_int(rows), C.c_int(cols),
+                                C.c_int(int(is_bin)), C.byref(v), vp(sol), stats)
+    ctx.check(st, "xpg_mip_warm_f64")
+    return st, v.value, sol, dict(nodes=stats[0], dual_pivots=stats[1], root_pivots=stats[2], max_depth=stats[3])
+
+
 def mip_batch(ctx, is_max, is_bin, tgtf, leq):
     """nb independent rational MIPs (x >= 0, inequalities only) advanced in lock step.
     tgtf [nb, cols(,2)], leq [nb, rows, cols(,2)]. Returns (status[nb], v[nb,2], sol[nb,cols,2], nodes)."""
