@@ -15,6 +15,27 @@ struct DevBuf {
 };
 
 inline int lineq_grid(int nb) { return nb < 256 * 16 ? nb : 256 * 16; }
+// Lanes per system: the smallest of 16 / 32 / 64 that covers `width` (the columns for the column-parallel Gauss
+// kernels; columns AND rows for reduce, whose duplicate-row and classification passes run one lane per row; fme
+// always takes the whole wave for its P x N result rows); a wave then carries 64 / L systems -- as long as their
+// LDS slices fit the 64 KB a workgroup gets by default. Groups of one wave that take different branches run one
+// after the other, so packing pays where the control flow is mostly shared (measured: DESIGN.md section 4).
+struct LineqGeom { int L, G; size_t lds; dim3 block; int grid; int sys_lds; };
+inline LineqGeom lineq_geom(int nb, int width, size_t sys_lds)
+{
+    LineqGeom q;
+    q.L = width <= 16 ? 16 : (width <= 32 ? 32 : 64);
+    if (const char * e = getenv("XPG_LINEQ_LANES")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) q.L = v > q.L ? v : q.L; }
+    sys_lds = (sys_lds + 15) & ~(size_t)15;
+    while (q.L < 64 && sys_lds * (size_t)(64 / q.L) > 64 * 1024) q.L *= 2;
+    q.G = 64 / q.L;
+    q.sys_lds = (int)sys_lds;
+    q.lds = sys_lds * (size_t)q.G;
+    q.block = dim3((unsigned)q.L, (unsigned)q.G);
+    const int wgs = (nb + q.G - 1) / q.G;
+    q.grid = lineq_grid(wgs);
+    return q;
+}
 
 #define XPG_TRY(e_) do { hipError_t err_ = (e_); if (err_ != hipSuccess) { ctx->err = std::string(#e_) + ": " + hipGetErrorString(err_); return XPG_ERR_HIP; } } while (0)
 
@@ -31,9 +52,10 @@ inline int lineq_reduce_batch(xpg_ctx * ctx, int nb, R32 * mats, int rows, int c
     DevBuf dm, dr, dk;
     XPG_TRY(dm.alloc(bytes)); XPG_TRY(dr.alloc((size_t)nb * 4)); XPG_TRY(dk.alloc((size_t)nb * 4));
     XPG_TRY(hipMemcpyAsync(dm.p, mats, bytes, hipMemcpyHostToDevice, ctx->stream));
-    XPG_TRY(hipFuncSetAttribute((const void *)k_reduce_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_reduce_batch, dim3(lineq_grid(nb)), dim3(64), lds, ctx->stream, nb, (R32 *)dm.p, rows,
-                       cols, rhs, mode, is_intersect, (int *)dr.p, (int *)dk.p);
+    const LineqGeom q = lineq_geom(nb, rows > cols ? rows : cols, lds);
+    XPG_TRY(hipFuncSetAttribute((const void *)k_reduce_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds));
+    hipLaunchKernelGGL(k_reduce_batch, dim3(q.grid), q.block, q.lds, ctx->stream, nb, (R32 *)dm.p, rows,
+                       cols, rhs, mode, is_intersect, (int *)dr.p, (int *)dk.p, q.sys_lds);
     XPG_TRY(hipGetLastError());
     XPG_TRY(hipMemcpyAsync(mats, dm.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     XPG_TRY(hipMemcpyAsync(out_rows, dr.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -61,10 +83,11 @@ inline int lineq_fme_batch(xpg_ctx * ctx, int nb, const R32 * mats, int rows, in
     XPG_TRY(di.alloc(bi)); XPG_TRY(dout.alloc(bo)); XPG_TRY(dr.alloc((size_t)nb * 4)); XPG_TRY(dk.alloc((size_t)nb * 4));
     XPG_TRY(hipMemcpyAsync(di.p, mats, bi, hipMemcpyHostToDevice, ctx->stream));
     XPG_TRY(hipMemsetAsync(dout.p, 0, bo, ctx->stream));
-    XPG_TRY(hipFuncSetAttribute((const void *)k_fme_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_fme_batch, dim3(lineq_grid(nb)), dim3(64), lds, ctx->stream, nb, (const R32 *)di.p, rows,
+    const LineqGeom q = lineq_geom(nb, 64, lds);
+    XPG_TRY(hipFuncSetAttribute((const void *)k_fme_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds));
+    hipLaunchKernelGGL(k_fme_batch, dim3(q.grid), q.block, q.lds, ctx->stream, nb, (const R32 *)di.p, rows,
                        (const int *)0, cols, rhs, u, darkshadow, (R32 *)dout.p, cap, (int *)dr.p, (int *)dk.p,
-                       res_global, (int *)0);
+                       res_global, (int *)0, q.sys_lds);
     XPG_TRY(hipGetLastError());
     XPG_TRY(hipMemcpyAsync(outs, dout.p, bo, hipMemcpyDeviceToHost, ctx->stream));
     XPG_TRY(hipMemcpyAsync(out_rows, dr.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -99,7 +122,8 @@ inline int lineq_calc_bound_batch(xpg_ctx * ctx, int nb, const R32 * mats, int r
                              hipMemcpyHostToDevice, ctx->stream));
     std::vector<int32_t> ones(nb, 1), init_rows(nb, rows);
     XPG_TRY(hipMemcpyAsync(chain.p, ones.data(), (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream));
-    XPG_TRY(hipFuncSetAttribute((const void *)k_fme_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const LineqGeom q = lineq_geom(nb, 64, lds);
+    XPG_TRY(hipFuncSetAttribute((const void *)k_fme_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds));
     for (int j = 0; j < rhs; j++) {
         void * cur = d0.p; void * cur_rows = ra.p;
         XPG_TRY(hipMemcpyAsync(ra.p, init_rows.data(), (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -108,9 +132,9 @@ inline int lineq_calc_bound_batch(xpg_ctx * ctx, int nb, const R32 * mats, int r
             if (i == j) continue;
             void * nxt = flip ? da.p : db.p;
             void * nxt_rows = (cur_rows == ra.p) ? rb.p : ra.p;
-            hipLaunchKernelGGL(k_fme_batch, dim3(lineq_grid(nb)), dim3(64), lds, ctx->stream, nb, (const R32 *)cur, cap,
+            hipLaunchKernelGGL(k_fme_batch, dim3(q.grid), q.block, q.lds, ctx->stream, nb, (const R32 *)cur, cap,
                                (const int *)cur_rows, cols, rhs, i, 0, (R32 *)nxt, cap, (int *)nxt_rows,
-                               (int *)step_ok.p, res_global, (int *)chain.p);
+                               (int *)step_ok.p, res_global, (int *)chain.p, q.sys_lds);
             cur = nxt; cur_rows = nxt_rows; flip = !flip;
         }
         XPG_TRY(hipGetLastError());
@@ -134,7 +158,7 @@ inline int gauss_batch(xpg_ctx * ctx, int nb, const R32 * mats, int rows, int co
     if (!ctx || nb < 0 || !mats || rows <= 0 || cols <= 0 || ((op == 1 || op == 2) && rows != cols)) return XPG_ERR_SHAPE;
     if (nb == 0) return 0;
     size_t lds = ((size_t)rows * cols * 8 * (op == 2 ? 2 : 1) + 15) & ~(size_t)15;
-    if (op == 3) lds += ((size_t)rows * 4 + 15) & ~(size_t)15;
+    lds += ((size_t)rows * 13 + 15) & ~(size_t)15;           // row factors, rowpos, live flags
     if (lds > 160 * 1024) return XPG_ERR_UNSUPPORTED;
     const size_t bi = (size_t)nb * rows * cols * 8;
     const size_t bo = op == 2 || op == 3 ? bi : (op == 4 ? (size_t)nb * cols * cols * 8 : 8);
@@ -143,9 +167,10 @@ inline int gauss_batch(xpg_ctx * ctx, int nb, const R32 * mats, int rows, int co
     XPG_TRY(dmat.alloc(bo));
     XPG_TRY(hipMemcpyAsync(di.p, mats, bi, hipMemcpyHostToDevice, ctx->stream));
     if (op >= 2) XPG_TRY(hipMemsetAsync(dmat.p, 0, bo, ctx->stream));
-    XPG_TRY(hipFuncSetAttribute((const void *)k_gauss_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_gauss_batch, dim3(lineq_grid(nb)), dim3(64), lds, ctx->stream, nb, (const R32 *)di.p, rows,
-                       cols, op, flag, (int *)dint.p, (R32 *)dval.p, (R32 *)dmat.p);
+    const LineqGeom q = lineq_geom(nb, op == 2 ? 2 * cols : cols, lds);
+    XPG_TRY(hipFuncSetAttribute((const void *)k_gauss_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds));
+    hipLaunchKernelGGL(k_gauss_batch, dim3(q.grid), q.block, q.lds, ctx->stream, nb, (const R32 *)di.p, rows,
+                       cols, op, flag, (int *)dint.p, (R32 *)dval.p, (R32 *)dmat.p, q.sys_lds);
     XPG_TRY(hipGetLastError());
     if (out_int) XPG_TRY(hipMemcpyAsync(out_int, dint.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (out_val) XPG_TRY(hipMemcpyAsync(out_val, dval.p, (size_t)nb * 8, hipMemcpyDeviceToHost, ctx->stream));

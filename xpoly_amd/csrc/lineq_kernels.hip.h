@@ -5,10 +5,14 @@
 //   row primitives mulOfRow / addRowToRow / mul_and_add_row / interch_row / is_rowequ
 //                                            (src/com/matt.h:1353, :1437-1460, :1493, :1097, :2344)
 // Systems are tiny (W ~ 9-20 columns, R ~ 10-60 rows) and
-// thousands are independent, so ONE WAVEFRONT owns one system: the matrix is
-// staged in LDS, the reference's data-dependent control flow is executed
-// wave-uniformly, and every row operation runs one lane per column. The
-// arithmetic is integer (gcd loops), so the bound is ALU/divergence, not HBM.
+// thousands are independent. A system is owned by a GROUP of 16, 32 or 64 lanes of one wavefront (the
+// smallest that covers its columns: round 1 gave every system a whole wave and left >= 44 of 64 lanes idle at
+// these widths); a wavefront carries 64 / L systems. The workgroup is dim3(L, 64 / L): threadIdx.x is the lane
+// within the group, threadIdx.y the group. The matrix is staged in the group's slice of LDS, the reference's
+// data-dependent control flow is uniform within a group (groups of one wave diverge from each other: the
+// hardware masks), every row operation runs one lane per column, and the only synchronisation a group needs is
+// the program order of its own wave -- an LDS fence, no s_barrier (which divergent groups could not share).
+// The arithmetic is integer (gcd loops), so the bound is ALU/divergence, not HBM.
 #pragma once
 #include "scalar.hip.h"
 #include <limits.h>
@@ -20,15 +24,30 @@ enum { CST_UNK = 1, CST_LT = 2, CST_GT = 3, CST_EQ = 4 };       // linsys.h:55-5
 // A small row-major rational matrix in LDS (or global scratch), one wave's property.
 struct WMat { R32 * a; int r, c, ld; };
 
-__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
-__device__ __forceinline__ void wave_sync() { __syncthreads(); }   // blockDim == 64: one wave
+__device__ __forceinline__ int lane_id() { return (int)threadIdx.x; }          // lane within the system's group
+__device__ __forceinline__ int wave_lanes() { return (int)blockDim.x; }         // lanes per system: 16, 32 or 64
+// One wave per workgroup: LDS operations of a wave complete in program order, so what a group needs between a
+// store and another lane's load is only that the compiler keeps the order.
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+// this group's system index / slice of the dynamic LDS
+__device__ __forceinline__ int sys_first() { return (int)(blockIdx.x * blockDim.y + threadIdx.y); }
+__device__ __forceinline__ int sys_stride() { return (int)(gridDim.x * blockDim.y); }
+// Ballot over the lanes of this system's group, bit l = lane l of the group. Control flow is uniform within a
+// group, so all of its lanes are here; lanes of the wave's other groups may or may not be and are masked out.
+__device__ __forceinline__ unsigned long long grp_ballot(bool p)
+{
+    const unsigned long long b = __ballot(p);
+    const int L = wave_lanes();
+    return L == 64 ? b : (b >> (threadIdx.y * L)) & ((1ull << L) - 1);
+}
+__device__ __forceinline__ int grp_rank(unsigned long long bal) { return __popcll(bal & ((1ull << lane_id()) - 1)); }
 
 // mulOfRow (matt.h:1353-1368): every lane evaluates the same shortcut tests.
 __device__ inline void w_scale_row(WMat & m, int row, R32 x)
 {
     const int mode = scale_mode(x);
     if (mode != SCALE_KEEP)
-        for (int j = lane_id(); j < m.c; j += 64) {
+        for (int j = lane_id(); j < m.c; j += wave_lanes()) {
             R32 * p = m.a + row * m.ld + j;
             *p = scaled(*p, x, mode);
         }
@@ -61,39 +80,64 @@ __device__ inline int w_cmp_rows(const WMat & m, int rhs, int r1, int r2)
     return CST_UNK;
 }
 
-// Compacts the rows whose flag is 0, keeping their order. flags/scratch in LDS.
+// Compacts the rows whose flag is 0, keeping their order. flags/scratch in LDS. The destinations come from a
+// ballot prefix; the cells move in ascending chunks of one per lane (a destination never lies above its source, so
+// a chunk that is read whole before it is written cannot overwrite anything still to be read).
 __device__ inline void w_compact(WMat & m, const unsigned char * drop, int * map)
 {
-    if (lane_id() == 0) {
-        int k = 0;
-        for (int i = 0; i < m.r; i++) map[i] = drop[i] ? -1 : k++;
-        map[m.r] = k;
+    const int L = wave_lanes(), lane = lane_id();
+    int keep = 0, first = -1;
+    for (int base = 0; base < m.r; base += L) {
+        const int i = base + lane;
+        const bool stays = i < m.r && !drop[i];
+        const unsigned long long bal = grp_ballot(stays), in = grp_ballot(i < m.r);
+        if (i < m.r) map[i] = stays ? keep + grp_rank(bal) : -1;
+        if (first < 0 && bal != in) first = base + __builtin_ctzll(bal ^ in);
+        keep += __popcll(bal);
     }
     wave_sync();
-    const int keep = map[m.r];
-    // rows only move up, so ascending order is safe row by row
-    for (int i = 0; i < m.r; i++) {
-        const int to = map[i];
-        if (to >= 0 && to != i)
-            for (int j = lane_id(); j < m.c; j += 64) m.a[to * m.ld + j] = m.a[i * m.ld + j];
-        wave_sync();
+    if (first >= 0) {
+        const int total = m.r * m.c;
+        for (int t0 = first * m.c; t0 < total; t0 += L) {
+            const int t = t0 + lane, i = t / m.c, j = t - i * m.c;
+            const int to = t < total ? map[i] : -1;
+            R32 v;
+            if (to >= 0) v = m.a[i * m.ld + j];
+            wave_sync();
+            if (to >= 0) m.a[to * m.ld + j] = v;
+            wave_sync();
+        }
     }
     m.r = keep;
 }
 
 // Lineq::removeIdenRow (linsys.cpp:1209-1268): a row goes iff an earlier row is
-// field-wise identical (the row-sum test there is only a prefilter).
+// field-wise identical (the row-sum test there is only a prefilter; ours is a hash of the fields in map[]).
 __device__ inline void w_remove_iden(WMat & m, unsigned char * drop, int * map)
 {
-    for (int k = lane_id(); k < m.r; k += 64) {
+    for (int k = lane_id(); k < m.r; k += wave_lanes()) {
+        unsigned h = 0;
+        for (int j = 0; j < m.c; j++) {
+            const R32 v = m.a[k * m.ld + j];
+            h = (h ^ (unsigned)v.num) * 0x9E3779B1u; h = (h ^ (unsigned)v.den) * 0x85EBCA77u;
+        }
+        map[k] = (int)h;
+    }
+    wave_sync();
+    bool any = false;
+    for (int k = lane_id(); k < m.r; k += wave_lanes()) {
         unsigned char gone = 0;
+        const int hk = map[k];
         for (int i = 0; i < k && !gone; i++) {
+            if (map[i] != hk) continue;
             bool same = true;
             for (int j = 0; j < m.c && same; j++) same = eq(m.a[i * m.ld + j], m.a[k * m.ld + j]);
             gone = same ? 1 : 0;
         }
         drop[k] = gone;
+        any |= gone != 0;
     }
+    if (grp_ballot(any) == 0) return;          // nothing identical: rows and order stay
     wave_sync();
     w_compact(m, drop, map);
 }
@@ -150,9 +194,10 @@ __device__ inline bool w_reduce(WMat & m, int rhs, bool is_intersect, WScratch &
     // single-variable classification: kind[i] = var (+1) with sign, 0 = other
     int * kind = s.map;
     if (lane_id() == 0) { *any_removed = 0; *bad = 0; }
-    for (int i = lane_id(); i < m.r; i += 64) { removed[i] = 0; kind[i] = 0; }
+    for (int i = lane_id(); i < m.r; i += wave_lanes()) { removed[i] = 0; kind[i] = 0; }
     wave_sync();
-    for (int i = lane_id(); i < m.r; i += 64) {                       // linsys.cpp:378-421
+    unsigned long long singles = 0;            // variables that own a single-variable row (bit 63: any var >= 63)
+    for (int i = lane_id(); i < m.r; i += wave_lanes()) {                       // linsys.cpp:378-421
         int vars = 0, single = -1;
         for (int j = 0; j < rhs; j++) if (ne(m.a[i * m.ld + j], R32(0, 1))) { vars++; single = j; }
         if (vars == 0) {
@@ -163,7 +208,12 @@ __device__ inline bool w_reduce(WMat & m, int rhs, bool is_intersect, WScratch &
             const R32 c = m.a[i * m.ld + single];
             if (gt(c, R32(0, 1))) kind[i] = single + 1;
             else if (lt(c, R32(0, 1))) kind[i] = -(single + 1);
+            singles |= 1ull << (single < 63 ? single : 63);
         }
+    }
+    for (int o = 1; o < wave_lanes(); o <<= 1) {                                // OR over the group (xor butterfly)
+        singles |= ((unsigned long long)(unsigned)__shfl_xor((int)(singles >> 32), o) << 32)
+                   | (unsigned)__shfl_xor((int)singles, o);
     }
     wave_sync();
     if (*bad) {
@@ -172,16 +222,16 @@ __device__ inline bool w_reduce(WMat & m, int rhs, bool is_intersect, WScratch &
         return false;
     }
     for (int var = 0; var < rhs; var++) {
-        if (lane_id() == 0) {
-            int np = 0, nn = 0;
-            for (int i = 0; i < m.r; i++) {
-                if (kind[i] == var + 1) s.pos[np++] = (short)i;
-                else if (kind[i] == -(var + 1)) s.negs[nn++] = (short)i;
-            }
-            s.flags[2] = np; s.flags[3] = nn;
+        if (!((singles >> (var < 63 ? var : 63)) & 1)) continue;       // no single-variable row of var: nothing to do
+        int np = 0, nn = 0;
+        for (int base = 0; base < m.r; base += wave_lanes()) {
+            const int i = base + lane_id();
+            const int kd = i < m.r ? kind[i] : 0;
+            const unsigned long long bp = grp_ballot(kd == var + 1), bn = grp_ballot(kd == -(var + 1));
+            if (kd == var + 1) s.pos[np + grp_rank(bp)] = (short)i;
+            if (kd == -(var + 1)) s.negs[nn + grp_rank(bn)] = (short)i;
+            np += __popcll(bp); nn += __popcll(bn);
         }
-        wave_sync();
-        const int np = s.flags[2], nn = s.flags[3];
         wave_sync();
         if (np) w_tighten(m, rhs, var, s.pos, np, false, is_intersect, removed, any_removed);
         if (nn) w_tighten(m, rhs, var, s.negs, nn, true, is_intersect, removed, any_removed);
@@ -212,12 +262,12 @@ __device__ inline bool w_reduce(WMat & m, int rhs, bool is_intersect, WScratch &
 __device__ inline void w_load(WMat & m, const R32 * src, int rows, int cols)
 {
     m.r = rows; m.c = cols;
-    for (int t = lane_id(); t < rows * cols; t += 64) m.a[(t / cols) * m.ld + (t % cols)] = src[t];
+    for (int t = lane_id(); t < rows * cols; t += wave_lanes()) m.a[(t / cols) * m.ld + (t % cols)] = src[t];
     wave_sync();
 }
 __device__ inline void w_store(const WMat & m, R32 * dst)
 {
-    for (int t = lane_id(); t < m.r * m.c; t += 64) dst[t] = m.a[(t / m.c) * m.ld + (t % m.c)];
+    for (int t = lane_id(); t < m.r * m.c; t += wave_lanes()) dst[t] = m.a[(t / m.c) * m.ld + (t % m.c)];
 }
 
 __device__ inline WScratch carve_scratch(unsigned char * p, int cap)
@@ -239,12 +289,13 @@ __host__ __device__ inline size_t lineq_lds_bytes(int cap, int cols)
 
 // mode 0: removeIdenRow, 1: reduce. One wave per system; in/out [nb][rows][cols] in place.
 __global__ __launch_bounds__(64) void k_reduce_batch(int nb, R32 * mats, int rows, int cols, int rhs,
-                                                     int mode, int is_intersect, int * out_rows, int * out_ok)
+                                                     int mode, int is_intersect, int * out_rows, int * out_ok, int sys_lds)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
+    unsigned char * lds = lds_all + (size_t)threadIdx.y * sys_lds;
     WMat m; m.a = (R32 *)lds; m.ld = cols;
     WScratch s = carve_scratch(lds + (size_t)rows * cols * 8, rows);
-    for (int b = blockIdx.x; b < nb; b += gridDim.x) {
+    for (int b = sys_first(); b < nb; b += sys_stride()) {
         R32 * g = mats + (size_t)b * rows * cols;
         w_load(m, g, rows, cols);
         bool ok = true;
@@ -266,14 +317,15 @@ __global__ __launch_bounds__(64) void k_reduce_batch(int nb, R32 * mats, int row
 // becomes 0 when this elimination finds the system inconsistent.
 __global__ __launch_bounds__(64) void k_fme_batch(int nb, const R32 * mats, int cap_in, const int * in_rows, int cols,
                                                   int rhs, int u, int darkshadow, R32 * outs, int cap, int * out_rows,
-                                                  int * out_ok, int res_global, int * chain_ok)
+                                                  int * out_ok, int res_global, int * chain_ok, int sys_lds)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
+    unsigned char * lds = lds_all + (size_t)threadIdx.y * sys_lds;
     // LDS layout: [result matrix (cap x cols) unless res_global] [normalised input (cap_in x cols)] [scratch]
     WMat res; res.a = (R32 *)lds; res.ld = cols; res.c = cols;
     WMat tmp; tmp.a = res_global ? (R32 *)lds : res.a + (size_t)cap * cols; tmp.ld = cols;
     WScratch s = carve_scratch((unsigned char *)(tmp.a + (size_t)cap_in * cols), cap > cap_in ? cap : cap_in);
-    for (int b = blockIdx.x; b < nb; b += gridDim.x) {
+    for (int b = sys_first(); b < nb; b += sys_stride()) {
         if (chain_ok && chain_ok[b] != 1) { if (lane_id() == 0) { out_rows[b] = 0; out_ok[b] = 0; } continue; }
         const int rows = in_rows ? in_rows[b] : cap_in;
         const R32 * g = mats + (size_t)b * cap_in * cols;
@@ -285,7 +337,7 @@ __global__ __launch_bounds__(64) void k_fme_batch(int nb, const R32 * mats, int 
         int * bad_at = &s.flags[1];
         if (lane_id() == 0) *bad_at = INT_MAX;
         wave_sync();
-        for (int i = lane_id(); i < rows; i += 64) {
+        for (int i = lane_id(); i < rows; i += wave_lanes()) {
             bool have = false;
             for (int j = 0; j < rhs && !have; j++) have = ne(tmp.a[i * cols + j], R32(0, 1));
             if (!have && w_cmp_value(tmp, rhs, i, R32(0, 1)) == CST_LT) atomicMin(bad_at, i);
@@ -307,21 +359,20 @@ __global__ __launch_bounds__(64) void k_fme_batch(int nb, const R32 * mats, int 
             }
         }
         // rows without u go first, in order (linsys.cpp:724-730)
-        if (lane_id() == 0) {
-            int k = 0, np = 0, nn = 0;
-            for (int i = 0; i < stop; i++) {
-                if (kind[i] == 0) kind[i] = -(k++) - 1;               // destination row, encoded negative
-                else if (kind[i] == 1) s.pos[np++] = (short)i;
-                else s.negs[nn++] = (short)i;
-            }
-            s.flags[0] = k; s.flags[2] = np; s.flags[3] = nn;
+        int nfree = 0, np = 0, nn = 0;
+        for (int base = 0; base < stop; base += wave_lanes()) {
+            const int i = base + lane_id();
+            const int kd = i < stop ? kind[i] : -1;
+            const unsigned long long bf = grp_ballot(kd == 0), bp = grp_ballot(kd == 1), bn = grp_ballot(kd == 2);
+            if (kd == 0) kind[i] = -(nfree + grp_rank(bf)) - 1;       // destination row, encoded negative
+            else if (kd == 1) s.pos[np + grp_rank(bp)] = (short)i;
+            else if (kd == 2) s.negs[nn + grp_rank(bn)] = (short)i;
+            nfree += __popcll(bf); np += __popcll(bp); nn += __popcll(bn);
         }
         wave_sync();
-        const int nfree = s.flags[0], np = s.flags[2], nn = s.flags[3];
-        for (int i = 0; i < stop; i++) {
-            if (kind[i] >= 0) continue;
-            const int to = -kind[i] - 1;
-            for (int j = lane_id(); j < cols; j += 64) res.a[to * cols + j] = tmp.a[i * cols + j];
+        for (int t = lane_id(); t < stop * cols; t += wave_lanes()) {
+            const int i = t / cols, j = t - i * cols;
+            if (kind[i] < 0) res.a[(-kind[i] - 1) * cols + j] = tmp.a[t];
         }
         res.r = nfree;
         bool ok = true;
@@ -335,11 +386,11 @@ __global__ __launch_bounds__(64) void k_fme_batch(int nb, const R32 * mats, int 
             if (res.r + extra > cap) { status_rows = res.r + extra; ok = false; }
             else if (np + nn == 1) {
                 const int pi = np == 1 ? s.pos[0] : s.negs[0];
-                for (int j = lane_id(); j < cols; j += 64) res.a[res.r * cols + j] = tmp.a[pi * cols + j];
+                for (int j = lane_id(); j < cols; j += wave_lanes()) res.a[res.r * cols + j] = tmp.a[pi * cols + j];
                 res.r += 1;
             } else if (np + nn > 1) {                                   // every (pos, neg) pair summed
                 const int base = res.r * cols, total = np * nn * cols;
-                for (int t = lane_id(); t < total; t += 64) {
+                for (int t = lane_id(); t < total; t += wave_lanes()) {
                     const int pair = t / cols, j = t % cols;
                     const int pi = s.pos[pair / nn], ni = s.negs[pair % nn];
                     res.a[base + t] = add(tmp.a[pi * cols + j], tmp.a[ni * cols + j]);
@@ -368,25 +419,17 @@ __device__ inline R32 abs_r(R32 v) { return lt(v, R32(0, 1)) ? neg(v) : v; }    
 __device__ inline void w_swap_rows(WMat & m, int a, int b)
 {
     if (a != b)
-        for (int j = lane_id(); j < m.c; j += 64) {
+        for (int j = lane_id(); j < m.c; j += wave_lanes()) {
             const R32 t = m.a[a * m.ld + j]; m.a[a * m.ld + j] = m.a[b * m.ld + j]; m.a[b * m.ld + j] = t;
         }
     wave_sync();
 }
-// mul_and_add_row (matt.h:1493-1501): to += from * v
-__device__ inline void w_axpy_row(WMat & m, int from, R32 v, int to)
-{
-    for (int j = lane_id(); j < m.c; j += 64)
-        m.a[to * m.ld + j] = add(mul(m.a[from * m.ld + j], v), m.a[to * m.ld + j]);
-    wave_sync();
-}
 // pivot choice shared by rank/det/inv: first nonzero, a later exact 1 wins at once,
 // otherwise the largest magnitude (matt.h:2644-2668, :1675-1695, :1796-1813).
-__device__ inline int w_find_pivot(const WMat & m, int col, int from, bool & unit_break)
+__device__ inline int w_find_pivot_seq(const WMat & m, int col, int from)
 {
     int swap_row = -1;
     R32 entry(0, 1);
-    unit_break = false;
     for (int k = from; k < m.r; k++) {
         const R32 t = m.a[k * m.ld + col];
         if (eq(t, R32(0, 1))) continue;
@@ -396,10 +439,63 @@ __device__ inline int w_find_pivot(const WMat & m, int col, int from, bool & uni
     }
     return swap_row;
 }
+// The same choice with one lane per row: the scan above ends at the first exact 1 if the column has one, and is
+// otherwise a running maximum under strict replacement -- the earliest row of maximal |t|. lt() orders by value
+// whenever the denominators are positive (every value the reference can hold); a column that shows any other
+// denominator takes the sequential scan.
+__device__ inline int w_find_pivot(const WMat & m, int col, int from, bool & unit_break)
+{
+    unit_break = false;
+    const int L = wave_lanes(), lane = lane_id();
+    int best = -1; R32 bestv(0, 1);
+    for (int base = from; base < m.r; base += L) {
+        const int k = base + lane;
+        const bool in = k < m.r;
+        const R32 t = in ? m.a[k * m.ld + col] : R32(0, 1);
+        if (grp_ballot(t.den <= 0)) return w_find_pivot_seq(m, col, from);
+        const bool nz = ne(t, R32(0, 1));
+        const unsigned long long ones = grp_ballot(nz && eq(t, R32(1, 1)));
+        if (ones) return base + __builtin_ctzll(ones);
+        if (!grp_ballot(nz)) continue;
+        R32 a = abs_r(t); int idx = nz ? k : -1;
+        for (int o = 1; o < L; o <<= 1) {
+            const R32 b(__shfl_xor(a.num, o), __shfl_xor(a.den, o)); const int bi = __shfl_xor(idx, o);
+            const bool take = bi >= 0 && (idx < 0 || lt(a, b) || (!lt(b, a) && bi < idx));
+            if (take) { a = b; idx = bi; }
+        }
+        if (best < 0 || lt(bestv, a)) { best = idx; bestv = a; }
+    }
+    return best;
+}
+
+// One elimination step of rank / det / inv: every row i of [lo, m.r) other than `row` whose entry e in `col` is not
+// zero becomes row_i + t_i * row_row, with t_i = -e / pivot spelled the way each caller of mul_and_add_row spells it
+// (KIND 0: div(neg(e), piv), matt.h:2689-2700; 1: neg(div(e, piv)), matt.h:1707-1718; 2: mul(-1, e), matt.h:1826-1838).
+// The rows do not depend on one another, so instead of the reference's row after row the factors are computed one
+// lane per row and the update runs one lane per CELL of the block of rows.
+template <int KIND>
+__device__ inline void w_eliminate(WMat & m, int row, int col, int lo, R32 * tfac, unsigned char * live)
+{
+    const R32 piv = m.a[row * m.ld + col];
+    for (int i = lo + lane_id(); i < m.r; i += wave_lanes()) {
+        const R32 e = m.a[i * m.ld + col];
+        const bool on = i != row && ne(e, R32(0, 1));
+        live[i] = on ? 1 : 0;
+        if (on) tfac[i] = KIND == 0 ? div(neg(e), piv) : (KIND == 1 ? neg(div(e, piv)) : mul(R32(-1, 1), e));
+    }
+    wave_sync();
+    const int n = (m.r - lo) * m.c;
+    for (int x = lane_id(); x < n; x += wave_lanes()) {
+        const int i = lo + x / m.c, j = x % m.c;
+        if (!live[i]) continue;
+        m.a[i * m.ld + j] = add(mul(m.a[row * m.ld + j], tfac[i]), m.a[i * m.ld + j]);
+    }
+    wave_sync();
+}
 
 // Matrix<Rational>::rank(basis, is_unitarize) (matt.h:2614-2726). basis == NULL in the
 // reference forces unitarize; rowpos (LDS, one int per row) tracks the row interchanges.
-__device__ inline int w_rank(WMat & p, bool unitarize = true, int * rowpos = nullptr)
+__device__ inline int w_rank(WMat & p, R32 * tfac, unsigned char * live, bool unitarize = true, int * rowpos = nullptr)
 {
     int rankv = 0;
     for (int row = 0, col = 0; row < p.r && col < p.c; row++, col++) {
@@ -416,14 +512,7 @@ __device__ inline int w_rank(WMat & p, bool unitarize = true, int * rowpos = nul
         const R32 d = p.a[row * p.ld + col];
         wave_sync();
         if (unitarize && ne(d, R32(1, 1))) w_scale_row(p, row, div(R32(1, 1), d));
-        for (int i = unitarize ? 0 : row + 1; i < p.r; i++) {
-            if (i == row) continue;
-            const R32 e = p.a[i * p.ld + col];
-            if (eq(e, R32(0, 1))) continue;
-            const R32 t = div(neg(e), p.a[row * p.ld + col]);
-            wave_sync();
-            w_axpy_row(p, row, t, i);
-        }
+        w_eliminate<0>(p, row, col, unitarize ? 0 : row + 1, tfac, live);
         rankv++;
     }
     return rankv;
@@ -441,7 +530,7 @@ __device__ inline bool w_tri(const WMat & m, int which)
 }
 
 // Matrix<Rational>::det (matt.h:1621-1736).
-__device__ inline R32 w_det(WMat & a)
+__device__ inline R32 w_det(WMat & a, R32 * tfac, unsigned char * live)
 {
     const int n = a.r;
 #define M_(i, j) a.a[(i) * a.ld + (j)]
@@ -467,13 +556,7 @@ __device__ inline R32 w_det(WMat & a)
         const int swap_row = w_find_pivot(a, j, j, ub);
         if (swap_row == -1) return R32(0, 1);
         if (swap_row != j) { w_swap_rows(a, swap_row, j); swaps++; }
-        for (int i = j + 1; i < n; i++) {
-            const R32 e = M_(i, j);
-            if (eq(e, R32(0, 1))) continue;
-            const R32 t = neg(div(e, M_(j, j)));
-            wave_sync();
-            w_axpy_row(a, j, t, i);
-        }
+        w_eliminate<1>(a, j, j, j + 1, tfac, live);
     }
     for (int j = 0; j < n; j++) d = mul(d, M_(j, j));
     if (swaps & 1) d = neg(d);
@@ -483,7 +566,7 @@ __device__ inline R32 w_det(WMat & a)
 
 // Matrix<Rational>::inv (matt.h:1743-1845) on the augmented matrix [p | e] (n x 2n) so
 // that the row operations hit both halves in one lane-parallel pass.
-__device__ inline bool w_inv(WMat & pe, int n)
+__device__ inline bool w_inv(WMat & pe, int n, R32 * tfac, unsigned char * live)
 {
 #define P_(i, j) pe.a[(i) * pe.ld + (j)]
 #define E_(i, j) pe.a[(i) * pe.ld + n + (j)]
@@ -510,14 +593,7 @@ __device__ inline bool w_inv(WMat & pe, int n)
         const R32 d = P_(j, j);
         wave_sync();
         if (ne(d, R32(1, 1))) w_scale_row(pe, j, div(R32(1, 1), d));
-        for (int i = 0; i < n; i++) {
-            if (i == j) continue;
-            const R32 e = P_(i, j);
-            if (eq(e, R32(0, 1))) continue;
-            const R32 t = mul(R32(-1, 1), e);
-            wave_sync();
-            w_axpy_row(pe, j, t, i);
-        }
+        w_eliminate<2>(pe, j, j, 0, tfac, live);
     }
     return true;
 #undef P_
@@ -528,61 +604,65 @@ __device__ inline bool w_inv(WMat & pe, int n)
 // (flag = is_unitarize; out_mat rows x cols, rows past the basis left zero), 4: null space
 // (out_mat cols x cols, matt.h:2546-2584). One wave per matrix.
 __global__ __launch_bounds__(64) void k_gauss_batch(int nb, const R32 * mats, int rows, int cols, int op, int flag,
-                                                    int * out_int, R32 * out_val, R32 * out_mat)
+                                                    int * out_int, R32 * out_val, R32 * out_mat, int sys_lds)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
+    unsigned char * lds = lds_all + (size_t)threadIdx.y * sys_lds;
     WMat m; m.a = (R32 *)lds;
-    for (int b = blockIdx.x; b < nb; b += gridDim.x) {
+    // LDS of one system: [matrix, twice as wide for inv] [row factors: rows x R32] [rowpos: rows ints] [live: rows bytes]
+    R32 * tfac = (R32 *)(lds + (((size_t)rows * cols * 8 * (op == 2 ? 2 : 1) + 15) & ~(size_t)15));
+    int * rowpos = (int *)(tfac + rows);
+    unsigned char * live = (unsigned char *)(rowpos + rows);
+    for (int b = sys_first(); b < nb; b += sys_stride()) {
         const R32 * g = mats + (size_t)b * rows * cols;
         if (op == 2) {
             const int n = rows;
             m.r = n; m.c = 2 * n; m.ld = 2 * n;
-            for (int t = lane_id(); t < n * n; t += 64) {
+            for (int t = lane_id(); t < n * n; t += wave_lanes()) {
                 m.a[(t / n) * m.ld + (t % n)] = g[t];
                 m.a[(t / n) * m.ld + n + (t % n)] = (t / n == t % n && n > 2) ? R32(1, 1) : R32(0, 1);
             }
             wave_sync();
-            const bool ok = w_inv(m, n);
+            const bool ok = w_inv(m, n, tfac, live);
             wave_sync();
-            if (ok) for (int t = lane_id(); t < n * n; t += 64) out_mat[(size_t)b * n * n + t] = m.a[(t / n) * m.ld + n + (t % n)];
+            if (ok) for (int t = lane_id(); t < n * n; t += wave_lanes()) out_mat[(size_t)b * n * n + t] = m.a[(t / n) * m.ld + n + (t % n)];
             if (lane_id() == 0) out_int[b] = ok ? 1 : 0;
         } else if (op == 3) {
-            int * rowpos = (int *)(lds + (((size_t)rows * cols * 8 + 15) & ~(size_t)15));
             m.ld = cols;
             w_load(m, g, rows, cols);
-            for (int t = lane_id(); t < rows; t += 64) rowpos[t] = t;
+            for (int t = lane_id(); t < rows; t += wave_lanes()) rowpos[t] = t;
             wave_sync();
             const bool unit = flag != 0;
-            const int rk = w_rank(m, unit, rowpos);
+            const int rk = w_rank(m, tfac, live, unit, rowpos);
             wave_sync();
             R32 * o = out_mat + (size_t)b * rows * cols;
             if (!unit && rk < rows) {           // the original rows in pivot order (matt.h:2710-2719)
-                for (int t = lane_id(); t < rk * cols; t += 64) o[t] = g[rowpos[t / cols] * cols + t % cols];
+                for (int t = lane_id(); t < rk * cols; t += wave_lanes()) o[t] = g[rowpos[t / cols] * cols + t % cols];
             } else {
-                for (int t = lane_id(); t < rows * cols; t += 64) o[t] = m.a[t];
+                for (int t = lane_id(); t < rows * cols; t += wave_lanes()) o[t] = m.a[t];
             }
             if (lane_id() == 0) out_int[b] = rk;
         } else if (op == 4) {
             m.ld = cols;
             w_load(m, g, rows, cols);
-            w_rank(m, true, nullptr);
+            w_rank(m, tfac, live, true, nullptr);
             wave_sync();
             R32 * ns = out_mat + (size_t)b * cols * cols;
-            for (int t = lane_id(); t < cols * cols; t += 64) ns[t] = (t / cols == t % cols) ? R32(1, 1) : R32(0, 1);
+            for (int t = lane_id(); t < cols * cols; t += wave_lanes()) ns[t] = (t / cols == t % cols) ? R32(1, 1) : R32(0, 1);
             wave_sync();
             for (int row = 0; row < rows; row++) {
                 int col = row;
                 while (col < cols && eq(m.a[row * cols + col], R32(0, 1))) col++;
                 if (col >= cols) break;
-                for (int k = col + lane_id(); k < cols; k += 64)
+                for (int k = col + lane_id(); k < cols; k += wave_lanes())
                     ns[col * cols + k] = (k == col) ? R32(0, 1) : neg(m.a[row * cols + k]);
                 wave_sync();
             }
         } else {
             m.ld = cols;
             w_load(m, g, rows, cols);
-            if (op == 0) { const int r = w_rank(m); if (lane_id() == 0) out_int[b] = r; }
-            else { const R32 d = (rows == cols) ? w_det(m) : R32(0, 1); if (lane_id() == 0) out_val[b] = d; }
+            if (op == 0) { const int r = w_rank(m, tfac, live); if (lane_id() == 0) out_int[b] = r; }
+            else { const R32 d = (rows == cols) ? w_det(m, tfac, live) : R32(0, 1); if (lane_id() == 0) out_val[b] = d; }
         }
         wave_sync();
     }
@@ -627,7 +707,7 @@ __global__ __launch_bounds__(64) void k_hnf_batch(int nb, const int * mats, int 
 #define H_(i, j) M[(i) * cols + (j)]
     for (int b = blockIdx.x; b < nb; b += gridDim.x) {
         const int * g = mats + (size_t)b * rows * cols;
-        for (int t = lane; t < tot * cols; t += 64) {
+        for (int t = lane; t < tot * cols; t += wave_lanes()) {
             const int r = t / cols, c = t % cols;
             M[t] = r < rows ? g[t] : (r - rows == c ? 1 : 0);
         }
@@ -642,7 +722,7 @@ __global__ __launch_bounds__(64) void k_hnf_batch(int nb, const int * mats, int 
                 int x, y;
                 const int gg = d_exgcd(aii, aij, x, y);               // gen_elim_mat, xmat.cpp:853-868
                 const int p = -aij / gg, q = aii / gg;
-                for (int t = lane; t < tot; t += 64) {
+                for (int t = lane; t < tot; t += wave_lanes()) {
                     const int a = H_(t, i), c = H_(t, j);
                     H_(t, i) = wadd(wmul(a, x), wmul(c, y));
                     H_(t, j) = wadd(wmul(a, p), wmul(c, q));
@@ -654,7 +734,7 @@ __global__ __launch_bounds__(64) void k_hnf_batch(int nb, const int * mats, int 
             wave_sync();
             if (dg < 0) {                                             // 2. positive diagonal
                 if (cols > rows) { st = -7; break; }
-                for (int t = lane; t < tot; t += 64) H_(t, i) = wmul(H_(t, i), -1);
+                for (int t = lane; t < tot; t += wave_lanes()) H_(t, i) = wmul(H_(t, i), -1);
                 wave_sync();
             }
             for (int j = 0; j < i; j++) {                             // 3. non-negative left of the diagonal
@@ -663,7 +743,7 @@ __global__ __launch_bounds__(64) void k_hnf_batch(int nb, const int * mats, int 
                 if (hij >= 0) continue;
                 if (hii == 0 || hij == IMIN) { st = -7; break; }
                 const int v = iabs32(hij) <= iabs32(hii) ? 1 : iabs32(hij / hii) + 1;
-                for (int t = lane; t < tot; t += 64) H_(t, j) = wadd(H_(t, j), wmul(H_(t, i), v));
+                for (int t = lane; t < tot; t += wave_lanes()) H_(t, j) = wadd(H_(t, j), wmul(H_(t, i), v));
                 wave_sync();
             }
             if (st) break;
@@ -673,14 +753,14 @@ __global__ __launch_bounds__(64) void k_hnf_batch(int nb, const int * mats, int 
                 if (hij < hii) continue;
                 if (hii == 0) { st = -7; break; }
                 const int d = hij / hii;
-                for (int t = lane; t < tot; t += 64) H_(t, j) = wadd(H_(t, j), wmul(H_(t, i), -d));
+                for (int t = lane; t < tot; t += wave_lanes()) H_(t, j) = wadd(H_(t, j), wmul(H_(t, i), -d));
                 wave_sync();
             }
         }
         wave_sync();
         if (st == 0) {
-            for (int t = lane; t < rows * cols; t += 64) hs[(size_t)b * rows * cols + t] = M[t];
-            for (int t = lane; t < cols * cols; t += 64) us[(size_t)b * cols * cols + t] = M[rows * cols + t];
+            for (int t = lane; t < rows * cols; t += wave_lanes()) hs[(size_t)b * rows * cols + t] = M[t];
+            for (int t = lane; t < cols * cols; t += wave_lanes()) us[(size_t)b * cols * cols + t] = M[rows * cols + t];
         }
         if (lane == 0) status[b] = st;
         wave_sync();
