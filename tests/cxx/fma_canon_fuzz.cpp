@@ -44,6 +44,14 @@ int main(int argc, char ** argv)
             printf("MISMATCH mul/add_canon a=%d/%d k=%d/%d e=%d/%d\n", a.num, a.den, k.num, k.den, e.num, e.den);
             return 1;
         }
+        if (k.num != 0) {
+            const R32 d1 = div(a, k), d2 = div_canon(a, k);
+            if (d1.num != d2.num || d1.den != d2.den || !canonical(d2)) {
+                printf("MISMATCH div_canon a=%d/%d k=%d/%d want=%d/%d got=%d/%d\n", a.num, a.den, k.num, k.den, d1.num, d1.den, d2.num, d2.den);
+                return 1;
+            }
+        }
+        if (!canonical(m2) || !canonical(a2)) { printf("mul/add_canon result not canonical\n"); return 1; }
         if (!canonical(got)) { printf("result not canonical: %d/%d\n", got.num, got.den); return 1; }
         if (want.den == 1000000 || want.den == 100000 || want.den == 10000 || want.den == 1000) appro_like++;
         if (want.num == 0) zeros++;

@@ -248,3 +248,66 @@ def test_move2var_and_dep_is_empty_with_symbols_and_vc(ctx, lq, port):
         ok, res = port.reduce(moved, nv + ns, True)
         want = 1 if not ok else (0 if res.shape[0] == 0 else -7)
         assert empty[b] == want, b
+
+
+def _scale_some_entries(rng, mats, every=2):
+    """k/k on a few entries of every `every`-th system: same values, not in lowest terms (rational.cpp never reduces
+    on construction), so those systems must take the generic 64-bit operations while their neighbours in the same
+    wavefront take the canonical forms."""
+    mats = mats.copy()
+    for b in range(0, mats.shape[0], every):
+        for _ in range(mats.shape[1]):
+            i, j, k = int(rng.integers(0, mats.shape[1])), int(rng.integers(0, mats.shape[2])), int(rng.integers(2, 5))
+            mats[b, i, j] = (mats[b, i, j, 0] * k, mats[b, i, j, 1] * k)
+    return mats
+
+
+def test_fractions_not_in_lowest_terms_match_oracle(lq, port):
+    rng = np.random.default_rng(2718)
+    nb, rows, nv = 32, 12, 5
+    mats = _scale_some_entries(rng, np.stack([gen.random_system(rng, rows, nv) for _ in range(nb)]))
+    ok, res = lq.reduce(mats, nv, True)
+    for b in range(nb):
+        wok, wres = port.reduce(mats[b], nv, True)
+        assert ok[b] == wok, b
+        if wok:
+            assert rows_equal(res[b], wres), b
+    ok, res = lq.fme(mats, nv, 1, False)
+    for b in range(nb):
+        wok, wres = port.fme(mats[b], nv, 1, False)
+        assert ok[b] == wok and rows_equal(res[b], wres), b
+    rk = lq.rank(mats)
+    for b in range(nb):
+        assert rk[b] == port.rat_rank(mats[b]), b
+    sq = _scale_some_entries(rng, np.stack([gen.random_square(rng, 5) for _ in range(nb)]))
+    rk, dt = lq.rank(sq), lq.det(sq)
+    ok, inv = lq.inv(sq)
+    for b in range(nb):
+        assert rk[b] == port.rat_rank(sq[b]), b
+        assert tuple(dt[b]) == port.rat_det(sq[b]), b
+        wok, winv = port.rat_inv(sq[b])
+        assert ok[b] == wok, b
+        if wok:
+            assert np.array_equal(inv[b], winv), b
+
+
+def test_tall_and_wide_gauss_match_oracle(lq, port):
+    """More rows than a wavefront has lanes (the pivot search and the row factors run in chunks), and an inverse
+    whose augmented matrix is wider than one."""
+    rng = np.random.default_rng(99)
+    tall = np.stack([gen.random_system(rng, 80, 9) for _ in range(8)])
+    tall[1, 40:] = tall[1, :40]
+    rk = lq.rank(tall)
+    for b in range(8):
+        assert rk[b] == port.rat_rank(tall[b]), b
+    sq = np.stack([gen.random_square(rng, 12) for _ in range(8)])
+    sq[2, 5] = sq[2, 4]
+    rk, dt = lq.rank(sq), lq.det(sq)
+    ok, inv = lq.inv(sq)
+    for b in range(8):
+        assert rk[b] == port.rat_rank(sq[b]), b
+        assert tuple(dt[b]) == port.rat_det(sq[b]), b
+        wok, winv = port.rat_inv(sq[b])
+        assert ok[b] == wok, b
+        if wok:
+            assert np.array_equal(inv[b], winv), b

@@ -167,7 +167,9 @@ inline int gauss_batch(xpg_ctx * ctx, int nb, const R32 * mats, int rows, int co
     XPG_TRY(dmat.alloc(bo));
     XPG_TRY(hipMemcpyAsync(di.p, mats, bi, hipMemcpyHostToDevice, ctx->stream));
     if (op >= 2) XPG_TRY(hipMemsetAsync(dmat.p, 0, bo, ctx->stream));
-    const LineqGeom q = lineq_geom(nb, op == 2 ? 2 * cols : cols, lds);
+    // small matrices share a wave (one lane per column); from a few hundred cells on the cell-parallel elimination
+    // fills the wave by itself and sharing only serialises the groups' branches
+    const LineqGeom q = lineq_geom(nb, rows * cols > 256 ? 64 : (op == 2 ? 2 * cols : cols), lds);
     XPG_TRY(hipFuncSetAttribute((const void *)k_gauss_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds));
     hipLaunchKernelGGL(k_gauss_batch, dim3(q.grid), q.block, q.lds, ctx->stream, nb, (const R32 *)di.p, rows,
                        cols, op, flag, (int *)dint.p, (R32 *)dval.p, (R32 *)dmat.p, q.sys_lds);

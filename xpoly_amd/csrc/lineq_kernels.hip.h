@@ -22,7 +22,7 @@ namespace xpg {
 enum { CST_UNK = 1, CST_LT = 2, CST_GT = 3, CST_EQ = 4 };       // linsys.h:55-58
 
 // A small row-major rational matrix in LDS (or global scratch), one wave's property.
-struct WMat { R32 * a; int r, c, ld; };
+struct WMat { R32 * a; int r, c, ld; bool cn; };     // cn: every cell canonical (set by w_load)
 
 __device__ __forceinline__ int lane_id() { return (int)threadIdx.x; }          // lane within the system's group
 __device__ __forceinline__ int wave_lanes() { return (int)blockDim.x; }         // lanes per system: 16, 32 or 64
@@ -42,6 +42,52 @@ __device__ __forceinline__ unsigned long long grp_ballot(bool p)
 }
 __device__ __forceinline__ int grp_rank(unsigned long long bal) { return __popcll(bal & ((1ull << lane_id()) - 1)); }
 
+// t / d for the cell loops (t = row * cols + col and the like): gfx950 has no integer divide, the generic sequence is
+// ~35 instructions. With M = ceil(2^32 / d), umulhi(t, M) == t / d whenever t * d < 2^32; otherwise the plain one.
+struct FastDiv {
+    unsigned d, M; bool ok;
+    __device__ FastDiv(int d_, int max_t)
+        : d((unsigned)d_), M(0xFFFFFFFFu / (unsigned)(d_ > 0 ? d_ : 1) + 1u),
+          ok(d_ > 1 && (unsigned long long)(max_t > 0 ? max_t : 0) * (unsigned long long)d_ < 0xFFFFFFFFull) {}
+    __device__ __forceinline__ int quot(int t) const { return d == 1 ? t : (ok ? (int)__umulhi((unsigned)t, M) : (int)((unsigned)t / d)); }
+};
+
+#ifdef XPG_STAMPS
+// diagnostic builds: clock ticks (s_memtime) per phase of k_fme_batch. Lane 0 of the system's wave adds them up in
+// LDS (a global atomic per stamp would be waited for by the next phase's fence and be what is measured); the
+// sums go to g_lq_ticks once per system, after the last stamp.
+__device__ unsigned long long g_lq_ticks[16];
+__shared__ unsigned long long lq_acc[16];
+#define LQ_T0 unsigned long long lq_t = __builtin_readcyclecounter();
+#define LQ_T(k) { const unsigned long long n_ = __builtin_readcyclecounter(); if (lane_id() == 0) lq_acc[k] += n_ - lq_t; lq_t = n_; }
+#define LQ_FLUSH { if (lane_id() < 16) { atomicAdd(&g_lq_ticks[lane_id()], lq_acc[lane_id()]); lq_acc[lane_id()] = 0; } }
+#define LQ_CLEAR { if (lane_id() < 16) lq_acc[lane_id()] = 0; }
+#else
+#define LQ_T0
+#define LQ_T(k)
+#define LQ_FLUSH
+#define LQ_CLEAR
+#endif
+
+// Rational arithmetic of a system. Every value the reference's Rational can hold is canonical (lowest terms,
+// den > 0), and a system whose cells all are -- checked when it is loaded, WMat::cn -- stays so under these
+// operations; it then takes the 32-bit cross-cancelling forms of scalar.hip.h, which equal the reference's
+// operations bit for bit on such operands (tests/cxx/fma_canon_fuzz.cpp). Any other system keeps the literal
+// 64-bit restatement, out of line.
+__device__ __noinline__ R32 add_any(R32 a, R32 b) { return add(a, b); }
+__device__ __noinline__ R32 mul_any(R32 a, R32 b) { return mul(a, b); }
+__device__ __noinline__ R32 div_any(R32 a, R32 b) { return div(a, b); }
+__device__ __forceinline__ R32 q_add(bool cn, R32 a, R32 b) { return cn ? add_canon(a, b) : add_any(a, b); }
+__device__ __forceinline__ R32 q_sub(bool cn, R32 a, R32 b) { return q_add(cn, a, neg(b)); }
+__device__ __forceinline__ R32 q_mul(bool cn, R32 a, R32 b) { return cn ? mul_canon(a, b) : mul_any(a, b); }
+__device__ __forceinline__ R32 q_div(bool cn, R32 a, R32 b) { return cn && b.num != 0 ? div_canon(a, b) : div_any(a, b); }
+// add(mul(k, e), a), the reference's mul_and_add_row cell (matt.h:1493-1501)
+__device__ __forceinline__ R32 q_fma(bool cn, R32 a, R32 k, R32 e) { return cn ? fma_canon(a, k, e) : add_any(mul_any(k, e), a); }
+__device__ __forceinline__ R32 q_scaled(bool cn, R32 cell, R32 x, int mode)
+{
+    return mode == SCALE_KEEP ? cell : (mode == SCALE_ZERO ? R32(0, 1) : q_mul(cn, cell, x));
+}
+
 // mulOfRow (matt.h:1353-1368): every lane evaluates the same shortcut tests.
 __device__ inline void w_scale_row(WMat & m, int row, R32 x)
 {
@@ -49,7 +95,7 @@ __device__ inline void w_scale_row(WMat & m, int row, R32 x)
     if (mode != SCALE_KEEP)
         for (int j = lane_id(); j < m.c; j += wave_lanes()) {
             R32 * p = m.a + row * m.ld + j;
-            *p = scaled(*p, x, mode);
+            *p = q_scaled(m.cn, *p, x, mode);
         }
     wave_sync();
 }
@@ -98,8 +144,9 @@ __device__ inline void w_compact(WMat & m, const unsigned char * drop, int * map
     wave_sync();
     if (first >= 0) {
         const int total = m.r * m.c;
+        const FastDiv by_c(m.c, total + L);
         for (int t0 = first * m.c; t0 < total; t0 += L) {
-            const int t = t0 + lane, i = t / m.c, j = t - i * m.c;
+            const int t = t0 + lane, i = by_c.quot(t), j = t - i * m.c;
             const int to = t < total ? map[i] : -1;
             R32 v;
             if (to >= 0) v = m.a[i * m.ld + j];
@@ -113,8 +160,50 @@ __device__ inline void w_compact(WMat & m, const unsigned char * drop, int * map
 
 // Lineq::removeIdenRow (linsys.cpp:1209-1268): a row goes iff an earlier row is
 // field-wise identical (the row-sum test there is only a prefilter; ours is a hash of the fields in map[]).
+// A lane owns rows kb + lane, kb + L + lane, ... (P of them in registers). The hashes of the rows below go by once,
+// in descending order, one broadcast LDS read each: what is left in first[] is the SMALLEST row index with the
+// lane's hash, so a row has an earlier look-alike iff first < k, and only such a row is compared field by field.
+template <int P>
+__device__ inline bool w_iden_rows(const WMat & m, const int * map, unsigned char * drop, int kb)
+{
+    const int L = wave_lanes(), lane = lane_id();
+    int hk[P], first[P];
+#pragma unroll
+    for (int q = 0; q < P; q++) { const int k = kb + q * L + lane; hk[q] = k < m.r ? map[k] : 0; first[q] = k; }
+    const int kend = m.r < kb + P * L ? m.r : kb + P * L;
+    // four hashes per trip, read before any is used (the LDS latency is paid once per four); the trip that holds
+    // kend - 1 may reach up to three entries past it -- inside the scratch, and harmless: a row's own index is
+    // visited after any larger one
+    for (int i4 = (kend - 1) & ~3; i4 >= 0; i4 -= 4) {
+        const int h3 = map[i4 + 3], h2 = map[i4 + 2], h1 = map[i4 + 1], h0 = map[i4];
+#pragma unroll
+        for (int q = 0; q < P; q++) {
+            first[q] = h3 == hk[q] ? i4 + 3 : first[q];
+            first[q] = h2 == hk[q] ? i4 + 2 : first[q];
+            first[q] = h1 == hk[q] ? i4 + 1 : first[q];
+            first[q] = h0 == hk[q] ? i4 : first[q];
+        }
+    }
+    bool any = false;
+#pragma unroll
+    for (int q = 0; q < P; q++) {
+        const int k = kb + q * L + lane;
+        if (k >= m.r) continue;
+        unsigned char gone = 0;
+        for (int i = first[q]; i < k && !gone; i++) {
+            if (map[i] != hk[q]) continue;
+            bool same = true;
+            for (int j = 0; j < m.c && same; j++) same = eq(m.a[i * m.ld + j], m.a[k * m.ld + j]);
+            gone = same ? 1 : 0;
+        }
+        drop[k] = gone;
+        any |= gone != 0;
+    }
+    return any;
+}
 __device__ inline void w_remove_iden(WMat & m, unsigned char * drop, int * map)
 {
+    LQ_T0
     for (int k = lane_id(); k < m.r; k += wave_lanes()) {
         unsigned h = 0;
         for (int j = 0; j < m.c; j++) {
@@ -124,22 +213,21 @@ __device__ inline void w_remove_iden(WMat & m, unsigned char * drop, int * map)
         map[k] = (int)h;
     }
     wave_sync();
+    LQ_T(12)
     bool any = false;
-    for (int k = lane_id(); k < m.r; k += wave_lanes()) {
-        unsigned char gone = 0;
-        const int hk = map[k];
-        for (int i = 0; i < k && !gone; i++) {
-            if (map[i] != hk) continue;
-            bool same = true;
-            for (int j = 0; j < m.c && same; j++) same = eq(m.a[i * m.ld + j], m.a[k * m.ld + j]);
-            gone = same ? 1 : 0;
-        }
-        drop[k] = gone;
-        any |= gone != 0;
+    const int L = wave_lanes();
+    for (int kb = 0; kb < m.r;) {
+        const int left = (m.r - kb + L - 1) / L;
+        if (left >= 8) { any |= w_iden_rows<8>(m, map, drop, kb); kb += 8 * L; }
+        else if (left > 2) { any |= w_iden_rows<4>(m, map, drop, kb); kb += 4 * L; }
+        else if (left == 2) { any |= w_iden_rows<2>(m, map, drop, kb); kb += 2 * L; }
+        else { any |= w_iden_rows<1>(m, map, drop, kb); kb += L; }
     }
+    LQ_T(13)
     if (grp_ballot(any) == 0) return;          // nothing identical: rows and order stay
     wave_sync();
     w_compact(m, drop, map);
+    LQ_T(14)
 }
 
 // One side of Lineq::reduce's pairwise tightening (linsys.cpp:433-497, :505-573).
@@ -153,14 +241,14 @@ __device__ inline void w_tighten(WMat & m, int rhs, int var, const short * rows,
         if (removed[r1]) continue;
         R32 c = m.a[r1 * m.ld + var];
         if (negative) c = neg(c);
-        if (ne(c, R32(1, 1))) w_scale_row(m, r1, div(R32(1, 1), c));
+        if (ne(c, R32(1, 1))) w_scale_row(m, r1, q_div(m.cn, R32(1, 1), c));
         bool r1_gone = false;
         for (int k2 = k1 + 1; k2 <= last; k2++) {
             const int r2 = rows[k2];
             if (removed[r2]) continue;
             c = m.a[r2 * m.ld + var];
             if (negative) c = neg(c);
-            if (ne(c, R32(1, 1))) w_scale_row(m, r2, div(R32(1, 1), c));
+            if (ne(c, R32(1, 1))) w_scale_row(m, r2, q_div(m.cn, R32(1, 1), c));
             const int cres = w_cmp_rows(m, rhs, r1, r2);
             wave_sync();
             if (is_intersect) {
@@ -187,7 +275,9 @@ struct WScratch {
 // Lineq::reduce (linsys.cpp:359-626). Returns consistency; m rewritten in place.
 __device__ inline bool w_reduce(WMat & m, int rhs, bool is_intersect, WScratch & s)
 {
+    LQ_T0
     w_remove_iden(m, s.drop, s.map);
+    LQ_T(8)
     unsigned char * removed = s.drop;
     int * any_removed = &s.flags[0];
     int * bad = &s.flags[1];
@@ -216,6 +306,7 @@ __device__ inline bool w_reduce(WMat & m, int rhs, bool is_intersect, WScratch &
                    | (unsigned)__shfl_xor((int)singles, o);
     }
     wave_sync();
+    LQ_T(9)
     if (*bad) {
         // The reference stops at the FIRST inconsistent row, having marked the constant-true
         // rows before it as removed -- but it returns without compacting, so only the flag matters.
@@ -239,12 +330,12 @@ __device__ inline bool w_reduce(WMat & m, int rhs, bool is_intersect, WScratch &
             for (int a = 0; a < np; a++) {
                 const int pi = s.pos[a];
                 R32 c = m.a[pi * m.ld + var];
-                if (ne(c, R32(1, 1))) w_scale_row(m, pi, div(R32(1, 1), c));
+                if (ne(c, R32(1, 1))) w_scale_row(m, pi, q_div(m.cn, R32(1, 1), c));
                 for (int b = 0; b < nn; b++) {
                     const int ni = s.negs[b];
                     c = neg(m.a[ni * m.ld + var]);
                     wave_sync();
-                    if (ne(c, R32(1, 1))) w_scale_row(m, ni, div(R32(-1, 1), c));
+                    if (ne(c, R32(1, 1))) w_scale_row(m, ni, q_div(m.cn, R32(-1, 1), c));
                     else w_scale_row(m, ni, R32(-1, 1));
                     const int cres = w_cmp_rows(m, rhs, pi, ni);
                     wave_sync();
@@ -254,7 +345,9 @@ __device__ inline bool w_reduce(WMat & m, int rhs, bool is_intersect, WScratch &
             }
         }
     }
+    LQ_T(10)
     if (*any_removed) w_compact(m, removed, s.map);
+    LQ_T(11)
     return true;
 }
 
@@ -262,12 +355,18 @@ __device__ inline bool w_reduce(WMat & m, int rhs, bool is_intersect, WScratch &
 __device__ inline void w_load(WMat & m, const R32 * src, int rows, int cols)
 {
     m.r = rows; m.c = cols;
-    for (int t = lane_id(); t < rows * cols; t += wave_lanes()) m.a[(t / cols) * m.ld + (t % cols)] = src[t];
+    bool bad = false;
+    for (int t = lane_id(); t < rows * cols; t += wave_lanes()) {
+        const R32 v = src[t];
+        bad |= !canonical(v);
+        m.a[t] = v;                              // ld == cols for every matrix that comes through here
+    }
+    m.cn = grp_ballot(bad) == 0;
     wave_sync();
 }
 __device__ inline void w_store(const WMat & m, R32 * dst)
 {
-    for (int t = lane_id(); t < m.r * m.c; t += wave_lanes()) dst[t] = m.a[(t / m.c) * m.ld + (t % m.c)];
+    for (int t = lane_id(); t < m.r * m.c; t += wave_lanes()) dst[t] = m.a[t];          // ld == c, as in w_load
 }
 
 __device__ inline WScratch carve_scratch(unsigned char * p, int cap)
@@ -325,13 +424,16 @@ __global__ __launch_bounds__(64) void k_fme_batch(int nb, const R32 * mats, int 
     WMat res; res.a = (R32 *)lds; res.ld = cols; res.c = cols;
     WMat tmp; tmp.a = res_global ? (R32 *)lds : res.a + (size_t)cap * cols; tmp.ld = cols;
     WScratch s = carve_scratch((unsigned char *)(tmp.a + (size_t)cap_in * cols), cap > cap_in ? cap : cap_in);
+    LQ_CLEAR
     for (int b = sys_first(); b < nb; b += sys_stride()) {
         if (chain_ok && chain_ok[b] != 1) { if (lane_id() == 0) { out_rows[b] = 0; out_ok[b] = 0; } continue; }
         const int rows = in_rows ? in_rows[b] : cap_in;
         const R32 * g = mats + (size_t)b * cap_in * cols;
         if (res_global) res.a = outs + (size_t)b * cap * cols;
+        LQ_T0
         w_load(tmp, g, rows, cols);
-        res.r = 0;
+        LQ_T(0)
+        res.r = 0; res.cn = tmp.cn;
         // classify rows: 0 = no u (copy), 1 = positive, 2 = negative; 3 = inconsistent constant row
         int * kind = s.map;
         int * bad_at = &s.flags[1];
@@ -346,18 +448,35 @@ __global__ __launch_bounds__(64) void k_fme_batch(int nb, const R32 * mats, int 
         }
         wave_sync();
         const int stop = *bad_at == INT_MAX ? rows : *bad_at;      // rows before the first bad one are processed
-        // normalise the rows that contain u (linsys.cpp:711-723); one lane per column
-        for (int i = 0; i < stop; i++) {
-            if (kind[i] == 0) continue;
-            R32 c = tmp.a[i * cols + u];
-            wave_sync();
-            if (kind[i] == 1) { if (ne(c, R32(1, 1))) w_scale_row(tmp, i, div(R32(1, 1), c)); }
-            else {
-                if (ne(c, R32(-1, 1))) w_scale_row(tmp, i, div(R32(1, 1), neg(c)));
-                if (darkshadow && lane_id() == 0) tmp.a[i * cols + rhs] = sub(tmp.a[i * cols + rhs], R32(1, 1));
-                wave_sync();
+        LQ_T(1)
+        // normalise the rows that contain u (linsys.cpp:711-723): the rows are independent, so the factors are
+        // found one lane per row (kept in the still empty result matrix) and applied one lane per cell
+        R32 * fac = res.a;
+        for (int i = lane_id(); i < stop; i += wave_lanes()) {
+            int mode = SCALE_KEEP;
+            if (kind[i] != 0) {
+                const R32 c = tmp.a[i * cols + u];
+                R32 f(1, 1);
+                if (kind[i] == 1) { if (ne(c, R32(1, 1))) f = q_div(tmp.cn, R32(1, 1), c); }
+                else if (ne(c, R32(-1, 1))) f = q_div(tmp.cn, R32(1, 1), neg(c));
+                mode = scale_mode(f);
+                fac[i] = f;
             }
+            s.drop[i] = (unsigned char)mode;
         }
+        wave_sync();
+        const FastDiv by_cols(cols, (cap > cap_in ? cap : cap_in) * cols + wave_lanes());
+        for (int t = lane_id(); t < stop * cols; t += wave_lanes()) {
+            const int i = by_cols.quot(t), mode = s.drop[i];
+            if (mode != SCALE_KEEP) tmp.a[t] = q_scaled(tmp.cn, tmp.a[t], fac[i], mode);
+        }
+        wave_sync();
+        if (darkshadow) {
+            for (int i = lane_id(); i < stop; i += wave_lanes())
+                if (kind[i] == 2) tmp.a[i * cols + rhs] = q_sub(tmp.cn, tmp.a[i * cols + rhs], R32(1, 1));
+            wave_sync();
+        }
+        LQ_T(2)
         // rows without u go first, in order (linsys.cpp:724-730)
         int nfree = 0, np = 0, nn = 0;
         for (int base = 0; base < stop; base += wave_lanes()) {
@@ -371,10 +490,11 @@ __global__ __launch_bounds__(64) void k_fme_batch(int nb, const R32 * mats, int 
         }
         wave_sync();
         for (int t = lane_id(); t < stop * cols; t += wave_lanes()) {
-            const int i = t / cols, j = t - i * cols;
+            const int i = by_cols.quot(t), j = t - i * cols;
             if (kind[i] < 0) res.a[(-kind[i] - 1) * cols + j] = tmp.a[t];
         }
         res.r = nfree;
+        LQ_T(3)
         bool ok = true;
         int status_rows = -1;
         if (stop < rows) {                                              // inconsistent constant row
@@ -390,15 +510,19 @@ __global__ __launch_bounds__(64) void k_fme_batch(int nb, const R32 * mats, int 
                 res.r += 1;
             } else if (np + nn > 1) {                                   // every (pos, neg) pair summed
                 const int base = res.r * cols, total = np * nn * cols;
+                const FastDiv by_nn(nn, np * nn);
                 for (int t = lane_id(); t < total; t += wave_lanes()) {
-                    const int pair = t / cols, j = t % cols;
-                    const int pi = s.pos[pair / nn], ni = s.negs[pair % nn];
-                    res.a[base + t] = add(tmp.a[pi * cols + j], tmp.a[ni * cols + j]);
+                    const int pair = by_cols.quot(t), j = t - pair * cols;
+                    const int pq = by_nn.quot(pair);
+                    const int pi = s.pos[pq], ni = s.negs[pair - pq * nn];
+                    res.a[base + t] = q_add(tmp.cn, tmp.a[pi * cols + j], tmp.a[ni * cols + j]);
                 }
                 res.r += np * nn;
             }
             wave_sync();
+            LQ_T(4)
             if (status_rows < 0 && res.r > 0) ok = w_reduce(res, rhs, true, s);
+            LQ_T(5)
         }
         wave_sync();
         R32 * go = outs + (size_t)b * cap * cols;
@@ -410,6 +534,8 @@ __global__ __launch_bounds__(64) void k_fme_batch(int nb, const R32 * mats, int 
             if (chain_ok && !ok) chain_ok[b] = status_rows < 0 ? 0 : -status_rows;
         }
         wave_sync();
+        LQ_T(6)
+        LQ_FLUSH
     }
 }
 
@@ -481,14 +607,15 @@ __device__ inline void w_eliminate(WMat & m, int row, int col, int lo, R32 * tfa
         const R32 e = m.a[i * m.ld + col];
         const bool on = i != row && ne(e, R32(0, 1));
         live[i] = on ? 1 : 0;
-        if (on) tfac[i] = KIND == 0 ? div(neg(e), piv) : (KIND == 1 ? neg(div(e, piv)) : mul(R32(-1, 1), e));
+        if (on) tfac[i] = KIND == 0 ? q_div(m.cn, neg(e), piv) : (KIND == 1 ? neg(q_div(m.cn, e, piv)) : q_mul(m.cn, R32(-1, 1), e));
     }
     wave_sync();
     const int n = (m.r - lo) * m.c;
+    const FastDiv by_c(m.c, n + wave_lanes());
     for (int x = lane_id(); x < n; x += wave_lanes()) {
-        const int i = lo + x / m.c, j = x % m.c;
+        const int q = by_c.quot(x), i = lo + q, j = x - q * m.c;
         if (!live[i]) continue;
-        m.a[i * m.ld + j] = add(mul(m.a[row * m.ld + j], tfac[i]), m.a[i * m.ld + j]);
+        m.a[i * m.ld + j] = q_fma(m.cn, m.a[i * m.ld + j], m.a[row * m.ld + j], tfac[i]);
     }
     wave_sync();
 }
@@ -511,7 +638,7 @@ __device__ inline int w_rank(WMat & p, R32 * tfac, unsigned char * live, bool un
         if (swap_row == -1) break;
         const R32 d = p.a[row * p.ld + col];
         wave_sync();
-        if (unitarize && ne(d, R32(1, 1))) w_scale_row(p, row, div(R32(1, 1), d));
+        if (unitarize && ne(d, R32(1, 1))) w_scale_row(p, row, q_div(p.cn, R32(1, 1), d));
         w_eliminate<0>(p, row, col, unitarize ? 0 : row + 1, tfac, live);
         rankv++;
     }
@@ -535,21 +662,21 @@ __device__ inline R32 w_det(WMat & a, R32 * tfac, unsigned char * live)
     const int n = a.r;
 #define M_(i, j) a.a[(i) * a.ld + (j)]
     if (n == 1) return M_(0, 0);
-    if (n == 2) return sub(mul(M_(0, 0), M_(1, 1)), mul(M_(0, 1), M_(1, 0)));
+    if (n == 2) return q_sub(a.cn, q_mul(a.cn, M_(0, 0), M_(1, 1)), q_mul(a.cn, M_(0, 1), M_(1, 0)));
     if (n == 3) {
-        if (w_tri(a, 0) || w_tri(a, 1)) return mul(mul(M_(0, 0), M_(1, 1)), M_(2, 2));
-        if (w_tri(a, 2) || w_tri(a, 3)) return mul(mul(mul(M_(2, 0), M_(1, 1)), M_(0, 2)), R32(-1, 1));
-        R32 d = mul(mul(M_(0, 0), M_(1, 1)), M_(2, 2));
-        d = add(d, mul(mul(M_(1, 0), M_(2, 1)), M_(0, 2)));
-        d = add(d, mul(mul(M_(0, 1), M_(1, 2)), M_(2, 0)));
-        d = sub(d, mul(mul(M_(0, 2), M_(1, 1)), M_(2, 0)));
-        d = sub(d, mul(mul(M_(0, 1), M_(1, 0)), M_(2, 2)));
-        d = sub(d, mul(mul(M_(2, 1), M_(1, 2)), M_(0, 0)));
+        if (w_tri(a, 0) || w_tri(a, 1)) return q_mul(a.cn, q_mul(a.cn, M_(0, 0), M_(1, 1)), M_(2, 2));
+        if (w_tri(a, 2) || w_tri(a, 3)) return q_mul(a.cn, q_mul(a.cn, q_mul(a.cn, M_(2, 0), M_(1, 1)), M_(0, 2)), R32(-1, 1));
+        R32 d = q_mul(a.cn, q_mul(a.cn, M_(0, 0), M_(1, 1)), M_(2, 2));
+        d = q_add(a.cn, d, q_mul(a.cn, q_mul(a.cn, M_(1, 0), M_(2, 1)), M_(0, 2)));
+        d = q_add(a.cn, d, q_mul(a.cn, q_mul(a.cn, M_(0, 1), M_(1, 2)), M_(2, 0)));
+        d = q_sub(a.cn, d, q_mul(a.cn, q_mul(a.cn, M_(0, 2), M_(1, 1)), M_(2, 0)));
+        d = q_sub(a.cn, d, q_mul(a.cn, q_mul(a.cn, M_(0, 1), M_(1, 0)), M_(2, 2)));
+        d = q_sub(a.cn, d, q_mul(a.cn, q_mul(a.cn, M_(2, 1), M_(1, 2)), M_(0, 0)));
         return d;
     }
     R32 d(1, 1);
-    if (w_tri(a, 0) || w_tri(a, 1)) { for (int i = 0; i < n; i++) d = mul(d, M_(i, i)); return d; }
-    if (w_tri(a, 2) || w_tri(a, 3)) { for (int i = 0; i < n; i++) d = mul(d, M_(i, n - 1 - i)); return d; }
+    if (w_tri(a, 0) || w_tri(a, 1)) { for (int i = 0; i < n; i++) d = q_mul(a.cn, d, M_(i, i)); return d; }
+    if (w_tri(a, 2) || w_tri(a, 3)) { for (int i = 0; i < n; i++) d = q_mul(a.cn, d, M_(i, n - 1 - i)); return d; }
     int swaps = 0;
     for (int j = 0; j < n; j++) {
         bool ub;
@@ -558,7 +685,7 @@ __device__ inline R32 w_det(WMat & a, R32 * tfac, unsigned char * live)
         if (swap_row != j) { w_swap_rows(a, swap_row, j); swaps++; }
         w_eliminate<1>(a, j, j, j + 1, tfac, live);
     }
-    for (int j = 0; j < n; j++) d = mul(d, M_(j, j));
+    for (int j = 0; j < n; j++) d = q_mul(a.cn, d, M_(j, j));
     if (swaps & 1) d = neg(d);
     return d;
 #undef M_
@@ -570,16 +697,16 @@ __device__ inline bool w_inv(WMat & pe, int n, R32 * tfac, unsigned char * live)
 {
 #define P_(i, j) pe.a[(i) * pe.ld + (j)]
 #define E_(i, j) pe.a[(i) * pe.ld + n + (j)]
-    if (n == 1) { if (lane_id() == 0) E_(0, 0) = div(R32(1, 1), P_(0, 0)); wave_sync(); return true; }
+    if (n == 1) { if (lane_id() == 0) E_(0, 0) = q_div(pe.cn, R32(1, 1), P_(0, 0)); wave_sync(); return true; }
     if (n == 2) {
-        R32 k = sub(mul(P_(0, 0), P_(1, 1)), mul(P_(0, 1), P_(1, 0)));
+        R32 k = q_sub(pe.cn, q_mul(pe.cn, P_(0, 0), P_(1, 1)), q_mul(pe.cn, P_(0, 1), P_(1, 0)));
         if (eq(k, R32(0, 1))) return false;
-        k = div(R32(1, 1), k);
+        k = q_div(pe.cn, R32(1, 1), k);
         wave_sync();
         if (lane_id() == 0) {
-            R32 v[4] = { P_(1, 1), mul(R32(-1, 1), P_(0, 1)), mul(R32(-1, 1), P_(1, 0)), P_(0, 0) };
+            R32 v[4] = { P_(1, 1), q_mul(pe.cn, R32(-1, 1), P_(0, 1)), q_mul(pe.cn, R32(-1, 1), P_(1, 0)), P_(0, 0) };
             const int mode = eq(k, R32(0, 1)) ? SCALE_ZERO : (eq(k, R32(1, 1)) ? SCALE_KEEP : SCALE_MUL);
-            for (int t = 0; t < 4; t++) E_(t / 2, t % 2) = scaled(v[t], k, mode);
+            for (int t = 0; t < 4; t++) E_(t / 2, t % 2) = q_scaled(pe.cn, v[t], k, mode);
         }
         wave_sync();
         return true;
@@ -592,7 +719,7 @@ __device__ inline bool w_inv(WMat & pe, int n, R32 * tfac, unsigned char * live)
         w_swap_rows(pe, swap_row, j);
         const R32 d = P_(j, j);
         wave_sync();
-        if (ne(d, R32(1, 1))) w_scale_row(pe, j, div(R32(1, 1), d));
+        if (ne(d, R32(1, 1))) w_scale_row(pe, j, q_div(pe.cn, R32(1, 1), d));
         w_eliminate<2>(pe, j, j, 0, tfac, live);
     }
     return true;
@@ -618,10 +745,14 @@ __global__ __launch_bounds__(64) void k_gauss_batch(int nb, const R32 * mats, in
         if (op == 2) {
             const int n = rows;
             m.r = n; m.c = 2 * n; m.ld = 2 * n;
+            bool bad = false;
             for (int t = lane_id(); t < n * n; t += wave_lanes()) {
-                m.a[(t / n) * m.ld + (t % n)] = g[t];
+                const R32 v = g[t];
+                bad |= !canonical(v);
+                m.a[(t / n) * m.ld + (t % n)] = v;
                 m.a[(t / n) * m.ld + n + (t % n)] = (t / n == t % n && n > 2) ? R32(1, 1) : R32(0, 1);
             }
+            m.cn = grp_ballot(bad) == 0;
             wave_sync();
             const bool ok = w_inv(m, n, tfac, live);
             wave_sync();

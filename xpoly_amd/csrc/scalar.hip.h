@@ -174,6 +174,44 @@ XPG_HD uint32_t gcd32(uint32_t x, uint32_t y)
     } while (y != 0);
     return x << sh;
 }
+// Division without a divide (gfx950 has none: a 32-bit quotient costs ~30 instructions, a 64-bit one far more, and
+// the canonical forms below would spend most of theirs there).
+//  * x / g where g divides x: shift out g's factors of two and multiply by the inverse of its odd part modulo
+//    2^32 (2^64) -- Newton's y <- y * (2 - o * y) doubles the correct low bits, (3 * o) ^ 2 starts with five.
+//  * x mod g for a 64-bit x < 2^63: two quotient estimates through fp64 (plain IEEE operations, the same on the
+//    host), each followed by an integer remainder; the first leaves |r| < 2^13 * g, the second at most one g off.
+struct ExactDiv32 {
+    uint32_t odd, inv; int sh;
+    XPG_HD explicit ExactDiv32(uint32_t g)
+    {
+        sh = __builtin_ctz(g);
+        odd = g >> sh;
+        uint32_t y = (3u * odd) ^ 2u;
+        y *= 2u - odd * y; y *= 2u - odd * y; y *= 2u - odd * y;
+        inv = y;
+    }
+    XPG_HD uint32_t operator()(uint32_t x) const { return (x >> sh) * inv; }
+    XPG_HD unsigned long long wide(unsigned long long x) const          // a 64-bit multiple of g
+    {
+        unsigned long long y = (unsigned long long)inv;                  // correct to 32 bits ...
+        y *= 2ull - (unsigned long long)odd * y;                         // ... to 64
+        return (x >> sh) * y;
+    }
+};
+XPG_HD uint32_t mod_u64_u32(unsigned long long x, uint32_t g)
+{
+    const double inv = 1.0 / (double)g;
+    const unsigned long long q = (unsigned long long)((double)x * inv);
+    long long r = (long long)(x - q * (unsigned long long)g);            // exact modulo 2^64; |r| < 2^13 * g
+    const double qf = (double)r * inv;
+    long long q2 = (long long)qf;
+    if ((double)q2 > qf) q2 -= 1;                                        // floor
+    r -= q2 * (long long)g;
+    if (r < 0) r += (long long)g;
+    if (r >= (long long)g) r -= (long long)g;
+    if ((unsigned long long)r >= (unsigned long long)g) return (uint32_t)(x % g);   // never (kept as the definition)
+    return (uint32_t)r;
+}
 XPG_HD bool canonical(R32 a)
 {
     if (a.den <= 0) return false;
@@ -181,12 +219,31 @@ XPG_HD bool canonical(R32 a)
     const uint32_t mag = a.num < 0 ? (uint32_t)(-(long long)a.num) : (uint32_t)a.num;
     return gcd32(mag, (uint32_t)a.den) == 1 && mag < 0x7fffFFFFu && a.den < 0x7fffFFFF;
 }
+// appro64 (rational.cpp:189-226) for n, d > 0: the same float32 operations, then its reduce64 on the 32-bit pair
+// they leave (n < 2^31, d a power of ten <= 10^6) with the binary gcd and the exact division above.
+XPG_HD void appro_lowest(long long & n, long long & d)
+{
+    float q = (float)n / (float)d;
+    uint32_t m, t;
+    if (q < 100.0) { q = q * 1000000.0f; m = (uint32_t)(int)q; t = 1000000; }
+    else if (q < 1000.0) { q = q * 100000.0f; m = (uint32_t)(int)q; t = 100000; }
+    else if (q < 100000.0) { q = q * 10000.0f; m = (uint32_t)(int)q; t = 10000; }
+    else if (q < 1000000.0) { q = q * 1000.0f; m = (uint32_t)(int)q; t = 1000; }
+    else if (q < 10000000.0) { q = q * 100.0f; m = (uint32_t)(int)q; t = 100; }
+    else if (q < 100000000.0) { q = q * 10.0f; m = (uint32_t)(int)q; t = 10; }
+    else if (q < 2147483647.0) { m = (uint32_t)(int)q; t = 1; }
+    else { m = 0; t = 1; }
+    if (m == 0) { n = 0; d = 1; return; }
+    const uint32_t g = gcd32(m, t);
+    if (g != 1) { const ExactDiv32 by(g); m = by(m); t = by(t); }
+    n = (long long)m; d = (long long)t;
+}
 XPG_HD R32 squeeze_lowest(long long n, long long d)            // squeeze() for a pair already in lowest terms, d > 0
 {
     const long long imax = 0x7fffFFFFLL;
     long long mag = n >= 0 ? n : -n;
     if (mag >= (imax >> 2) || d >= (imax >> 2)) {
-        if (mag >= imax || d >= imax) appro64(mag, d);
+        if (mag >= imax || d >= imax) appro_lowest(mag, d);
     }
     return R32((int32_t)(n < 0 ? -mag : mag), (int32_t)d);
 }
@@ -195,48 +252,53 @@ XPG_HD R32 mul_canon(R32 a, R32 b)                             // == mul(a, b) f
     if (a.num == 0 || b.num == 0) return R32(0, 1);
     const uint32_t an = a.num < 0 ? (uint32_t)(-(long long)a.num) : (uint32_t)a.num;
     const uint32_t bn = b.num < 0 ? (uint32_t)(-(long long)b.num) : (uint32_t)b.num;
-    const uint32_t g1 = gcd32(an, (uint32_t)b.den), g2 = gcd32(bn, (uint32_t)a.den);
-    const long long mag = (long long)(an / g1) * (long long)(bn / g2);
-    const long long den = (long long)((uint32_t)a.den / g2) * (long long)((uint32_t)b.den / g1);
+    const ExactDiv32 by1(gcd32(an, (uint32_t)b.den)), by2(gcd32(bn, (uint32_t)a.den));
+    const long long mag = (long long)by1(an) * (long long)by2(bn);
+    const long long den = (long long)by2((uint32_t)a.den) * (long long)by1((uint32_t)b.den);
     return squeeze_lowest(((a.num < 0) != (b.num < 0)) ? -mag : mag, den);
+}
+XPG_HD R32 div_canon(R32 a, R32 b)                             // == div(a, b) for canonical a, b with b != 0
+{
+    if (a.num == 0) return R32(0, 1);
+    const R32 r = b.num < 0 ? R32(-b.den, -b.num) : R32(b.den, b.num);     // canonical: |b.num| < 2^31 - 1
+    if (a.num == a.den) return r;
+    return mul_canon(a, r);                                    // the lowest terms of (a.num * b.den) / (a.den * b.num)
+}
+// a + p for canonical non-zero a, p: with g = gcd(a.den, p.den), A = a.den / g, P = p.den / g the numerator
+// n' = a.num * P + p.num * A is coprime to A and to P, so gcd(n', A * P * g) = gcd(n' mod g, g).
+XPG_HD R32 add_lowest(R32 a, R32 p)
+{
+    const uint32_t g = gcd32((uint32_t)a.den, (uint32_t)p.den);
+    const ExactDiv32 by(g);
+    const uint32_t A = by((uint32_t)a.den), P = by((uint32_t)p.den);
+    const long long n = (long long)a.num * (long long)P + (long long)p.num * (long long)A;
+    if (n == 0) return R32(0, 1);
+    unsigned long long nm = n < 0 ? (unsigned long long)(-n) : (unsigned long long)n;
+    unsigned long long d = (unsigned long long)A * (unsigned long long)(uint32_t)p.den;
+    if (g != 1) {
+        const uint32_t h = gcd32(mod_u64_u32(nm, g), g);
+        if (h != 1) { const ExactDiv32 byh(h); nm = byh.wide(nm); d = byh.wide(d); }
+    }
+    return squeeze_lowest(n < 0 ? -(long long)nm : (long long)nm, (long long)d);
 }
 XPG_HD R32 add_canon(R32 a, R32 p)                             // == add(a, p) for canonical a, p
 {
     if (p.num == 0) return a;
     if (a.num == 0) return p;
-    const uint32_t g = gcd32((uint32_t)a.den, (uint32_t)p.den);
-    const uint32_t A = (uint32_t)a.den / g, P = (uint32_t)p.den / g;
-    long long n = (long long)a.num * (long long)P + (long long)p.num * (long long)A;
-    if (n == 0) return R32(0, 1);
-    long long d = (long long)A * (long long)p.den;
-    if (g != 1) {
-        const unsigned long long nm = n < 0 ? (unsigned long long)(-n) : (unsigned long long)n;
-        const uint32_t h = gcd32((uint32_t)(nm % g), g);
-        if (h != 1) { n /= (long long)h; d /= (long long)h; }
-    }
-    return squeeze_lowest(n, d);
+    return add_lowest(a, p);
 }
 XPG_HD R32 fma_canon(R32 a, R32 k, R32 e)
 {
     if (k.num == 0 || e.num == 0) return a;
     const uint32_t kn = k.num < 0 ? (uint32_t)(-(long long)k.num) : (uint32_t)k.num;
     const uint32_t en = e.num < 0 ? (uint32_t)(-(long long)e.num) : (uint32_t)e.num;
-    const uint32_t g1 = gcd32(kn, (uint32_t)e.den), g2 = gcd32(en, (uint32_t)k.den);
-    const long long pmag = (long long)(kn / g1) * (long long)(en / g2);
-    const long long pden = (long long)((uint32_t)k.den / g2) * (long long)((uint32_t)e.den / g1);
+    const ExactDiv32 by1(gcd32(kn, (uint32_t)e.den)), by2(gcd32(en, (uint32_t)k.den));
+    const long long pmag = (long long)by1(kn) * (long long)by2(en);
+    const long long pden = (long long)by2((uint32_t)k.den) * (long long)by1((uint32_t)e.den);
     const R32 p = squeeze_lowest(((k.num < 0) != (e.num < 0)) ? -pmag : pmag, pden);
     if (p.num == 0) return a;                                  // (appro can return 0/1)
-    const uint32_t g = gcd32((uint32_t)a.den, (uint32_t)p.den);
-    const uint32_t A = (uint32_t)a.den / g, P = (uint32_t)p.den / g;
-    long long n = (long long)a.num * (long long)P + (long long)p.num * (long long)A;
-    if (n == 0) return R32(0, 1);
-    long long d = (long long)A * (long long)p.den;
-    if (g != 1) {
-        const unsigned long long nm = n < 0 ? (unsigned long long)(-n) : (unsigned long long)n;
-        const uint32_t h = gcd32((uint32_t)(nm % g), g);
-        if (h != 1) { n /= (long long)h; d /= (long long)h; }
-    }
-    return squeeze_lowest(n, d);
+    if (a.num == 0) return p;                                  // 0/1 + p = squeeze(p.num, p.den) = p
+    return add_lowest(a, p);
 }
 XPG_HD R32 sub(R32 a, R32 b) { return add(a, neg(b)); }
 XPG_HD bool eq(R32 a, R32 b) { return a.num == b.num && a.den == b.den; }   // rational.h:80-83

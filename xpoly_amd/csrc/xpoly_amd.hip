@@ -357,6 +357,15 @@ int xpg_lp_counters(xpg_lp * lp, unsigned * sweeps_full, unsigned * sweeps_parti
 }
 
 #ifdef XPG_STAMPS
+// diagnostic builds only: reads and clears the phase tick sums of k_fme_batch
+int xpg_lineq_debug(xpg_ctx * ctx, unsigned long long * out16)
+{
+    XPG_BIND(ctx);
+    unsigned long long z[16] = {0};
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_lq_ticks), sizeof(z)) != hipSuccess) return XPG_ERR_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_lq_ticks), z, sizeof(z)) != hipSuccess) return XPG_ERR_HIP;
+    return 0;
+}
 // diagnostic builds only (not declared in the header): the phase tick sums of the blocked loop
 int xpg_lp_debug(xpg_lp * lp, unsigned long long * out8)
 {
