@@ -9,6 +9,7 @@
 // the feasibility check and the final objective.
 #pragma once
 #include "lp_kernels.hip.h"
+#include "rat_ops.hip.h"
 
 namespace xpg {
 
@@ -21,6 +22,7 @@ template <class S> struct Small {
     int * sh_w;                     // 8 words of broadcast scratch
     unsigned pivots;
     unsigned closes;                // iterations that ended in disableNV (no pivot), for profiling
+    bool cn;                        // Rational: every input cell canonical -> the 32-bit forms (rat_ops.hip.h)
 };
 
 template <class S> __device__ __forceinline__ bool sm_seen(const Small<S> & P, int nv, int b)
@@ -33,16 +35,16 @@ template <class S> __device__ __forceinline__ void sm_pivot(Small<S> & P, int nv
     const S piv = P.tab[r * ld + nv];
     const S cnv = P.obj[nv];
     __syncthreads();
-    const S s = div(one<S>(), piv);
+    const S s = q_div(P.cn, one<S>(), piv);
     const int smode = scale_mode(s), cmode = scale_mode(cnv);
     for (int j = threadIdx.x; j < W; j += blockDim.x) {
-        const S ej = scaled(P.tab[r * ld + j], s, smode);
+        const S ej = q_scaled(P.cn, P.tab[r * ld + j], s, smode);
         P.e[j] = ej;
         P.tab[r * ld + j] = ej;
-        S t = mul(ej, minus_one<S>());
+        S t = q_mul(P.cn, ej, minus_one<S>());
         if (j >= P.rhs) t = neg(t);
-        t = scaled(t, cnv, cmode);
-        P.obj[j] = add(t, P.obj[j]);
+        t = q_scaled(P.cn, t, cnv, cmode);
+        P.obj[j] = q_add(P.cn, t, P.obj[j]);
     }
     for (int i = threadIdx.x; i < P.R; i += blockDim.x)
         if (i != r) P.k[i] = neg(P.tab[i * ld + nv]);
@@ -56,7 +58,7 @@ template <class S> __device__ __forceinline__ void sm_pivot(Small<S> & P, int nv
             const S ej = P.e[j];
             S * p = P.tab + ty * ld + j;
             for (int i = ty; i < P.R; i += ny, p += ny * ld)
-                if (i != r) *p = add(*p, mul(P.k[i], ej));
+                if (i != r) *p = q_fma(P.cn, *p, P.k[i], ej);
         }
     }
     if (threadIdx.x == 0) {
@@ -78,7 +80,7 @@ template <class S> __device__ __forceinline__ int sm_ratio(const Small<S> & P, i
             if (pass == 0 ? le(a, zero<S>()) : eq(a, zero<S>())) continue;
             const int b = P.eq2bv[i];
             if (sm_seen(P, nv, b) || P.colcnt[b] >= lim) continue;
-            Cand<S> c; c.q = div(P.tab[i * P.ld + P.rhs], a); c.idx = i;
+            Cand<S> c; c.q = q_div(P.cn, P.tab[i * P.ld + P.rhs], a); c.idx = i;
             best = better(best, c);
         }
         best = block_argmin(best, P.sh_c);
@@ -128,7 +130,7 @@ template <class S> __device__ __forceinline__ void sm_select_wave0(Small<S> & P)
     const int cc = P.colcnt[b];
     const bool open = lane < R && !((w >> (b & 31)) & 1u) && cc < lim;
     const bool nonzero = open && !eq(a, zero<S>());
-    Cand<S> c; c.q = nonzero ? div(bc, a) : zero<S>();
+    Cand<S> c; c.q = nonzero ? q_div(P.cn, bc, a) : zero<S>();
     c.idx = (nonzero && !le(a, zero<S>())) ? lane : INT_MAX;
     Cand<S> best = wave_argmin(c);
     if (best.idx == INT_MAX) {                                       // relaxed second pass: a != 0
@@ -163,16 +165,16 @@ template <class S> __device__ __forceinline__ void sm_select_wave0(Small<S> & P)
 template <class S> __device__ __forceinline__ void sm_pivot_fast(Small<S> & P, int nv, int bv, int r, S piv, S cnv)
 {
     const int W = P.W, ld = P.ld;
-    const S s = div(one<S>(), piv);
+    const S s = q_div(P.cn, one<S>(), piv);
     const int smode = scale_mode(s), cmode = scale_mode(cnv);
     for (int j = threadIdx.x; j < W; j += blockDim.x) {
-        const S ej = scaled(P.tab[r * ld + j], s, smode);
+        const S ej = q_scaled(P.cn, P.tab[r * ld + j], s, smode);
         P.e[j] = ej;
         P.tab[r * ld + j] = ej;
-        S t = mul(ej, minus_one<S>());
+        S t = q_mul(P.cn, ej, minus_one<S>());
         if (j >= P.rhs) t = neg(t);
-        t = scaled(t, cnv, cmode);
-        P.obj[j] = add(t, P.obj[j]);
+        t = q_scaled(P.cn, t, cnv, cmode);
+        P.obj[j] = q_add(P.cn, t, P.obj[j]);
     }
     for (int i = threadIdx.x; i < P.R; i += blockDim.x)
         P.k[i] = i != r ? neg(P.tab[i * ld + nv]) : zero<S>();
@@ -191,10 +193,10 @@ template <class S> __device__ __forceinline__ void sm_pivot_fast(Small<S> & P, i
                 const S a0 = P.tab[min(i0, last) * ld + j], a1 = P.tab[min(i1, last) * ld + j];
                 const S a2 = P.tab[min(i2, last) * ld + j], a3 = P.tab[min(i3, last) * ld + j];
                 const S k0 = P.k[min(i0, last)], k1 = P.k[min(i1, last)], k2 = P.k[min(i2, last)], k3 = P.k[min(i3, last)];
-                if (i0 != r) P.tab[i0 * ld + j] = add(a0, mul(k0, ej));
-                if (i1 <= last && i1 != r) P.tab[i1 * ld + j] = add(a1, mul(k1, ej));
-                if (i2 <= last && i2 != r) P.tab[i2 * ld + j] = add(a2, mul(k2, ej));
-                if (i3 <= last && i3 != r) P.tab[i3 * ld + j] = add(a3, mul(k3, ej));
+                if (i0 != r) P.tab[i0 * ld + j] = q_fma(P.cn, a0, k0, ej);
+                if (i1 <= last && i1 != r) P.tab[i1 * ld + j] = q_fma(P.cn, a1, k1, ej);
+                if (i2 <= last && i2 != r) P.tab[i2 * ld + j] = q_fma(P.cn, a2, k2, ej);
+                if (i3 <= last && i3 != r) P.tab[i3 * ld + j] = q_fma(P.cn, a3, k3, ej);
             }
         }
     }
@@ -219,7 +221,7 @@ template <class S> __device__ __forceinline__ int sm_ratio_wave(const Small<S> &
     cc = P.colcnt[b];
     const bool open = lane < R && !((w >> (b & 31)) & 1u) && cc < lim;
     const bool nonzero = open && !eq(a, zero<S>());
-    Cand<S> c; c.q = nonzero ? div(bc, a) : zero<S>();
+    Cand<S> c; c.q = nonzero ? q_div(P.cn, bc, a) : zero<S>();
     c.idx = (nonzero && !le(a, zero<S>())) ? lane : INT_MAX;
     Cand<S> best = wave_argmin(c);
     if (best.idx == INT_MAX) {                                  // relaxed second pass: a != 0
@@ -283,7 +285,7 @@ template <class S> __device__ __forceinline__ void sm_findpair_wave0(Small<S> & 
 //             others: scaled pivot row -> e, -column -> k
 //   barrier
 //   stage C   wave 0: basis swap of pivot t; the two columns the next choice needs -- `first` and the constant
-//                     column -- updated for its rows with the sweep's own add(a, mul(k, e)); ratio test
+//                     column -- updated for its rows with the sweep's own q_fma(P.cn, a, k, e); ratio test
 //                     (lpsol.h:553-663) on those fresh values, pair-table upkeep -> pivot t+1;
 //             others: the sweep of every other column (row r := e)
 //   barrier
@@ -316,7 +318,7 @@ template <class S> __device__ __forceinline__ int sm_fast_loop(Small<S> & P, uns
         const int enter = P.sh_w[1], leave = P.sh_w[2], r = P.sh_w[3];
         const S * park = (const S *)P.sh_c;
         const S piv = park[0], cnv = park[1];
-        const S s = div(one<S>(), piv);
+        const S s = q_div(P.cn, one<S>(), piv);
         const int smode = scale_mode(s), cmode = scale_mode(cnv);
         const bool last = done + 1 >= max_iter;                 // while (cnt < m_max_iter), lpsol.h:1039: no pricing after the last pivot
         // ---- stage A
@@ -329,11 +331,11 @@ template <class S> __device__ __forceinline__ int sm_fast_loop(Small<S> & P, uns
             const S ob0 = P.obj[q0], ob1 = P.obj[q1];
             const int nvm0 = P.nv[q0 < rhs ? q0 : 0], nvm1 = P.nv[q1 < rhs ? q1 : 0];
             rc0 = P.rowcnt[q0 < rhs ? q0 : 0]; rc1 = P.rowcnt[q1 < rhs ? q1 : 0];
-            S x0 = mul(scaled(t0, s, smode), minus_one<S>()), x1 = mul(scaled(t1, s, smode), minus_one<S>());   // nvexp.mul(-1), lpsol.h:1496
+            S x0 = q_mul(P.cn, q_scaled(P.cn, t0, s, smode), minus_one<S>()), x1 = q_mul(P.cn, q_scaled(P.cn, t1, s, smode), minus_one<S>());   // nvexp.mul(-1), lpsol.h:1496
             if (j0 >= rhs) x0 = neg(x0);                        // :1497-1499
             if (j1 >= rhs) x1 = neg(x1);
-            o0 = add(scaled(x0, cnv, cmode), ob0);              // :1500-1501
-            o1 = add(scaled(x1, cnv, cmode), ob1);
+            o0 = q_add(P.cn, q_scaled(P.cn, x0, cnv, cmode), ob0);              // :1500-1501
+            o1 = q_add(P.cn, q_scaled(P.cn, x1, cnv, cmode), ob1);
             int first = INT_MAX; bool anyc = false;
             if (!last) {
                 // basis after this pivot's swap
@@ -352,7 +354,7 @@ template <class S> __device__ __forceinline__ int sm_fast_loop(Small<S> & P, uns
             if (in1) P.obj[j1] = o1;
             if (lane == 0) { P.sh_w[5] = first; P.sh_w[6] = anyc ? 1 : 0; }
         } else {
-            for (int j = st; j < W; j += nsw) P.e[j] = scaled(P.tab[r * ld + j], s, smode);
+            for (int j = st; j < W; j += nsw) P.e[j] = q_scaled(P.cn, P.tab[r * ld + j], s, smode);
             for (int i = st; i < R; i += nsw) P.k[i] = i != r ? neg(P.tab[i * ld + enter]) : zero<S>();
         }
         __syncthreads();
@@ -369,8 +371,8 @@ template <class S> __device__ __forceinline__ int sm_fast_loop(Small<S> & P, uns
             const S kb = P.k[li], ef = P.e[fc], eb = P.e[rhs];
             const S a_old = P.tab[li * ld + fc], b_old = P.tab[li * ld + rhs];
             const int b = P.eq2bv[li];
-            const S a = li == r ? ef : add(a_old, mul(kb, ef));
-            const S bc = li == r ? eb : add(b_old, mul(kb, eb));
+            const S a = li == r ? ef : q_fma(P.cn, a_old, kb, ef);
+            const S bc = li == r ? eb : q_fma(P.cn, b_old, kb, eb);
             if (lane < R) { if (have_first) P.tab[li * ld + fc] = a; P.tab[li * ld + rhs] = bc; }
             if (last) {
                 if (lane == 0) P.sh_w[0] = ACT_TIMEOUT;
@@ -382,7 +384,7 @@ template <class S> __device__ __forceinline__ int sm_fast_loop(Small<S> & P, uns
                 const int cc = P.colcnt[b];
                 const bool open = lane < R && !((w >> (b & 31)) & 1u) && cc < lim;
                 const bool nonzero = open && !eq(a, zero<S>());
-                Cand<S> c; c.q = nonzero ? div(bc, a) : zero<S>();
+                Cand<S> c; c.q = nonzero ? q_div(P.cn, bc, a) : zero<S>();
                 c.idx = (nonzero && !le(a, zero<S>())) ? lane : INT_MAX;
                 Cand<S> best = wave_argmin(c);
                 if (best.idx == INT_MAX) {                      // relaxed second pass: a != 0
@@ -424,10 +426,10 @@ template <class S> __device__ __forceinline__ int sm_fast_loop(Small<S> & P, uns
                     const S a0 = P.tab[min(i0, last_i) * ld + j], a1 = P.tab[min(i1, last_i) * ld + j];
                     const S a2 = P.tab[min(i2, last_i) * ld + j], a3 = P.tab[min(i3, last_i) * ld + j];
                     const S k0 = P.k[min(i0, last_i)], k1 = P.k[min(i1, last_i)], k2 = P.k[min(i2, last_i)], k3 = P.k[min(i3, last_i)];
-                    P.tab[i0 * ld + j] = i0 == r ? ej : add(a0, mul(k0, ej));
-                    if (i1 <= last_i) P.tab[i1 * ld + j] = i1 == r ? ej : add(a1, mul(k1, ej));
-                    if (i2 <= last_i) P.tab[i2 * ld + j] = i2 == r ? ej : add(a2, mul(k2, ej));
-                    if (i3 <= last_i) P.tab[i3 * ld + j] = i3 == r ? ej : add(a3, mul(k3, ej));
+                    P.tab[i0 * ld + j] = i0 == r ? ej : q_fma(P.cn, a0, k0, ej);
+                    if (i1 <= last_i) P.tab[i1 * ld + j] = i1 == r ? ej : q_fma(P.cn, a1, k1, ej);
+                    if (i2 <= last_i) P.tab[i2 * ld + j] = i2 == r ? ej : q_fma(P.cn, a2, k2, ej);
+                    if (i3 <= last_i) P.tab[i3 * ld + j] = i3 == r ? ej : q_fma(P.cn, a3, k3, ej);
                 }
             }
         }
@@ -498,13 +500,13 @@ template <class S> __device__ __forceinline__ int sm_solve(Small<S> & P, unsigne
                     S xv = zero<S>();
                     if (j < rhs && P.bv[j]) xv = P.tab[P.bv2eq[j] * P.ld + rhs];
                     P.x[j] = xv;
-                    if (j < rhs && gt(mul(minus_one<S>(), xv), zero<S>())) P.sh_w[1] = 1;
+                    if (j < rhs && gt(q_mul(P.cn, minus_one<S>(), xv), zero<S>())) P.sh_w[1] = 1;
                 }
                 __syncthreads();
                 for (int i = threadIdx.x; i < P.R; i += blockDim.x) {
                     S sum = zero<S>();
                     const S * row = P.tab + i * P.ld;
-                    for (int j = 0; j < rhs; j++) sum = add(sum, mul(row[j], P.x[j]));
+                    for (int j = 0; j < rhs; j++) sum = q_fma(P.cn, sum, row[j], P.x[j]);
                     reduce(sum);
                     S b = row[rhs];
                     reduce(b);
@@ -579,15 +581,15 @@ template <class S> __device__ __forceinline__ int sm_solve(Small<S> & P, unsigne
 // Source of the slack form: the primal (is_max) or the dual built the way
 // SIX::calcDualMaxm does (lpsol.h:1602-1629) straight from the caller's arrays.
 template <class S> struct Source {
-    const S * leq; const S * tgtf; int m, cols, is_max;
+    const S * leq; const S * tgtf; int m, cols, is_max; bool cn;
     __device__ int rows() const { return is_max ? m : cols - 1; }
     __device__ int vars() const { return is_max ? cols - 1 : m; }
     __device__ S A(int i, int j) const
-    { return is_max ? leq[i * cols + j] : mul(leq[j * cols + i], minus_one<S>()); }
+    { return is_max ? leq[i * cols + j] : q_mul(cn, leq[j * cols + i], minus_one<S>()); }
     __device__ S b(int i) const { return is_max ? leq[i * cols + cols - 1] : tgtf[i]; }
     __device__ S c(int j) const
-    { return is_max ? tgtf[j] : mul(leq[j * cols + cols - 1], minus_one<S>()); }
-    __device__ S c0() const { return is_max ? tgtf[cols - 1] : mul(zero<S>(), minus_one<S>()); }
+    { return is_max ? tgtf[j] : q_mul(cn, leq[j * cols + cols - 1], minus_one<S>()); }
+    __device__ S c0() const { return is_max ? tgtf[cols - 1] : q_mul(cn, zero<S>(), minus_one<S>()); }
 };
 
 template <class S> __device__ __forceinline__ void sm_build(Small<S> & P, const Source<S> & src, int with_xa)
@@ -670,19 +672,19 @@ template <class S> __device__ __forceinline__ int sm_phase_one(Small<S> & P, con
         if (go) {
             const S * expr = P.tab + P.bv2eq[i] * P.ld;
             const S ev = expr[i];
-            if (threadIdx.x == 0) P.obj[rhs] = mul(P.obj[rhs], minus_one<S>());
+            if (threadIdx.x == 0) P.obj[rhs] = q_mul(P.cn, P.obj[rhs], minus_one<S>());
             __syncthreads();
             if (!eq(ev, zero<S>())) {
                 S kk; int mode;
                 if (ne(f, ev)) {
-                    kk = div(neg(f), ev);
+                    kk = q_div(P.cn, neg(f), ev);
                     mode = eq(kk, zero<S>()) ? SCALE_ZERO : (eq(kk, one<S>()) ? SCALE_KEEP : SCALE_MUL);
                 } else { kk = minus_one<S>(); mode = SCALE_MUL; }
                 for (int j = threadIdx.x; j < W; j += blockDim.x)
-                    P.obj[j] = add(scaled(expr[j], kk, mode), P.obj[j]);
+                    P.obj[j] = q_add(P.cn, q_scaled(P.cn, expr[j], kk, mode), P.obj[j]);
             }
             __syncthreads();
-            if (threadIdx.x == 0) P.obj[rhs] = mul(P.obj[rhs], minus_one<S>());
+            if (threadIdx.x == 0) P.obj[rhs] = q_mul(P.cn, P.obj[rhs], minus_one<S>());
             __syncthreads();
         }
     }
@@ -764,8 +766,16 @@ template <class S> __global__ __launch_bounds__(256, 4) void k_batch(int nb, con
         P.pivots = 0; P.closes = 0;
         __syncthreads();
         // stage1 trigger (lpsol.h:1794-1803)
-        if (threadIdx.x == 0) { P.sh_w[3] = 0; P.sh_w[4] = 0; }
+        if (threadIdx.x == 0) { P.sh_w[3] = 0; P.sh_w[4] = 0; P.sh_w[5] = 0; }
         __syncthreads();
+        if (!is_f64<S>::value) {                       // one non-canonical input cell sends the LP down the generic forms
+            bool bad = false;
+            for (int t = threadIdx.x; t < m * cols; t += blockDim.x) bad |= !q_canonical(src.leq[t]);
+            for (int t = threadIdx.x; t < cols; t += blockDim.x) bad |= !q_canonical(src.tgtf[t]);
+            if (bad) P.sh_w[5] = 1;
+            __syncthreads();
+        }
+        P.cn = src.cn = !is_f64<S>::value && P.sh_w[5] == 0;
         for (int j = threadIdx.x; j < V; j += blockDim.x) if (gt(src.c(j), zero<S>())) P.sh_w[3] = 1;
         for (int i = threadIdx.x; i < R; i += blockDim.x) if (lt(src.b(i), zero<S>())) P.sh_w[4] = 1;
         __syncthreads();
@@ -794,8 +804,8 @@ template <class S> __global__ __launch_bounds__(256, 4) void k_batch(int nb, con
             if (threadIdx.x == 0) {
                 sol[n] = one<S>();
                 S v = zero<S>();
-                for (int j = 0; j < n; j++) v = add(v, mul(P.e[j], src.tgtf[j]));
-                v = add(v, mul(one<S>(), src.tgtf[n]));
+                for (int j = 0; j < n; j++) v = q_fma(P.cn, v, P.e[j], src.tgtf[j]);
+                v = q_add(P.cn, v, q_mul(P.cn, one<S>(), src.tgtf[n]));
                 reduce(v);
                 out_v[lp] = v;
             }

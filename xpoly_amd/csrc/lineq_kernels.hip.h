@@ -15,6 +15,7 @@
 // The arithmetic is integer (gcd loops), so the bound is ALU/divergence, not HBM.
 #pragma once
 #include "scalar.hip.h"
+#include "rat_ops.hip.h"
 #include <limits.h>
 
 namespace xpg {
@@ -68,25 +69,6 @@ __shared__ unsigned long long lq_acc[16];
 #define LQ_FLUSH
 #define LQ_CLEAR
 #endif
-
-// Rational arithmetic of a system. Every value the reference's Rational can hold is canonical (lowest terms,
-// den > 0), and a system whose cells all are -- checked when it is loaded, WMat::cn -- stays so under these
-// operations; it then takes the 32-bit cross-cancelling forms of scalar.hip.h, which equal the reference's
-// operations bit for bit on such operands (tests/cxx/fma_canon_fuzz.cpp). Any other system keeps the literal
-// 64-bit restatement, out of line.
-__device__ __noinline__ R32 add_any(R32 a, R32 b) { return add(a, b); }
-__device__ __noinline__ R32 mul_any(R32 a, R32 b) { return mul(a, b); }
-__device__ __noinline__ R32 div_any(R32 a, R32 b) { return div(a, b); }
-__device__ __forceinline__ R32 q_add(bool cn, R32 a, R32 b) { return cn ? add_canon(a, b) : add_any(a, b); }
-__device__ __forceinline__ R32 q_sub(bool cn, R32 a, R32 b) { return q_add(cn, a, neg(b)); }
-__device__ __forceinline__ R32 q_mul(bool cn, R32 a, R32 b) { return cn ? mul_canon(a, b) : mul_any(a, b); }
-__device__ __forceinline__ R32 q_div(bool cn, R32 a, R32 b) { return cn && b.num != 0 ? div_canon(a, b) : div_any(a, b); }
-// add(mul(k, e), a), the reference's mul_and_add_row cell (matt.h:1493-1501)
-__device__ __forceinline__ R32 q_fma(bool cn, R32 a, R32 k, R32 e) { return cn ? fma_canon(a, k, e) : add_any(mul_any(k, e), a); }
-__device__ __forceinline__ R32 q_scaled(bool cn, R32 cell, R32 x, int mode)
-{
-    return mode == SCALE_KEEP ? cell : (mode == SCALE_ZERO ? R32(0, 1) : q_mul(cn, cell, x));
-}
 
 // mulOfRow (matt.h:1353-1368): every lane evaluates the same shortcut tests.
 __device__ inline void w_scale_row(WMat & m, int row, R32 x)

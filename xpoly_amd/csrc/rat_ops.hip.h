@@ -1,0 +1,35 @@
+// Arithmetic of the small-problem kernels (LDS-resident LPs, row elimination), selected per PROBLEM.
+// Every value the reference's Rational can hold is canonical (lowest terms, den > 0), and a problem whose input
+// cells all are -- checked when it is loaded -- stays so under these operations; it takes the 32-bit
+// cross-cancelling forms of scalar.hip.h, which equal the reference's operations bit for bit on such operands
+// (tests/cxx/fma_canon_fuzz.cpp). Any other problem keeps the literal 64-bit restatement, out of line. For Float
+// the flag is ignored.
+#pragma once
+#include "scalar.hip.h"
+
+namespace xpg {
+
+__device__ __noinline__ R32 add_any(R32 a, R32 b) { return add(a, b); }
+__device__ __noinline__ R32 mul_any(R32 a, R32 b) { return mul(a, b); }
+__device__ __noinline__ R32 div_any(R32 a, R32 b) { return div(a, b); }
+__device__ __forceinline__ R32 q_add(bool cn, R32 a, R32 b) { return cn ? add_canon(a, b) : add_any(a, b); }
+__device__ __forceinline__ R32 q_sub(bool cn, R32 a, R32 b) { return q_add(cn, a, neg(b)); }
+__device__ __forceinline__ R32 q_mul(bool cn, R32 a, R32 b) { return cn ? mul_canon(a, b) : mul_any(a, b); }
+__device__ __forceinline__ R32 q_div(bool cn, R32 a, R32 b) { return cn && b.num != 0 ? div_canon(a, b) : div_any(a, b); }
+// add(a, mul(k, e)): the cell of a pivot sweep (lpsol.h:1481-1490) and of mul_and_add_row (matt.h:1493-1501)
+__device__ __forceinline__ R32 q_fma(bool cn, R32 a, R32 k, R32 e) { return cn ? fma_canon(a, k, e) : add_any(a, mul_any(k, e)); }
+__device__ __forceinline__ R32 q_scaled(bool cn, R32 cell, R32 x, int mode)
+{
+    return mode == SCALE_KEEP ? cell : (mode == SCALE_ZERO ? R32(0, 1) : q_mul(cn, cell, x));
+}
+__device__ __forceinline__ bool q_canonical(R32 a) { return canonical(a); }
+
+__device__ __forceinline__ F64 q_add(bool, F64 a, F64 b) { return add(a, b); }
+__device__ __forceinline__ F64 q_sub(bool, F64 a, F64 b) { return sub(a, b); }
+__device__ __forceinline__ F64 q_mul(bool, F64 a, F64 b) { return mul(a, b); }
+__device__ __forceinline__ F64 q_div(bool, F64 a, F64 b) { return div(a, b); }
+__device__ __forceinline__ F64 q_fma(bool, F64 a, F64 k, F64 e) { return add(a, mul(k, e)); }
+__device__ __forceinline__ F64 q_scaled(bool, F64 cell, F64 x, int mode) { return scaled(cell, x, mode); }
+__device__ __forceinline__ bool q_canonical(F64) { return true; }
+
+} // namespace xpg
