@@ -51,7 +51,8 @@ BATCH_M, BATCH_COLS = 32, 64
 PREWARM_SECONDS = 0.5
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "round2_pmc_hbm_traffic.json")
 PMC_BATCH = os.path.join(ROOT, "profiles", "round2_pmc_batch_issue.json")
-LEGS = ("pivots", "batched", "cfg2b", "rational", "mip")
+LEGS = ("pivots", "batched", "cfg2b", "rational", "mip", "lineq")
+LINEQ_NB = 16384                           # systems per row-elimination launch (the dependence tests' shapes)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -466,6 +467,8 @@ def main():
             out["rational"] = leg_rational(ctx, xpoly_amd, gen)
         if "mip" in legs:
             out["mip"] = leg_mip(ctx, xpoly_amd, gen)
+        if "lineq" in legs:
+            out["lineq"] = leg_lineq(ctx, xpoly_amd, gen)
 
     if rank == 0:
         out["cpu_baseline"] = cpu
@@ -572,6 +575,38 @@ def leg_mip(ctx, xpoly_amd, gen):
                 nodes_per_problem=round(nodes / MIP_NB, 2), wall_ms=round(dt * 1e3, 2),
                 status_hist=np.bincount(np.clip(st, 0, 4), minlength=5).tolist(), dtype="int32 num/den",
                 sample="xpg_mip_batch_rat32, host arrays in and out (PCIe included)")
+
+
+def leg_lineq(ctx, xpoly_amd, gen):
+    """The small exact problems either side of the LP: batches of rational systems through
+    Lineq::reduce / fme / Matrix::rank (src/com/linsys.cpp:359-626, :656-774, matt.h:2614-2726) at the dependence
+    tests' shapes, and batches of small rational LPs through SIX. Host arrays in and out (PCIe included); the
+    kernels alone are in profiles/round2_kernel_stats_lineq_probe.csv. Integer-issue bound (gcd loops)."""
+    from xpoly_amd.lineq import Lineq
+    lq = Lineq(ctx)
+    rng = np.random.default_rng(0)
+    rows_out = []
+    for rows, nv in ((16, 8), (40, 12), (60, 19)):
+        base = np.stack([gen.random_system(rng, rows, nv) for _ in range(256)])
+        mats = np.ascontiguousarray(np.tile(base, (LINEQ_NB // 256, 1, 1, 1)))
+        rec = dict(rows=rows, cols=nv + 1)
+        for name, fn in (("reduce", lambda: lq.reduce(mats, nv, True)), ("fme", lambda: lq.fme(mats, nv, 0)),
+                         ("rank", lambda: lq.rank(mats))):
+            fn()
+            t0 = time.perf_counter(); fn(); dt = time.perf_counter() - t0
+            rec[name + "_systems_per_s"] = round(LINEQ_NB / dt, 0)
+        rows_out.append(rec)
+    # small rational LPs, dependence-test-like integer data (12 rows, 16 variables)
+    nb, m, cols = 8192, 12, 17
+    leq, tg = gen.small_lp_batch_f64(nb, m, cols, 1)
+    rl, rt = gen.to_rat(leq.astype(np.int32)), gen.to_rat(tg.astype(np.int32))
+    ctx.six_batch(xpoly_amd.RAT, True, rt[:64], rl[:64])
+    t0 = time.perf_counter(); st, _, _ = ctx.six_batch(xpoly_amd.RAT, True, rt, rl); dt = time.perf_counter() - t0
+    return dict(metric="rational row elimination and small rational LPs, batched", systems=LINEQ_NB, shapes=rows_out,
+                rational_lps=dict(lps=nb, rows=m, cols=cols, lps_per_s=round(nb / dt, 0),
+                                  status_hist=np.bincount(np.clip(st, 0, 4), minlength=5).tolist()),
+                dtype="int32 num/den", bound="integer issue (gcd loops), not HBM",
+                sample="host arrays in and out (PCIe included), second call timed")
 
 
 if __name__ == "__main__":

@@ -24,6 +24,7 @@
 // canBeNVCandidate / canBeBVCandidate (lpsol.h:124-153) are O(1).
 #pragma once
 #include "scalar.hip.h"
+#include "rat_ops.hip.h"
 #include <limits.h>
 
 namespace xpg {
@@ -222,6 +223,7 @@ template <class S> __device__ int ratio_test(const LpView<S> & v, int nv, Cand<S
 {
     const int lim = v.rhs - 1, T = blockDim.x;
     constexpr int U = 4;
+    const bool cn = !is_f64<S>::value && v.st->noncanon == 0;      // Rational: the canonical quotient (rat_ops.hip.h)
     for (int pass = pass0 == -1 ? 1 : 0; pass < 2; pass++) {
         Cand<S> best; best.q = zero<S>(); best.idx = INT_MAX;
         // every load of a row is issued before the first test (two dependent rounds per U rows
@@ -243,7 +245,7 @@ template <class S> __device__ int ratio_test(const LpView<S> & v, int nv, Cand<S
                 if (i >= v.m) continue;
                 if (pass == 0 ? le(a[u], zero<S>()) : eq(a[u], zero<S>())) continue;
                 if (((w[u] >> (b[u] & 31)) & 1u) || cc[u] >= lim) continue;
-                Cand<S> c; c.q = div(bb[u], a[u]); c.idx = i;
+                Cand<S> c; c.q = q_div(cn, bb[u], a[u]); c.idx = i;
                 best = better(best, c);
             }
         }
