@@ -888,4 +888,60 @@ int batch_host(xpg_ctx * ctx, int is_max, int nb, const S * tgtf, const S * leq,
     return rc;
 }
 
+// The same call for a caller that builds its batch itself (the MIP controller, one batch per lock-step round):
+// batch_stage_prepare hands out pinned host arrays laid out like the device staging, the caller fills leq / tgtf,
+// batch_stage_run copies them down in ONE transfer, launches, and brings status / value / solution back in one.
+// (Pageable std::vector staging cost the controller six transfers of ~0.1 ms each per round.) Solutions of LPs
+// whose status is not 0 are whatever the slot held before.
+template <class S> struct BatchStage {
+    int nb, m, cols;
+    S * h_leq; S * h_tgtf; S * h_sol; S * h_v; int32_t * h_st;      // pinned host
+    S * d_leq; S * d_tgtf; S * d_sol; S * d_v; int32_t * d_st;      // device
+    size_t in_bytes, out_bytes;
+};
+template <class S>
+int batch_stage_prepare(xpg_ctx * ctx, int nb, int m, int cols, BatchStage<S> & bs)
+{
+    if (!ctx || nb <= 0 || m <= 0 || cols < 2) return XPG_ERR_SHAPE;
+    const size_t bl = (size_t)nb * m * cols * 8, bt = (size_t)nb * cols * 8;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t need = up(bl) + 2 * up(bt) + up((size_t)nb * 8) + up((size_t)nb * 4);
+    if (need > ctx->stage_cap) {
+        if (ctx->stage) (void)hipFree(ctx->stage);
+        ctx->stage = 0; ctx->stage_cap = 0;
+        const size_t cap = need + need / 2;
+        if (hipMalloc(&ctx->stage, cap) != hipSuccess) { ctx->err = "hipMalloc(batch staging)"; return XPG_ERR_ALLOC; }
+        ctx->stage_cap = cap;
+    }
+    if (need > ctx->hstage_cap) {
+        if (ctx->hstage) (void)hipHostFree(ctx->hstage);
+        ctx->hstage = 0; ctx->hstage_cap = 0;
+        const size_t cap = need + need / 2;
+        if (hipHostMalloc(&ctx->hstage, cap, hipHostMallocDefault) != hipSuccess) { ctx->err = "hipHostMalloc(batch staging)"; return XPG_ERR_ALLOC; }
+        ctx->hstage_cap = cap;
+    }
+    bs.nb = nb; bs.m = m; bs.cols = cols;
+    char * d = (char *)ctx->stage; char * h = (char *)ctx->hstage;
+    size_t o = 0;
+    bs.d_leq = (S *)(d + o); bs.h_leq = (S *)(h + o); o += up(bl);
+    bs.d_tgtf = (S *)(d + o); bs.h_tgtf = (S *)(h + o); o += up(bt);
+    bs.in_bytes = o;
+    bs.d_sol = (S *)(d + o); bs.h_sol = (S *)(h + o); o += up(bt);
+    bs.d_v = (S *)(d + o); bs.h_v = (S *)(h + o); o += up((size_t)nb * 8);
+    bs.d_st = (int32_t *)(d + o); bs.h_st = (int32_t *)(h + o); o += up((size_t)nb * 4);
+    bs.out_bytes = o - bs.in_bytes;
+    return 0;
+}
+template <class S>
+int batch_stage_run(xpg_ctx * ctx, BatchStage<S> & bs, int is_max, unsigned max_iter, int raw_sol)
+{
+    hipError_t e = hipMemcpyAsync(bs.d_leq, bs.h_leq, bs.in_bytes, hipMemcpyHostToDevice, ctx->stream);
+    int rc = 0;
+    if (e == hipSuccess) rc = batch_dev<S>(ctx, is_max, bs.nb, bs.d_tgtf, bs.d_leq, bs.m, bs.cols, max_iter, bs.d_st, bs.d_v, bs.d_sol, 0, raw_sol);
+    if (e == hipSuccess && rc == 0) e = hipMemcpyAsync(bs.h_sol, bs.d_sol, bs.out_bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return XPG_ERR_HIP; }
+    return rc;
+}
+
 } // namespace xpg

@@ -180,68 +180,74 @@ template <class S> struct MipTask {
 
 // The host half of a lock-step round -- normalising every tree's pending node (equality substitution, dual
 // construction: O(rows x cols^2) exact operations each) and feeding the answers back into the stack machines --
-// is independent per tree. Measured at 1024 knapsacks of 24 variables on one host thread: prepare 7.9 ms + feed-back
-// 9.3 ms against 7.9 ms for the 15 node-batch launches -- the controller, not the node kernel, set the rate. A
-// small pool of persistent host threads (XPG_HOST_THREADS, default min(16, cores)) takes both loops.
-class MipPool {                                         // a few persistent host threads, shared by every context
+// is independent per tree, and at a few nodes per tree it costs more than the node-batch launches (1024 knapsacks
+// of 24 variables on one host thread: prepare 7.9 ms + feed-back 8.6 ms against 8 ms for 15 launches). A small pool
+// of persistent host threads (XPG_HOST_THREADS, default min(4, cores)) takes both loops with STATIC shares --
+// worker w always gets the same slice of the index range, so a tree's heap blocks are allocated and freed by one
+// thread and stay in one core's cache (handing out chunks dynamically made the loops SLOWER than one thread on a
+// 256-core host: 12 + 18 ms) -- and the workers spin for a moment before they sleep: a round has three loops a
+// fraction of a millisecond apart. Measured with 1 / 4 / 8 / 16 / 32 threads: 37 / 48 / 38 / 43 / 36 k MIPs/s; the
+// node normalisation scales to 4 threads (7.5 -> 3.5 ms), the feed-back (deep copies of a problem per DFS frame,
+// i.e. the allocator) does not scale at all.
+class MipPool {
     std::vector<std::thread> th_;
-    std::mutex m_;
-    std::condition_variable cv_, done_;
-    std::function<void(size_t)> job_;
-    size_t n_ = 0;
-    std::atomic<size_t> next_{0};
-    unsigned gen_ = 0, running_ = 0;
+    std::mutex m_, run_m_;
+    std::condition_variable cv_;
+    std::function<void(int)> job_;                      // job_(w): the share of worker w, 0 <= w < size()
+    std::atomic<unsigned> gen_{0};
+    std::atomic<int> pending_{0};
     bool stop_ = false;
-    void worker()
+    static void relax() { __builtin_ia32_pause(); }
+    void worker(int w)
     {
         unsigned seen = 0;
         for (;;) {
-            {
+            for (int spin = 0; spin < 20000 && gen_.load(std::memory_order_acquire) == seen; spin++) relax();
+            if (gen_.load(std::memory_order_acquire) == seen) {
                 std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
-                if (stop_) return;
-                seen = gen_;
+                cv_.wait(lk, [&] { return stop_ || gen_.load(std::memory_order_acquire) != seen; });
             }
-            for (;;) {
-                const size_t i0 = next_.fetch_add(16);
-                if (i0 >= n_) break;
-                const size_t i1 = i0 + 16 < n_ ? i0 + 16 : n_;
-                for (size_t i = i0; i < i1; i++) job_(i);
-            }
-            std::unique_lock<std::mutex> lk(m_);
-            if (--running_ == 0) done_.notify_all();
+            if (stop_) return;
+            seen = gen_.load(std::memory_order_acquire);
+            job_(w);
+            pending_.fetch_sub(1, std::memory_order_acq_rel);
         }
     }
 public:
     MipPool()
     {
         unsigned nt = std::thread::hardware_concurrency();
-        nt = nt > 16 ? 16 : (nt < 1 ? 1 : nt);
+        nt = nt > 4 ? 4 : (nt < 1 ? 1 : nt);
         if (const char * e = getenv("XPG_HOST_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) nt = (unsigned)v; }
-        for (unsigned w = 0; w + 1 < nt; w++) th_.emplace_back([this] { worker(); });
+        for (unsigned w = 1; w < nt; w++) th_.emplace_back([this, w] { worker((int)w); });
     }
     ~MipPool()
     {
-        { std::unique_lock<std::mutex> lk(m_); stop_ = true; }
+        { std::unique_lock<std::mutex> lk(m_); stop_ = true; gen_.fetch_add(1, std::memory_order_release); }
         cv_.notify_all();
         for (auto & t : th_) t.join();
     }
-    void run(size_t n, std::function<void(size_t)> f)
+    int size() const { return (int)th_.size() + 1; }
+    // f(i) for every i of [0, n): worker w takes the w-th of size() contiguous slices; the caller is worker 0
+    void run(size_t n, const std::function<void(size_t)> & f)
     {
-        if (n < 128 || th_.empty()) { for (size_t i = 0; i < n; i++) f(i); return; }
+        // one caller at a time: a second controller (the _multi entry points run one per device) keeps its loop to itself
+        std::unique_lock<std::mutex> mine(run_m_, std::try_to_lock);
+        if (n < 128 || th_.empty() || !mine.owns_lock()) { for (size_t i = 0; i < n; i++) f(i); return; }
+        const int nt = size();
+        std::function<void(int)> share = [&, n, nt](int w) {
+            const size_t lo = n * (size_t)w / (size_t)nt, hi = n * (size_t)(w + 1) / (size_t)nt;
+            for (size_t i = lo; i < hi; i++) f(i);
+        };
         {
             std::unique_lock<std::mutex> lk(m_);
-            job_ = f; n_ = n; next_ = 0; running_ = (unsigned)th_.size(); gen_++;
+            job_ = share;
+            pending_.store(nt - 1, std::memory_order_release);
+            gen_.fetch_add(1, std::memory_order_release);
         }
         cv_.notify_all();
-        for (;;) {                                          // the calling thread works too
-            const size_t i0 = next_.fetch_add(16);
-            if (i0 >= n) break;
-            const size_t i1 = i0 + 16 < n ? i0 + 16 : n;
-            for (size_t i = i0; i < i1; i++) f(i);
-        }
-        std::unique_lock<std::mutex> lk(m_);
-        done_.wait(lk, [&] { return running_ == 0; });
+        share(0);
+        while (pending_.load(std::memory_order_acquire) != 0) relax();
     }
 };
 inline MipPool & mip_pool() { static MipPool p; return p; }
@@ -287,23 +293,28 @@ template <class S> int run_mip_tasks(xpg_ctx * ctx, int kind, std::vector<MipTas
             const Key & k = g->first;
             const std::vector<int> & ids = g->second;
             const int nb = (int)ids.size();
-            std::vector<S> tg((size_t)nb * k.cols), lq((size_t)nb * k.rows * k.cols), vv(nb), raw((size_t)nb * k.cols);
-            std::vector<int32_t> st(nb);
+            // the round's node LPs are packed straight into the context's pinned staging and the answers are read
+            // from it: one copy each way per launch (batch_staged, batch_kernels.hip.h)
+            BatchStage<S> bs;
+            int rc = batch_stage_prepare<S>(ctx, nb, k.rows, k.cols, bs);
+            if (rc) return rc;
             mip_parallel_for((size_t)nb, [&](size_t b) {
                 const NormalForm<S> & F = tasks[ids[b]].F;
-                for (int j = 0; j < k.cols; j++) tg[b * k.cols + j] = F.obj[j];
-                for (size_t e = 0; e < F.N.a.size(); e++) lq[b * k.rows * k.cols + e] = F.N.a[e];
+                S * tg = bs.h_tgtf + b * k.cols;
+                S * lq = bs.h_leq + b * (size_t)k.rows * k.cols;
+                for (int j = 0; j < k.cols; j++) tg[j] = F.obj[j];
+                for (size_t e = 0; e < F.N.a.size(); e++) lq[e] = F.N.a[e];
             });
             const double t1 = now();
-            int rc = batch_host<S>(ctx, k.is_max, nb, tg.data(), lq.data(), k.rows, k.cols, 10000u, st.data(), vv.data(),
-                                   raw.data(), /*raw_sol=*/1);
+            rc = batch_stage_run<S>(ctx, bs, k.is_max, 10000u, /*raw_sol=*/1);
             if (rc) return rc;
             launches++;
             const double t2 = now();
             t_gpu += t2 - t1;
             mip_parallel_for((size_t)nb, [&](size_t b) {
-                std::vector<S> y(raw.begin() + b * k.cols, raw.begin() + b * k.cols + (k.cols - 1));
-                tasks[ids[b]].on_lp(st[b], y);
+                const S * raw = bs.h_sol + b * k.cols;
+                std::vector<S> y(raw, raw + (k.cols - 1));
+                tasks[ids[b]].on_lp(bs.h_st[b], y);
             });
             t_feed += now() - t2;
         }

@@ -50,6 +50,7 @@ int xpg_create(xpg_ctx ** out, int device)
     c->device = device;
     c->rowbuf = c->colbuf = 0; c->st = 0; c->row_cap = c->col_cap = 0;
     c->stage = 0; c->stage_cap = 0;
+    c->hstage = 0; c->hstage_cap = 0;
     const char * var = getenv("XPG_UPDATE_VARIANT");
     c->update_variant = var ? atoi(var) : 0;
     const char * lm = getenv("XPG_LOOP");              // "serial": the three-launch loop, for A/B runs
@@ -85,6 +86,7 @@ void xpg_destroy(xpg_ctx * ctx)
     if (ctx->colbuf) (void)hipFree(ctx->colbuf);
     if (ctx->st) (void)hipFree(ctx->st);
     if (ctx->stage) (void)hipFree(ctx->stage);
+    if (ctx->hstage) (void)hipHostFree(ctx->hstage);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
