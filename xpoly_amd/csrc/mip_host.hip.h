@@ -115,13 +115,19 @@ template <class S> struct MipTask {
         rows[(size_t)nrows * cols + rhs] = b;
         nrows++;
     }
-    void push_branch(const Frame & p, bool ceiling)
+    // The child of frame `pi`: its problem plus one bound row. Built in place at the top of the stack -- ONE copy of
+    // the parent's problem (by index: the emplace may move the frames).
+    void push_branch(size_t pi, bool ceiling)
     {
-        MipProblem<S> B = p.Q;
+        stack.emplace_back();
+        const Frame & p = stack[pi];
+        Frame & c = stack.back();
+        c.stage = 0; c.col = 0; c.lo = 0; c.hi = 1; c.kept = false; c.kept_v = zero<S>();
+        c.Q = p.Q;
+        MipProblem<S> & B = c.Q;
         if (is_bin) add_row(B.eq, B.eq_rows, B.cols, p.col, one<S>(), rhs0, S::from_int(ceiling ? p.hi : p.lo));   // lpsol.h:2506-2512, :2548-2553
         else if (!ceiling) add_row(B.leq, B.leq_rows, B.cols, p.col, one<S>(), rhs0, S::from_int(p.lo));          // :2514-2520
         else add_row(B.leq, B.leq_rows, B.cols, p.col, minus_one<S>(), rhs0, S::from_int(-p.hi));                  // :2555-2559
-        push(B);
     }
 
     // Feeds the answer of the pending LP (st: SIX status or a negative error; y: raw values of
@@ -152,8 +158,7 @@ template <class S> struct MipTask {
                     f.col = col; f.lo = 0; f.hi = 1;
                     if (!is_bin) { f.lo = to_int(sol[col]); f.hi = f.lo + 1; }
                     f.stage = 1;
-                    const Frame snapshot = f;          // push() may reallocate the stack
-                    push_branch(snapshot, false);
+                    push_branch(stack.size() - 1, false);
                     return;
                 }
             }
@@ -166,8 +171,7 @@ template <class S> struct MipTask {
             if (p.stage == 1) {                         // floor branch came back, lpsol.h:2527-2543
                 if (ret == XPG_IP_SUCC) { p.kept_sol = sol; p.kept_v = v; p.kept = true; remember(); }
                 p.stage = 2;
-                const Frame snapshot = p;
-                push_branch(snapshot, true);
+                push_branch(stack.size() - 1, true);
                 return;
             }
             if (ret == XPG_IP_SUCC) {                   // ceiling branch came back, lpsol.h:2563-2611
@@ -182,13 +186,13 @@ template <class S> struct MipTask {
 // construction: O(rows x cols^2) exact operations each) and feeding the answers back into the stack machines --
 // is independent per tree, and at a few nodes per tree it costs more than the node-batch launches (1024 knapsacks
 // of 24 variables on one host thread: prepare 7.9 ms + feed-back 8.6 ms against 8 ms for 15 launches). A small pool
-// of persistent host threads (XPG_HOST_THREADS, default min(4, cores)) takes both loops with STATIC shares --
+// of persistent host threads (XPG_HOST_THREADS; default 1, i.e. off) can take both loops with STATIC shares --
 // worker w always gets the same slice of the index range, so a tree's heap blocks are allocated and freed by one
 // thread and stay in one core's cache (handing out chunks dynamically made the loops SLOWER than one thread on a
 // 256-core host: 12 + 18 ms) -- and the workers spin for a moment before they sleep: a round has three loops a
-// fraction of a millisecond apart. Measured with 1 / 4 / 8 / 16 / 32 threads: 37 / 48 / 38 / 43 / 36 k MIPs/s; the
-// node normalisation scales to 4 threads (7.5 -> 3.5 ms), the feed-back (deep copies of a problem per DFS frame,
-// i.e. the allocator) does not scale at all.
+// fraction of a millisecond apart. Measured with 1 / 4 / 8 / 16 / 32 threads on one box: 37 / 48 / 38 / 43 / 36 k
+// MIPs/s, on another 39 k with 1 and 30 k with 4: loops of half a millisecond do not pay for waking threads on a
+// 256-core host reliably, so the default is the calling thread alone.
 class MipPool {
     std::vector<std::thread> th_;
     std::mutex m_, run_m_;
@@ -217,7 +221,7 @@ public:
     MipPool()
     {
         unsigned nt = std::thread::hardware_concurrency();
-        nt = nt > 4 ? 4 : (nt < 1 ? 1 : nt);
+        nt = 1;
         if (const char * e = getenv("XPG_HOST_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) nt = (unsigned)v; }
         for (unsigned w = 1; w < nt; w++) th_.emplace_back([this, w] { worker((int)w); });
     }
