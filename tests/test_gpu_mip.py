@@ -12,6 +12,7 @@ from tools import gen
 pytestmark = pytest.mark.gpu
 F64, RAT = 0, 1
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def dec(d):
@@ -159,3 +160,22 @@ def test_six_through_the_hbm_resident_path(ctx, port, kind, monkeypatch):
             assert np.array_equal(np.asarray(got[1]), np.asarray(want[1]))
             if want[0] == 0:
                 assert np.array_equal(got[2], want[2])
+
+
+def test_mip_batch_with_the_host_thread_pool_matches_the_default(ctx):
+    """XPG_HOST_THREADS > 1 hands the controller's per-tree loops to persistent host threads with static shares
+    (read once per process, so the threaded run is a child process); the trees are independent, so every status,
+    value, solution and the node count must be those of the calling thread alone."""
+    import subprocess, sys, hashlib
+    from xpoly_amd.six import mip_batch
+    leq, tgtf = gen.knapsack_batch_rat(300, 12)
+    st, v, sol, nodes = mip_batch(ctx, True, True, tgtf, leq)
+    want = hashlib.sha256(st.tobytes() + v.tobytes() + sol.tobytes()).hexdigest() + " %d" % nodes
+    code = ("import hashlib, xpoly_amd; from tools import gen; from xpoly_amd.six import mip_batch\n"
+            "ctx = xpoly_amd.Context(0); leq, tgtf = gen.knapsack_batch_rat(300, 12)\n"
+            "st, v, sol, nodes = mip_batch(ctx, True, True, tgtf, leq)\n"
+            "print(hashlib.sha256(st.tobytes() + v.tobytes() + sol.tobytes()).hexdigest(), nodes)\n")
+    env = dict(os.environ, XPG_HOST_THREADS="3", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.strip().splitlines()[-1] == want
