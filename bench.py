@@ -602,7 +602,17 @@ def leg_lineq(ctx, xpoly_amd, gen):
     rl, rt = gen.to_rat(leq.astype(np.int32)), gen.to_rat(tg.astype(np.int32))
     ctx.six_batch(xpoly_amd.RAT, True, rt[:64], rl[:64])
     t0 = time.perf_counter(); st, _, _ = ctx.six_batch(xpoly_amd.RAT, True, rt, rl); dt = time.perf_counter() - t0
+    # DepPoly::is_empty (src/eng/poly.cpp:530-573): reduce, then has_solution(integer, unique) = MIP maxm / minm
+    from xpoly_amd.six import dep_is_empty_batch
+    dnb, drows, dnv = 4096, 12, 4
+    dm = np.stack([gen.random_system(rng, drows, dnv) for _ in range(256)])
+    dm[..., 1] = 1                                     # dependence polyhedra are integer systems
+    dm = np.ascontiguousarray(np.tile(dm, (dnb // 256, 1, 1, 1)))
+    dep_is_empty_batch(ctx, dm[:256])
+    t0 = time.perf_counter(); empty, dnodes = dep_is_empty_batch(ctx, dm); ddt = time.perf_counter() - t0
     return dict(metric="rational row elimination and small rational LPs, batched", systems=LINEQ_NB, shapes=rows_out,
+                dep_is_empty=dict(polyhedra=dnb, rows=drows, vars=dnv, polyhedra_per_s=round(dnb / ddt, 0),
+                                  nodes=int(dnodes), empty=int(np.sum(empty == 1))),
                 rational_lps=dict(lps=nb, rows=m, cols=cols, lps_per_s=round(nb / dt, 0),
                                   status_hist=np.bincount(np.clip(st, 0, 4), minlength=5).tolist()),
                 dtype="int32 num/den", bound="integer issue (gcd loops), not HBM",
