@@ -120,6 +120,8 @@ def _pool_worker(args):
     while time.perf_counter() < t_end:
         if kind == "lp":
             port.six_solve(0, True, st["tg"][i], st["vc"], None, st["leq"][i])
+        elif kind == "fme":
+            port.fme(st["leq"][i], st["tg"], 0, False)       # tg: the number of variables
         else:
             port.mip_solve(RAT, True, True, st["tg"][i], st["vc"], None, st["leq"][i])
         n += 1
@@ -169,6 +171,12 @@ def cpu_baselines(legs, no_ref):
         r = cpu_per_core("mip", tg_m, gen.to_rat(gen.vc_nonneg(MIP_NV, False)), leq_m, 4.0, "0-1 knapsack MIPs (%d vars)" % MIP_NV)
         r["unit"] = "MIPs/s"
         cpu["mip"] = r
+    if "lineq" in legs:
+        rng = np.random.default_rng(0)
+        sysm = np.stack([gen.random_system(rng, 40, 12) for _ in range(512)])
+        r = cpu_per_core("fme", 12, None, sysm, 3.0, "Lineq::fme eliminations (40x13 systems)")
+        r["unit"] = "systems/s"
+        cpu["lineq"] = r
     return cpu
 
 
@@ -580,21 +588,53 @@ def leg_mip(ctx, xpoly_amd, gen):
 def leg_lineq(ctx, xpoly_amd, gen):
     """The small exact problems either side of the LP: batches of rational systems through
     Lineq::reduce / fme / Matrix::rank (src/com/linsys.cpp:359-626, :656-774, matt.h:2614-2726) at the dependence
-    tests' shapes, and batches of small rational LPs through SIX. Host arrays in and out (PCIe included); the
-    kernels alone are in profiles/round2_kernel_stats_lineq_probe.csv. Integer-issue bound (gcd loops)."""
+    tests' shapes -- resident in HBM through the *_dev entry points, and through the host-array entry points (PCIe
+    and the cap-row result slots included) -- and batches of small rational LPs and of dependence polyhedra through
+    SIX / MIP. Integer-issue bound (gcd loops)."""
+    import torch
+    from xpoly_amd import lineq as LQ
     from xpoly_amd.lineq import Lineq
     lq = Lineq(ctx)
+    dev = torch.device("cuda", 0)
     rng = np.random.default_rng(0)
     rows_out = []
     for rows, nv in ((16, 8), (40, 12), (60, 19)):
+        cols = nv + 1
         base = np.stack([gen.random_system(rng, rows, nv) for _ in range(256)])
         mats = np.ascontiguousarray(np.tile(base, (LINEQ_NB // 256, 1, 1, 1)))
-        rec = dict(rows=rows, cols=nv + 1)
+        rec = dict(rows=rows, cols=cols)
+        # (i) systems resident in HBM, results left there: the *_dev entry points, timed around xpg_sync
+        cap = max(rows, rows * rows // 4 + rows + 1)
+        d_in = torch.from_numpy(mats).to(dev)
+        d_work = torch.empty_like(d_in)
+        d_out = torch.zeros(LINEQ_NB, cap, cols, 2, dtype=torch.int32, device=dev)
+        d_r = torch.empty(LINEQ_NB, dtype=torch.int32, device=dev); d_k = torch.empty_like(d_r)
+
+        def resident(name):
+            if name == "reduce":
+                d_work.copy_(d_in); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                LQ.reduce_dev(ctx, LINEQ_NB, d_work.data_ptr(), rows, cols, nv, True, d_r.data_ptr(), d_k.data_ptr())
+            elif name == "fme":
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                LQ.fme_dev(ctx, LINEQ_NB, d_in.data_ptr(), rows, cols, nv, 0, False, d_out.data_ptr(), cap, d_r.data_ptr(), d_k.data_ptr())
+            else:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                LQ.rank_dev(ctx, LINEQ_NB, d_in.data_ptr(), rows, cols, d_r.data_ptr())
+            ctx.sync()
+            return time.perf_counter() - t0
+        for name in ("reduce", "fme", "rank"):
+            resident(name)
+            rec[name + "_systems_per_s"] = round(LINEQ_NB / min(resident(name) for _ in range(3)), 0)
+        del d_in, d_work, d_out, d_r, d_k
+        # (ii) the host-array entry points: PCIe and the cap-row result slots included
         for name, fn in (("reduce", lambda: lq.reduce(mats, nv, True)), ("fme", lambda: lq.fme(mats, nv, 0)),
                          ("rank", lambda: lq.rank(mats))):
             fn()
             t0 = time.perf_counter(); fn(); dt = time.perf_counter() - t0
-            rec[name + "_systems_per_s"] = round(LINEQ_NB / dt, 0)
+            rec[name + "_host_arrays_systems_per_s"] = round(LINEQ_NB / dt, 0)
         rows_out.append(rec)
     # small rational LPs, dependence-test-like integer data (12 rows, 16 variables)
     nb, m, cols = 8192, 12, 17
@@ -616,7 +656,8 @@ def leg_lineq(ctx, xpoly_amd, gen):
                 rational_lps=dict(lps=nb, rows=m, cols=cols, lps_per_s=round(nb / dt, 0),
                                   status_hist=np.bincount(np.clip(st, 0, 4), minlength=5).tolist()),
                 dtype="int32 num/den", bound="integer issue (gcd loops), not HBM",
-                sample="host arrays in and out (PCIe included), second call timed")
+                sample="*_systems_per_s: 16384 systems resident in HBM, best of 3 calls timed to xpg_sync; *_host_arrays_*, "
+                       "rational_lps and dep_is_empty: host arrays in and out (PCIe included), second call timed")
 
 
 if __name__ == "__main__":

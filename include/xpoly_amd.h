@@ -285,6 +285,15 @@ int xpg_lineq_fme_batch_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int
 int xpg_lineq_calc_bound_batch_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols,
                                      int rhs_idx, int cap_rows, xpg_rat32 * bounds, int32_t * out_rows,
                                      int32_t * out_ok);
+/* The same three on DEVICE arrays (xpg_malloc / any HIP allocation of the handle's device), enqueue only: the
+ * results are there after xpg_sync.  For chains of eliminations that stay in HBM, and for measuring the kernels
+ * without PCIe.  d_outs is not cleared: rows of a slot past d_out_rows[b] keep what they held. */
+int xpg_lineq_reduce_batch_rat32_dev(xpg_ctx * ctx, int nb, xpg_rat32 * d_mats, int rows, int cols, int rhs_idx,
+                                     int is_intersect, int32_t * d_out_rows, int32_t * d_out_ok);
+int xpg_lineq_fme_batch_rat32_dev(xpg_ctx * ctx, int nb, const xpg_rat32 * d_mats, int rows, int cols, int rhs_idx,
+                                  int u, int darkshadow, xpg_rat32 * d_outs, int cap_rows, int32_t * d_out_rows,
+                                  int32_t * d_out_ok);
+int xpg_rat_rank_batch_dev(xpg_ctx * ctx, int nb, const xpg_rat32 * d_mats, int rows, int cols, int32_t * d_out_rank);
 int xpg_rat_rank_batch(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols,
                        int32_t * out_rank);
 int xpg_rat_det_batch(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int n, xpg_rat32 * out_det);

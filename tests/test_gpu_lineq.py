@@ -334,3 +334,41 @@ def test_gauss_with_nonpositive_denominators_matches_oracle(lq, port):
         assert ok[b] == wok, b
         if wok:
             assert np.array_equal(inv[b], winv), b
+
+
+def test_device_resident_entry_points_match_the_host_array_ones(ctx, lq):
+    """xpg_lineq_{reduce,fme}_batch_rat32_dev / xpg_rat_rank_batch_dev on HBM-resident systems: the same kernels
+    as the host-array calls, so the same rows, flags and ranks."""
+    from xpoly_amd import lineq as LQ
+    rng = np.random.default_rng(77)
+    nb, rows, nv = 96, 14, 6
+    cols = nv + 1
+    mats = np.stack([gen.random_system(rng, rows, nv) for _ in range(nb)])
+    cap = rows * rows // 4 + rows + 1
+    d_in, d_w = ctx.malloc(mats.nbytes), ctx.malloc(mats.nbytes)
+    d_o = ctx.malloc(nb * cap * cols * 8)
+    d_r, d_k = ctx.malloc(nb * 4), ctx.malloc(nb * 4)
+    try:
+        ctx.upload(d_in, mats); ctx.upload(d_w, mats)
+        r, k = np.zeros(nb, dtype=np.int32), np.zeros(nb, dtype=np.int32)
+        # reduce, in place
+        ok, res = lq.reduce(mats, nv, True)
+        LQ.reduce_dev(ctx, nb, d_w, rows, cols, nv, True, d_r, d_k); ctx.sync()
+        w = ctx.download(np.zeros_like(mats), d_w); ctx.download(r, d_r); ctx.download(k, d_k)
+        for b in range(nb):
+            assert bool(k[b]) == bool(ok[b]), b
+            if ok[b]:
+                assert rows_equal(w[b][: r[b]], res[b]), b
+        # fme
+        fok, fres = lq.fme(mats, nv, 2, False)
+        ctx.upload(d_o, np.zeros((nb, cap, cols, 2), dtype=np.int32))
+        LQ.fme_dev(ctx, nb, d_in, rows, cols, nv, 2, False, d_o, cap, d_r, d_k); ctx.sync()
+        o = ctx.download(np.zeros((nb, cap, cols, 2), dtype=np.int32), d_o); ctx.download(r, d_r); ctx.download(k, d_k)
+        for b in range(nb):
+            assert bool(k[b]) == bool(fok[b]) and rows_equal(o[b][: r[b]], fres[b]), b
+        # rank
+        LQ.rank_dev(ctx, nb, d_in, rows, cols, d_r); ctx.sync()
+        assert np.array_equal(ctx.download(r, d_r), lq.rank(mats))
+    finally:
+        for p_ in (d_in, d_w, d_o, d_r, d_k):
+            ctx.free(p_)

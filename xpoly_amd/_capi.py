@@ -22,7 +22,8 @@ SYMBOLS = [
     "xpg_mip_maxm_rat32", "xpg_mip_minm_rat32", "xpg_mip_maxm_f64", "xpg_mip_minm_f64",
     "xpg_has_solution_rat32", "xpg_mip_batch_rat32", "xpg_dep_is_empty_batch_rat32",
     "xpg_lineq_reduce_batch_rat32", "xpg_lineq_remove_iden_batch_rat32", "xpg_lineq_fme_batch_rat32",
-    "xpg_lineq_calc_bound_batch_rat32", "xpg_rat_rank_batch", "xpg_rat_det_batch", "xpg_rat_inv_batch",
+    "xpg_lineq_calc_bound_batch_rat32", "xpg_lineq_reduce_batch_rat32_dev", "xpg_lineq_fme_batch_rat32_dev",
+    "xpg_rat_rank_batch_dev", "xpg_rat_rank_batch", "xpg_rat_det_batch", "xpg_rat_inv_batch",
     "xpg_rat_rank_basis_batch", "xpg_rat_null_batch", "xpg_int_hnf_batch", "xpg_int_gcd_batch",
     "xpg_six_batch_f64_multi", "xpg_six_batch_rat32_multi", "xpg_mip_batch_rat32_multi",
     "xpg_dep_is_empty_batch_rat32_multi", "xpg_dep_is_empty_batch_ex_rat32", "xpg_lineq_move2var_batch_rat32", "xpg_mip_warm_f64",

@@ -39,24 +39,35 @@ inline LineqGeom lineq_geom(int nb, int width, size_t sys_lds)
 
 #define XPG_TRY(e_) do { hipError_t err_ = (e_); if (err_ != hipSuccess) { ctx->err = std::string(#e_) + ": " + hipGetErrorString(err_); return XPG_ERR_HIP; } } while (0)
 
-// mode 0: removeIdenRow, 1: reduce -- in place on mats[nb][rows][cols]
+// mode 0: removeIdenRow, 1: reduce -- in place on mats[nb][rows][cols]. The *_dev forms take device arrays and
+// only enqueue (the caller synchronises the handle's stream); the host-array forms stage through them.
+inline int lineq_reduce_batch_dev(xpg_ctx * ctx, int nb, R32 * d_mats, int rows, int cols, int rhs, int mode,
+                                  int is_intersect, int32_t * d_rows, int32_t * d_ok)
+{
+    if (!ctx || nb < 0 || !d_mats || rows <= 0 || cols <= 0 || !d_rows || !d_ok || (mode == 1 && (rhs < 0 || rhs >= cols)))
+        return XPG_ERR_SHAPE;
+    if (nb == 0) return 0;
+    const size_t lds = lineq_lds_bytes(rows, cols);
+    if (lds > 160 * 1024 || rows > 32767) return XPG_ERR_UNSUPPORTED;
+    const LineqGeom q = lineq_geom(nb, rows > cols ? rows : cols, lds);
+    XPG_TRY(hipFuncSetAttribute((const void *)k_reduce_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds));
+    hipLaunchKernelGGL(k_reduce_batch, dim3(q.grid), q.block, q.lds, ctx->stream, nb, d_mats, rows,
+                       cols, rhs, mode, is_intersect, (int *)d_rows, (int *)d_ok, q.sys_lds);
+    XPG_TRY(hipGetLastError());
+    return 0;
+}
 inline int lineq_reduce_batch(xpg_ctx * ctx, int nb, R32 * mats, int rows, int cols, int rhs, int mode,
                               int is_intersect, int32_t * out_rows, int32_t * out_ok)
 {
     if (!ctx || nb < 0 || !mats || rows <= 0 || cols <= 0 || !out_rows || (mode == 1 && (rhs < 0 || rhs >= cols)))
         return XPG_ERR_SHAPE;
     if (nb == 0) return 0;
-    const size_t lds = lineq_lds_bytes(rows, cols);
-    if (lds > 160 * 1024 || rows > 32767) return XPG_ERR_UNSUPPORTED;
     const size_t bytes = (size_t)nb * rows * cols * 8;
     DevBuf dm, dr, dk;
     XPG_TRY(dm.alloc(bytes)); XPG_TRY(dr.alloc((size_t)nb * 4)); XPG_TRY(dk.alloc((size_t)nb * 4));
     XPG_TRY(hipMemcpyAsync(dm.p, mats, bytes, hipMemcpyHostToDevice, ctx->stream));
-    const LineqGeom q = lineq_geom(nb, rows > cols ? rows : cols, lds);
-    XPG_TRY(hipFuncSetAttribute((const void *)k_reduce_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds));
-    hipLaunchKernelGGL(k_reduce_batch, dim3(q.grid), q.block, q.lds, ctx->stream, nb, (R32 *)dm.p, rows,
-                       cols, rhs, mode, is_intersect, (int *)dr.p, (int *)dk.p, q.sys_lds);
-    XPG_TRY(hipGetLastError());
+    const int rc = lineq_reduce_batch_dev(ctx, nb, (R32 *)dm.p, rows, cols, rhs, mode, is_intersect, (int32_t *)dr.p, (int32_t *)dk.p);
+    if (rc) return rc;
     XPG_TRY(hipMemcpyAsync(mats, dm.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     XPG_TRY(hipMemcpyAsync(out_rows, dr.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (out_ok) XPG_TRY(hipMemcpyAsync(out_ok, dk.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -64,11 +75,12 @@ inline int lineq_reduce_batch(xpg_ctx * ctx, int nb, R32 * mats, int rows, int c
     return 0;
 }
 
-inline int lineq_fme_batch(xpg_ctx * ctx, int nb, const R32 * mats, int rows, int cols, int rhs, int u,
-                           int darkshadow, R32 * outs, int cap, int32_t * out_rows, int32_t * out_ok)
+// d_outs must be zeroed by the caller where it wants zeros past a result's last row (the host form does).
+inline int lineq_fme_batch_dev(xpg_ctx * ctx, int nb, const R32 * d_mats, int rows, int cols, int rhs, int u,
+                               int darkshadow, R32 * d_outs, int cap, int32_t * d_rows, int32_t * d_ok)
 {
-    if (!ctx || nb < 0 || !mats || !outs || rows <= 0 || cols <= 1 || rhs < 1 || rhs >= cols || u < 0 || u >= rhs ||
-        cap < rows || !out_rows || !out_ok)
+    if (!ctx || nb < 0 || !d_mats || !d_outs || rows <= 0 || cols <= 1 || rhs < 1 || rhs >= cols || u < 0 || u >= rhs ||
+        cap < rows || !d_rows || !d_ok)
         return XPG_ERR_SHAPE;
     if (nb == 0) return 0;
     size_t lds = lineq_lds_bytes(cap, cols) + (size_t)rows * cols * 8;
@@ -78,17 +90,27 @@ inline int lineq_fme_batch(xpg_ctx * ctx, int nb, const R32 * mats, int rows, in
         lds = lineq_lds_bytes(cap, cols) - (size_t)cap * cols * 8 + (size_t)rows * cols * 8 + 16;
     }
     if (lds > 160 * 1024 || cap > 32767) return XPG_ERR_UNSUPPORTED;
+    const LineqGeom q = lineq_geom(nb, 64, lds);
+    XPG_TRY(hipFuncSetAttribute((const void *)k_fme_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds));
+    hipLaunchKernelGGL(k_fme_batch, dim3(q.grid), q.block, q.lds, ctx->stream, nb, d_mats, rows,
+                       (const int *)0, cols, rhs, u, darkshadow, d_outs, cap, (int *)d_rows, (int *)d_ok,
+                       res_global, (int *)0, q.sys_lds);
+    XPG_TRY(hipGetLastError());
+    return 0;
+}
+inline int lineq_fme_batch(xpg_ctx * ctx, int nb, const R32 * mats, int rows, int cols, int rhs, int u,
+                           int darkshadow, R32 * outs, int cap, int32_t * out_rows, int32_t * out_ok)
+{
+    if (!ctx || nb < 0 || !mats || !outs || rows <= 0 || cols <= 1 || cap < rows || !out_rows || !out_ok) return XPG_ERR_SHAPE;
+    if (nb == 0) return 0;
     const size_t bi = (size_t)nb * rows * cols * 8, bo = (size_t)nb * cap * cols * 8;
     DevBuf di, dout, dr, dk;
     XPG_TRY(di.alloc(bi)); XPG_TRY(dout.alloc(bo)); XPG_TRY(dr.alloc((size_t)nb * 4)); XPG_TRY(dk.alloc((size_t)nb * 4));
     XPG_TRY(hipMemcpyAsync(di.p, mats, bi, hipMemcpyHostToDevice, ctx->stream));
     XPG_TRY(hipMemsetAsync(dout.p, 0, bo, ctx->stream));
-    const LineqGeom q = lineq_geom(nb, 64, lds);
-    XPG_TRY(hipFuncSetAttribute((const void *)k_fme_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds));
-    hipLaunchKernelGGL(k_fme_batch, dim3(q.grid), q.block, q.lds, ctx->stream, nb, (const R32 *)di.p, rows,
-                       (const int *)0, cols, rhs, u, darkshadow, (R32 *)dout.p, cap, (int *)dr.p, (int *)dk.p,
-                       res_global, (int *)0, q.sys_lds);
-    XPG_TRY(hipGetLastError());
+    const int rc = lineq_fme_batch_dev(ctx, nb, (const R32 *)di.p, rows, cols, rhs, u, darkshadow, (R32 *)dout.p, cap,
+                                       (int32_t *)dr.p, (int32_t *)dk.p);
+    if (rc) return rc;
     XPG_TRY(hipMemcpyAsync(outs, dout.p, bo, hipMemcpyDeviceToHost, ctx->stream));
     XPG_TRY(hipMemcpyAsync(out_rows, dr.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
     XPG_TRY(hipMemcpyAsync(out_ok, dk.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -148,6 +170,22 @@ inline int lineq_calc_bound_batch(xpg_ctx * ctx, int nb, const R32 * mats, int r
     XPG_TRY(hipMemcpyAsync(out_rows, drows.p, (size_t)nb * rhs * 4, hipMemcpyDeviceToHost, ctx->stream));
     XPG_TRY(hipMemcpyAsync(out_ok, chain.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
     XPG_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// Matrix<Rational>::rank on device arrays, enqueue only: d_rank [nb].
+inline int rat_rank_batch_dev(xpg_ctx * ctx, int nb, const R32 * d_mats, int rows, int cols, int32_t * d_rank)
+{
+    if (!ctx || nb < 0 || !d_mats || !d_rank || rows <= 0 || cols <= 0) return XPG_ERR_SHAPE;
+    if (nb == 0) return 0;
+    size_t lds = ((size_t)rows * cols * 8 + 15) & ~(size_t)15;
+    lds += ((size_t)rows * 13 + 15) & ~(size_t)15;           // row factors, rowpos, live flags
+    if (lds > 160 * 1024) return XPG_ERR_UNSUPPORTED;
+    const LineqGeom q = lineq_geom(nb, rows * cols > 256 ? 64 : cols, lds);
+    XPG_TRY(hipFuncSetAttribute((const void *)k_gauss_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds));
+    hipLaunchKernelGGL(k_gauss_batch, dim3(q.grid), q.block, q.lds, ctx->stream, nb, d_mats, rows, cols, 0, 0,
+                       (int *)d_rank, (R32 *)0, (R32 *)0, q.sys_lds);
+    XPG_TRY(hipGetLastError());
     return 0;
 }
 

@@ -704,6 +704,19 @@ int xpg_lineq_calc_bound_batch_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * ma
                                      int cap_rows, xpg_rat32 * bounds, int32_t * out_rows, int32_t * out_ok)
 {
     XPG_BIND(ctx); return lineq_calc_bound_batch(ctx, nb, (const R32 *)mats, rows, cols, rhs_idx, cap_rows, (R32 *)bounds, out_rows, out_ok); }
+int xpg_lineq_reduce_batch_rat32_dev(xpg_ctx * ctx, int nb, xpg_rat32 * d_mats, int rows, int cols, int rhs_idx,
+                                     int is_intersect, int32_t * d_out_rows, int32_t * d_out_ok)
+{
+    XPG_BIND(ctx); return lineq_reduce_batch_dev(ctx, nb, (R32 *)d_mats, rows, cols, rhs_idx, 1, is_intersect, d_out_rows, d_out_ok); }
+int xpg_lineq_fme_batch_rat32_dev(xpg_ctx * ctx, int nb, const xpg_rat32 * d_mats, int rows, int cols, int rhs_idx,
+                                  int u, int darkshadow, xpg_rat32 * d_outs, int cap_rows, int32_t * d_out_rows,
+                                  int32_t * d_out_ok)
+{
+    XPG_BIND(ctx); return lineq_fme_batch_dev(ctx, nb, (const R32 *)d_mats, rows, cols, rhs_idx, u, darkshadow, (R32 *)d_outs,
+                                              cap_rows, d_out_rows, d_out_ok); }
+int xpg_rat_rank_batch_dev(xpg_ctx * ctx, int nb, const xpg_rat32 * d_mats, int rows, int cols, int32_t * d_out_rank)
+{
+    XPG_BIND(ctx); return rat_rank_batch_dev(ctx, nb, (const R32 *)d_mats, rows, cols, d_out_rank); }
 int xpg_rat_rank_batch(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols, int32_t * out_rank)
 {
     XPG_BIND(ctx); return out_rank ? gauss_batch(ctx, nb, (const R32 *)mats, rows, cols, 0, out_rank, 0, 0) : XPG_ERR_SHAPE; }

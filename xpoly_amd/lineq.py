@@ -148,3 +148,24 @@ class Lineq:
         self.ctx.check(lib().xpg_rat_inv_batch(self.ctx._h, C.c_int(nb), vp(a), C.c_int(n), vp(out), vp(ok)),
                        "xpg_rat_inv_batch")
         return ok, out
+
+
+def reduce_dev(ctx, nb, mats_ptr, rows, cols, rhs_idx, is_intersect, out_rows_ptr, out_ok_ptr):
+    """xpg_lineq_reduce_batch_rat32_dev: Lineq::reduce in place on device arrays, enqueue only (ctx.sync() after)."""
+    ctx.check(lib().xpg_lineq_reduce_batch_rat32_dev(ctx._h, C.c_int(nb), C.c_void_p(mats_ptr), C.c_int(rows), C.c_int(cols),
+                                                     C.c_int(rhs_idx), C.c_int(int(is_intersect)), C.c_void_p(out_rows_ptr),
+                                                     C.c_void_p(out_ok_ptr)), "xpg_lineq_reduce_batch_rat32_dev")
+
+
+def fme_dev(ctx, nb, mats_ptr, rows, cols, rhs_idx, u, darkshadow, outs_ptr, cap_rows, out_rows_ptr, out_ok_ptr):
+    """xpg_lineq_fme_batch_rat32_dev: Lineq::fme on device arrays, enqueue only."""
+    ctx.check(lib().xpg_lineq_fme_batch_rat32_dev(ctx._h, C.c_int(nb), C.c_void_p(mats_ptr), C.c_int(rows), C.c_int(cols),
+                                                  C.c_int(rhs_idx), C.c_int(u), C.c_int(int(darkshadow)), C.c_void_p(outs_ptr),
+                                                  C.c_int(cap_rows), C.c_void_p(out_rows_ptr), C.c_void_p(out_ok_ptr)),
+              "xpg_lineq_fme_batch_rat32_dev")
+
+
+def rank_dev(ctx, nb, mats_ptr, rows, cols, out_rank_ptr):
+    """xpg_rat_rank_batch_dev: Matrix<Rational>::rank on device arrays, enqueue only."""
+    ctx.check(lib().xpg_rat_rank_batch_dev(ctx._h, C.c_int(nb), C.c_void_p(mats_ptr), C.c_int(rows), C.c_int(cols),
+                                           C.c_void_p(out_rank_ptr)), "xpg_rat_rank_batch_dev")
