@@ -7,11 +7,43 @@
 
 namespace xpg {
 
+// Device scratch of one host-array call. The blocks come from, and go back to, a small cache the handle owns
+// (freed with it): a caller that eliminates one system per call -- the drop-in adapter does -- would otherwise pay
+// four hipMalloc / hipFree pairs per call, more than the kernel.
 struct DevBuf {
-    void * p;
-    DevBuf() : p(0) {}
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    void * p; size_t cap; xpg_ctx * owner;
+    DevBuf() : p(0), cap(0), owner(0) {}
+    ~DevBuf()
+    {
+        if (!p) return;
+        if (owner && owner->dev_cache.size() < 24 && owner->dev_cache_bytes + cap <= ((size_t)4 << 30)) {
+            owner->dev_cache.push_back(std::make_pair(p, cap));
+            owner->dev_cache_bytes += cap;
+        } else (void)hipFree(p);
+    }
+    hipError_t alloc(xpg_ctx * ctx, size_t bytes)
+    {
+        if (bytes < 256) bytes = 256;
+        owner = ctx;
+        int best = -1;                                   // the smallest cached block that is large enough
+        for (size_t i = 0; i < ctx->dev_cache.size(); i++)
+            if (ctx->dev_cache[i].second >= bytes && (best < 0 || ctx->dev_cache[i].second < ctx->dev_cache[(size_t)best].second)) best = (int)i;
+        if (best >= 0 && ctx->dev_cache[(size_t)best].second <= 2 * bytes + 4096) {
+            p = ctx->dev_cache[(size_t)best].first; cap = ctx->dev_cache[(size_t)best].second;
+            ctx->dev_cache_bytes -= cap;
+            ctx->dev_cache.erase(ctx->dev_cache.begin() + best);
+            return hipSuccess;
+        }
+        cap = bytes;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {                           // make room: drop the cache and try once more
+            for (auto & b : ctx->dev_cache) (void)hipFree(b.first);
+            ctx->dev_cache.clear(); ctx->dev_cache_bytes = 0;
+            e = hipMalloc(&p, bytes);
+        }
+        if (e != hipSuccess) { p = 0; cap = 0; }
+        return e;
+    }
 };
 
 inline int lineq_grid(int nb) { return nb < 256 * 16 ? nb : 256 * 16; }
@@ -64,7 +96,7 @@ inline int lineq_reduce_batch(xpg_ctx * ctx, int nb, R32 * mats, int rows, int c
     if (nb == 0) return 0;
     const size_t bytes = (size_t)nb * rows * cols * 8;
     DevBuf dm, dr, dk;
-    XPG_TRY(dm.alloc(bytes)); XPG_TRY(dr.alloc((size_t)nb * 4)); XPG_TRY(dk.alloc((size_t)nb * 4));
+    XPG_TRY(dm.alloc(ctx, bytes)); XPG_TRY(dr.alloc(ctx, (size_t)nb * 4)); XPG_TRY(dk.alloc(ctx, (size_t)nb * 4));
     XPG_TRY(hipMemcpyAsync(dm.p, mats, bytes, hipMemcpyHostToDevice, ctx->stream));
     const int rc = lineq_reduce_batch_dev(ctx, nb, (R32 *)dm.p, rows, cols, rhs, mode, is_intersect, (int32_t *)dr.p, (int32_t *)dk.p);
     if (rc) return rc;
@@ -105,7 +137,7 @@ inline int lineq_fme_batch(xpg_ctx * ctx, int nb, const R32 * mats, int rows, in
     if (nb == 0) return 0;
     const size_t bi = (size_t)nb * rows * cols * 8, bo = (size_t)nb * cap * cols * 8;
     DevBuf di, dout, dr, dk;
-    XPG_TRY(di.alloc(bi)); XPG_TRY(dout.alloc(bo)); XPG_TRY(dr.alloc((size_t)nb * 4)); XPG_TRY(dk.alloc((size_t)nb * 4));
+    XPG_TRY(di.alloc(ctx, bi)); XPG_TRY(dout.alloc(ctx, bo)); XPG_TRY(dr.alloc(ctx, (size_t)nb * 4)); XPG_TRY(dk.alloc(ctx, (size_t)nb * 4));
     XPG_TRY(hipMemcpyAsync(di.p, mats, bi, hipMemcpyHostToDevice, ctx->stream));
     XPG_TRY(hipMemsetAsync(dout.p, 0, bo, ctx->stream));
     const int rc = lineq_fme_batch_dev(ctx, nb, (const R32 *)di.p, rows, cols, rhs, u, darkshadow, (R32 *)dout.p, cap,
@@ -135,9 +167,9 @@ inline int lineq_calc_bound_batch(xpg_ctx * ctx, int nb, const R32 * mats, int r
     if (lds > 160 * 1024 || cap > 32767) return XPG_ERR_UNSUPPORTED;
     const size_t slot = (size_t)cap * cols * 8, bsz = (size_t)nb * slot;
     DevBuf d0, da, db, ra, rb, step_ok, chain, dres, drows;
-    XPG_TRY(d0.alloc(bsz)); XPG_TRY(da.alloc(bsz)); XPG_TRY(db.alloc(bsz));
-    XPG_TRY(ra.alloc((size_t)nb * 4)); XPG_TRY(rb.alloc((size_t)nb * 4)); XPG_TRY(step_ok.alloc((size_t)nb * 4));
-    XPG_TRY(chain.alloc((size_t)nb * 4)); XPG_TRY(dres.alloc(bsz * rhs)); XPG_TRY(drows.alloc((size_t)nb * rhs * 4));
+    XPG_TRY(d0.alloc(ctx, bsz)); XPG_TRY(da.alloc(ctx, bsz)); XPG_TRY(db.alloc(ctx, bsz));
+    XPG_TRY(ra.alloc(ctx, (size_t)nb * 4)); XPG_TRY(rb.alloc(ctx, (size_t)nb * 4)); XPG_TRY(step_ok.alloc(ctx, (size_t)nb * 4));
+    XPG_TRY(chain.alloc(ctx, (size_t)nb * 4)); XPG_TRY(dres.alloc(ctx, bsz * rhs)); XPG_TRY(drows.alloc(ctx, (size_t)nb * rhs * 4));
     // the input, repacked to the [nb][cap][cols] slot layout
     XPG_TRY(hipMemsetAsync(d0.p, 0, bsz, ctx->stream));
     XPG_TRY(hipMemcpy2DAsync(d0.p, slot, mats, (size_t)rows * cols * 8, (size_t)rows * cols * 8, nb,
@@ -201,8 +233,8 @@ inline int gauss_batch(xpg_ctx * ctx, int nb, const R32 * mats, int rows, int co
     const size_t bi = (size_t)nb * rows * cols * 8;
     const size_t bo = op == 2 || op == 3 ? bi : (op == 4 ? (size_t)nb * cols * cols * 8 : 8);
     DevBuf di, dint, dval, dmat;
-    XPG_TRY(di.alloc(bi)); XPG_TRY(dint.alloc((size_t)nb * 4)); XPG_TRY(dval.alloc((size_t)nb * 8));
-    XPG_TRY(dmat.alloc(bo));
+    XPG_TRY(di.alloc(ctx, bi)); XPG_TRY(dint.alloc(ctx, (size_t)nb * 4)); XPG_TRY(dval.alloc(ctx, (size_t)nb * 8));
+    XPG_TRY(dmat.alloc(ctx, bo));
     XPG_TRY(hipMemcpyAsync(di.p, mats, bi, hipMemcpyHostToDevice, ctx->stream));
     if (op >= 2) XPG_TRY(hipMemsetAsync(dmat.p, 0, bo, ctx->stream));
     // small matrices share a wave (one lane per column); from a few hundred cells on the cell-parallel elimination
@@ -229,7 +261,7 @@ inline int int_hnf_batch(xpg_ctx * ctx, int nb, const int32_t * mats, int rows, 
     if (lds > 160 * 1024) return XPG_ERR_UNSUPPORTED;
     const size_t bi = (size_t)nb * rows * cols * 4, bu = (size_t)nb * cols * cols * 4;
     DevBuf di, dh, du, ds;
-    XPG_TRY(di.alloc(bi)); XPG_TRY(dh.alloc(bi)); XPG_TRY(du.alloc(bu)); XPG_TRY(ds.alloc((size_t)nb * 4));
+    XPG_TRY(di.alloc(ctx, bi)); XPG_TRY(dh.alloc(ctx, bi)); XPG_TRY(du.alloc(ctx, bu)); XPG_TRY(ds.alloc(ctx, (size_t)nb * 4));
     XPG_TRY(hipMemcpyAsync(di.p, mats, bi, hipMemcpyHostToDevice, ctx->stream));
     XPG_TRY(hipMemsetAsync(dh.p, 0, bi, ctx->stream));
     XPG_TRY(hipMemsetAsync(du.p, 0, bu, ctx->stream));
@@ -252,7 +284,7 @@ inline int int_gcd_batch(xpg_ctx * ctx, int nb, int32_t * mats, int rows, int co
     const size_t bi = (size_t)nb * rows * cols * 4;
     const long long total = (long long)nb * rows;
     DevBuf di;
-    XPG_TRY(di.alloc(bi));
+    XPG_TRY(di.alloc(ctx, bi));
     XPG_TRY(hipMemcpyAsync(di.p, mats, bi, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_int_gcd_batch, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, total,
                        (int *)di.p, cols);

@@ -23,6 +23,8 @@ struct xpg_ctx {
     void * rowbuf; void * colbuf; xpg::LoopState * st; size_t row_cap, col_cap;
     void * stage; size_t stage_cap;   // grow-only device staging of the host-array batch entry points
     void * hstage; size_t hstage_cap; // its pinned host mirror (the MIP controller packs node batches into it)
+    std::vector<std::pair<void *, size_t> > dev_cache;   // device blocks between host-array row-elimination calls (DevBuf)
+    size_t dev_cache_bytes = 0;
     int update_variant;     // tuning knob for the fp64 sweep (see launch_update_f64)
     int loop_mode;          // 0: pipelined fp64 loop (2 launches per pivot), 1: serial pick/prep/update
     int zigzag;             // pipelined sweep alternates its tile order (Infinity Cache reuse)

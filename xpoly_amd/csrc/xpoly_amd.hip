@@ -87,6 +87,7 @@ void xpg_destroy(xpg_ctx * ctx)
     if (ctx->st) (void)hipFree(ctx->st);
     if (ctx->stage) (void)hipFree(ctx->stage);
     if (ctx->hstage) (void)hipHostFree(ctx->hstage);
+    for (auto & b : ctx->dev_cache) (void)hipFree(b.first);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
