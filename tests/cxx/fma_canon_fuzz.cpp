@@ -26,9 +26,31 @@ static R32 draw()
     }
 }
 
+// the divide-free helpers on their own: remainders of 64-bit values below 2^63 (random, and at the edges of the
+// fp64 estimates), exact quotients of 32- and 64-bit multiples
+static int check_division_helpers(long n)
+{
+    static const uint32_t gs[] = { 1u, 2u, 3u, 5u, 7u, 10u, 1000000u, 0x7ffffffeu, 0x7fffffffu, 0x40000000u, 0x3fffffffu, 65537u, 0xfffeu };
+    for (long it = 0; it < n; it++) {
+        uint32_t g = (it % 7 == 0) ? gs[rnd() % (sizeof(gs) / sizeof(gs[0]))] : (uint32_t)(rnd() % 0x7fffffffu) + 1u;
+        unsigned long long x = rnd() >> (1 + rnd() % 40);
+        if (it % 11 == 0) x = 0x7fffffffffffffffull - rnd() % 1000;
+        if (it % 13 == 0) x = (unsigned long long)g * (rnd() % 0xffffffffull) + (it % 3 == 0 ? g - 1 : 0);
+        if (x >> 63) x >>= 1;
+        if (mod_u64_u32(x, g) != (uint32_t)(x % g)) { printf("MISMATCH mod_u64_u32 x=%llu g=%u\n", x, g); return 1; }
+        const uint32_t q32 = (uint32_t)(rnd() % (0xffffffffull / g + 1));
+        const ExactDiv32 by(g);
+        if (by(q32 * g) != q32) { printf("MISMATCH ExactDiv32 q=%u g=%u\n", q32, g); return 1; }
+        const unsigned long long q64 = rnd() % (0xffffffffffffffffull / g);
+        if (by.wide(q64 * g) != q64) { printf("MISMATCH ExactDiv32::wide q=%llu g=%u\n", q64, g); return 1; }
+    }
+    return 0;
+}
+
 int main(int argc, char ** argv)
 {
     const long N = argc > 1 ? atol(argv[1]) : 3000000;
+    if (check_division_helpers(N)) return 1;
     long appro_like = 0, zeros = 0;
     for (long it = 0; it < N; it++) {
         const R32 a = draw(), k = draw(), e = draw();
