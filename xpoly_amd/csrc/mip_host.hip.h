@@ -200,7 +200,7 @@ class MipPool {
     std::function<void(int)> job_;                      // job_(w): the share of worker w, 0 <= w < size()
     std::atomic<unsigned> gen_{0};
     std::atomic<int> pending_{0};
-    bool stop_ = false;
+    std::atomic<bool> stop_{false};
     static void relax() { __builtin_ia32_pause(); }
     void worker(int w)
     {
@@ -209,9 +209,9 @@ class MipPool {
             for (int spin = 0; spin < 20000 && gen_.load(std::memory_order_acquire) == seen; spin++) relax();
             if (gen_.load(std::memory_order_acquire) == seen) {
                 std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [&] { return stop_ || gen_.load(std::memory_order_acquire) != seen; });
+                cv_.wait(lk, [&] { return stop_.load() || gen_.load(std::memory_order_acquire) != seen; });
             }
-            if (stop_) return;
+            if (stop_.load()) return;
             seen = gen_.load(std::memory_order_acquire);
             job_(w);
             pending_.fetch_sub(1, std::memory_order_acq_rel);
@@ -227,7 +227,7 @@ public:
     }
     ~MipPool()
     {
-        { std::unique_lock<std::mutex> lk(m_); stop_ = true; gen_.fetch_add(1, std::memory_order_release); }
+        { std::unique_lock<std::mutex> lk(m_); stop_.store(true); gen_.fetch_add(1, std::memory_order_release); }
         cv_.notify_all();
         for (auto & t : th_) t.join();
     }
