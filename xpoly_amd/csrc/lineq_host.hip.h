@@ -107,6 +107,30 @@ inline int lineq_reduce_batch(xpg_ctx * ctx, int nb, R32 * mats, int rows, int c
     return 0;
 }
 
+// LDS of one system in k_fme_batch and the rows of its result area. The whole cap-row result in LDS when that
+// takes <= 32 KB; else a result area for the TYPICAL result (about rows^2 / 10 pair rows on random systems, against
+// the caller's worst case cap = rows^2 / 4 + rows) inside 32 KB, larger results going to their HBM slot -- 40 x 13:
+// 32 KB instead of 54 KB per system, 5 systems per CU instead of 2; else the whole result if it fits 64 KB (2 per
+// CU); else every result in HBM.
+struct FmeLds { int cap_lds; size_t lds; };
+inline FmeLds fme_lds(int cap, int cap_in, int cols)
+{
+    const int capx = cap > cap_in ? cap : cap_in;
+    const size_t scratch = lineq_lds_bytes(capx, cols) - (size_t)capx * cols * 8 + 16;
+    const size_t tmp = (size_t)cap_in * cols * 8;
+    const size_t full = (size_t)cap * cols * 8 + tmp + scratch;
+    FmeLds f;
+    if (full <= 32 * 1024) { f.cap_lds = cap; f.lds = full; return f; }
+    const long avail = 32 * 1024 - (long)tmp - (long)scratch;
+    const int part = avail > 0 ? (int)(avail / ((long)cols * 8)) : 0;
+    const int typical = cap_in * cap_in / 10 + cap_in / 2;
+    if (part >= typical && (size_t)part * cols >= (size_t)cap_in && part < cap) {
+        f.cap_lds = part; f.lds = (size_t)part * cols * 8 + tmp + scratch; return f;
+    }
+    if (full <= 64 * 1024) { f.cap_lds = cap; f.lds = full; return f; }
+    f.cap_lds = 0; f.lds = tmp + scratch;
+    return f;
+}
 // d_outs must be zeroed by the caller where it wants zeros past a result's last row (the host form does).
 inline int lineq_fme_batch_dev(xpg_ctx * ctx, int nb, const R32 * d_mats, int rows, int cols, int rhs, int u,
                                int darkshadow, R32 * d_outs, int cap, int32_t * d_rows, int32_t * d_ok)
@@ -115,18 +139,13 @@ inline int lineq_fme_batch_dev(xpg_ctx * ctx, int nb, const R32 * d_mats, int ro
         cap < rows || !d_rows || !d_ok)
         return XPG_ERR_SHAPE;
     if (nb == 0) return 0;
-    size_t lds = lineq_lds_bytes(cap, cols) + (size_t)rows * cols * 8;
-    int res_global = 0;
-    if (lds > 64 * 1024) {                       // keep >= 2 systems per CU; else build the result in HBM
-        res_global = 1;
-        lds = lineq_lds_bytes(cap, cols) - (size_t)cap * cols * 8 + (size_t)rows * cols * 8 + 16;
-    }
-    if (lds > 160 * 1024 || cap > 32767) return XPG_ERR_UNSUPPORTED;
-    const LineqGeom q = lineq_geom(nb, 64, lds);
+    const FmeLds fl = fme_lds(cap, rows, cols);
+    if (fl.lds > 160 * 1024 || cap > 32767) return XPG_ERR_UNSUPPORTED;
+    const LineqGeom q = lineq_geom(nb, 64, fl.lds);
     XPG_TRY(hipFuncSetAttribute((const void *)k_fme_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds));
     hipLaunchKernelGGL(k_fme_batch, dim3(q.grid), q.block, q.lds, ctx->stream, nb, d_mats, rows,
                        (const int *)0, cols, rhs, u, darkshadow, d_outs, cap, (int *)d_rows, (int *)d_ok,
-                       res_global, (int *)0, q.sys_lds);
+                       fl.cap_lds, (int *)0, q.sys_lds);
     XPG_TRY(hipGetLastError());
     return 0;
 }
@@ -161,10 +180,8 @@ inline int lineq_calc_bound_batch(xpg_ctx * ctx, int nb, const R32 * mats, int r
         !out_rows || !out_ok)
         return XPG_ERR_SHAPE;
     if (nb == 0) return 0;
-    size_t lds = lineq_lds_bytes(cap, cols) + (size_t)cap * cols * 8;
-    int res_global = 0;
-    if (lds > 64 * 1024) { res_global = 1; lds = lineq_lds_bytes(cap, cols) + 16; }
-    if (lds > 160 * 1024 || cap > 32767) return XPG_ERR_UNSUPPORTED;
+    const FmeLds fl = fme_lds(cap, cap, cols);
+    if (fl.lds > 160 * 1024 || cap > 32767) return XPG_ERR_UNSUPPORTED;
     const size_t slot = (size_t)cap * cols * 8, bsz = (size_t)nb * slot;
     DevBuf d0, da, db, ra, rb, step_ok, chain, dres, drows;
     XPG_TRY(d0.alloc(ctx, bsz)); XPG_TRY(da.alloc(ctx, bsz)); XPG_TRY(db.alloc(ctx, bsz));
@@ -176,7 +193,7 @@ inline int lineq_calc_bound_batch(xpg_ctx * ctx, int nb, const R32 * mats, int r
                              hipMemcpyHostToDevice, ctx->stream));
     std::vector<int32_t> ones(nb, 1), init_rows(nb, rows);
     XPG_TRY(hipMemcpyAsync(chain.p, ones.data(), (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream));
-    const LineqGeom q = lineq_geom(nb, 64, lds);
+    const LineqGeom q = lineq_geom(nb, 64, fl.lds);
     XPG_TRY(hipFuncSetAttribute((const void *)k_fme_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds));
     for (int j = 0; j < rhs; j++) {
         void * cur = d0.p; void * cur_rows = ra.p;
@@ -188,7 +205,7 @@ inline int lineq_calc_bound_batch(xpg_ctx * ctx, int nb, const R32 * mats, int r
             void * nxt_rows = (cur_rows == ra.p) ? rb.p : ra.p;
             hipLaunchKernelGGL(k_fme_batch, dim3(q.grid), q.block, q.lds, ctx->stream, nb, (const R32 *)cur, cap,
                                (const int *)cur_rows, cols, rhs, i, 0, (R32 *)nxt, cap, (int *)nxt_rows,
-                               (int *)step_ok.p, res_global, (int *)chain.p, q.sys_lds);
+                               (int *)step_ok.p, fl.cap_lds, (int *)chain.p, q.sys_lds);
             cur = nxt; cur_rows = nxt_rows; flip = !flip;
         }
         XPG_TRY(hipGetLastError());

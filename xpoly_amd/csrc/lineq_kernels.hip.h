@@ -389,29 +389,33 @@ __global__ __launch_bounds__(64) void k_reduce_batch(int nb, R32 * mats, int row
     }
 }
 
-// Lineq::fme (linsys.cpp:656-774) for one system per wave. out has cap rows.
-// res_global != 0: the P*N result does not fit LDS next to the input, so it is built and
-// reduced directly in its HBM output slot (flat pointers; L2-resident at these sizes).
+// Lineq::fme (linsys.cpp:656-774) for one system per wave. out has cap rows; cap_lds of them have room in LDS
+// (see the layout note in the body).
 // Inputs are [nb][cap_in][cols] with in_rows[b] live rows each (NULL: all cap_in rows), which
 // lets eliminations be chained on the device (Lineq::calcBound). chain_ok (may be NULL) carries
 // a system's state through a chain: only systems whose entry is 1 are processed, and the entry
 // becomes 0 when this elimination finds the system inconsistent.
 __global__ __launch_bounds__(64) void k_fme_batch(int nb, const R32 * mats, int cap_in, const int * in_rows, int cols,
                                                   int rhs, int u, int darkshadow, R32 * outs, int cap, int * out_rows,
-                                                  int * out_ok, int res_global, int * chain_ok, int sys_lds)
+                                                  int * out_ok, int cap_lds, int * chain_ok, int sys_lds)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
     unsigned char * lds = lds_all + (size_t)threadIdx.y * sys_lds;
-    // LDS layout: [result matrix (cap x cols) unless res_global] [normalised input (cap_in x cols)] [scratch]
-    WMat res; res.a = (R32 *)lds; res.ld = cols; res.c = cols;
-    WMat tmp; tmp.a = res_global ? (R32 *)lds : res.a + (size_t)cap * cols; tmp.ld = cols;
+    // LDS layout: [result area (cap_lds x cols)] [normalised input (cap_in x cols)] [scratch]. A system whose result
+    // (free rows + P x N pair rows, known once its rows are classified) fits cap_lds rows is built and reduced in
+    // LDS and stored at the end; a larger one is built and reduced directly in its HBM output slot (flat pointers;
+    // L2-resident at these sizes). The host sizes cap_lds for the typical result, not for the caller's worst-case
+    // cap, so that more systems share a CU (lineq_host.hip.h, fme_lds).
+    R32 * const res_lds = (R32 *)lds;
+    WMat res; res.a = res_lds; res.ld = cols; res.c = cols;
+    WMat tmp; tmp.a = res_lds + (size_t)cap_lds * cols; tmp.ld = cols;
     WScratch s = carve_scratch((unsigned char *)(tmp.a + (size_t)cap_in * cols), cap > cap_in ? cap : cap_in);
     LQ_CLEAR
     for (int b = sys_first(); b < nb; b += sys_stride()) {
         if (chain_ok && chain_ok[b] != 1) { if (lane_id() == 0) { out_rows[b] = 0; out_ok[b] = 0; } continue; }
         const int rows = in_rows ? in_rows[b] : cap_in;
         const R32 * g = mats + (size_t)b * cap_in * cols;
-        if (res_global) res.a = outs + (size_t)b * cap * cols;
+        R32 * const go = outs + (size_t)b * cap * cols;
         LQ_T0
         w_load(tmp, g, rows, cols);
         LQ_T(0)
@@ -431,12 +435,28 @@ __global__ __launch_bounds__(64) void k_fme_batch(int nb, const R32 * mats, int 
         wave_sync();
         const int stop = *bad_at == INT_MAX ? rows : *bad_at;      // rows before the first bad one are processed
         LQ_T(1)
+        // the row lists: rows without u go first, in order (linsys.cpp:724-730); positive and negative rows of u
+        int nfree = 0, np = 0, nn = 0;
+        for (int base = 0; base < stop; base += wave_lanes()) {
+            const int i = base + lane_id();
+            const int kd = i < stop ? kind[i] : -1;
+            const unsigned long long bf = grp_ballot(kd == 0), bp = grp_ballot(kd == 1), bn = grp_ballot(kd == 2);
+            if (kd == 0) kind[i] = -(nfree + grp_rank(bf)) - 1;       // destination row, encoded negative
+            else if (kd == 1) s.pos[np + grp_rank(bp)] = (short)i;
+            else if (kd == 2) s.negs[nn + grp_rank(bn)] = (short)i;
+            nfree += __popcll(bf); np += __popcll(bp); nn += __popcll(bn);
+        }
+        wave_sync();
+        // where this system's result lives
+        const int need = nfree + (np + nn == 1 ? 1 : np * nn);
+        const bool in_lds = need <= cap_lds;
+        res.a = in_lds ? res_lds : go;
         // normalise the rows that contain u (linsys.cpp:711-723): the rows are independent, so the factors are
         // found one lane per row (kept in the still empty result matrix) and applied one lane per cell
-        R32 * fac = res.a;
+        R32 * fac = cap_lds ? res_lds : go;                       // (the host keeps cap_lds * cols >= cap_in when cap_lds > 0)
         for (int i = lane_id(); i < stop; i += wave_lanes()) {
             int mode = SCALE_KEEP;
-            if (kind[i] != 0) {
+            if (kind[i] > 0) {
                 const R32 c = tmp.a[i * cols + u];
                 R32 f(1, 1);
                 if (kind[i] == 1) { if (ne(c, R32(1, 1))) f = q_div(tmp.cn, R32(1, 1), c); }
@@ -459,17 +479,7 @@ __global__ __launch_bounds__(64) void k_fme_batch(int nb, const R32 * mats, int 
             wave_sync();
         }
         LQ_T(2)
-        // rows without u go first, in order (linsys.cpp:724-730)
-        int nfree = 0, np = 0, nn = 0;
-        for (int base = 0; base < stop; base += wave_lanes()) {
-            const int i = base + lane_id();
-            const int kd = i < stop ? kind[i] : -1;
-            const unsigned long long bf = grp_ballot(kd == 0), bp = grp_ballot(kd == 1), bn = grp_ballot(kd == 2);
-            if (kd == 0) kind[i] = -(nfree + grp_rank(bf)) - 1;       // destination row, encoded negative
-            else if (kd == 1) s.pos[np + grp_rank(bp)] = (short)i;
-            else if (kd == 2) s.negs[nn + grp_rank(bn)] = (short)i;
-            nfree += __popcll(bf); np += __popcll(bp); nn += __popcll(bn);
-        }
+        // rows without u are copied first
         wave_sync();
         for (int t = lane_id(); t < stop * cols; t += wave_lanes()) {
             const int i = by_cols.quot(t), j = t - i * cols;
@@ -507,9 +517,7 @@ __global__ __launch_bounds__(64) void k_fme_batch(int nb, const R32 * mats, int 
             LQ_T(5)
         }
         wave_sync();
-        R32 * go = outs + (size_t)b * cap * cols;
-        if (status_rows < 0 && !res_global) w_store(res, go);
-        (void)go;
+        if (status_rows < 0 && in_lds) w_store(res, go);
         if (lane_id() == 0) {
             out_rows[b] = status_rows < 0 ? res.r : -status_rows;       // negative: did not fit, needs that many rows
             out_ok[b] = ok ? 1 : 0;
