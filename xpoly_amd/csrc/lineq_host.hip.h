@@ -107,28 +107,26 @@ inline int lineq_reduce_batch(xpg_ctx * ctx, int nb, R32 * mats, int rows, int c
     return 0;
 }
 
-// LDS of one system in k_fme_batch and the rows of its result area. The whole cap-row result in LDS when that
-// takes <= 32 KB; else a result area for the TYPICAL result (about rows^2 / 10 pair rows on random systems, against
-// the caller's worst case cap = rows^2 / 4 + rows) inside 32 KB, larger results going to their HBM slot -- 40 x 13:
-// 32 KB instead of 54 KB per system, 5 systems per CU instead of 2; else the whole result if it fits 64 KB (2 per
-// CU); else every result in HBM.
+// LDS of one system in k_fme_batch and the rows of its result area. Occupancy beats residency here: the result of
+// a system is read and written a few times per row (pair sums, hash, classification, compaction) and its HBM slot
+// is L2-resident, while every KB of LDS per system is fewer systems per CU for a kernel that waits on dependent
+// gcd chains. Measured at 40 x 13 (16 384 systems): whole cap-row result in LDS (54 KB, 2 per CU) 8.0 M systems/s;
+// a result area for the typical result in 32 KB 14.6 M; in 20 KB 20.2 M; NO result area (9 KB: the normalised
+// input and the scratch) 27.9 M. So the result stays in LDS only while the whole layout is small (<= 12 KB: the
+// 16 x 9 class), and otherwise the area holds just the row factors of the normalisation.
 struct FmeLds { int cap_lds; size_t lds; };
 inline FmeLds fme_lds(int cap, int cap_in, int cols)
 {
+    static const int full_kb = [] { const char * e = getenv("XPG_FME_FULL_KB"); return e ? atoi(e) : 12; }();   // A/B knob
     const int capx = cap > cap_in ? cap : cap_in;
     const size_t scratch = lineq_lds_bytes(capx, cols) - (size_t)capx * cols * 8 + 16;
     const size_t tmp = (size_t)cap_in * cols * 8;
     const size_t full = (size_t)cap * cols * 8 + tmp + scratch;
     FmeLds f;
-    if (full <= 32 * 1024) { f.cap_lds = cap; f.lds = full; return f; }
-    const long avail = 32 * 1024 - (long)tmp - (long)scratch;
-    const int part = avail > 0 ? (int)(avail / ((long)cols * 8)) : 0;
-    const int typical = cap_in * cap_in / 10 + cap_in / 2;
-    if (part >= typical && (size_t)part * cols >= (size_t)cap_in && part < cap) {
-        f.cap_lds = part; f.lds = (size_t)part * cols * 8 + tmp + scratch; return f;
-    }
-    if (full <= 64 * 1024) { f.cap_lds = cap; f.lds = full; return f; }
-    f.cap_lds = 0; f.lds = tmp + scratch;
+    if (full <= (size_t)full_kb * 1024) { f.cap_lds = cap; f.lds = full; return f; }
+    f.cap_lds = (cap_in + cols - 1) / cols;                       // room for one factor per input row
+    if (f.cap_lds > cap) f.cap_lds = cap;
+    f.lds = (size_t)f.cap_lds * cols * 8 + tmp + scratch;
     return f;
 }
 // d_outs must be zeroed by the caller where it wants zeros past a result's last row (the host form does).
