@@ -730,17 +730,10 @@ template <class S> __host__ __device__ inline size_t small_lds_bytes(int R, int 
     return (b + 15) & ~(size_t)15;
 }
 
-template <class S> __global__ __launch_bounds__(256, 4) void k_batch(int nb, const S * tgtf, const S * leq, int m, int cols,
-                                           int is_max, unsigned max_iter, int32_t * out_status,
-                                           S * out_v, S * out_sol, uint32_t * out_pivots, int raw_sol)
+// The LDS arrays of one LP with at most R rows and V variables (small_lds_bytes is their size).
+template <class S> __device__ __forceinline__ void sm_carve(Small<S> & P, unsigned char * lds, int R, int V)
 {
-    const bool getenv_closes = (raw_sol & 2) != 0;     // profiling: report disableNV iterations instead
-    raw_sol &= 1;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int n = cols - 1;
-    const int R = is_max ? m : n, V = is_max ? n : m;
     const int Wmax = V + 1 + R + 1, nmax = Wmax - 1;
-    Small<S> P;
     unsigned char * p = lds;
     P.tab = (S *)p; p += (size_t)R * Wmax * 8;
     P.obj = (S *)p; p += (size_t)Wmax * 8;
@@ -759,59 +752,84 @@ template <class S> __global__ __launch_bounds__(256, 4) void k_batch(int nb, con
     P.nv = (uint8_t *)p; p += (size_t)((nmax + 3) & ~3);
     P.bv = (uint8_t *)p;
     P.ld = Wmax;
+}
+
+// One LP by the whole workgroup: SIX::maxm / minm of an x >= 0, inequality-only problem (src: m rows, cols - 1
+// variables + constant), stage 1 included. Returns the SIX status (or XPG_ERR_REF_UNDEFINED). On status 0 the
+// solution goes to sol[0 .. cols) (global; raw_sol: entries not reduced, the caller finishes calcFinalSolution
+// itself) and the objective to *v_out; otherwise *v_out = 0 and sol is left alone.
+template <class S> __device__ __forceinline__ int sm_solve_lp(Small<S> & P, Source<S> & src, unsigned max_iter, int raw_sol,
+                                                              S * sol, S * v_out)
+{
+    const int m = src.m, cols = src.cols, is_max = src.is_max, n = cols - 1;
+    const int R = is_max ? m : n, V = is_max ? n : m;
+    P.pivots = 0; P.closes = 0;
+    __syncthreads();
+    // stage1 trigger (lpsol.h:1794-1803)
+    if (threadIdx.x == 0) { P.sh_w[3] = 0; P.sh_w[4] = 0; P.sh_w[5] = 0; }
+    __syncthreads();
+    if (!is_f64<S>::value) {                       // one non-canonical input cell sends the LP down the generic forms
+        bool bad = false;
+        for (int t = threadIdx.x; t < m * cols; t += blockDim.x) bad |= !q_canonical(src.leq[t]);
+        for (int t = threadIdx.x; t < cols; t += blockDim.x) bad |= !q_canonical(src.tgtf[t]);
+        if (bad) P.sh_w[5] = 1;
+        __syncthreads();
+    }
+    P.cn = src.cn = !is_f64<S>::value && P.sh_w[5] == 0;
+    for (int j = threadIdx.x; j < V; j += blockDim.x) if (gt(src.c(j), zero<S>())) P.sh_w[3] = 1;
+    for (int i = threadIdx.x; i < R; i += blockDim.x) if (lt(src.b(i), zero<S>())) P.sh_w[4] = 1;
+    __syncthreads();
+    const bool phase1 = !P.sh_w[3] || P.sh_w[4];
+    __syncthreads();
+    int status = -1;
+    if (phase1) {
+        const int ok = sm_phase_one<S>(P, src, max_iter);
+        if (ok == 0) status = 2;
+        else if (ok < 0) status = XPG_ERR_REF_UNDEFINED;
+    } else {
+        sm_build(P, src, 0);
+    }
+    S top = zero<S>();
+    if (status == -1) status = sm_solve<S>(P, max_iter, top);
+    // SIX::calcFinalSolution (lpsol.h:1851-1899) / minm read-out (lpsol.h:1713-1716)
+    if (status == 0) {
+        for (int j = threadIdx.x; j < n; j += blockDim.x) {
+            S val = is_max ? P.x[j] : neg(P.obj[m + j]);
+            P.e[j] = val;
+            if (!raw_sol) reduce(val);          // raw_sol: the host finishes calcFinalSolution itself
+            sol[j] = val;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            sol[n] = one<S>();
+            S v = zero<S>();
+            for (int j = 0; j < n; j++) v = q_fma(P.cn, v, P.e[j], src.tgtf[j]);
+            v = q_fma(P.cn, v, one<S>(), src.tgtf[n]);
+            reduce(v);
+            *v_out = v;
+        }
+    } else if (threadIdx.x == 0) {
+        *v_out = zero<S>();
+    }
+    __syncthreads();
+    return status;
+}
+
+template <class S> __global__ __launch_bounds__(256, 4) void k_batch(int nb, const S * tgtf, const S * leq, int m, int cols,
+                                           int is_max, unsigned max_iter, int32_t * out_status,
+                                           S * out_v, S * out_sol, uint32_t * out_pivots, int raw_sol)
+{
+    const bool getenv_closes = (raw_sol & 2) != 0;     // profiling: report disableNV iterations instead
+    raw_sol &= 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int n = cols - 1;
+    Small<S> P;
+    sm_carve(P, lds, is_max ? m : n, is_max ? n : m);
     for (int lp = blockIdx.x; lp < nb; lp += gridDim.x) {
         Source<S> src;
         src.leq = leq + (size_t)lp * m * cols; src.tgtf = tgtf + (size_t)lp * cols;
         src.m = m; src.cols = cols; src.is_max = is_max;
-        P.pivots = 0; P.closes = 0;
-        __syncthreads();
-        // stage1 trigger (lpsol.h:1794-1803)
-        if (threadIdx.x == 0) { P.sh_w[3] = 0; P.sh_w[4] = 0; P.sh_w[5] = 0; }
-        __syncthreads();
-        if (!is_f64<S>::value) {                       // one non-canonical input cell sends the LP down the generic forms
-            bool bad = false;
-            for (int t = threadIdx.x; t < m * cols; t += blockDim.x) bad |= !q_canonical(src.leq[t]);
-            for (int t = threadIdx.x; t < cols; t += blockDim.x) bad |= !q_canonical(src.tgtf[t]);
-            if (bad) P.sh_w[5] = 1;
-            __syncthreads();
-        }
-        P.cn = src.cn = !is_f64<S>::value && P.sh_w[5] == 0;
-        for (int j = threadIdx.x; j < V; j += blockDim.x) if (gt(src.c(j), zero<S>())) P.sh_w[3] = 1;
-        for (int i = threadIdx.x; i < R; i += blockDim.x) if (lt(src.b(i), zero<S>())) P.sh_w[4] = 1;
-        __syncthreads();
-        const bool phase1 = !P.sh_w[3] || P.sh_w[4];
-        __syncthreads();
-        int status = -1;
-        if (phase1) {
-            const int ok = sm_phase_one<S>(P, src, max_iter);
-            if (ok == 0) status = 2;
-            else if (ok < 0) status = XPG_ERR_REF_UNDEFINED;
-        } else {
-            sm_build(P, src, 0);
-        }
-        S top = zero<S>();
-        if (status == -1) status = sm_solve<S>(P, max_iter, top);
-        // SIX::calcFinalSolution (lpsol.h:1851-1899) / minm read-out (lpsol.h:1713-1716)
-        if (status == 0) {
-            S * sol = out_sol + (size_t)lp * cols;
-            for (int j = threadIdx.x; j < n; j += blockDim.x) {
-                S val = is_max ? P.x[j] : neg(P.obj[m + j]);
-                P.e[j] = val;
-                if (!raw_sol) reduce(val);          // raw_sol: the host finishes calcFinalSolution itself
-                sol[j] = val;
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                sol[n] = one<S>();
-                S v = zero<S>();
-                for (int j = 0; j < n; j++) v = q_fma(P.cn, v, P.e[j], src.tgtf[j]);
-                v = q_add(P.cn, v, q_mul(P.cn, one<S>(), src.tgtf[n]));
-                reduce(v);
-                out_v[lp] = v;
-            }
-        } else if (threadIdx.x == 0) {
-            out_v[lp] = zero<S>();
-        }
+        const int status = sm_solve_lp<S>(P, src, max_iter, raw_sol, out_sol + (size_t)lp * cols, out_v + lp);
         if (threadIdx.x == 0) {
             out_status[lp] = status;
             if (out_pivots) out_pivots[lp] = getenv_closes ? P.closes : P.pivots;

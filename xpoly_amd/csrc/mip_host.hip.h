@@ -22,6 +22,7 @@
 #include <vector>
 #include "six_host.hip.h"
 #include "lineq_host.hip.h"
+#include "mip_kernels.hip.h"
 
 namespace xpg {
 
@@ -352,6 +353,48 @@ int mip_solve(xpg_ctx * ctx, int kind, bool is_max, bool is_bin, const S * tgtf,
     return T.final_status;
 }
 
+// The same batch with the tree walks on the device (mip_kernels.hip.h): one workgroup per problem. Returns
+// XPG_ERR_UNSUPPORTED where a node LP of the deepest path would not fit the LDS budget -- the caller then takes the
+// host controller below.
+template <class S>
+int mip_batch_device(xpg_ctx * ctx, int nb, bool is_max, bool is_bin, const S * tgtf, const S * leq, int leq_rows,
+                     int cols, int32_t * out_status, S * out_v, S * out_sol, long long * out_nodes)
+{
+    const int n = cols - 1;
+    const int rmax = leq_rows + (is_bin ? 0 : n);         // integer branching appends one row per ancestor
+    const int depth = n + 2;
+    const int R = is_max ? rmax : n, V = is_max ? n : rmax;
+    const size_t lds = small_lds_bytes<S>(R, V);
+    if (lds > 64 * 1024) return XPG_ERR_UNSUPPORTED;
+    const int cells = R * (V + R + 2);
+    const int threads = cells >= 2048 ? 256 : (cells >= 1024 ? 128 : 64);
+    const int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
+    int grid = (ctx->num_cus > 0 ? ctx->num_cus : 256) * (per_cu > 8 ? 8 : per_cu) * 4;
+    if (grid > nb) grid = nb;
+    const size_t ws_words = mip_ws_words(rmax, cols, depth);
+    const size_t bl = (size_t)nb * leq_rows * cols * 8, bt = (size_t)nb * cols * 8;
+    DevBuf dl, dt, dws, dst, dv, dsol, dn;
+    XPG_TRY(dl.alloc(ctx, bl)); XPG_TRY(dt.alloc(ctx, bt)); XPG_TRY(dws.alloc(ctx, (size_t)grid * ws_words * 8));
+    XPG_TRY(dst.alloc(ctx, (size_t)nb * 4)); XPG_TRY(dv.alloc(ctx, (size_t)nb * 8)); XPG_TRY(dsol.alloc(ctx, bt));
+    XPG_TRY(dn.alloc(ctx, (size_t)nb * 4));
+    XPG_TRY(hipMemcpyAsync(dl.p, leq, bl, hipMemcpyHostToDevice, ctx->stream));
+    XPG_TRY(hipMemcpyAsync(dt.p, tgtf, bt, hipMemcpyHostToDevice, ctx->stream));
+    if (out_sol) XPG_TRY(hipMemcpyAsync(dsol.p, out_sol, bt, hipMemcpyHostToDevice, ctx->stream));
+    XPG_TRY(hipFuncSetAttribute((const void *)k_mip_tree<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_mip_tree<S>), dim3(grid), dim3(threads), lds, ctx->stream, nb, (const S *)dt.p, (const S *)dl.p,
+                       leq_rows, cols, is_max ? 1 : 0, is_bin ? 1 : 0, rmax, depth, (unsigned long long *)dws.p, ws_words,
+                       (int32_t *)dst.p, (S *)dv.p, out_sol ? (S *)dsol.p : (S *)0, (int *)dn.p);
+    XPG_TRY(hipGetLastError());
+    std::vector<int32_t> nodes((size_t)nb);
+    XPG_TRY(hipMemcpyAsync(out_status, dst.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+    XPG_TRY(hipMemcpyAsync(out_v, dv.p, (size_t)nb * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_sol) XPG_TRY(hipMemcpyAsync(out_sol, dsol.p, bt, hipMemcpyDeviceToHost, ctx->stream));
+    XPG_TRY(hipMemcpyAsync(nodes.data(), dn.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+    XPG_TRY(hipStreamSynchronize(ctx->stream));
+    if (out_nodes) { long long t = 0; for (int b = 0; b < nb; b++) t += nodes[(size_t)b]; *out_nodes = t; }
+    return 0;
+}
+
 // nb independent MIPs of one shape (x >= 0, inequalities only), advanced together.
 template <class S>
 int mip_batch(xpg_ctx * ctx, int kind, int nb, bool is_max, bool is_bin, const S * tgtf, const S * leq, int leq_rows,
@@ -359,6 +402,12 @@ int mip_batch(xpg_ctx * ctx, int kind, int nb, bool is_max, bool is_bin, const S
 {
     if (!ctx || nb < 0 || !tgtf || !leq || leq_rows <= 0 || cols < 2 || !out_status || !out_v) return XPG_ERR_SHAPE;
     if (nb == 0) return 0;
+    // the whole tree walk on the device where the node LPs fit (XPG_MIP_DEVICE=0: the host controller, for A/B runs)
+    static const bool on_device = [] { const char * e = getenv("XPG_MIP_DEVICE"); return !(e && e[0] == '0'); }();
+    if (on_device) {
+        const int rc = mip_batch_device<S>(ctx, nb, is_max, is_bin, tgtf, leq, leq_rows, cols, out_status, out_v, out_sol, out_nodes);
+        if (rc != XPG_ERR_UNSUPPORTED) return rc;
+    }
     const int rhs = cols - 1;
     std::vector<S> vc((size_t)rhs * cols, zero<S>());
     for (int i = 0; i < rhs; i++) vc[(size_t)i * cols + i] = minus_one<S>();

@@ -1,0 +1,269 @@
+// MIP<Mat,T>::RecusivePart (src/com/lpsol.h:2427-2612) for a batch of independent problems, one WORKGROUP per
+// problem and the whole depth-first tree walk on the device: the node's problem is rebuilt from the root and the
+// branch rows of the path, normalised as SIX::normalize would (for 0-1 problems that is convertEq2Ineq's
+// substitution of the branch equalities, lpsol.h:1197-1278, quirks included), solved in LDS by the same code the
+// batch kernel runs (sm_solve_lp), and the answer is fed to the reference's recursion written as a stack machine
+// -- the very logic of MipTask::on_lp (mip_host.hip.h), statement for statement, run by thread 0 on state that
+// lives in a per-problem workspace in HBM.
+//
+// Why: with the tree walk on the host a batch advances in lock-step rounds -- normalise on the host, one launch,
+// feed back on the host -- and at 4-5 nodes per tree the host half and the rounds' tails cost more than the node
+// LPs (1024 knapsacks of 24 variables: 22-29 ms, against 13 ms for the oracle on all 256 host cores). Here a tree
+// never leaves its workgroup and the trees do not wait for each other.
+//
+// Scope: x >= 0, inequalities only at the root (xpg_mip_batch_*: the caller's vc is -I), binary or integer
+// branching, no rational_indicator. Anything else keeps the host controller.
+#pragma once
+#include "batch_kernels.hip.h"
+
+namespace xpg {
+
+// Per-problem workspace, in units of 8 bytes (S and long long are both 8): see mip_ws_words.
+template <class S> struct MipWs {
+    S * L;            // [rmax][cols]  the node's inequalities
+    S * y;            // [cols]        raw LP solution of the node
+    S * sol;          // [cols]        the recursion's by-reference solution
+    S * best_sol;     // [cols]
+    S * kept_sol;     // [depth][cols] per frame
+    S * kept_v;       // [depth]
+    S * vals;         // v, best_v
+    int * frame;      // [depth][6]: stage, col, lo, hi, kept, -
+    int * forks;      // [cols]
+    int * ctl;        // have_best, top, nodes, final_status
+};
+__host__ __device__ inline size_t mip_ws_words(int rmax, int cols, int depth)
+{
+    size_t w = (size_t)rmax * cols + 3 * (size_t)cols + (size_t)depth * cols + depth + 2;
+    w += ((size_t)depth * 6 + cols + 8 + 1) / 2;
+    return (w + 1) & ~(size_t)1;
+}
+template <class S> __device__ __forceinline__ MipWs<S> mip_ws_carve(unsigned long long * base, int rmax, int cols, int depth)
+{
+    MipWs<S> w;
+    S * p = (S *)base;
+    w.L = p; p += (size_t)rmax * cols;
+    w.y = p; p += cols;
+    w.sol = p; p += cols;
+    w.best_sol = p; p += cols;
+    w.kept_sol = p; p += (size_t)depth * cols;
+    w.kept_v = p; p += depth;
+    w.vals = p; p += 2;
+    int * q = (int *)p;
+    w.frame = q; q += depth * 6;
+    w.forks = q; q += cols;
+    w.ctl = q;
+    return w;
+}
+
+enum { MF_STAGE = 0, MF_COL = 1, MF_LO = 2, MF_HI = 3, MF_KEPT = 4 };
+enum { MC_HAVE_BEST = 0, MC_TOP = 1, MC_NODES = 2, MC_FINAL = 3 };
+
+__device__ __forceinline__ bool mip_int_cast_ok(F64) { return true; }
+__device__ __forceinline__ bool mip_int_cast_ok(R32 a) { return a.den != 0; }
+
+// The node's problem (MipTask::push_branch + normalize_host): root inequalities, then -- integer branching -- one
+// bound row per ancestor, or -- 0-1 branching -- the ancestors' equalities x_col = b substituted into the
+// inequalities column by column (fold_eq of six_host.hip.h; every branch equality has one variable, so each is
+// "the only nonzero of its column" and none is left to become a pair of inequalities). All threads; returns the
+// row count, or a negative status where the reference's behaviour is undefined.
+template <class S> __device__ int mip_build_node(const MipWs<S> & w, const S * root_leq, int leq_rows, int cols, bool is_bin,
+                                                  int top, int * sh_flag)
+{
+    const int rhs0 = cols - 1;
+    for (int t = threadIdx.x; t < leq_rows * cols; t += blockDim.x) w.L[t] = root_leq[t];
+    if (threadIdx.x == 0) *sh_flag = 0;
+    int rows = leq_rows;
+    if (!is_bin) {
+        for (int f = 0; f < top; f++) {                      // frame f's child row (lpsol.h:2514-2520, :2555-2559)
+            const int * fr = w.frame + f * 6;
+            const bool ceiling = fr[MF_STAGE] == 2;
+            for (int j = threadIdx.x; j < cols; j += blockDim.x) {
+                S val = zero<S>();
+                if (j == fr[MF_COL]) val = ceiling ? minus_one<S>() : one<S>();
+                if (j == rhs0) val = S::from_int(ceiling ? -fr[MF_HI] : fr[MF_LO]);
+                w.L[(size_t)rows * cols + j] = val;
+            }
+            rows++;
+        }
+        __syncthreads();
+        return rows;
+    }
+    __syncthreads();
+    for (int j = 0; j < rhs0; j++) {                         // convertEq2Ineq, lpsol.h:1218-1262
+        int at = -1;
+        for (int f = 0; f < top; f++) if (w.frame[f * 6 + MF_COL] == j) { at = f; break; }
+        if (at < 0) continue;
+        const int * fr = w.frame + at * 6;
+        const S b = S::from_int(fr[MF_STAGE] == 2 ? fr[MF_HI] : fr[MF_LO]);   // lpsol.h:2506-2512, :2548-2553
+        for (int q = threadIdx.x; q < rows; q += blockDim.x) {
+            S * Lq = w.L + (size_t)q * cols;
+            const S coef = Lq[j];
+            if (eq(coef, zero<S>())) continue;
+            if (q >= cols) { *sh_flag = 1; continue; }       // the reference reads the equality at the ROW's index
+            // the equality row: 1 in column j, b in the constant column
+            const S lead = q == j ? one<S>() : (q == rhs0 ? b : zero<S>());
+            const bool rescale = ne(lead, one<S>());
+            const S x1 = rescale ? div(one<S>(), lead) : one<S>();
+            const int m1 = rescale ? scale_mode(x1) : SCALE_KEEP, m2 = scale_mode(coef);
+            Lq[j] = zero<S>();
+            for (int k = 0; k < cols; k++) {
+                S t = k == j ? one<S>() : (k == rhs0 ? b : zero<S>());
+                t = scaled(t, x1, m1);
+                t = scaled(t, coef, m2);
+                if (k >= rhs0) t = neg(t);
+                Lq[k] = add(t, Lq[k]);
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    return *sh_flag ? XPG_ERR_REF_UNDEFINED : rows;
+}
+
+// MipTask::on_lp: feeds the node's answer to the recursion and runs it until the next LP is needed (returns
+// false) or the tree ends (returns true, ctl[MC_FINAL] set). Thread 0 only.
+template <class S> __device__ bool mip_feed(const MipWs<S> & w, const S * tgtf, int cols, bool is_max, bool is_bin, int st)
+{
+    const int n0 = cols - 1;
+    int top = w.ctl[MC_TOP];
+    S v = zero<S>();
+    int ret;
+    {
+        int * f = w.frame + top * 6;
+        if (st == XPG_SIX_SUCC) {                            // finish_host (SIX::calcFinalSolution, lpsol.h:1851-1899)
+            for (int j = 0; j < n0; j++) w.sol[j] = w.y[j];
+            w.sol[n0] = one<S>();
+            for (int j = 0; j < cols; j++) v = add(v, mul(w.sol[j], tgtf[j]));
+            reduce(v);
+            for (int j = 0; j < cols; j++) { S t = w.sol[j]; reduce(t); w.sol[j] = t; }
+        }
+        if (st < 0) ret = st;
+        else if (st == XPG_SIX_UNBOUND) ret = XPG_IP_UNBOUND;
+        else if (st == XPG_SIX_TIME_OUT) ret = XPG_ERR_REF_UNDEFINED;         // UNREACH() in the reference
+        else if (st != XPG_SIX_SUCC) ret = XPG_IP_NO_PRI_FEASIBLE_SOL;
+        else {
+            int col = 0;
+            bool sat = true;                                 // MIP::is_satisfying (lpsol.h:2364-2408)
+            for (int j = 0; j < cols; j++) {
+                S t = w.sol[j];
+                if (is_bin) { reduce(t); w.sol[j] = t; }
+                const bool bad = is_bin ? (ne(t, zero<S>()) && ne(t, one<S>())) : !is_int(t);
+                if (bad) { col = j; sat = false; break; }
+            }
+            const bool have_best = w.ctl[MC_HAVE_BEST] != 0;
+            const S best_v = w.vals[1];
+            if (sat) ret = XPG_IP_SUCC;
+            else if (have_best && (is_max ? le(v, best_v) : ge(v, best_v))) ret = XPG_IP_NO_BETTER_THAN_BEST_SOL;
+            else if (w.forks[col] >= 1) ret = XPG_IP_NO_PRI_FEASIBLE_SOL;                  // lpsol.h:2486-2496
+            else if (!is_bin && !mip_int_cast_ok(w.sol[col])) ret = XPG_ERR_REF_UNDEFINED;
+            else {
+                w.forks[col] += 1;
+                f[MF_COL] = col; f[MF_LO] = 0; f[MF_HI] = 1;
+                if (!is_bin) { f[MF_LO] = to_int(w.sol[col]); f[MF_HI] = f[MF_LO] + 1; }
+                f[MF_STAGE] = 1;
+                int * c = w.frame + (top + 1) * 6;           // push_branch(floor)
+                c[MF_STAGE] = 0; c[MF_COL] = 0; c[MF_LO] = 0; c[MF_HI] = 1; c[MF_KEPT] = 0;
+                w.kept_v[top + 1] = zero<S>();
+                w.ctl[MC_TOP] = top + 1;
+                w.vals[0] = v;
+                return false;
+            }
+        }
+    }
+    for (;;) {                                               // hand `ret` to the callers up the stack
+        top -= 1;
+        if (top < 0) { w.ctl[MC_FINAL] = ret; w.ctl[MC_TOP] = 0; w.vals[0] = v; return true; }
+        int * p = w.frame + top * 6;
+        if (ret < 0) continue;
+        if (p[MF_STAGE] == 1) {                              // floor branch came back, lpsol.h:2527-2543
+            if (ret == XPG_IP_SUCC) {
+                for (int j = 0; j < cols; j++) w.kept_sol[(size_t)top * cols + j] = w.sol[j];
+                w.kept_v[top] = v; p[MF_KEPT] = 1;
+                const bool have_best = w.ctl[MC_HAVE_BEST] != 0;                           // remember()
+                if (!have_best || (is_max ? lt(w.vals[1], v) : gt(w.vals[1], v))) {
+                    for (int j = 0; j < cols; j++) w.best_sol[j] = w.sol[j];
+                    w.vals[1] = v; w.ctl[MC_HAVE_BEST] = 1;
+                }
+            }
+            p[MF_STAGE] = 2;
+            int * c = w.frame + (top + 1) * 6;               // push_branch(ceiling)
+            c[MF_STAGE] = 0; c[MF_COL] = 0; c[MF_LO] = 0; c[MF_HI] = 1; c[MF_KEPT] = 0;
+            w.kept_v[top + 1] = zero<S>();
+            w.ctl[MC_TOP] = top + 1;
+            w.vals[0] = v;
+            return false;
+        }
+        bool rem = false;
+        if (ret == XPG_IP_SUCC) {                            // ceiling branch came back, lpsol.h:2563-2611
+            if (p[MF_KEPT] && (is_max ? gt(w.kept_v[top], v) : lt(w.kept_v[top], v))) {
+                v = w.kept_v[top];
+                for (int j = 0; j < cols; j++) w.sol[j] = w.kept_sol[(size_t)top * cols + j];
+            }
+            rem = true;
+        } else if (p[MF_KEPT]) {
+            v = w.kept_v[top];
+            for (int j = 0; j < cols; j++) w.sol[j] = w.kept_sol[(size_t)top * cols + j];
+            rem = true; ret = XPG_IP_SUCC;
+        }
+        if (rem) {
+            const bool have_best = w.ctl[MC_HAVE_BEST] != 0;
+            if (!have_best || (is_max ? lt(w.vals[1], v) : gt(w.vals[1], v))) {
+                for (int j = 0; j < cols; j++) w.best_sol[j] = w.sol[j];
+                w.vals[1] = v; w.ctl[MC_HAVE_BEST] = 1;
+            }
+        }
+    }
+}
+
+template <class S> __global__ __launch_bounds__(256, 2)
+void k_mip_tree(int nb, const S * tgtf_all, const S * leq_all, int leq_rows, int cols, int is_max, int is_bin, int rmax,
+                int depth, unsigned long long * ws_all, size_t ws_words, int32_t * out_status, S * out_v, S * out_sol,
+                int * out_nodes)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    __shared__ int sh_ctl[4];
+    const int n = cols - 1;
+    Small<S> P;
+    sm_carve(P, lds, is_max ? rmax : n, is_max ? n : rmax);
+    for (int b = blockIdx.x; b < nb; b += gridDim.x) {
+        const S * tgtf = tgtf_all + (size_t)b * cols;
+        const S * root = leq_all + (size_t)b * leq_rows * cols;
+        const MipWs<S> w = mip_ws_carve<S>(ws_all + (size_t)blockIdx.x * ws_words, rmax, cols, depth);
+        // MipTask::start
+        for (int j = threadIdx.x; j < cols; j += blockDim.x) w.forks[j] = 0;
+        if (threadIdx.x == 0) {
+            w.ctl[MC_HAVE_BEST] = 0; w.ctl[MC_TOP] = 0; w.ctl[MC_NODES] = 0; w.ctl[MC_FINAL] = 0;
+            w.vals[0] = zero<S>(); w.vals[1] = zero<S>();
+            int * f = w.frame;
+            f[MF_STAGE] = 0; f[MF_COL] = 0; f[MF_LO] = 0; f[MF_HI] = 1; f[MF_KEPT] = 0;
+            w.kept_v[0] = zero<S>();
+        }
+        __syncthreads();
+        for (;;) {
+            const int top = w.ctl[MC_TOP];
+            __syncthreads();
+            if (threadIdx.x == 0) w.ctl[MC_NODES] += 1;
+            int st = mip_build_node<S>(w, root, leq_rows, cols, is_bin != 0, top, &sh_ctl[1]);
+            if (st >= 0) {
+                Source<S> src;
+                src.leq = w.L; src.tgtf = tgtf; src.m = st; src.cols = cols; src.is_max = is_max;
+                __shared__ unsigned long long sh_v;              // the node's own objective: recomputed by mip_feed
+                st = sm_solve_lp<S>(P, src, 10000u, /*raw_sol=*/1, w.y, (S *)&sh_v);
+            }
+            if (threadIdx.x == 0) sh_ctl[0] = mip_feed<S>(w, tgtf, cols, is_max != 0, is_bin != 0, st) ? 1 : 0;
+            __syncthreads();
+            if (sh_ctl[0]) break;
+        }
+        if (threadIdx.x == 0) {
+            const int fin = w.ctl[MC_FINAL];
+            out_status[b] = fin;
+            out_v[b] = w.vals[0];
+            out_nodes[b] = w.ctl[MC_NODES];
+        }
+        if (w.ctl[MC_FINAL] == XPG_IP_SUCC && out_sol)
+            for (int j = threadIdx.x; j < cols; j += blockDim.x) out_sol[(size_t)b * cols + j] = w.sol[j];
+        __syncthreads();
+    }
+}
+
+} // namespace xpg
