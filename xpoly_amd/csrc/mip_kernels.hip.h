@@ -55,6 +55,14 @@ template <class S> __device__ __forceinline__ MipWs<S> mip_ws_carve(unsigned lon
     return w;
 }
 
+#ifdef XPG_STAMPS
+__device__ unsigned long long g_mip_ticks[4];                 // diagnostic builds: 100 MHz ticks in build / solve / feed, summed over nodes
+#define MIP_T0 unsigned long long mt_ = wall_clock64();
+#define MIP_T(k) { const unsigned long long n_ = wall_clock64(); if (threadIdx.x == 0) atomicAdd(&g_mip_ticks[k], n_ - mt_); mt_ = n_; }
+#else
+#define MIP_T0
+#define MIP_T(k)
+#endif
 enum { MF_STAGE = 0, MF_COL = 1, MF_LO = 2, MF_HI = 3, MF_KEPT = 4 };
 enum { MC_HAVE_BEST = 0, MC_TOP = 1, MC_NODES = 2, MC_FINAL = 3 };
 
@@ -243,15 +251,19 @@ void k_mip_tree(int nb, const S * tgtf_all, const S * leq_all, int leq_rows, int
             const int top = w.ctl[MC_TOP];
             __syncthreads();
             if (threadIdx.x == 0) w.ctl[MC_NODES] += 1;
+            MIP_T0
             int st = mip_build_node<S>(w, root, leq_rows, cols, is_bin != 0, top, &sh_ctl[1]);
+            MIP_T(0)
             if (st >= 0) {
                 Source<S> src;
                 src.leq = w.L; src.tgtf = tgtf; src.m = st; src.cols = cols; src.is_max = is_max;
                 __shared__ unsigned long long sh_v;              // the node's own objective: recomputed by mip_feed
                 st = sm_solve_lp<S>(P, src, 10000u, /*raw_sol=*/1, w.y, (S *)&sh_v);
             }
+            MIP_T(1)
             if (threadIdx.x == 0) sh_ctl[0] = mip_feed<S>(w, tgtf, cols, is_max != 0, is_bin != 0, st) ? 1 : 0;
             __syncthreads();
+            MIP_T(2)
             if (sh_ctl[0]) break;
         }
         if (threadIdx.x == 0) {

@@ -360,6 +360,15 @@ int xpg_lp_counters(xpg_lp * lp, unsigned * sweeps_full, unsigned * sweeps_parti
 }
 
 #ifdef XPG_STAMPS
+// diagnostic builds only: reads and clears the tick sums of k_mip_tree (build, solve, feed)
+int xpg_mip_debug(xpg_ctx * ctx, unsigned long long * out4)
+{
+    XPG_BIND(ctx);
+    unsigned long long z[4] = {0};
+    if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_mip_ticks), sizeof(z)) != hipSuccess) return XPG_ERR_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_mip_ticks), z, sizeof(z)) != hipSuccess) return XPG_ERR_HIP;
+    return 0;
+}
 // diagnostic builds only: reads and clears the phase tick sums of k_fme_batch
 int xpg_lineq_debug(xpg_ctx * ctx, unsigned long long * out16)
 {
