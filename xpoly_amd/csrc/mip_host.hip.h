@@ -10,6 +10,7 @@
 // the answers back into the stack machines. A node is a from-scratch SIX solve with
 // max_iter = 10000 (lpsol.h:2441), exactly as in the reference.
 #pragma once
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -353,6 +354,12 @@ int mip_solve(xpg_ctx * ctx, int kind, bool is_max, bool is_bin, const S * tgtf,
     return T.final_status;
 }
 
+// Whether the node LPs of the deepest path fit the device tree walk's LDS budget, maximising and minimising.
+template <class S> inline bool mip_device_fits(int leq_rows, int cols, bool is_bin)
+{
+    const int n = cols - 1, rmax = leq_rows + (is_bin ? 0 : n);
+    return small_lds_bytes<S>(rmax, n) <= 64 * 1024 && small_lds_bytes<S>(n, rmax) <= 64 * 1024;
+}
 // The same batch with the tree walks on the device (mip_kernels.hip.h): one workgroup per problem. Returns
 // XPG_ERR_UNSUPPORTED where a node LP of the deepest path would not fit the LDS budget -- the caller then takes the
 // host controller below.
@@ -518,6 +525,42 @@ inline int dep_is_empty_batch(xpg_ctx * ctx, int nb, const R32 * mats, int rows,
         else { out_empty[b] = 1; open.push_back(b); }
     }
     long nodes = 0;
+    // x >= 0 and inequalities only (the default vc): the integer MIPs of a pass go to the device-side tree walk,
+    // one launch per surviving row count (reduce leaves the systems ragged)
+    static const bool on_device = [] { const char * e = getenv("XPG_MIP_DEVICE"); return !(e && e[0] == '0'); }();
+    bool device_ok = on_device && !vc_in && mip_device_fits<R32>(rows, cols, false);
+    for (int pass = 0; pass < 2 && !open.empty() && device_ok; pass++) {
+        std::map<int, std::vector<int> > by_rows;
+        for (int b : open) by_rows[kept[b]].push_back(b);
+        std::vector<int> still;
+        for (auto & g : by_rows) {
+            const int k = g.first, nbk = (int)g.second.size();
+            std::vector<R32> lq((size_t)nbk * k * cols), tg((size_t)nbk * cols), vv(nbk);
+            std::vector<int32_t> st(nbk);
+            for (int t = 0; t < nbk; t++) {
+                const R32 * leq = work.data() + (size_t)g.second[(size_t)t] * rows * cols;
+                for (size_t e = 0; e < (size_t)k * cols; e++) lq[(size_t)t * k * cols + e] = leq[e];
+                const std::vector<R32> f = feasibility_objective(leq, k, (const R32 *)0, 0, cols, last);
+                for (int j = 0; j < cols; j++) tg[(size_t)t * cols + j] = f[(size_t)j];
+            }
+            long long nn = 0;
+            rc = mip_batch_device<R32>(ctx, nbk, pass == 0, false, tg.data(), lq.data(), k, cols, st.data(), vv.data(), (R32 *)0, &nn);
+            if (rc == XPG_ERR_UNSUPPORTED) { device_ok = false; break; }
+            if (rc) return rc;
+            nodes += (long)nn;
+            for (int t = 0; t < nbk; t++) {
+                const int b = g.second[(size_t)t];
+                if (st[t] < 0) out_empty[b] = st[t];
+                else if (st[t] == XPG_IP_SUCC) out_empty[b] = 0;
+                else still.push_back(b);
+            }
+        }
+        if (!device_ok) break;                               // (nothing of this pass is kept: the host controller redoes it)
+        std::sort(still.begin(), still.end());
+        open.swap(still);
+        if (pass == 1 || open.empty()) { if (out_nodes) *out_nodes = nodes; return 0; }
+    }
+    if (device_ok && open.empty()) { if (out_nodes) *out_nodes = nodes; return 0; }
     for (int pass = 0; pass < 2 && !open.empty(); pass++) {          // maxm, then minm (linsys.cpp:864-876)
         std::vector<MipTask<R32> > tasks(open.size());
         for (size_t t = 0; t < open.size(); t++) {
