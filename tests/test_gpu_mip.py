@@ -162,10 +162,11 @@ def test_six_through_the_hbm_resident_path(ctx, port, kind, monkeypatch):
                 assert np.array_equal(got[2], want[2])
 
 
-def test_mip_batch_with_the_host_thread_pool_matches_the_default(ctx):
-    """XPG_HOST_THREADS > 1 hands the controller's per-tree loops to persistent host threads with static shares
-    (read once per process, so the threaded run is a child process); the trees are independent, so every status,
-    value, solution and the node count must be those of the calling thread alone."""
+def test_mip_batch_host_controller_with_thread_pool_matches_the_device_tree_walk(ctx):
+    """xpg_mip_batch_rat32 walks its trees on the device (one workgroup per problem); XPG_MIP_DEVICE=0 keeps the host
+    controller (lock-step rounds), and XPG_HOST_THREADS > 1 hands that controller's per-tree loops to persistent
+    host threads with static shares. Both knobs are read once per process, so that run is a child process; every
+    status, value, solution and the node count must be the same either way."""
     import subprocess, sys, hashlib
     from xpoly_amd.six import mip_batch
     leq, tgtf = gen.knapsack_batch_rat(300, 12)
@@ -175,7 +176,7 @@ def test_mip_batch_with_the_host_thread_pool_matches_the_default(ctx):
             "ctx = xpoly_amd.Context(0); leq, tgtf = gen.knapsack_batch_rat(300, 12)\n"
             "st, v, sol, nodes = mip_batch(ctx, True, True, tgtf, leq)\n"
             "print(hashlib.sha256(st.tobytes() + v.tobytes() + sol.tobytes()).hexdigest(), nodes)\n")
-    env = dict(os.environ, XPG_HOST_THREADS="3", PYTHONPATH=ROOT)
+    env = dict(os.environ, XPG_HOST_THREADS="3", XPG_MIP_DEVICE="0", PYTHONPATH=ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.strip().splitlines()[-1] == want
