@@ -223,12 +223,17 @@ int xpg_has_solution_rat32(xpg_ctx * ctx, const xpg_rat32 * leq, int leq_rows, c
                            int is_int_sol, int is_unique_sol);
 
 /* Batches: nb independent problems of one shape, x >= 0, inequalities only
- * (tgtf[nb][cols], leq[nb][leq_rows][cols]).  All trees advance in lock step; in each
- * round the node LPs of equal shape share one launch of the LDS-resident kernel.
+ * (tgtf[nb][cols], leq[nb][leq_rows][cols]).  Every tree is walked on the device by one
+ * workgroup (node rebuild, normalisation, LDS solve, the recursion of lpsol.h:2427-2612 as a
+ * stack machine); problems whose node LPs do not fit 64 KB of LDS advance in lock step from the
+ * host instead, the node LPs of a round sharing one launch.
  * out_nodes (may be NULL) receives the total number of node LPs solved. */
 int xpg_mip_batch_rat32(xpg_ctx * ctx, int nb, int is_max, int is_bin, const xpg_rat32 * tgtf,
                         const xpg_rat32 * leq, int leq_rows, int cols, int32_t * out_status,
                         xpg_rat32 * out_v, xpg_rat32 * out_sol, long long * out_nodes);
+int xpg_mip_batch_f64(xpg_ctx * ctx, int nb, int is_max, int is_bin, const double * tgtf,
+                      const double * leq, int leq_rows, int cols, int32_t * out_status,
+                      double * out_v, double * out_sol, long long * out_nodes);
 /* DepPoly::is_empty(keepit, vc = NULL), src/eng/poly.cpp:530-573, for nb dependence polyhedra
  * mats[nb][rows][cols] without constant symbols (constant in the last column):
  * Lineq::reduce pre-filter, then Lineq::has_solution(is_int_sol, is_unique_sol) = MIP::maxm

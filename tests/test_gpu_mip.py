@@ -180,3 +180,33 @@ def test_mip_batch_host_controller_with_thread_pool_matches_the_device_tree_walk
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.strip().splitlines()[-1] == want
+
+
+def test_mip_batch_f64_matches_oracle(ctx, port):
+    """xpg_mip_batch_f64: the device tree walk in Float arithmetic (integer and 0-1 branching, maxm and minm)
+    against MIP<FloatMat,Float> of the oracle, problem by problem."""
+    from xpoly_amd.six import mip_batch
+    rng = np.random.default_rng(23)
+    checked = 0
+    for is_bin in (False, True):
+        for (m, nv) in ((3, 4), (2, 6), (4, 8)):
+            nb = 48
+            probs = [gen.random_mip(rng, 1 if is_bin else m, nv, False) for _ in range(nb)]
+            if is_bin:
+                for p in probs:
+                    ub = np.zeros((nv, nv + 1), dtype=np.int32); ub[np.arange(nv), np.arange(nv)] = 1; ub[:, nv] = 1
+                    p["leq"] = np.concatenate([p["leq"], gen.to_rat(ub)], axis=0)
+            leq = np.stack([p["leq"][..., 0].astype(np.float64) for p in probs])
+            tg = np.stack([p["tgtf"][..., 0].astype(np.float64) for p in probs])
+            vc = probs[0]["vc"][..., 0].astype(np.float64)
+            for is_max in (True, False):
+                st, v, sol, nodes = mip_batch(ctx, is_max, is_bin, tg, leq, kind=F64)
+                assert nodes >= nb
+                for b in range(nb):
+                    want = port.mip_solve(F64, is_max, is_bin, tg[b], vc, None, leq[b])
+                    assert st[b] == want[0], (is_bin, m, nv, is_max, b, st[b], want[0])
+                    assert np.array_equal(np.atleast_1d(v[b]), np.atleast_1d(want[1])), (is_bin, m, nv, is_max, b)
+                    if want[0] == 0:
+                        assert np.array_equal(sol[b], want[2]), (is_bin, m, nv, is_max, b)
+                    checked += 1
+    assert checked == 2 * 3 * 2 * 48

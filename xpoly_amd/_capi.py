@@ -20,7 +20,7 @@ SYMBOLS = [
     "xpg_six_maxm_f64", "xpg_six_minm_f64", "xpg_six_maxm_rat32", "xpg_six_minm_rat32",
     "xpg_six_batch_f64", "xpg_six_batch_rat32", "xpg_six_batch_f64_dev", "xpg_six_batch_rat32_dev",
     "xpg_mip_maxm_rat32", "xpg_mip_minm_rat32", "xpg_mip_maxm_f64", "xpg_mip_minm_f64",
-    "xpg_has_solution_rat32", "xpg_mip_batch_rat32", "xpg_dep_is_empty_batch_rat32",
+    "xpg_has_solution_rat32", "xpg_mip_batch_rat32", "xpg_mip_batch_f64", "xpg_dep_is_empty_batch_rat32",
     "xpg_lineq_reduce_batch_rat32", "xpg_lineq_remove_iden_batch_rat32", "xpg_lineq_fme_batch_rat32",
     "xpg_lineq_calc_bound_batch_rat32", "xpg_lineq_reduce_batch_rat32_dev", "xpg_lineq_fme_batch_rat32_dev",
     "xpg_rat_rank_batch_dev", "xpg_rat_rank_batch", "xpg_rat_det_batch", "xpg_rat_inv_batch",

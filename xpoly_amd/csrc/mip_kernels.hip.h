@@ -8,7 +8,7 @@
 //
 // Why: with the tree walk on the host a batch advances in lock-step rounds -- normalise on the host, one launch,
 // feed back on the host -- and at 4-5 nodes per tree the host half and the rounds' tails cost more than the node
-// LPs (1024 knapsacks of 24 variables: 22-29 ms, against 13 ms for the oracle on all 256 host cores). Here a tree
+// LPs (1024 knapsacks of 24 variables: 22-29 ms, against 13 ms for the reference arithmetic restated on all 256 host cores). Here a tree
 // never leaves its workgroup and the trees do not wait for each other.
 //
 // Scope: x >= 0, inequalities only at the root (xpg_mip_batch_*: the caller's vc is -I), binary or integer

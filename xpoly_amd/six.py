@@ -312,16 +312,16 @@ def mip_warm(ctx, is_max, tgtf, leq, is_bin=False):
     return st, v.value, sol, dict(nodes=stats[0], dual_pivots=stats[1], root_pivots=stats[2], max_depth=stats[3])
 
 
-def mip_batch(ctx, is_max, is_bin, tgtf, leq):
-    """nb independent rational MIPs (x >= 0, inequalities only) advanced in lock step.
-    tgtf [nb, cols(,2)], leq [nb, rows, cols(,2)]. Returns (status[nb], v[nb,2], sol[nb,cols,2], nodes)."""
-    tgtf = as_kind(tgtf, RAT, 2); leq = as_kind(leq, RAT, 3)
+def mip_batch(ctx, is_max, is_bin, tgtf, leq, kind=RAT):
+    """nb independent MIPs (x >= 0, inequalities only), each tree walked on the device by one workgroup.
+    tgtf [nb, cols(,2)], leq [nb, rows, cols(,2)]. Returns (status[nb], v[nb(,2)], sol[nb,cols(,2)], nodes)."""
+    tgtf = as_kind(tgtf, kind, 2); leq = as_kind(leq, kind, 3)
     nb, rows, cols = leq.shape[0], leq.shape[1], leq.shape[2]
-    st = np.zeros(nb, dtype=np.int32); v = empty_kind((nb,), RAT); sol = empty_kind((nb, cols), RAT)
+    st = np.zeros(nb, dtype=np.int32); v = empty_kind((nb,), kind); sol = empty_kind((nb, cols), kind)
     nodes = C.c_longlong()
-    ctx.check(lib().xpg_mip_batch_rat32(ctx._h, C.c_int(nb), C.c_int(int(is_max)), C.c_int(int(is_bin)), vp(tgtf),
-                                        vp(leq), C.c_int(rows), C.c_int(cols), vp(st), vp(v), vp(sol),
-                                        C.byref(nodes)), "xpg_mip_batch_rat32")
+    fn = lib().xpg_mip_batch_rat32 if kind == RAT else lib().xpg_mip_batch_f64
+    ctx.check(fn(ctx._h, C.c_int(nb), C.c_int(int(is_max)), C.c_int(int(is_bin)), vp(tgtf),
+                 vp(leq), C.c_int(rows), C.c_int(cols), vp(st), vp(v), vp(sol), C.byref(nodes)), "xpg_mip_batch")
     return st, v, sol, nodes.value
 
 
