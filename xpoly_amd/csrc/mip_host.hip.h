@@ -333,6 +333,11 @@ template <class S> int run_mip_tasks(xpg_ctx * ctx, int kind, std::vector<MipTas
     }
 }
 
+template <class S> inline bool mip_device_fits(int leq_rows, int cols, bool is_bin);
+template <class S>
+int mip_batch_device(xpg_ctx * ctx, int nb, bool is_max, bool is_bin, const S * tgtf, const S * leq, int leq_rows,
+                     int cols, int32_t * out_status, S * out_v, S * out_sol, long long * out_nodes);
+
 // MIP::maxm / minm (lpsol.h:2636-2657, :2681-2702).
 template <class S>
 int mip_solve(xpg_ctx * ctx, int kind, bool is_max, bool is_bin, const S * tgtf, const S * vc, int vc_rows,
@@ -342,6 +347,26 @@ int mip_solve(xpg_ctx * ctx, int kind, bool is_max, bool is_bin, const S * tgtf,
     if (!ctx || !tgtf || !vc || !out_v || cols < 2 || vc_rows != cols - 1 || eq_rows < 0 || leq_rows < 0 ||
         (eq_rows == 0 && leq_rows == 0) || (eq_rows > 0 && !eqs) || (leq_rows > 0 && !leq))
         return XPG_ERR_SHAPE;
+    // the plain case (x >= 0, inequalities only, no rational_indicator) is what the device tree walk takes
+    static const bool on_device = [] { const char * e = getenv("XPG_MIP_DEVICE"); return !(e && e[0] == '0'); }();
+    if (on_device && eq_rows == 0 && !allow_rational && leq_rows > 0 && mip_device_fits<S>(leq_rows, cols, is_bin)) {
+        bool plain = true;
+        for (int i = 0; i < vc_rows && plain; i++)
+            for (int j = 0; j < cols && plain; j++)
+                plain = eq(vc[(size_t)i * cols + j], i == j ? minus_one<S>() : zero<S>());
+        if (plain) {
+            int32_t st = 0; long long nodes = 0;
+            std::vector<S> sol((size_t)cols, zero<S>());
+            if (out_sol) for (int j = 0; j < cols; j++) sol[(size_t)j] = out_sol[j];
+            const int rc = mip_batch_device<S>(ctx, 1, is_max, is_bin, tgtf, leq, leq_rows, cols, &st, out_v, sol.data(), &nodes);
+            if (rc != XPG_ERR_UNSUPPORTED) {
+                if (rc) return rc;
+                if (st == XPG_IP_SUCC && out_sol) for (int j = 0; j < cols; j++) out_sol[j] = sol[(size_t)j];
+                if (out_nodes) *out_nodes = (long)nodes;
+                return st;
+            }
+        }
+    }
     std::vector<MipTask<S> > tasks(1);
     tasks[0].start(make_problem(tgtf, vc, vc_rows, eqs, eq_rows, leq, leq_rows, cols), is_max, is_bin, allow_rational);
     int rc = run_mip_tasks(ctx, kind, tasks);
