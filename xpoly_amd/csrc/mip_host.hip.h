@@ -399,7 +399,11 @@ int mip_batch_device(xpg_ctx * ctx, int nb, bool is_max, bool is_bin, const S * 
     const size_t lds = small_lds_bytes<S>(R, V);
     if (lds > 64 * 1024) return XPG_ERR_UNSUPPORTED;
     const int cells = R * (V + R + 2);
-    const int threads = cells >= 2048 ? 256 : (cells >= 1024 ? 128 : 64);
+    int threads = cells >= 2048 ? 256 : (cells >= 1024 ? 128 : 64);
+    // more trees than the chip holds at that width: one wave per tree, more trees in flight (8192 knapsacks of 24
+    // variables: 64 / 128 / 256 threads 623 k / 425 k / 318 k MIPs/s; at 1024, where the deepest tree decides, 163 / 171 / 170 k)
+    if (nb >= 8 * (ctx->num_cus > 0 ? ctx->num_cus : 256)) threads = 64;
+    if (const char * t = getenv("XPG_BATCH_THREADS")) { const int v = atoi(t); if (v >= 64 && v <= 256 && v % 64 == 0) threads = v; }
     const int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
     int grid = (ctx->num_cus > 0 ? ctx->num_cus : 256) * (per_cu > 8 ? 8 : per_cu) * 4;
     if (grid > nb) grid = nb;
