@@ -47,10 +47,36 @@ static int check_division_helpers(long n)
     return 0;
 }
 
+// the divide-free GENERIC operations against the literal ones on arbitrary operands: small and large numerators,
+// denominators that are zero, negative, not coprime -- everything the flat ABI lets through (INT_MIN excepted)
+static R32 draw_any()
+{
+    static const int64_t caps[] = { 1, 3, 10, 1000, 1000000, 0x3fffffff, 0x7fffffff };
+    const int64_t cn = caps[rnd() % 7], cd = caps[rnd() % 7];
+    int64_t n = (int64_t)(rnd() % (uint64_t)(2 * cn + 1)) - cn, d = (int64_t)(rnd() % (uint64_t)(2 * cd + 1)) - cd;
+    if (rnd() % 4 == 0) d = 1;
+    if (rnd() % 11 == 0) d = 0;
+    return R32((int32_t)n, (int32_t)d);
+}
+static int check_generic_forms(long n)
+{
+    for (long it = 0; it < n; it++) {
+        const R32 a = draw_any(), b = draw_any();
+        const R32 m1 = mul(a, b), m2 = mul_any_fast(a, b), s1 = add(a, b), s2 = add_any_fast(a, b), d1 = div(a, b), d2 = div_any_fast(a, b);
+        if (m1.num != m2.num || m1.den != m2.den || s1.num != s2.num || s1.den != s2.den || d1.num != d2.num || d1.den != d2.den) {
+            printf("MISMATCH generic a=%d/%d b=%d/%d mul %d/%d vs %d/%d add %d/%d vs %d/%d div %d/%d vs %d/%d\n", a.num, a.den, b.num, b.den,
+                   m1.num, m1.den, m2.num, m2.den, s1.num, s1.den, s2.num, s2.den, d1.num, d1.den, d2.num, d2.den);
+            return 1;
+        }
+    }
+    return 0;
+}
+
 int main(int argc, char ** argv)
 {
     const long N = argc > 1 ? atol(argv[1]) : 3000000;
     if (check_division_helpers(N)) return 1;
+    if (check_generic_forms(N)) return 1;
     long appro_like = 0, zeros = 0;
     for (long it = 0; it < N; it++) {
         const R32 a = draw(), k = draw(), e = draw();

@@ -111,15 +111,15 @@ template <class S> __device__ int mip_build_node(const MipWs<S> & w, const S * r
             // the equality row: 1 in column j, b in the constant column
             const S lead = q == j ? one<S>() : (q == rhs0 ? b : zero<S>());
             const bool rescale = ne(lead, one<S>());
-            const S x1 = rescale ? div(one<S>(), lead) : one<S>();
+            const S x1 = rescale ? q_div(false, one<S>(), lead) : one<S>();
             const int m1 = rescale ? scale_mode(x1) : SCALE_KEEP, m2 = scale_mode(coef);
             Lq[j] = zero<S>();
             for (int k = 0; k < cols; k++) {
                 S t = k == j ? one<S>() : (k == rhs0 ? b : zero<S>());
-                t = scaled(t, x1, m1);
-                t = scaled(t, coef, m2);
+                t = q_scaled(false, t, x1, m1);
+                t = q_scaled(false, t, coef, m2);
                 if (k >= rhs0) t = neg(t);
-                Lq[k] = add(t, Lq[k]);
+                Lq[k] = q_add(false, t, Lq[k]);
             }
         }
         __syncthreads();
@@ -141,7 +141,7 @@ template <class S> __device__ bool mip_feed(const MipWs<S> & w, const S * tgtf, 
         if (st == XPG_SIX_SUCC) {                            // finish_host (SIX::calcFinalSolution, lpsol.h:1851-1899)
             for (int j = 0; j < n0; j++) w.sol[j] = w.y[j];
             w.sol[n0] = one<S>();
-            for (int j = 0; j < cols; j++) v = add(v, mul(w.sol[j], tgtf[j]));
+            for (int j = 0; j < cols; j++) v = q_add(false, v, q_mul(false, w.sol[j], tgtf[j]));
             reduce(v);
             for (int j = 0; j < cols; j++) { S t = w.sol[j]; reduce(t); w.sol[j] = t; }
         }

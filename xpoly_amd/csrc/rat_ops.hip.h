@@ -2,16 +2,17 @@
 // Every value the reference's Rational can hold is canonical (lowest terms, den > 0), and a problem whose input
 // cells all are -- checked when it is loaded -- stays so under these operations; it takes the 32-bit
 // cross-cancelling forms of scalar.hip.h, which equal the reference's operations bit for bit on such operands
-// (tests/cxx/fma_canon_fuzz.cpp). Any other problem keeps the literal 64-bit restatement, out of line. For Float
-// the flag is ignored.
+// (tests/cxx/fma_canon_fuzz.cpp). Any other problem takes the generic forms -- valid for any (num, den), out of line.
+// For Float the flag is ignored.
 #pragma once
 #include "scalar.hip.h"
 
 namespace xpg {
 
-__device__ __noinline__ R32 add_any(R32 a, R32 b) { return add(a, b); }
-__device__ __noinline__ R32 mul_any(R32 a, R32 b) { return mul(a, b); }
-__device__ __noinline__ R32 div_any(R32 a, R32 b) { return div(a, b); }
+// (the generic forms without a divide: scalar.hip.h, equal to add / mul / div for every operand pair)
+__device__ __noinline__ R32 add_any(R32 a, R32 b) { return add_any_fast(a, b); }
+__device__ __noinline__ R32 mul_any(R32 a, R32 b) { return mul_any_fast(a, b); }
+__device__ __noinline__ R32 div_any(R32 a, R32 b) { return div_any_fast(a, b); }
 __device__ __forceinline__ R32 q_add(bool cn, R32 a, R32 b) { return cn ? add_canon(a, b) : add_any(a, b); }
 __device__ __forceinline__ R32 q_sub(bool cn, R32 a, R32 b) { return q_add(cn, a, neg(b)); }
 __device__ __forceinline__ R32 q_mul(bool cn, R32 a, R32 b) { return cn ? mul_canon(a, b) : mul_any(a, b); }

@@ -300,6 +300,70 @@ XPG_HD R32 fma_canon(R32 a, R32 k, R32 e)
     if (a.num == 0) return p;                                  // 0/1 + p = squeeze(p.num, p.den) = p
     return add_lowest(a, p);
 }
+// ---- the GENERIC operations without a divide -----------------------------------------------------------------
+// mul / div / add above are the literal restatement (64-bit Euclid with remainders, two 64-bit quotients) and stay
+// the definition. These compute the same results for EVERY pair of operands whose products stay below 2^63 in
+// magnitude -- any numerators, any denominators above INT_MIN, zero and negative ones included (a problem whose
+// cells are not canonical, e.g. the den = 0 values MIP's equality substitution produces, runs on them) -- with a
+// binary gcd on 64 bits and the exact quotients by modular inverse. tests/cxx/fma_canon_fuzz.cpp compares them
+// with the literal forms on arbitrary operands.
+XPG_HD unsigned long long gcd_u64(unsigned long long x, unsigned long long y)      // x > 0; gcd(x, 0) = x
+{
+    if (y == 0) return x;
+    const int sh = __builtin_ctzll(x | y);
+    x >>= __builtin_ctzll(x);
+    do {
+        y >>= __builtin_ctzll(y);
+        const unsigned long long lo = x < y ? x : y, hi = x < y ? y : x;
+        x = lo; y = hi - lo;
+    } while (y != 0);
+    return x << sh;
+}
+XPG_HD unsigned long long exact_div_u64(unsigned long long x, unsigned long long g)    // g divides x, g > 0
+{
+    const int sh = __builtin_ctzll(g);
+    const unsigned long long o = g >> sh;
+    unsigned long long y = (3ull * o) ^ 2ull;
+    y *= 2ull - o * y; y *= 2ull - o * y; y *= 2ull - o * y; y *= 2ull - o * y;
+    return (x >> sh) * y;
+}
+XPG_HD R32 squeeze_any(long long n, long long d)               // == squeeze(n, d)
+{
+    const long long imax = 0x7fffFFFFLL;
+    if (n == d) return R32(1, 1);
+    if (n == -d) return R32(-1, 1);
+    if (d < 0) { n = -n; d = -d; }
+    const bool minus = n < 0;
+    unsigned long long un = minus ? 0ull - (unsigned long long)n : (unsigned long long)n, ud = (unsigned long long)d;
+    if (un == 0) ud = 1;                                       // reduce64: n == 0 -> d = 1
+    else {
+        const unsigned long long g = gcd_u64(un, ud);
+        if (g != 1) { un = exact_div_u64(un, g); ud = exact_div_u64(ud, g); }
+    }
+    long long mag = (long long)un, dd = (long long)ud;
+    if (mag >= (imax >> 2) || dd >= (imax >> 2)) {
+        if (mag >= imax || dd >= imax) appro64(mag, dd);
+    }
+    return R32((int32_t)(minus ? -mag : mag), (int32_t)dd);
+}
+XPG_HD R32 mul_any_fast(R32 a, R32 b)
+{
+    const long long n = (long long)a.num * (long long)b.num;
+    if (n == 0) return R32(0, 1);
+    return squeeze_any(n, (long long)a.den * (long long)b.den);
+}
+XPG_HD R32 div_any_fast(R32 a, R32 b)
+{
+    if (a.num == 0) return R32(0, 1);
+    if (a.num == a.den) return b.num < 0 ? R32(-b.den, -b.num) : R32(b.den, b.num);
+    return squeeze_any((long long)a.num * (long long)b.den, (long long)a.den * (long long)b.num);
+}
+XPG_HD R32 add_any_fast(R32 a, R32 b)
+{
+    const long long n = (long long)a.num * (long long)b.den + (long long)a.den * (long long)b.num;
+    if (n == 0) return R32(0, 1);
+    return squeeze_any(n, (long long)a.den * (long long)b.den);
+}
 XPG_HD R32 sub(R32 a, R32 b) { return add(a, neg(b)); }
 XPG_HD bool eq(R32 a, R32 b) { return a.num == b.num && a.den == b.den; }   // rational.h:80-83
 XPG_HD bool ne(R32 a, R32 b) { return a.num != b.num || a.den != b.den; }
