@@ -1,4 +1,4 @@
-"""GPU cross-check, larger than the test suite's: batched rational LPs (k_batch<R32>, canonical and generic
+"""GPU cross-check, larger than the collected tests' (run by hand: python tests/crosscheck_batch_rat.py [seed] [count]): batched rational LPs (k_batch<R32>, canonical and generic
 arithmetic mixed in one launch) against the CPU oracle -- status, objective, solution -- maxm and minm."""
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

@@ -1,4 +1,4 @@
-"""GPU cross-check, larger than the test suite's: the row-elimination kernels against the CPU oracle on a few
+"""GPU cross-check, larger than the collected tests' (run by hand: python tests/crosscheck_lineq.py [seed] [count]): the row-elimination kernels against the CPU oracle on a few
 thousand random systems per shape (both intersect modes, dark shadow, several eliminated variables, rank / det /
 inv), including batches that mix systems with fractions not in lowest terms."""
 import sys, os

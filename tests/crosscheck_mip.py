@@ -1,4 +1,4 @@
-"""GPU cross-check, larger than the test suite's: xpg_mip_batch_rat32 (the tree walks on the device) against the
+"""GPU cross-check, larger than the collected tests' (run by hand: python tests/crosscheck_mip.py [seed] [count]): xpg_mip_batch_rat32 (the tree walks on the device) against the
 CPU oracle's MIP::maxm / minm -- status, value, solution -- on random integer and 0-1 problems, including 0-1
 problems with more rows than columns (where the reference's equality substitution is undefined) and knapsacks of
 the bench shape. XPG_MIP_DEVICE=0 checks the host controller instead."""
