@@ -730,6 +730,9 @@ template <class S> __host__ __device__ inline size_t small_lds_bytes(int R, int 
     return (b + 15) & ~(size_t)15;
 }
 
+#ifdef XPG_STAMPS
+__device__ unsigned long long g_lp_ticks[8];     // diagnostic builds: ticks in phase one / plain build / main solve, pivots, counts
+#endif
 // The LDS arrays of one LP with at most R rows and V variables (small_lds_bytes is their size).
 template <class S> __device__ __forceinline__ void sm_carve(Small<S> & P, unsigned char * lds, int R, int V)
 {
@@ -782,6 +785,9 @@ template <class S> __device__ __forceinline__ int sm_solve_lp(Small<S> & P, Sour
     const bool phase1 = !P.sh_w[3] || P.sh_w[4];
     __syncthreads();
     int status = -1;
+#ifdef XPG_STAMPS
+    unsigned long long lp_t_ = wall_clock64();
+#endif
     if (phase1) {
         const int ok = sm_phase_one<S>(P, src, max_iter);
         if (ok == 0) status = 2;
@@ -789,8 +795,14 @@ template <class S> __device__ __forceinline__ int sm_solve_lp(Small<S> & P, Sour
     } else {
         sm_build(P, src, 0);
     }
+#ifdef XPG_STAMPS
+    { const unsigned long long n_ = wall_clock64(); if (threadIdx.x == 0) { atomicAdd(&g_lp_ticks[phase1 ? 0 : 1], n_ - lp_t_); atomicAdd(&g_lp_ticks[phase1 ? 4 : 5], 1ull); } lp_t_ = n_; }
+#endif
     S top = zero<S>();
     if (status == -1) status = sm_solve<S>(P, max_iter, top);
+#ifdef XPG_STAMPS
+    { const unsigned long long n_ = wall_clock64(); if (threadIdx.x == 0) { atomicAdd(&g_lp_ticks[2], n_ - lp_t_); atomicAdd(&g_lp_ticks[3], (unsigned long long)P.pivots); } }
+#endif
     // SIX::calcFinalSolution (lpsol.h:1851-1899) / minm read-out (lpsol.h:1713-1716)
     if (status == 0) {
         for (int j = threadIdx.x; j < n; j += blockDim.x) {

@@ -369,6 +369,15 @@ int xpg_mip_debug(xpg_ctx * ctx, unsigned long long * out4)
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_mip_ticks), z, sizeof(z)) != hipSuccess) return XPG_ERR_HIP;
     return 0;
 }
+// diagnostic builds only: reads and clears sm_solve_lp's tick sums (phase one, plain build, main solve, pivots, counts)
+int xpg_lp_solve_debug(xpg_ctx * ctx, unsigned long long * out8)
+{
+    XPG_BIND(ctx);
+    unsigned long long z[8] = {0};
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_lp_ticks), sizeof(z)) != hipSuccess) return XPG_ERR_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_lp_ticks), z, sizeof(z)) != hipSuccess) return XPG_ERR_HIP;
+    return 0;
+}
 // diagnostic builds only: reads and clears the phase tick sums of k_fme_batch
 int xpg_lineq_debug(xpg_ctx * ctx, unsigned long long * out16)
 {
