@@ -464,9 +464,9 @@ template <class S> __global__ __launch_bounds__(1024) void k_pick(LpView<S> v)
 // (the forced pivots of phase 1 are neither, lpsol.h:906-908, :939).
 // canonical-operand forms of the rational operations (scalar.hip.h), selected where every operand is known canonical
 template <class S> __device__ __forceinline__ S mul_c(S a, S b, bool) { return mul(a, b); }
-template <> __device__ __forceinline__ R32 mul_c<R32>(R32 a, R32 b, bool canon) { return canon ? mul_canon(a, b) : mul(a, b); }
+template <> __device__ __forceinline__ R32 mul_c<R32>(R32 a, R32 b, bool canon) { return canon ? mul_canon(a, b) : mul_any(a, b); }
 template <class S> __device__ __forceinline__ S add_c(S a, S b, bool) { return add(a, b); }
-template <> __device__ __forceinline__ R32 add_c<R32>(R32 a, R32 b, bool canon) { return canon ? add_canon(a, b) : add(a, b); }
+template <> __device__ __forceinline__ R32 add_c<R32>(R32 a, R32 b, bool canon) { return canon ? add_canon(a, b) : add_any(a, b); }
 template <class S> __device__ __forceinline__ S scaled_c(S cell, S x, int mode, bool canon)
 { return mode == SCALE_KEEP ? cell : (mode == SCALE_ZERO ? zero<S>() : mul_c(cell, x, canon)); }
 
@@ -578,7 +578,7 @@ void k_update_r32(LpView<R32> v, int guarded)
         const int i = i0 + ii;
         if (i >= v.m) break;
         R32 * p = v.tab + (size_t)i * v.ld + j;
-        const R32 o = (i == r) ? e : (canon ? fma_canon(*p, v.colbuf[i], e) : add(*p, mul(v.colbuf[i], e)));
+        const R32 o = (i == r) ? e : (canon ? fma_canon(*p, v.colbuf[i], e) : add_any(*p, mul_any(v.colbuf[i], e)));
         *p = o;
         if (ex_col) v.nextcol[i] = o;
         if (ex_b) v.bcol[i] = o;
