@@ -419,7 +419,7 @@ int mip_batch_device(xpg_ctx * ctx, int nb, bool is_max, bool is_bin, const S * 
     XPG_TRY(hipFuncSetAttribute((const void *)k_mip_tree<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((k_mip_tree<S>), dim3(grid), dim3(threads), lds, ctx->stream, nb, (const S *)dt.p, (const S *)dl.p,
                        leq_rows, cols, is_max ? 1 : 0, is_bin ? 1 : 0, rmax, depth, (unsigned long long *)dws.p, ws_words,
-                       (int32_t *)dst.p, (S *)dv.p, out_sol ? (S *)dsol.p : (S *)0, (int *)dn.p);
+                       (int32_t *)dst.p, (S *)dv.p, out_sol ? (S *)dsol.p : (S *)0, (int *)dn.p, (const int *)0, (const int *)0);
     XPG_TRY(hipGetLastError());
     std::vector<int32_t> nodes((size_t)nb);
     XPG_TRY(hipMemcpyAsync(out_status, dst.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -532,6 +532,51 @@ inline int dep_is_empty_batch(xpg_ctx * ctx, int nb, const R32 * mats, int rows,
     if (!ctx || nb < 0 || !mats || rows <= 0 || cols < 2 || !out_empty || rhs_idx < 1 || rhs_idx > cols - 1) return XPG_ERR_SHAPE;
     if (nb == 0) return 0;
     const int last = cols - 1, nsym = last - rhs_idx;
+    // No constant symbols and the default x >= 0: the whole test stays on the device -- reduce, the feasibility
+    // objectives, the integer maxm walk, the minm walk of what that left open -- and only the verdicts come back.
+    static const bool on_dev = [] { const char * e = getenv("XPG_MIP_DEVICE"); return !(e && e[0] == '0'); }();
+    if (on_dev && nsym == 0 && !vc_in && mip_device_fits<R32>(rows, cols, false) &&
+        lineq_lds_bytes(rows, cols) <= 160 * 1024 && rows <= 32767) {
+        const int n = cols - 1, rmax = rows + n, depth = n + 2;
+        const size_t bm = (size_t)nb * rows * cols * 8, bt = (size_t)nb * cols * 8;
+        DevBuf dm, dt, dk, dok, dact, demp, dst, dv, dn, dws;
+        XPG_TRY(dm.alloc(ctx, bm)); XPG_TRY(dt.alloc(ctx, bt)); XPG_TRY(dk.alloc(ctx, (size_t)nb * 4));
+        XPG_TRY(dok.alloc(ctx, (size_t)nb * 4)); XPG_TRY(dact.alloc(ctx, (size_t)nb * 4)); XPG_TRY(demp.alloc(ctx, (size_t)nb * 4));
+        XPG_TRY(dst.alloc(ctx, (size_t)nb * 4)); XPG_TRY(dv.alloc(ctx, (size_t)nb * 8)); XPG_TRY(dn.alloc(ctx, (size_t)nb * 4));
+        XPG_TRY(hipMemcpyAsync(dm.p, mats, bm, hipMemcpyHostToDevice, ctx->stream));
+        int rc = lineq_reduce_batch_dev(ctx, nb, (R32 *)dm.p, rows, cols, last, 1, 1, (int32_t *)dk.p, (int32_t *)dok.p);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_dep_prepare, dim3((nb + 3) / 4), dim3(64, 4), 0, ctx->stream, nb, (const R32 *)dm.p, rows, cols,
+                           (const int *)dk.p, (const int *)dok.p, (R32 *)dt.p, (int *)dact.p, (int32_t *)demp.p);
+        XPG_TRY(hipMemsetAsync(dn.p, 0, (size_t)nb * 4, ctx->stream));
+        std::vector<int32_t> nodes_a((size_t)nb, 0), nodes_b((size_t)nb, 0);
+        for (int pass = 0; pass < 2; pass++) {
+            const bool is_max = pass == 0;
+            const int R = is_max ? rmax : n, V = is_max ? n : rmax;
+            const size_t lds = small_lds_bytes<R32>(R, V);
+            const int cells = R * (V + R + 2);
+            int threads = cells >= 2048 ? 256 : (cells >= 1024 ? 128 : 64);
+            if (nb >= 8 * (ctx->num_cus > 0 ? ctx->num_cus : 256)) threads = 64;
+            const int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
+            int grid = (ctx->num_cus > 0 ? ctx->num_cus : 256) * (per_cu > 8 ? 8 : per_cu) * 4;
+            if (grid > nb) grid = nb;
+            const size_t ws_words = mip_ws_words(rmax, cols, depth);
+            if (pass == 0) XPG_TRY(dws.alloc(ctx, (size_t)((ctx->num_cus > 0 ? ctx->num_cus : 256) * 8 * 4 < nb ? (ctx->num_cus > 0 ? ctx->num_cus : 256) * 8 * 4 : nb) * ws_words * 8));
+            XPG_TRY(hipMemsetAsync(dn.p, 0, (size_t)nb * 4, ctx->stream));
+            XPG_TRY(hipFuncSetAttribute((const void *)k_mip_tree<R32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_mip_tree<R32>), dim3(grid), dim3(threads), lds, ctx->stream, nb, (const R32 *)dt.p, (const R32 *)dm.p,
+                               rows, cols, is_max ? 1 : 0, 0, rmax, depth, (unsigned long long *)dws.p, ws_words,
+                               (int32_t *)dst.p, (R32 *)dv.p, (R32 *)0, (int *)dn.p, (const int *)dk.p, (const int *)dact.p);
+            XPG_TRY(hipGetLastError());
+            XPG_TRY(hipMemcpyAsync(pass == 0 ? nodes_a.data() : nodes_b.data(), dn.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+            hipLaunchKernelGGL(k_dep_update, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, nb, (const int32_t *)dst.p,
+                               (int *)dact.p, (int32_t *)demp.p);
+        }
+        XPG_TRY(hipMemcpyAsync(out_empty, demp.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+        XPG_TRY(hipStreamSynchronize(ctx->stream));
+        if (out_nodes) { long t = 0; for (int b = 0; b < nb; b++) t += nodes_a[(size_t)b] + nodes_b[(size_t)b]; *out_nodes = t; }
+        return 0;
+    }
     std::vector<R32> work((size_t)nb * rows * cols);
     if (nsym > 0) {
         for (int b = 0; b < nb; b++)
@@ -554,42 +599,6 @@ inline int dep_is_empty_batch(xpg_ctx * ctx, int nb, const R32 * mats, int rows,
         else { out_empty[b] = 1; open.push_back(b); }
     }
     long nodes = 0;
-    // x >= 0 and inequalities only (the default vc): the integer MIPs of a pass go to the device-side tree walk,
-    // one launch per surviving row count (reduce leaves the systems ragged)
-    static const bool on_device = [] { const char * e = getenv("XPG_MIP_DEVICE"); return !(e && e[0] == '0'); }();
-    bool device_ok = on_device && !vc_in && mip_device_fits<R32>(rows, cols, false);
-    for (int pass = 0; pass < 2 && !open.empty() && device_ok; pass++) {
-        std::map<int, std::vector<int> > by_rows;
-        for (int b : open) by_rows[kept[b]].push_back(b);
-        std::vector<int> still;
-        for (auto & g : by_rows) {
-            const int k = g.first, nbk = (int)g.second.size();
-            std::vector<R32> lq((size_t)nbk * k * cols), tg((size_t)nbk * cols), vv(nbk);
-            std::vector<int32_t> st(nbk);
-            for (int t = 0; t < nbk; t++) {
-                const R32 * leq = work.data() + (size_t)g.second[(size_t)t] * rows * cols;
-                for (size_t e = 0; e < (size_t)k * cols; e++) lq[(size_t)t * k * cols + e] = leq[e];
-                const std::vector<R32> f = feasibility_objective(leq, k, (const R32 *)0, 0, cols, last);
-                for (int j = 0; j < cols; j++) tg[(size_t)t * cols + j] = f[(size_t)j];
-            }
-            long long nn = 0;
-            rc = mip_batch_device<R32>(ctx, nbk, pass == 0, false, tg.data(), lq.data(), k, cols, st.data(), vv.data(), (R32 *)0, &nn);
-            if (rc == XPG_ERR_UNSUPPORTED) { device_ok = false; break; }
-            if (rc) return rc;
-            nodes += (long)nn;
-            for (int t = 0; t < nbk; t++) {
-                const int b = g.second[(size_t)t];
-                if (st[t] < 0) out_empty[b] = st[t];
-                else if (st[t] == XPG_IP_SUCC) out_empty[b] = 0;
-                else still.push_back(b);
-            }
-        }
-        if (!device_ok) break;                               // (nothing of this pass is kept: the host controller redoes it)
-        std::sort(still.begin(), still.end());
-        open.swap(still);
-        if (pass == 1 || open.empty()) { if (out_nodes) *out_nodes = nodes; return 0; }
-    }
-    if (device_ok && open.empty()) { if (out_nodes) *out_nodes = nodes; return 0; }
     for (int pass = 0; pass < 2 && !open.empty(); pass++) {          // maxm, then minm (linsys.cpp:864-876)
         std::vector<MipTask<R32> > tasks(open.size());
         for (size_t t = 0; t < open.size(); t++) {

@@ -226,16 +226,21 @@ template <class S> __device__ bool mip_feed(const MipWs<S> & w, const S * tgtf, 
 template <class S> __global__ __launch_bounds__(256, 2)
 void k_mip_tree(int nb, const S * tgtf_all, const S * leq_all, int leq_rows, int cols, int is_max, int is_bin, int rmax,
                 int depth, unsigned long long * ws_all, size_t ws_words, int32_t * out_status, S * out_v, S * out_sol,
-                int * out_nodes)
+                int * out_nodes, const int * rows_of, const int * active)
 {
+    // rows_of (may be NULL): problem b has rows_of[b] of its leq_rows-row slot live (ragged batches: the systems
+    // Lineq::reduce leaves); active (may be NULL): only problems whose entry is 1 are walked, the others' outputs
+    // are left alone.
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     __shared__ int sh_ctl[4];
     const int n = cols - 1;
     Small<S> P;
     sm_carve(P, lds, is_max ? rmax : n, is_max ? n : rmax);
     for (int b = blockIdx.x; b < nb; b += gridDim.x) {
+        if (active && active[b] != 1) continue;
         const S * tgtf = tgtf_all + (size_t)b * cols;
         const S * root = leq_all + (size_t)b * leq_rows * cols;
+        const int my_rows = rows_of ? rows_of[b] : leq_rows;
         const MipWs<S> w = mip_ws_carve<S>(ws_all + (size_t)blockIdx.x * ws_words, rmax, cols, depth);
         // MipTask::start
         for (int j = threadIdx.x; j < cols; j += blockDim.x) w.forks[j] = 0;
@@ -252,7 +257,7 @@ void k_mip_tree(int nb, const S * tgtf_all, const S * leq_all, int leq_rows, int
             __syncthreads();
             if (threadIdx.x == 0) w.ctl[MC_NODES] += 1;
             MIP_T0
-            int st = mip_build_node<S>(w, root, leq_rows, cols, is_bin != 0, top, &sh_ctl[1]);
+            int st = mip_build_node<S>(w, root, my_rows, cols, is_bin != 0, top, &sh_ctl[1]);
             MIP_T(0)
             if (st >= 0) {
                 Source<S> src;
@@ -276,6 +281,40 @@ void k_mip_tree(int nb, const S * tgtf_all, const S * leq_all, int leq_rows, int
             for (int j = threadIdx.x; j < cols; j += blockDim.x) out_sol[(size_t)b * cols + j] = w.sol[j];
         __syncthreads();
     }
+}
+
+// ---- DepPoly::is_empty (src/eng/poly.cpp:530-573) after the reduce, on the device ------------------------------
+// Per polyhedron b with reduce's outputs kept[b] / ok[b]: the verdict reduce alone gives, else the feasibility
+// objective of Lineq::has_solution (SIX::reviseTargetFunc on all ones, lpsol.h:2053-2074 / linsys.cpp:851-862: 1 for
+// every variable that occurs in some inequality) and the "still open" mark for the MIP walks that follow.
+__global__ void k_dep_prepare(int nb, const R32 * mats, int rows, int cols, const int * kept, const int * ok, R32 * tgtf,
+                              int * active, int32_t * empty)
+{
+    const int b = blockIdx.x * blockDim.y + threadIdx.y;
+    if (b >= nb) return;
+    const int last = cols - 1, k = kept[b];
+    const bool open = ok[b] != 0 && k > 0;
+    if (threadIdx.x == 0) {
+        active[b] = open ? 1 : 0;
+        empty[b] = !ok[b] ? 1 : (k == 0 ? 0 : 1);       // inconsistent bounds: empty; only redundant constraints: not
+    }
+    const R32 * m = mats + (size_t)b * rows * cols;
+    for (int j = threadIdx.x; j < cols; j += blockDim.x) {
+        bool nz = false;
+        if (open && j < last)
+            for (int i = 0; i < k && !nz; i++) nz = ne(m[(size_t)i * cols + j], R32(0, 1));
+        tgtf[(size_t)b * cols + j] = nz ? R32(1, 1) : R32(0, 1);
+    }
+}
+// After a walk (maxm, then minm; linsys.cpp:864-876): success = a solution exists = not empty, decided; a negative
+// status = the reference is undefined on this system, decided; anything else stays open for the next walk.
+__global__ void k_dep_update(int nb, const int32_t * status, int * active, int32_t * empty)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb || active[b] != 1) return;
+    const int st = status[b];
+    if (st < 0) { empty[b] = st; active[b] = 0; }
+    else if (st == XPG_IP_SUCC) { empty[b] = 0; active[b] = 0; }
 }
 
 } // namespace xpg
