@@ -658,9 +658,14 @@ def leg_lineq(ctx, xpoly_amd, gen):
     dm = np.ascontiguousarray(np.tile(dm, (dnb // 256, 1, 1, 1)))
     dep_is_empty_batch(ctx, dm[:256])
     t0 = time.perf_counter(); empty, dnodes = dep_is_empty_batch(ctx, dm); ddt = time.perf_counter() - t0
+    dbig = 16 * dnb                                    # the same call with 16x the polyhedra: throughput
+    dm16 = np.ascontiguousarray(np.tile(dm, (16, 1, 1, 1)))
+    dep_is_empty_batch(ctx, dm16)
+    t0 = time.perf_counter(); dep_is_empty_batch(ctx, dm16); ddt16 = time.perf_counter() - t0
     return dict(metric="rational row elimination and small rational LPs, batched", systems=LINEQ_NB, shapes=rows_out,
                 dep_is_empty=dict(polyhedra=dnb, rows=drows, vars=dnv, polyhedra_per_s=round(dnb / ddt, 0),
-                                  nodes=int(dnodes), empty=int(np.sum(empty == 1))),
+                                  nodes=int(dnodes), empty=int(np.sum(empty == 1)),
+                                  larger_batch=dict(polyhedra=dbig, polyhedra_per_s=round(dbig / ddt16, 0))),
                 rational_lps=dict(lps=nb, rows=m, cols=cols, lps_per_s=round(nb / dt, 0),
                                   status_hist=np.bincount(np.clip(st, 0, 4), minlength=5).tolist()),
                 dtype="int32 num/den", bound="integer issue (gcd loops), not HBM",
