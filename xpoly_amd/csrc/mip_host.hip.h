@@ -385,6 +385,24 @@ template <class S> inline bool mip_device_fits(int leq_rows, int cols, bool is_b
     const int n = cols - 1, rmax = leq_rows + (is_bin ? 0 : n);
     return small_lds_bytes<S>(rmax, n) <= 64 * 1024 && small_lds_bytes<S>(n, rmax) <= 64 * 1024;
 }
+// Launch shape of k_mip_tree for nb trees whose node LPs have at most rmax rows and n variables.
+struct MipGeom { size_t lds; int threads, grid; };
+template <class S> inline MipGeom mip_geom(const xpg_ctx * ctx, int nb, int rmax, int n, bool is_max)
+{
+    MipGeom g;
+    const int R = is_max ? rmax : n, V = is_max ? n : rmax;
+    g.lds = small_lds_bytes<S>(R, V);
+    const int cells = R * (V + R + 2), cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+    g.threads = cells >= 2048 ? 256 : (cells >= 1024 ? 128 : 64);
+    // more trees than the chip holds at that width: one wave per tree, more trees in flight (8192 knapsacks of 24
+    // variables: 64 / 128 / 256 threads 623 k / 425 k / 318 k MIPs/s; at 1024, where the deepest tree decides, 163 / 171 / 170 k)
+    if (nb >= 8 * cus) g.threads = 64;
+    if (const char * t = getenv("XPG_BATCH_THREADS")) { const int v = atoi(t); if (v >= 64 && v <= 256 && v % 64 == 0) g.threads = v; }
+    const int per_cu = (int)((160 * 1024) / g.lds) > 0 ? (int)((160 * 1024) / g.lds) : 1;
+    g.grid = cus * (per_cu > 8 ? 8 : per_cu) * 4;
+    if (g.grid > nb) g.grid = nb;
+    return g;
+}
 // The same batch with the tree walks on the device (mip_kernels.hip.h): one workgroup per problem. Returns
 // XPG_ERR_UNSUPPORTED where a node LP of the deepest path would not fit the LDS budget -- the caller then takes the
 // host controller below.
@@ -395,18 +413,10 @@ int mip_batch_device(xpg_ctx * ctx, int nb, bool is_max, bool is_bin, const S * 
     const int n = cols - 1;
     const int rmax = leq_rows + (is_bin ? 0 : n);         // integer branching appends one row per ancestor
     const int depth = n + 2;
-    const int R = is_max ? rmax : n, V = is_max ? n : rmax;
-    const size_t lds = small_lds_bytes<S>(R, V);
-    if (lds > 64 * 1024) return XPG_ERR_UNSUPPORTED;
-    const int cells = R * (V + R + 2);
-    int threads = cells >= 2048 ? 256 : (cells >= 1024 ? 128 : 64);
-    // more trees than the chip holds at that width: one wave per tree, more trees in flight (8192 knapsacks of 24
-    // variables: 64 / 128 / 256 threads 623 k / 425 k / 318 k MIPs/s; at 1024, where the deepest tree decides, 163 / 171 / 170 k)
-    if (nb >= 8 * (ctx->num_cus > 0 ? ctx->num_cus : 256)) threads = 64;
-    if (const char * t = getenv("XPG_BATCH_THREADS")) { const int v = atoi(t); if (v >= 64 && v <= 256 && v % 64 == 0) threads = v; }
-    const int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
-    int grid = (ctx->num_cus > 0 ? ctx->num_cus : 256) * (per_cu > 8 ? 8 : per_cu) * 4;
-    if (grid > nb) grid = nb;
+    const MipGeom g = mip_geom<S>(ctx, nb, rmax, n, is_max);
+    if (g.lds > 64 * 1024) return XPG_ERR_UNSUPPORTED;
+    const size_t lds = g.lds;
+    const int threads = g.threads, grid = g.grid;
     const size_t ws_words = mip_ws_words(rmax, cols, depth);
     const size_t bl = (size_t)nb * leq_rows * cols * 8, bt = (size_t)nb * cols * 8;
     DevBuf dl, dt, dws, dst, dv, dsol, dn;
@@ -552,16 +562,12 @@ inline int dep_is_empty_batch(xpg_ctx * ctx, int nb, const R32 * mats, int rows,
         std::vector<int32_t> nodes_a((size_t)nb, 0), nodes_b((size_t)nb, 0);
         for (int pass = 0; pass < 2; pass++) {
             const bool is_max = pass == 0;
-            const int R = is_max ? rmax : n, V = is_max ? n : rmax;
-            const size_t lds = small_lds_bytes<R32>(R, V);
-            const int cells = R * (V + R + 2);
-            int threads = cells >= 2048 ? 256 : (cells >= 1024 ? 128 : 64);
-            if (nb >= 8 * (ctx->num_cus > 0 ? ctx->num_cus : 256)) threads = 64;
-            const int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
-            int grid = (ctx->num_cus > 0 ? ctx->num_cus : 256) * (per_cu > 8 ? 8 : per_cu) * 4;
-            if (grid > nb) grid = nb;
+            const MipGeom g = mip_geom<R32>(ctx, nb, rmax, n, is_max);
+            const size_t lds = g.lds;
+            const int threads = g.threads, grid = g.grid;
             const size_t ws_words = mip_ws_words(rmax, cols, depth);
-            if (pass == 0) XPG_TRY(dws.alloc(ctx, (size_t)((ctx->num_cus > 0 ? ctx->num_cus : 256) * 8 * 4 < nb ? (ctx->num_cus > 0 ? ctx->num_cus : 256) * 8 * 4 : nb) * ws_words * 8));
+            const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+            if (pass == 0) XPG_TRY(dws.alloc(ctx, (size_t)(cus * 32 < nb ? cus * 32 : nb) * ws_words * 8));   // the largest grid of either pass
             XPG_TRY(hipMemsetAsync(dn.p, 0, (size_t)nb * 4, ctx->stream));
             XPG_TRY(hipFuncSetAttribute((const void *)k_mip_tree<R32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL((k_mip_tree<R32>), dim3(grid), dim3(threads), lds, ctx->stream, nb, (const R32 *)dt.p, (const R32 *)dm.p,
