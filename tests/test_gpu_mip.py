@@ -210,3 +210,24 @@ def test_mip_batch_f64_matches_oracle(ctx, port):
                         assert np.array_equal(sol[b], want[2]), (is_bin, m, nv, is_max, b)
                     checked += 1
     assert checked == 2 * 3 * 2 * 48
+
+
+def test_mip_batch_bench_shape_matches_the_reference_fixture(ctx):
+    """The device tree walk on 0-1 knapsacks of the bench shape (24 variables, 26 rows) against the answers of the
+    REAL reference's MIP<RMat,Rational>::maxm(is_bin) (tests/golden/g10_mip_bench.json; inputs regenerated and
+    checked by hash). Problems on which the reference is undefined return XPG_ERR_REF_UNDEFINED."""
+    import hashlib
+    from xpoly_amd.six import mip_batch
+    g = json.load(open(os.path.join(GOLD, "g10_mip_bench.json")))
+    leq, tgtf = gen.knapsack_batch_rat(g["nb"], g["nv"])
+    assert hashlib.sha256(np.ascontiguousarray(leq).tobytes() + np.ascontiguousarray(tgtf).tobytes()).hexdigest() == g["inputs_sha256"]
+    st, v, sol, nodes = mip_batch(ctx, True, True, tgtf, leq)
+    for b in range(g["nb"]):
+        want = g["results"][b]
+        if want is None:
+            assert st[b] == -7, b
+            continue
+        assert st[b] == want["status"], (b, st[b], want["status"])
+        assert [int(v[b][0]), int(v[b][1])] == want["v"], b
+        if want["status"] == 0:
+            assert [int(x) for x in sol[b].reshape(-1)] == want["sol"], b
