@@ -182,22 +182,26 @@ template <class S> __device__ __forceinline__ void sm_pivot_fast(Small<S> & P, i
     {
         const int CW = blockDim.x >= 128 && W > 64 ? 128 : 64;
         const int tx = threadIdx.x % CW, ty = threadIdx.x / CW, ny = blockDim.x / CW;
-        // Four rows of LDS reads are issued before the first use: the loop is latency-bound
-        // (one dependent ds_read -> mul -> add -> ds_write chain per cell otherwise).
-        const int last = P.R - 1;
+        // Four rows of LDS reads are issued before the first use: the loop is latency-bound (one dependent
+        // ds_read -> mul -> add -> ds_write chain per cell otherwise). No clamp, select or range test per cell:
+        // four rows while all four are in range, then the tail; the pivot row goes through a + 0*e (k_r = 0)
+        // and is put back to e afterwards.
+        const int R = P.R;
         for (int j = tx; j < W; j += CW) {
             const S ej = P.e[j];
-            for (int i0 = ty; i0 < P.R; i0 += ny * 4) {
-                const int i1 = i0 + ny, i2 = i0 + 2 * ny, i3 = i0 + 3 * ny;
-                // loads are unconditional (row index clamped), stores are guarded
-                const S a0 = P.tab[min(i0, last) * ld + j], a1 = P.tab[min(i1, last) * ld + j];
-                const S a2 = P.tab[min(i2, last) * ld + j], a3 = P.tab[min(i3, last) * ld + j];
-                const S k0 = P.k[min(i0, last)], k1 = P.k[min(i1, last)], k2 = P.k[min(i2, last)], k3 = P.k[min(i3, last)];
-                if (i0 != r) P.tab[i0 * ld + j] = q_fma(P.cn, a0, k0, ej);
-                if (i1 <= last && i1 != r) P.tab[i1 * ld + j] = q_fma(P.cn, a1, k1, ej);
-                if (i2 <= last && i2 != r) P.tab[i2 * ld + j] = q_fma(P.cn, a2, k2, ej);
-                if (i3 <= last && i3 != r) P.tab[i3 * ld + j] = q_fma(P.cn, a3, k3, ej);
+            S * col = P.tab + j;
+            int i = ty;
+            for (; i + 3 * ny < R; i += 4 * ny) {
+                const int i1 = i + ny, i2 = i + 2 * ny, i3 = i + 3 * ny;
+                const S a0 = col[i * ld], a1 = col[i1 * ld], a2 = col[i2 * ld], a3 = col[i3 * ld];
+                const S k0 = P.k[i], k1 = P.k[i1], k2 = P.k[i2], k3 = P.k[i3];
+                col[i * ld] = q_fma(P.cn, a0, k0, ej);
+                col[i1 * ld] = q_fma(P.cn, a1, k1, ej);
+                col[i2 * ld] = q_fma(P.cn, a2, k2, ej);
+                col[i3 * ld] = q_fma(P.cn, a3, k3, ej);
             }
+            for (; i < R; i += ny) col[i * ld] = q_fma(P.cn, col[i * ld], P.k[i], ej);
+            if (r >= ty && (r - ty) % ny == 0) col[r * ld] = ej;
         }
     }
     if (threadIdx.x == 0) {
