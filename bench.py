@@ -181,6 +181,63 @@ def cpu_baselines(legs, no_ref):
 
 
 # ---------------------------------------------------------------------------------------------------
+# Self-checks: what the timed regions computed, compared AFTER the timing with fixtures generated from the
+# real reference (tests/golden, tools/gen_golden*.py). A mismatch aborts the run: no JSON line, non-zero exit.
+# ---------------------------------------------------------------------------------------------------
+def checksum(a):
+    import zlib
+    a = np.ascontiguousarray(a)
+    v = a.view(np.uint64).reshape(-1) if a.dtype.itemsize == 8 else a.view(np.uint32).reshape(-1).astype(np.uint64)
+    return dict(crc32="%08x" % (zlib.crc32(a.tobytes()) & 0xFFFFFFFF), sum="%016x" % int(v.sum(dtype=np.uint64)),
+                xor="%016x" % int(np.bitwise_xor.reduce(v)))
+
+
+def golden(name):
+    return json.load(open(os.path.join(ROOT, "tests", "golden", name)))
+
+
+def selfcheck_bench_lp(lp):
+    """The device state the LAST timed step left (3840 pivots after xpg_lp_begin) against the real reference's
+    TwoStageMethod(max_iter = 3840) on the same LP: whole tableau, objective row, basis."""
+    rec = [r for r in golden("g11_bench_lp.json")["bench_lp"] if r["K"] == PIVOTS_PER_STEP][0]
+    got = lp.read()
+    bad = []
+    if checksum(got["tab"]) != rec["tab"]:
+        bad.append("tableau")
+    if checksum(got["tgtf"]) != rec["tgtf"] or float(got["tgtf"][got["rhs"]]).hex() != rec["obj_const"]:
+        bad.append("objective row")
+    if checksum(got["eq2bv"].astype(np.int32)) != rec["eq2bv"] or checksum(got["bv2eq"].astype(np.int32)) != rec["bv2eq"]:
+        bad.append("basis")
+    if bad:
+        sys.exit("bench.py self-check FAILED: after %d pivots the %s differ(s) from the reference fixture "
+                 "tests/golden/g11_bench_lp.json" % (PIVOTS_PER_STEP, ", ".join(bad)))
+    return dict(checked="tableau 4096x8192 (CRC-32 + sum + xor of all 33.5 M cells), objective row, eq2bv, bv2eq after the "
+                        "last timed step's %d pivots" % PIVOTS_PER_STEP,
+                against="tests/golden/g11_bench_lp.json: xcom::SIX<FloatMat,Float>::TwoStageMethod(max_iter=%d) of the real "
+                        "reference on this LP (tools/gen_golden_bench.py)" % PIVOTS_PER_STEP,
+                result="bit-identical")
+
+
+def selfcheck_batched(fam, d_st, d_v, d_sol, gathered):
+    """The first 256 LPs of rank 0's shard are the LPs of tests/golden/g8_large.json (g3_large: the real reference's
+    SIX<FloatMat,Float>::maxm on each): status, objective bits and solution CRC of what the LAST timed pass left in
+    the result arrays -- and, for N > 1, of the records the all_gather delivered."""
+    import zlib
+    rec = golden("g8_large.json")["g3_large"][fam]["records"]
+    st = d_st[:256].cpu().numpy(); v = d_v[:256].cpu().numpy(); sol = d_sol[:256].cpu().numpy()
+    for b, want in enumerate(rec):
+        ok = st[b] == want["status"] and float(v[b]).hex() == want["v"]
+        if ok and want["status"] == 0:
+            ok = "%08x" % (zlib.crc32(np.ascontiguousarray(sol[b]).tobytes()) & 0xFFFFFFFF) == want["sol_crc32"]
+        if ok and gathered is not None:
+            g = gathered[b].cpu().numpy()
+            ok = int(g[0]) == want["status"] and float(g[1]).hex() == want["v"]
+        if not ok:
+            sys.exit("bench.py self-check FAILED: batched LP %d of family %d differs from the reference fixture "
+                     "tests/golden/g8_large.json (status %d v %s, want %s)" % (b, fam, st[b], float(v[b]).hex(), want))
+    return "256 LPs of the timed batch (the g3_large fixture of tests/golden/g8_large.json, real reference): status, objective bits, solution CRC identical"
+
+
 def spawn_ranks(a, argv):
     """--gpus N without a launcher: start N ranks of this script, before any GPU call, and exit with
     the launcher's code. A rank that cannot get its GPU fails loudly (XPG_ERR_NO_DEVICE) and the whole
@@ -364,10 +421,13 @@ def main():
                 caveat="fraction of the 8 TB/s HBM peak; the 268 MB tableau nearly fits the 256 MiB Infinity Cache "
                        "(MALL) and FETCH_SIZE counts its hits, so part of the stream is served by the MALL -- which is "
                        "how `achieved` can exceed the ~6.3 TB/s a pure HBM copy reaches")
+        if rank == 0:
+            out["self_check"] = {"pivots": selfcheck_bench_lp(lp)}      # outside the timed region
         lp.close()
 
     # ---- leg 2: batched 32 x 64 LPs, sharded across ranks, one all_gather at the end ----------------
     b_leq = b_tg = None
+    checks = {}
     if "batched" in legs:
         total = BATCH_PER_GPU * world
         lo, hi = shard_range(total, rank, world)
@@ -383,6 +443,10 @@ def main():
             else:
                 b_leq, b_tg = gen.small_lp_batch_f64(nloc, BATCH_M, BATCH_COLS, fam,
                                                      seed=gen.XS_SEED + 1000 * (rank + 1) + fam)
+                if rank == 0 and nloc >= 256:           # the 256 LPs of the reference fixture lead rank 0's shard: checked after the timing
+                    g_rec = golden("g8_large.json")["g3_large"][fam]
+                    g_leq, g_tg = gen.small_lp_batch_f64(256, BATCH_M, BATCH_COLS, fam, seed=gen.XS_SEED + g_rec["seed_offset"])
+                    b_leq[:256] = g_leq; b_tg[:256] = g_tg
                 d_leq = torch.from_numpy(b_leq).to(dev)
                 d_tg = torch.from_numpy(b_tg).to(dev)
                 d_st = torch.empty(nloc, dtype=torch.int32, device=dev)
@@ -420,6 +484,8 @@ def main():
                     assert torch.equal(full[:, 2], gi)
             piv = sum_over_ranks(float(d_piv.sum().item()))
             hist = torch.bincount(d_st.clamp(min=0), minlength=5).tolist()
+            if rank == 0 and not stub and nloc >= 256:
+                checks.setdefault("batched", {})[name] = selfcheck_batched(fam, d_st, d_v, d_sol, full)
             fams[name] = dict(lps_per_s=round(total * reps / bdt, 1), pivots_per_s=round(piv * reps / bdt, 1),
                               status_hist_rank0=hist, ms_per_pass=round(bdt / reps * 1e3, 3))
         batched = dict(metric="batched LPs/sec", value=fams["dep_test_like"]["lps_per_s"], unit="LPs/s",
@@ -479,6 +545,10 @@ def main():
             out["lineq"] = leg_lineq(ctx, xpoly_amd, gen)
 
     if rank == 0:
+        if checks or "self_check" in out:
+            out.setdefault("self_check", {}).update(checks)
+            if "mip" in out and "self_check" in out["mip"]:
+                out["self_check"]["mip"] = out["mip"].pop("self_check")
         out["cpu_baseline"] = cpu
         print(json.dumps(out))
     if ctx is not None:
@@ -498,27 +568,42 @@ def leg_cfg2b(ctx, xpoly_amd, gen, m=4096, n=8192):
     lp = xpoly_amd.DeviceLP(ctx, xpoly_amd.F64, leq, tgtf)
     del leq
     W = n + m + 1
-    res = {}
-    for rep in range(2):                                # the first pass warms every launch path
-        lp.begin()
-        ts = {}
+    launches = sweep_ms = 0
+    pers = []
+    for rep in range(3):                                # the first pass warms every launch path; the rate is the better of the
+        lp.begin()                                      # other two (the runtime was seen to stall a stream once for tens of ms)
+        if rep == 2:
+            ctx.profile_begin(40, 2)                    # HIP events on every other full-batch sweep launch of the last pass
         t0 = time.perf_counter()
         assert lp.iterate(256) == RUNNING
-        ts[256] = time.perf_counter() - t0
+        t1 = time.perf_counter()
         assert lp.iterate(1024) == RUNNING
-        ts[1280] = time.perf_counter() - t0
-        res = ts
-    per = (res[1280] - res[256]) / 1024.0
+        t2 = time.perf_counter()
+        if rep == 2:
+            launches, sweep_ms = ctx.profile_end()
+        if rep:
+            pers.append((t2 - t1) / 1024.0)
+    per = min(pers)
     f, p = lp.counters()
     lp.close()
     bytes_per_launch = 2 * m * W * 8
-    return dict(metric="simplex pivots/sec, LP m=4096 n=8192 (tableau 4096x12289 fp64)", value=round(1.0 / per, 1),
-                unit="pivots/s", us_per_pivot=round(per * 1e6, 3), tableau=[m, W],
-                algorithmic_bytes_per_launch=bytes_per_launch, pivots_per_launch=BLOCK,
-                sweeps=dict(full=f, partial=p),
-                loop_effective_gbs=round(bytes_per_launch / BLOCK / per / 1e9, 1),
-                loop_effective_frac=round(bytes_per_launch / BLOCK / per / 1e9 / HBM_PEAK_GBS, 4),
-                sample="(t[K=1280] - t[K=256]) / 1024 on one LP, device-resident blocked loop")
+    out = dict(metric="simplex pivots/sec, LP m=4096 n=8192 (tableau 4096x12289 fp64)", value=round(1.0 / per, 1),
+               unit="pivots/s", us_per_pivot=round(per * 1e6, 3), tableau=[m, W],
+               algorithmic_bytes_per_launch=bytes_per_launch, pivots_per_launch=BLOCK,
+               sweeps=dict(full=f, partial=p),
+               loop_effective_gbs=round(bytes_per_launch / BLOCK / per / 1e9, 1),
+               loop_effective_frac=round(bytes_per_launch / BLOCK / per / 1e9 / HBM_PEAK_GBS, 4),
+               sample="(t[K=1280] - t[K=256]) / 1024 on one LP, device-resident blocked loop, better of two passes")
+    if launches:
+        avg = sweep_ms / 1e3 / launches
+        out["roofline"] = dict(
+            bound="hbm", kernel="k_blk_sweep_full<16,4> on the 403 MB tableau (1.57 x the 256 MiB Infinity Cache)",
+            achieved=round(bytes_per_launch / avg / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+            frac=round(bytes_per_launch / avg / 1e9 / HBM_PEAK_GBS, 4), avg_launch_us=round(avg * 1e6, 2),
+            launches_sampled=launches,
+            note="HIP events on the sweep launches of the timed pass; a plain in-place copy of this tableau with the same "
+                 "tiling runs at 0.79 of the peak (tools/lab/sweep_lab2.hip, profiles/round3_sweep_lab.txt)")
+    return out
 
 
 RAT_M, RAT_N, RAT_K = 1024, 1023, 16                  # tableau 1024 x (1023 + 1024 + 1) = 1024 x 2048
@@ -574,10 +659,23 @@ def leg_mip(ctx, xpoly_amd, gen):
     the whole tree walk on the device (mip_kernels.hip.h: node rebuild, normalisation, LDS solve, recursion)."""
     from xpoly_amd.six import mip_batch
     leq, tgtf = gen.knapsack_batch_rat(MIP_NB, MIP_NV)
+    g = golden("g10_mip_bench.json")                    # the 128 knapsacks of the reference fixture lead the timed batch
+    assert g["nv"] == MIP_NV
+    g_leq, g_tg = gen.knapsack_batch_rat(g["nb"], g["nv"])
+    leq[:g["nb"]] = g_leq; tgtf[:g["nb"]] = g_tg
     mip_batch(ctx, True, True, tgtf, leq)               # warm (also sizes the handle's device scratch)
     t0 = time.perf_counter()
     st, v, sol, nodes = mip_batch(ctx, True, True, tgtf, leq)
     dt = time.perf_counter() - t0
+    for b, want in enumerate(g["results"]):             # self-check, outside the timing
+        if want is None:
+            ok = st[b] == -7                            # the reference is undefined there; the ABI says so
+        else:
+            ok = st[b] == want["status"] and [int(v[b][0]), int(v[b][1])] == want["v"]
+            if ok and want["status"] == 0:
+                ok = [int(x) for x in sol[b].reshape(-1)] == want["sol"]
+        if not ok:
+            sys.exit("bench.py self-check FAILED: MIP %d of the timed batch differs from tests/golden/g10_mip_bench.json" % b)
     big = 8 * MIP_NB                                    # the same call with 8x the trees: throughput, not tree depth
     leq8, tgtf8 = gen.knapsack_batch_rat(big, MIP_NV)
     mip_batch(ctx, True, True, tgtf8, leq8)
@@ -590,6 +688,8 @@ def leg_mip(ctx, xpoly_amd, gen):
                 status_hist=np.bincount(np.clip(st, 0, 4), minlength=5).tolist(), dtype="int32 num/den",
                 larger_batch=dict(problems=big, mips_per_s=round(big / dt8, 1), nodes_per_s=round(nodes8 / dt8, 1),
                                   wall_ms=round(dt8 * 1e3, 2)),
+                self_check="128 MIPs of the timed batch (tests/golden/g10_mip_bench.json: the real reference's MIP<RMat,Rational>::maxm(is_bin)): "
+                           "status, value and solution identical (4 on which the reference is undefined report XPG_ERR_REF_UNDEFINED)",
                 sample="xpg_mip_batch_rat32, host arrays in and out (PCIe included); a batch takes as long as its deepest tree")
 
 

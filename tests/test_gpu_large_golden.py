@@ -95,3 +95,43 @@ def test_cfg2b_lp_4096x8192_against_the_reference(ctx):
         assert sorted(int(x) for x in got["eq2bv"] if x < 8192) == rec["entered"]
         del got
     lp.close()
+
+
+GOLD_BENCH = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g11_bench_lp.json")))
+
+
+def check_bench_lp_state(got, rec):
+    """One record of tests/golden/g11_bench_lp.json (tools/gen_golden_bench.py: the REAL reference's
+    SIX::TwoStageMethod with set_param(0, K) on the bench LP) against a downloaded device state."""
+    assert list(got["tab"].shape) == rec["tab_shape"] and got["rhs"] == rec["rhs"]
+    assert checksum(got["eq2bv"].astype(np.int32)) == rec["eq2bv"], rec["K"]
+    assert [int(x) for x in got["eq2bv"][:32]] == rec["eq2bv_head"], rec["K"]
+    assert checksum(got["bv2eq"].astype(np.int32)) == rec["bv2eq"], rec["K"]
+    assert float(got["tgtf"][got["rhs"]]).hex() == rec["obj_const"], rec["K"]
+    assert checksum(got["tgtf"]) == rec["tgtf"], rec["K"]
+    assert checksum(got["tab"]) == rec["tab"], rec["K"]
+
+
+def test_bench_lp_through_the_whole_timed_range_against_the_reference(ctx):
+    """The exact LP bench.py times (gen.hard_lp_f64(4096, 4095), slack tableau 4096 x 8192), through the default
+    device loop (blocked + chain) to K = 1024, 2048 and 3840 pivots -- 3840 is where a bench step ends -- with the
+    whole 268 MB tableau, the objective row and the basis compared with what the reference left there
+    (src/com/lpsol.h:1039-1188 through :1907-1930)."""
+    import xpoly_amd
+    leq, tgtf = gen.hard_lp_f64(4096, 4095)
+    lp = xpoly_amd.DeviceLP(ctx, F64, leq, tgtf)
+    lp.begin()
+    done = 0
+    for rec in GOLD_BENCH["bench_lp"]:
+        assert rec["status"] == 4                      # SIX_TIME_OUT: the reference stopped at max_iter = K
+        assert lp.iterate(rec["K"] - done) == xpoly_amd.six.XPG_RUNNING
+        done = rec["K"]
+        assert lp.pivots_done() == done
+        got = lp.read()
+        check_bench_lp_state(got, rec)
+        del got
+    # and a second solve on the same handle, straight to the end of a bench step, as the timed loop does it
+    lp.begin()
+    assert lp.iterate(3840) == xpoly_amd.six.XPG_RUNNING
+    check_bench_lp_state(lp.read(), GOLD_BENCH["bench_lp"][-1])
+    lp.close()

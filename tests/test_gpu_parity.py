@@ -302,3 +302,39 @@ def test_rational_device_loop_with_fractions_not_in_lowest_terms(ctx, port):
                 assert np.array_equal(got[k], want[k]), (it, K, k)
             checked += 1
     assert checked == 36
+
+
+def test_rational_phase_one_with_an_objective_constant_not_in_lowest_terms(ctx, port):
+    """after phase one k_rebuild_obj brings the caller's objective back with its constant copied
+    unreduced (lpsol.h:944-953), so an objective such as c.x + 2/4 must switch the HBM-resident rational loop to the
+    generic forms even though phase one itself started from the auxiliary objective and every leq cell is canonical
+    (add_canon(0/1, 2/4) would keep 2/4 where the reference's add gives 1/2)."""
+    import xpoly_amd
+    rng = np.random.default_rng(2718)
+    six = xpoly_amd.SIX(ctx, RAT)
+    checked = phase1 = 0
+    for it in range(40):
+        m, nv = int(rng.integers(3, 9)), int(rng.integers(3, 9))
+        A = rng.integers(-3, 6, size=(m, nv)); b = rng.integers(1, 3 * nv, size=m); c = rng.integers(-2, 6, size=nv)
+        neg_rows = rng.random(m) < 0.35                    # a negative constant: the origin is infeasible -> phase one
+        A[neg_rows] = -np.abs(A[neg_rows]) - 1; b[neg_rows] = -rng.integers(1, 4, size=int(neg_rows.sum()))
+        leq = gen.to_rat(np.concatenate([A, b[:, None]], axis=1).astype(np.int32))
+        tg = gen.to_rat(np.concatenate([c, [0]]).astype(np.int32))
+        k = int(rng.integers(2, 5))
+        tg[nv] = (int(rng.integers(1, 4)) * k, int(rng.integers(2, 4)) * k)      # e.g. 2/4, 6/9: value kept, not canonical
+        if it % 3 == 0:
+            j = int(rng.integers(0, nv)); tg[j] = (tg[j, 0] * 2, 2)
+        for K in (2, 6, 0xFFFFFFFF):
+            want = port.two_stage(RAT, leq, tg, K)
+            six.set_param(0, K)
+            got = six.TwoStageMethod(leq, tg)
+            assert got["status"] == want["status"], (it, K, got["status"], want["status"])
+            if want["status"] == 2:
+                continue
+            phase1 += int(neg_rows.any())
+            for key in ("tab", "tgtf", "nvset", "bvset", "bv2eq", "eq2bv"):
+                assert np.array_equal(got[key], want[key]), (it, K, key)
+            if want["status"] == 0:
+                assert np.array_equal(got["maxv"], want["maxv"]) and np.array_equal(got["sol"], want["sol"]), (it, K)
+            checked += 1
+    assert checked >= 40 and phase1 >= 20

@@ -470,7 +470,7 @@ void blk_sweep_body(double * __restrict__ tab, int m, int W, int ld, const doubl
     for (int s = 0; s < NB; s++) rs[s] = st->blk.r[s];
     const int i0 = blockIdx.y * ROWS;
     const int iend = min(i0 + ROWS, m);
-    if (j + 1 < W) {
+    {                                                         // (ld is a multiple of 16: a live first column owns a whole pair; the cells beyond W are padding)
         double2 e[NB];
 #pragma unroll
         for (int s = 0; s < NB; s++) e[s] = *reinterpret_cast<const double2 *>(E + (size_t)s * ld + j);
@@ -509,18 +509,6 @@ void blk_sweep_body(double * __restrict__ tab, int m, int W, int ld, const doubl
             *reinterpret_cast<double2 *>(base) = a;
             base += ld;
         }
-    } else {                                                  // odd last column
-        for (int i = i0; i < iend; i++) {
-            double * p = tab + (size_t)i * ld + j;
-            double a = *p;
-#pragma unroll
-            for (int s = 0; s < NB; s++) {
-                const double es = E[(size_t)s * ld + j];
-                const double q = K[(size_t)i * BLK_MAX + s] * es;
-                a = (i == rs[s]) ? es : (a + q);
-            }
-            *p = a;
-        }
     }
 }
 
@@ -540,17 +528,53 @@ void blk_sweep_body(double * __restrict__ tab, int m, int W, int ld, const doubl
 //    any other row (what it leaves there is meaningless) and the workgroup that owns them rewrites
 //    them once its stream is through -- their final contents depend on E and K only (e_s, then stages
 //    s+1.. applied to it with the same two roundings per stage), and e is still in registers.
+// Which tile a workgroup takes (round 3; tools/lab/sweep_lab2.hip, profiles/round3_sweep_lab.txt). Two things decide
+// whether this pass runs at the rate of a plain in-place copy of the tableau or 15-30 % below it:
+//  * E must stay in the L2 of the XCD that uses it. A workgroup re-reads 16 x 4 KB of E for every 64 KB of tableau
+//    it streams, i.e. a third of its L2 traffic. Workgroups are dealt round-robin over the 8 XCDs, so with S column
+//    strips in a plain 2-D grid an XCD meets strip s every 8 / gcd(S, 8) row blocks: S = 24 -> every row block (E
+//    hits), S = 25 (the 4096 x 12289 tableau of BASELINE configs[1]) -> every 8th, by which time 4.6 MB have gone
+//    through its 4 MB L2 and E comes from the fabric again: 146 us against 122 us at S = 24. Here strip s below
+//    F = 8 * floor(S / 8) ALWAYS runs on XCD s % 8 (linear id -> XCD id % 8, then that XCD's own strips row block by
+//    row block), and the S - F leftover strips are dealt over the XCDs by row block ((q + y) % 8), so the load stays
+//    even for every S and an odd last column costs no XCD more than an eighth of a strip.
+//  * Alternate passes walk the row blocks in opposite directions (rev): the tail of pass t is the head of pass
+//    t + 1, so whatever the 256 MiB Infinity Cache still holds of the tableau is read back from it instead of
+//    being evicted unread by a cyclic sweep (4096 x 12289: 154 -> 129 us; 8192 x 8192: 193 -> 160 us).
+// One-dimensional grid of blk_sweep_grid() workgroups.
+__host__ __device__ __forceinline__ int blk_sweep_grid(int strips, int rowblocks)
+{
+    return 8 * ((rowblocks + 7) / 8) * (8 * (strips >> 3) + (strips & 7));
+}
+__device__ __forceinline__ bool blk_sweep_tile(int lid, int strips, int rowblocks, int rev, int & bx, int & by)
+{
+    const int c = lid & 7, k = lid >> 3;
+    const int nown = strips >> 3, L = strips & 7, per = 8 * nown + L;
+    const int super = k / per, rem = k - super * per;
+    int yy;
+    if (rem < 8 * nown) { yy = rem / nown; bx = c + 8 * (rem - yy * nown); }
+    else { const int q = rem - 8 * nown; yy = (c - q) & 7; bx = 8 * nown + q; }
+    by = 8 * super + yy;
+    if (by >= rowblocks) return false;
+    if (rev) by = rowblocks - 1 - by;
+    return true;
+}
+
 template <int ROWS, int U> __global__ __launch_bounds__(256)
 void k_blk_sweep_full(double * __restrict__ tab, int m, int W, int ld, const double * __restrict__ E,
-                      const double * __restrict__ K, LoopState * __restrict__ st, int batch, int only_full)
+                      const double * __restrict__ K, LoopState * __restrict__ st, int batch, int only_full, int rev)
 {
     constexpr int NB = BLK_MAX;
     static_assert(ROWS % (2 * U) == 0, "a row block holds whole ping-pong pairs");
-    const int j = blockIdx.x * 512 + threadIdx.x * 2;
-    const int i0 = blockIdx.y * ROWS;
+    int bx, by;
+    if (!blk_sweep_tile((int)blockIdx.x, (W + 511) / 512, (m + ROWS - 1) / ROWS, rev, bx, by)) return;
+    const int j = bx * 512 + threadIdx.x * 2;
+    const int i0 = by * ROWS;
     const int iend = min(i0 + ROWS, m);
-    // the first row group goes out before anything else: it comes from HBM, the state and E from the L2
-    const bool full = i0 + ROWS <= m && j + 1 < W;
+    // the first row group goes out before anything else: it comes from HBM, the state and E from the L2.
+    // ld is a multiple of 16 and the cells of a row beyond W are padding nobody reads (E is zero there), so a thread
+    // whose first column is live always owns a whole 16-byte pair: an odd W has no scalar last column.
+    const bool full = i0 + ROWS <= m && j < W;
     double2 a[U], b[U];
     if (full) {
 #pragma unroll
@@ -562,28 +586,26 @@ void k_blk_sweep_full(double * __restrict__ tab, int m, int W, int ld, const dou
     // only_full: a second launch (k_blk_sweep, the stage count as a template switch) follows for the batches that
     // closed early -- the host turns that on for LPs that close batches often (Lp::queue_blocked)
     if (only_full && n != NB) return;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {     // xpg_lp_counters
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                        // xpg_lp_counters
         if (n == NB) st->blk.sweeps_full += 1u; else st->blk.sweeps_part += 1u;
     }
 
-    if (n != NB || j + 1 >= W) {
-        // A partial batch (the iteration budget ran out, or a pick closed the batch early) and the odd
-        // last column: the plain form, stage count and row list read at run time, e_s re-read from the
-        // cache per row. Rare, and kept light on registers so that it does not weigh on the path below.
-        const bool pair = j + 1 < W;
+    if (n != NB) {
+        // A partial batch (the iteration budget ran out, or a pick closed the batch early): the plain form,
+        // stage count and row list read at run time, e_s re-read from the cache per row. Rare, and kept light
+        // on registers so that it does not weigh on the path below.
         for (int i = i0; i < iend; i++) {
             double * p = tab + (size_t)i * ld + j;
-            double ax = p[0], ay = pair ? p[1] : 0.0;
+            double ax = p[0], ay = p[1];
             for (int s = 0; s < n; s++) {
                 const double k = K[(size_t)i * BLK_MAX + s];
-                const double ex = E[(size_t)s * ld + j], ey = pair ? E[(size_t)s * ld + j + 1] : 0.0;
+                const double ex = E[(size_t)s * ld + j], ey = E[(size_t)s * ld + j + 1];
                 const double p0 = k * ex, p1 = k * ey;
                 const bool piv = st->blk.r[s] == i;
                 ax = piv ? ex : ax + p0;
                 ay = piv ? ey : ay + p1;
             }
-            p[0] = ax;
-            if (pair) p[1] = ay;
+            p[0] = ax; p[1] = ay;
         }
         return;
     }

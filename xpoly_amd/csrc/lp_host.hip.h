@@ -66,6 +66,20 @@ struct DeviceGuard {
 
 inline int round_up(int x, int a) { return (x + a - 1) / a * a; }
 
+// Leading dimension of a device tableau of W live columns. Always a multiple of 16 elements: rows start on 128-byte
+// lines, every 16-byte access is aligned, and a thread whose first column is live owns a whole pair. A width that is
+// itself a multiple of 16 is kept (4096 x 8192 runs best at ld = 8192: 78 us per blocked sweep against 82 at 8208);
+// any other goes to the next multiple of 64 (rows on 512-byte boundaries: 4096 x 12289 126 us at 12352 against 131
+// at 12304), stepping over the row strides the sweep was measured to run 10-20 % slower at (tools/lab/sweep_lab2.hip
+// ldscan, profiles/round3_sweep_lab.txt: k * (32 KiB + 128 B) -- 8224, 12336, 16448 elements -- and 32 KiB - 128 B).
+inline int pick_ld(int W)
+{
+    static const int align = [] { const char * s = getenv("XPG_LD_ALIGN"); const int a = s ? atoi(s) : 64; return a >= 16 && a % 16 == 0 ? a : 64; }();
+    int ld = W % 16 == 0 ? W : round_up(W, align);
+    if (ld % 4112 == 0 || (ld + 16) % 4096 == 0) ld += 16;
+    return ld;
+}
+
 // fp64 sweep launch. Variants are (rows per workgroup, rows in flight); the
 // default is what measured best on MI355X (profiles/), the others stay
 // reachable through XPG_UPDATE_VARIANT for A/B runs.
@@ -165,14 +179,17 @@ template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> &
     const bool timed = B == ctx->block_len && ctx->prof_n < ctx->prof_cap && (ctx->prof_seen++ % ctx->prof_stride) == 0;
     hipEvent_t e0 = timed ? ctx->ev0[ctx->prof_n] : nullptr, e1 = timed ? ctx->ev1[ctx->prof_n] : nullptr;
     static const int rows_env = [] { const char * s = getenv("XPG_BLK_ROWS"); return s ? atoi(s) : 32; }();
+    // alternate passes walk the row blocks in opposite directions (Infinity Cache reuse across passes); XPG_SERPENTINE=0 for A/B runs
+    static const int serpentine = [] { const char * s = getenv("XPG_SERPENTINE"); return s ? atoi(s) : 1; }();
 #define XPG_BLK_LAUNCH(ROWS_, UNR_, CAP_)                                                                                 \
     hipExtLaunchKernelGGL((k_blk_sweep<ROWS_, UNR_, CAP_>), dim3(strips, (v.m + ROWS_ - 1) / ROWS_), dim3(256), 0,        \
                           ctx->stream, e0, e1, 0, (double *)v.tab, v.m, v.W, v.ld, (const double *)v.blkE,                \
                           (const double *)v.blkK, v.st, batch, 0)
 #define XPG_BLK_FULL(ROWS_, UNR_)                                                                                         \
-    hipExtLaunchKernelGGL((k_blk_sweep_full<ROWS_, UNR_>), dim3(strips, (v.m + ROWS_ - 1) / ROWS_), dim3(256), 0,         \
-                          ctx->stream, e0, e1, 0, (double *)v.tab, v.m, v.W, v.ld, (const double *)v.blkE,                \
-                          (const double *)v.blkK, v.st, batch, closes_often ? 1 : 0)
+    hipExtLaunchKernelGGL((k_blk_sweep_full<ROWS_, UNR_>), dim3(blk_sweep_grid(strips, (v.m + ROWS_ - 1) / ROWS_)),      \
+                          dim3(256), 0, ctx->stream, e0, e1, 0, (double *)v.tab, v.m, v.W, v.ld,                          \
+                          (const double *)v.blkE, (const double *)v.blkK, v.st, batch, closes_often ? 1 : 0,              \
+                          serpentine ? (batch & 1) : 0)
     if (B <= 8) XPG_BLK_LAUNCH(32, 8, 8);
     else if (B < BLK_MAX || rows_env == 1) XPG_BLK_LAUNCH(32, 4, 16);
     else if (rows_env == 324) XPG_BLK_FULL(32, 4);
@@ -215,6 +232,7 @@ template <class S> struct Lp : LpBase {
     S * d_maxv;
     std::vector<void *> owned;
     size_t tab_elems;
+    int ld_cap = 0;         // leading dimension the buffers were allocated for (>= v.ld)
     int row_cap = 0;        // rows the tableau has room for (m + extra)
     bool began;
     int final_status;
@@ -257,7 +275,10 @@ template <class S> struct Lp : LpBase {
         m = m_; n0 = cols - 1; began = false; final_status = XPG_RUNNING;
         const int mcap = m + extra;
         const int Wmax = n0 + 1 + mcap + 1;         // with the phase-1 column
-        const int ld = round_up(Wmax, 16);
+        // the allocation's leading dimension; build() picks the one in use from the width the slack form really has
+        // (with or without the phase-1 column), so that a 4096 x 8192 tableau runs at ld = 8192, not 8208
+        const int ld = pick_ld(Wmax) > pick_ld(Wmax - 1) ? pick_ld(Wmax) : pick_ld(Wmax - 1);
+        ld_cap = ld;
         const int nmax = Wmax - 1;
         v.m = m; v.ld = ld; v.W = 0; v.rhs = 0;
         v.pw = (nmax + 31) / 32;
@@ -304,6 +325,10 @@ template <class S> struct Lp : LpBase {
         XPG_HIP(ctx, hipMemcpyAsync(v.vcr, hr.data(), (size_t)ld * sizeof(S), hipMemcpyHostToDevice, s));
         XPG_HIP(ctx, hipMemsetAsync(v.st, 0, sizeof(LoopState), s));
         XPG_HIP(ctx, hipMemsetAsync(v.pickrec, 0, (size_t)PICK_WORDS * 8, s));
+        // the cells of a row beyond W are padding: the sweeps update them along with the last live column (whole
+        // 16-byte pairs) and nobody reads them; zero E there keeps them finite
+        XPG_HIP(ctx, hipMemsetAsync(v.tab, 0, tab_elems * sizeof(S), s));
+        XPG_HIP(ctx, hipMemsetAsync(v.blkE, 0, (size_t)BLK_MAX * ld * sizeof(S), s));
         // launch-throttle events, exercised once so their first use is not inside a solve
         for (int i = 0; i < 2; i++) {
             XPG_HIP(ctx, hipEventCreateWithFlags(&throttle[i], hipEventDisableTiming));
@@ -326,6 +351,8 @@ template <class S> struct Lp : LpBase {
     {
         v.W = n0 + (with_xa ? 1 : 0) + m + 1;
         v.rhs = v.W - 1;
+        // (a tableau that may grow -- warm-started branch and bound appends rows and slack columns -- keeps the allocation's)
+        v.ld = row_cap == m ? pick_ld(v.W) : ld_cap;
         hipLaunchKernelGGL((k_build<S>), dim3(2048), dim3(256), 0, ctx->stream, v, d_leq, d_tgtf, n0, with_xa);
         hipLaunchKernelGGL((k_init_basis<S>), dim3(64), dim3(256), 0, ctx->stream, v, n0 + (with_xa ? 1 : 0));
     }

@@ -1089,11 +1089,13 @@ template <class S> __global__ void k_build(LpView<S> v, const S * leq, const S *
             v.tab[(size_t)i * v.ld + j] = val;
             if (!is_canonical_cell(val)) v.st->noncanon = 1;
         } else {
+            // the caller's objective comes back after phase one (k_rebuild_obj copies tgtf, its constant unreduced,
+            // lpsol.h:944-953), so its cells count for the canonical forms whichever objective goes in now
+            const S tv = j < n ? tgtf[j] : (j == v.rhs ? tgtf[n] : zero<S>());
             if (with_xa) { if (j == n) val = minus_one<S>(); }
-            else if (j < n) val = tgtf[j];
-            else if (j == v.rhs) val = tgtf[n];
+            else val = tv;
             v.obj[j] = val;
-            if (!is_canonical_cell(val)) v.st->noncanon = 1;
+            if (!is_canonical_cell(tv)) v.st->noncanon = 1;
         }
     }
 }

@@ -1,6 +1,8 @@
 // Arithmetic of the small-problem kernels (LDS-resident LPs, row elimination), selected per PROBLEM.
-// Every value the reference's Rational can hold is canonical (lowest terms, den > 0), and a problem whose input
-// cells all are -- checked when it is loaded -- stays so under these operations; it takes the 32-bit
+// Every RESULT of the reference's Rational arithmetic is canonical (lowest terms, den > 0) -- but not every value it
+// can hold: Rational(INT, INT) stores num / den as given (rational.cpp:60-64: 2/4, 0/3, 1/-2 stay), so inputs are
+// checked. A problem whose input cells all are canonical -- checked when it is loaded, the objective's constant
+// included -- stays so under these operations; it takes the 32-bit
 // cross-cancelling forms of scalar.hip.h, which equal the reference's operations bit for bit on such operands
 // (tests/cxx/fma_canon_fuzz.cpp). Any other problem takes the generic forms -- valid for any (num, den), out of line.
 // For Float the flag is ignored.
