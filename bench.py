@@ -42,7 +42,7 @@ sys.path.insert(0, ROOT)
 M, NVARS = 4096, 4095                      # tableau 4096 x (4095 + 4096 + 1) = 4096 x 8192
 TAB_W = NVARS + M + 1
 BLOCK = 16                                 # pivots one blocked sweep applies (XPG_BLOCK default)
-PIVOTS_PER_STEP = 3840                     # 240 full batches; the LP ends after 4165 (tools/probe_count.py)
+PIVOTS_PER_STEP = 3840                     # 240 full batches; the LP ends after 4165 (tools/lab/probe_count.py)
 ALG_BYTES_PER_LAUNCH = 2 * M * TAB_W * 8   # one sweep LAUNCH reads and writes every entry once (SURVEY 8d:
                                            # 2*m*W*8 B; the blocked loop pays it per 16 pivots, not per pivot)
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s
@@ -348,7 +348,7 @@ def main():
         # set-up, not measured: one pass through every code path of the timed region (launch throttling,
         # event pairs) so lazy runtime initialisation does not land inside it. The ROCm runtime was measured
         # to stall the stream once for 60-80 ms somewhere in the first ~100 ms of queued-loop activity of a
-        # process (tools/probe_stall.py), so the set-up pass runs for at least PREWARM_SECONDS of wall time.
+        # process (tools/lab/probe_stall.py), so the set-up pass runs for at least PREWARM_SECONDS of wall time.
         ctx.profile_begin(8, 32)
         t_pre = time.perf_counter()
         run_step()
@@ -510,7 +510,7 @@ def main():
                                     salu_busy_percent=pb.get("dense_busy_percent", {}).get("SALUBusy"),
                                     wave_instructions_per_pivot=pb.get("dense_per_pivot")),
                 source="profiles/round2_pmc_batch_issue.json (rocprofv3 --pmc VALUBusy / SALUBusy / SQ_INSTS_* on "
-                       "tools/probe_batch.py; not collected in this run)")
+                       "tools/lab/probe_batch.py; not collected in this run)")
         if world == 1 and not stub:
             # N = 1 reference point for STRONG scaling: the whole 65 536-LP batch of cfg 3 on one GPU
             full_n = BATCH_PER_GPU * 8

@@ -3,7 +3,7 @@
 // such a chain (pick -> prep -> pick -> ...: each step reduces ~64-128 small records the previous
 // step's workgroups left, gathers a strided column or a row, and leaves records of its own).
 //
-//   hipcc --offload-arch=gfx950 -O3 -o tools/_build/launch_lab tools/launch_lab.hip && tools/_build/launch_lab
+//   hipcc --offload-arch=gfx950 -O3 -o tools/_build/launch_lab tools/lab/launch_lab.hip && tools/_build/launch_lab
 //
 // Steps measured (host wall time over N dependent steps, one stream):
 //   A  trivial kernel, 1 workgroup

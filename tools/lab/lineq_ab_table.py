@@ -1,4 +1,4 @@
-"""Prints the per-launch kernel times of tools/run_lineq_pack.sh's two rocprofv3 traces side by side."""
+"""Prints the per-launch kernel times of tools/lab/run_lineq_pack.sh's two rocprofv3 traces side by side."""
 import csv, glob, os, sys
 d = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/lineq"
 out = {}

@@ -1,6 +1,6 @@
 """GPU probe: batched 32x64 LP throughput (device-resident inputs)."""
 import sys, os, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 import torch
 import xpoly_amd

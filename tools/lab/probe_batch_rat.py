@@ -1,6 +1,6 @@
 """GPU probe: batched rational (int32 num/den) LP throughput, dependence-test-like integer data, inputs resident."""
 import sys, os, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 import torch
 import xpoly_amd

@@ -1,6 +1,6 @@
 """GPU probe: the dependence-test front end (DepPoly::is_empty) and batched 0-1 MIPs (config 5)."""
 import sys, os, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 import xpoly_amd
 from xpoly_amd.six import dep_is_empty_batch, mip_batch

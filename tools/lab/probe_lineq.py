@@ -1,6 +1,6 @@
 """GPU probe: throughput of the wave-per-system row-elimination kernels at dependence-test sizes."""
 import sys, os, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 import xpoly_amd
 from xpoly_amd.lineq import Lineq

@@ -1,7 +1,7 @@
 """GPU probe: latency of ONE-system row-elimination calls through the host-array entry points (what the drop-in
 Lineq adapter issues per call)."""
 import sys, os, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 import xpoly_amd
 from xpoly_amd.lineq import Lineq

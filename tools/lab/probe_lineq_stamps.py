@@ -1,7 +1,7 @@
-"""GPU probe (diagnostic build, tools/run_lineq_stamps.sh): where k_fme_batch spends its clock ticks, per phase,
+"""GPU probe (diagnostic build, tools/lab/run_lineq_stamps.sh): where k_fme_batch spends its clock ticks, per phase,
 summed over the systems of a batch by lane 0 of each."""
 import sys, os, ctypes as C
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 import xpoly_amd
 from xpoly_amd import _capi

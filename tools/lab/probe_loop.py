@@ -1,7 +1,7 @@
 """GPU probe: per-call timing of DeviceLP.iterate to separate fixed stalls from per-pivot cost.
 usage: probe_loop.py [torch] [sync]"""
 import sys, os, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 use_torch = "torch" in sys.argv
 if use_torch:

@@ -1,4 +1,4 @@
-"""GPU diagnostic (-DXPG_STAMPS build, tools/run_mip_stamps.sh): where a node of the device-side tree walk spends
+"""GPU diagnostic (-DXPG_STAMPS build, tools/lab/run_mip_stamps.sh): where a node of the device-side tree walk spends
 its time -- rebuilding the node problem, the LDS solve, the recursion's feed-back."""
 import ctypes as C
 import xpoly_amd

@@ -1,6 +1,6 @@
 """GPU probe: config 4 -- rational tableau 1024 x 2048, K = 16 pivots (crosses the first appro)."""
 import sys, os, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 import xpoly_amd
 from tools import gen

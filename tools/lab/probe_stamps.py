@@ -1,5 +1,5 @@
 """GPU diagnostic: where does the time of a pick / prep launch of the blocked loop go? Needs a library built
-with -DXPG_STAMPS (tools/run_stamps.sh builds tools/_build/libxpoly_stamps.so and points XPG_SO_PATH at it)."""
+with -DXPG_STAMPS (tools/lab/run_stamps.sh builds tools/_build/libxpoly_stamps.so and points XPG_SO_PATH at it)."""
 import ctypes as C
 import os
 

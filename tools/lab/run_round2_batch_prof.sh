@@ -8,7 +8,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -- python3 $R/benc
 cp $(find $O/ks -name "*kernel_stats.csv" | head -1) $O/kernel_stats_batched_leg.csv; head -4 $O/kernel_stats_batched_leg.csv | cut -c1-220
 find $O -name "*kernel_trace.csv" -delete
 for c in VALUBusy SALUBusy SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS; do
-  rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/tools/probe_batch.py > $O/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/tools/lab/probe_batch.py > $O/pmc_$c.log 2>&1
 done
 cd $R && python3 - <<'PY'
 import csv, glob, json, os, re
@@ -23,7 +23,7 @@ for c in ("VALUBusy", "SALUBusy", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LD
     out[c] = vals
 log = open(os.path.join(O, "pmc_VALUBusy.log")).read()
 fam = re.findall(r"fam (\d).*?LPs/s (\d+) pivots/s ([\d.]+)M ms ([\d.]+)", log)
-res = dict(command="rocprofv3 --pmc <counter> -- python3 tools/probe_batch.py (8192 LPs of 32x64 per family, 4 launches each: dense first, then dependence-test-like)",
+res = dict(command="rocprofv3 --pmc <counter> -- python3 tools/lab/probe_batch.py (8192 LPs of 32x64 per family, 4 launches each: dense first, then dependence-test-like)",
            probe=[dict(family=int(a), lps_per_s=int(b), mpivots_per_s=float(c), ms=float(d)) for a, b, c, d in fam], counters=out)
 # per-pivot instruction counts of the dependence-test-like family (launches 5..8)
 try:

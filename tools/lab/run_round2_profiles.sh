@@ -39,10 +39,10 @@ print({c: {k: round(v["avg"], 2) for k, v in d.items() if "update" in k or "pick
 PY
 # the row-elimination kernels: per-launch times of the probe and their VALU / SALU occupancy
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_lineq -- python3 $R/tools/probe_lineq.py > $O/ks_lineq.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_lineq -- python3 $R/tools/lab/probe_lineq.py > $O/ks_lineq.log 2>&1
 cp $(find $O/ks_lineq -name "*kernel_stats.csv" | head -1) $O/kernel_stats_lineq_probe.csv; head -5 $O/kernel_stats_lineq_probe.csv | cut -c1-150
 for c in VALUBusy SALUBusy; do
-  rocprofv3 --pmc $c --output-format csv -d $O/pmcl_$c -- python3 $R/tools/probe_lineq.py > $O/pmcl_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $O/pmcl_$c -- python3 $R/tools/lab/probe_lineq.py > $O/pmcl_$c.log 2>&1
 done
 cd $R && python3 - <<'PY'
 import csv, glob, json, os

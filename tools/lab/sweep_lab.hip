@@ -1,7 +1,7 @@
 // Lab bench for the blocked sweep (k_blk_sweep, lp_blocked.hip.h): times variants of the 16-stage body
 // on the bench-sized tableau (4096 x 8192 fp64) with HIP events, outside the library, so that a register
 // or scheduling idea can be tried in seconds. Not part of the product; build and run:
-//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -o tools/_build/sweep_lab tools/sweep_lab.hip
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -o tools/_build/sweep_lab tools/lab/sweep_lab.hip
 //   gpurun -- tools/_build/sweep_lab
 #include <hip/hip_runtime.h>
 #include <stdio.h>

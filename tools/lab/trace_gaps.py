@@ -1,6 +1,6 @@
 """Reads a rocprofv3 kernel_trace.csv and prints, for the blocked loop, the average duration of each
 kernel and the average gap (previous kernel's end -> this kernel's start) in front of it, split by
-what the previous kernel was. Usage: python tools/trace_gaps.py <..._kernel_trace.csv>"""
+what the previous kernel was. Usage: python tools/lab/trace_gaps.py <..._kernel_trace.csv>"""
 import csv
 import sys
 from collections import defaultdict

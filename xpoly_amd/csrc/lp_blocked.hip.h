@@ -44,7 +44,7 @@
 
 namespace xpg {
 
-// Diagnostic builds (-DXPG_STAMPS, tools/run_stamps.sh): 100 MHz ticks between points of pick / prep, summed by
+// Diagnostic builds (-DXPG_STAMPS, tools/lab/run_stamps.sh): 100 MHz ticks between points of pick / prep, summed by
 // workgroup 0 lane 0 into LoopState::blk.dbg (a full memory wait precedes every stamp).
 #ifdef XPG_STAMPS
 #define XPG_STAMP_DECL unsigned long long stamp_prev_ = wall_clock64()
@@ -513,7 +513,7 @@ void blk_sweep_body(double * __restrict__ tab, int m, int W, int ld, const doubl
 }
 
 // The full batch (n == BLK_MAX, the steady state) as a kernel of its own, shaped by measurements on the
-// bench tableau (tools/sweep_lab.hip):
+// bench tableau (tools/lab/sweep_lab.hip):
 //  * compiled alone the 16-stage body fits 128 VGPRs (four wavefronts per SIMD) with next to no SGPR
 //    spills; inside the switch kernel below the allocator settles on the union of all 32 bodies
 //    (131 VGPRs + 102 spilled SGPRs);

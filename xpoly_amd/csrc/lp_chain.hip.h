@@ -1,10 +1,10 @@
 // Blocked fp64 simplex loop, stages 1 .. B-1 of a batch in ONE launch.
 //
 // The launch-per-stage chain of lp_blocked.hip.h (pick(t) -> prep(t) -> pick(t+1) ...) is a latency
-// chain: measured at 4096 x 8192 (tools/probe_stamps.py) a pick or prep launch lasts 5.8-6.0 us of
+// chain: measured at 4096 x 8192 (tools/lab/probe_stamps.py) a pick or prep launch lasts 5.8-6.0 us of
 // which ~2 us each are its two dependent memory rounds -- first touches of a fresh launch (cold L2,
 // cold TLBs) -- and a launch boundary. The same chain step as a phase of a persistent launch costs
-// 2.2-2.8 us in the lab (tools/launch_lab.hip, rows D against B). This kernel is that persistent form.
+// 2.2-2.8 us in the lab (tools/lab/launch_lab.hip, rows D against B). This kernel is that persistent form.
 //
 // Workers are one-wave workgroups: worker w owns rows 64w .. 64w+63 (pick role, w < npick) and columns
 // 64w .. 64w+63 (prep role, w < nprep); one more worker, the committer, owns the basis arrays. There is

@@ -198,7 +198,7 @@ template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> &
     else XPG_BLK_FULL(16, 4);                           // the default: full batches of 16
     // An LP whose batches often close early (a rare branch of solveSlackForm met with pivots staged: 34-44 % of
     // the sweeps on whole solves of 300 x 300 and 1024 x 1500 LPs, 1 of 261 on the bench LP,
-    // tools/probe_partial_batches.py) gets a second launch with the stage count as a template switch for those
+    // tools/lab/probe_partial_batches.py) gets a second launch with the stage count as a template switch for those
     // batches; the full-batch kernel above then leaves them alone.
     if (closes_often && B == BLK_MAX && rows_env != 1)
         hipLaunchKernelGGL((k_blk_sweep<32, 4, 16>), dim3(strips, (v.m + 31) / 32), dim3(256), 0, ctx->stream, (double *)v.tab,
