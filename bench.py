@@ -46,6 +46,7 @@ PIVOTS_PER_STEP = 3840                     # 240 full batches; the LP ends after
 ALG_BYTES_PER_LAUNCH = 2 * M * TAB_W * 8   # one sweep LAUNCH reads and writes every entry once (SURVEY 8d:
                                            # 2*m*W*8 B; the blocked loop pays it per 16 pivots, not per pivot)
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s
+PCIE_GBS = 63.0                            # MI355X_MICROARCH.md: host link PCIe Gen5 x16, 63 GB/s (spec)
 BATCH_PER_GPU = 8192                       # 65 536 LPs over 8 GPUs (BASELINE.json configs[2])
 BATCH_M, BATCH_COLS = 32, 64
 PREWARM_SECONDS = 0.5
@@ -738,11 +739,22 @@ def leg_lineq(ctx, xpoly_amd, gen):
             rec[name + "_systems_per_s"] = round(LINEQ_NB / min(resident(name) for _ in range(3)), 0)
         del d_in, d_work, d_out, d_r, d_k
         # (ii) the host-array entry points: PCIe and the cap-row result slots included
-        for name, fn in (("reduce", lambda: lq.reduce(mats, nv, True)), ("fme", lambda: lq.fme(mats, nv, 0)),
-                         ("rank", lambda: lq.rank(mats))):
+        for name, fn in (("reduce", lambda: lq.reduce(mats, nv, True)), ("fme_slots", lambda: lq.fme(mats, nv, 0, slots=True)),
+                         ("fme", lambda: lq.fme_packed(mats, nv, 0, copy=False)), ("rank", lambda: lq.rank(mats))):
             fn()
             t0 = time.perf_counter(); fn(); dt = time.perf_counter() - t0
             rec[name + "_host_arrays_systems_per_s"] = round(LINEQ_NB / dt, 0)
+        # what the link allows for the packed form: the systems up, the live rows down
+        _, off, _ = lq.fme_packed(mats[:256], nv, 0)
+        bytes_per_system = rows * cols * 8 + float(off[-1]) / 256 * cols * 8
+        rec["fme_result_rows_mean"] = round(float(off[-1]) / 256, 1)
+        rec["fme_host_arrays_pcie_bound_systems_per_s"] = round(PCIE_GBS * 1e9 / bytes_per_system, 0)
+        one = mats[:1]
+        lq.fme_packed(one, nv, 0)
+        t0 = time.perf_counter()
+        for _ in range(200):
+            lq.fme_packed(one, nv, 0, copy=False)
+        rec["fme_one_system_call_us"] = round((time.perf_counter() - t0) / 200 * 1e6, 1)
         rows_out.append(rec)
     # small rational LPs, dependence-test-like integer data (12 rows, 16 variables)
     nb, m, cols = 8192, 12, 17
@@ -770,7 +782,10 @@ def leg_lineq(ctx, xpoly_amd, gen):
                                   status_hist=np.bincount(np.clip(st, 0, 4), minlength=5).tolist()),
                 dtype="int32 num/den", bound="integer issue (gcd loops), not HBM",
                 sample="*_systems_per_s: 16384 systems resident in HBM, best of 3 calls timed to xpg_sync; *_host_arrays_*, "
-                       "rational_lps and dep_is_empty: host arrays in and out (PCIe included), second call timed")
+                       "rational_lps and dep_is_empty: host arrays in and out (PCIe included), second call timed; fme_host_arrays = "
+                       "the packed entry point (row offsets + live rows through pinned memory), fme_slots_host_arrays = round 2's "
+                       "cap-row slots; *_pcie_bound_* = 63 GB/s / (system bytes up + mean live-row bytes down); "
+                       "fme_one_system_call_us = mean of 200 one-system packed calls incl. the ctypes layer")
 
 
 if __name__ == "__main__":

@@ -283,6 +283,23 @@ int xpg_lineq_move2var_batch_rat32(xpg_ctx * ctx, int nb, xpg_rat32 * mats, int 
 int xpg_lineq_fme_batch_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols,
                               int rhs_idx, int u, int darkshadow, xpg_rat32 * outs, int cap_rows,
                               int32_t * out_rows, int32_t * out_ok);
+/* Lineq::fme (src/com/linsys.cpp:656-774) with a PACKED result -- the form a host-resident caller wants: the
+ * worst case of a result is rows^2/4 + rows rows, the typical one a third of it, and the slots of the entry point
+ * above come back whole.  Here row_offsets[nb + 1] (in rows) and only the live rows of every system, back to back
+ * ([row_offsets[nb]][cols]), travel; both directions go through pinned memory of the handle.
+ *   outs      (may be NULL) receives the rows; outs_cap_rows is its capacity in rows.  Too small: XPG_ERR_SHAPE with
+ *             row_offsets filled, so the caller can size the buffer and call again.
+ *   out_view  (may be NULL) receives a pointer to the same rows in the handle's pinned buffer, valid until the next
+ *             packed call on this handle (or xpg_destroy): the zero-copy form the C++ adapter uses.
+ *   cap_rows  rows of the device slot per system; <= 0: the worst case.  A result that needs more: XPG_ERR_UNSUPPORTED.
+ * out_ok[b] as above.  One handle is used by one host thread at a time. */
+int xpg_lineq_fme_batch_packed_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols,
+                                     int rhs_idx, int u, int darkshadow, int cap_rows, xpg_rat32 * outs,
+                                     long long outs_cap_rows, const xpg_rat32 ** out_view, long long * row_offsets,
+                                     int32_t * out_ok);
+/* Gives the device blocks and pinned staging a handle keeps between host-array calls back to the runtime (they are
+ * kept to spare one-system callers four hipMalloc / hipFree pairs per call; at most 1 GiB / 16 blocks). */
+int xpg_trim(xpg_ctx * ctx);
 /* Lineq::calcBound, src/com/linsys.cpp:1047-1078, for nb systems: for each variable j every
  * other variable is eliminated (innermost first) by chained fme launches that stay on the
  * device.  bounds is [nb][rhs_idx][cap_rows][cols], out_rows is [nb][rhs_idx];

@@ -69,18 +69,17 @@ public:
     // Lineq::fme on the system given to the constructor / set_param, linsys.cpp:656-774
     bool fme(unsigned u, RMatT & res, bool darkshadow = false)
     {
+        // the packed form: only the live rows travel, and they are read straight out of the handle's pinned buffer
         const int rows = (int)m_coeff->get_row_size(), cols = (int)m_coeff->get_col_size();
-        int cap = rows * rows / 4 + rows + 1;
-        for (int attempt = 0; attempt < 2; attempt++) {
-            std::vector<xpg_rat32> out((size_t)cap * cols);
-            int32_t orows = 0, ok = 0;
-            if (xpg_lineq_fme_batch_rat32(ctx(), 1, (const xpg_rat32 *)m_coeff->get_matrix(), rows, cols, m_rhs_idx, (int)u,
-                                          darkshadow ? 1 : 0, out.data(), cap, &orows, &ok) != 0) return false;
-            if (orows < 0) { cap = -orows; continue; }
-            put(res, out, orows, cols);
-            return ok != 0;
-        }
-        return false;
+        const xpg_rat32 * view = 0;
+        long long off[2] = {0, 0};
+        int32_t ok = 0;
+        if (xpg_lineq_fme_batch_packed_rat32(ctx(), 1, (const xpg_rat32 *)m_coeff->get_matrix(), rows, cols, m_rhs_idx, (int)u,
+                                             darkshadow ? 1 : 0, 0, (xpg_rat32 *)0, 0, &view, off, &ok) != 0) return false;
+        const int orows = (int)off[1];
+        res.reinit(orows, cols);
+        if (orows * cols) std::memcpy((void *)res.get_matrix(), (const void *)view, sizeof(xpg_rat32) * (size_t)orows * cols);
+        return ok != 0;
     }
     // Lineq::has_solution, linsys.cpp:830-906
     bool has_solution(RMatT const & leq, RMatT const & eq, RMatT & vc, unsigned rhs_idx, bool is_int_sol, bool is_unique_sol)

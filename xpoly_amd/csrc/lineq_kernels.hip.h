@@ -919,4 +919,56 @@ __global__ __launch_bounds__(256) void k_int_gcd_batch(long long total_rows, int
     for (int j = 0; j < cols; j++) r[j] = r[j] / (int)g;
 }
 
+// ---- packed results (host-array boundary of fme / calcBound): row offsets, then live rows only -------------------
+// One workgroup: off[b] = sum of max(rows[k], 0) for k < b, off[nb] = the total (exclusive scan, 64-bit).
+__global__ __launch_bounds__(1024) void k_rows_scan(int nb, const int * __restrict__ rows, long long * __restrict__ off)
+{
+    __shared__ long long sh[16];
+    __shared__ long long carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += 1024) {
+        const int b = base + tid;
+        const long long x = b < nb ? (rows[b] > 0 ? rows[b] : 0) : 0;
+        long long incl = x;                                       // inclusive scan inside the wave
+        for (int o = 1; o < 64; o <<= 1) {
+            const long long y = ((long long)__shfl_up((int)(incl >> 32), o) << 32) | (unsigned)__shfl_up((int)(unsigned)incl, o);
+            if (lane >= o) incl += y;
+        }
+        if (lane == 63) sh[wv] = incl;
+        __syncthreads();
+        long long before = carry_s;
+        for (int k = 0; k < wv; k++) before += sh[k];
+        if (b < nb) off[b] = before + incl - x;
+        __syncthreads();
+        if (tid == 1023) carry_s = before + incl;
+        __syncthreads();
+    }
+    if (tid == 0) off[nb] = carry_s;
+}
+// System b's live rows (rows[b] of them, at the front of its cap_rows-row slot) to packed[off[b] ..]: 16 bytes per lane.
+__global__ __launch_bounds__(256) void k_pack_rows(int nb, const R32 * __restrict__ slots, int cap_rows, int cols,
+                                                   const int * __restrict__ rows, const long long * __restrict__ off,
+                                                   R32 * __restrict__ packed)
+{
+    for (int b = blockIdx.x; b < nb; b += gridDim.x) {
+        const int r = rows[b];
+        if (r <= 0) continue;
+        const size_t cells = (size_t)r * cols;
+        const R32 * src = slots + (size_t)b * cap_rows * cols;
+        R32 * dst = packed + (size_t)off[b] * cols;
+        // slot bases are 16-byte aligned when cap_rows * cols is even, destinations when off[b] * cols is: else by cell
+        if ((((size_t)src | (size_t)dst) & 15) == 0) {
+            const size_t pairs = cells >> 1;
+            const uint4 * s4 = reinterpret_cast<const uint4 *>(src);
+            uint4 * d4 = reinterpret_cast<uint4 *>(dst);
+            for (size_t t = threadIdx.x; t < pairs; t += blockDim.x) d4[t] = s4[t];
+            if ((cells & 1) && threadIdx.x == 0) dst[cells - 1] = src[cells - 1];
+        } else {
+            for (size_t t = threadIdx.x; t < cells; t += blockDim.x) dst[t] = src[t];
+        }
+    }
+}
+
 } // namespace xpg

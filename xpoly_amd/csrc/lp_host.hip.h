@@ -6,8 +6,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <map>
+#include <mutex>
 #include <string>
 #include <type_traits>
+#include <utility>
 #include <vector>
 #include <stdio.h>
 #include "../../include/xpoly_amd.h"
@@ -23,6 +26,7 @@ struct xpg_ctx {
     void * rowbuf; void * colbuf; xpg::LoopState * st; size_t row_cap, col_cap;
     void * stage; size_t stage_cap;   // grow-only device staging of the host-array batch entry points
     void * hstage; size_t hstage_cap; // its pinned host mirror (the MIP controller packs node batches into it)
+    void * hpack = 0; size_t hpack_cap = 0;   // pinned host buffer of the packed-result entry points (the view they return)
     std::vector<std::pair<void *, size_t> > dev_cache;   // device blocks between host-array row-elimination calls (DevBuf)
     size_t dev_cache_bytes = 0;
     int update_variant;     // tuning knob for the fp64 sweep (see launch_update_f64)
@@ -65,6 +69,21 @@ struct DeviceGuard {
 #define XPG_BIND(ctx_) xpg::DeviceGuard xpg_bind_guard_((ctx_) ? (ctx_)->device : -1)
 
 inline int round_up(int x, int a) { return (x + a - 1) / a * a; }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is one value per (function, device): two host threads -- two handles,
+// or the _multi entry points given the same device twice -- setting "exactly what this launch needs" could lower
+// it between the other thread's set and its launch. So the limit is only ever RAISED, under a mutex.
+inline hipError_t lds_limit(const void * fn, int device, size_t bytes)
+{
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, size_t> cur;
+    std::lock_guard<std::mutex> g(mu);
+    size_t & c = cur[std::make_pair(fn, device)];
+    if (bytes <= c) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) c = bytes;
+    return e;
+}
 
 // Leading dimension of a device tableau of W live columns. Always a multiple of 16 elements: rows start on 128-byte
 // lines, every 16-byte access is aligned, and a thread whose first column is live owns a whole pair. A width that is
@@ -258,6 +277,11 @@ template <class S> struct Lp : LpBase {
     int alloc(void ** p, size_t bytes)
     {
         hipError_t e = hipMalloc(p, bytes ? bytes : 8);
+        if (e != hipSuccess && !ctx->dev_cache.empty()) {       // the blocks parked by host-array row-elimination calls make room
+            for (auto & b : ctx->dev_cache) (void)hipFree(b.first);
+            ctx->dev_cache.clear(); ctx->dev_cache_bytes = 0;
+            e = hipMalloc(p, bytes ? bytes : 8);
+        }
         if (e != hipSuccess) { ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e); return XPG_ERR_ALLOC; }
         owned.push_back(*p);
         return 0;

@@ -426,7 +426,7 @@ int mip_batch_device(xpg_ctx * ctx, int nb, bool is_max, bool is_bin, const S * 
     XPG_TRY(hipMemcpyAsync(dl.p, leq, bl, hipMemcpyHostToDevice, ctx->stream));
     XPG_TRY(hipMemcpyAsync(dt.p, tgtf, bt, hipMemcpyHostToDevice, ctx->stream));
     if (out_sol) XPG_TRY(hipMemcpyAsync(dsol.p, out_sol, bt, hipMemcpyHostToDevice, ctx->stream));
-    XPG_TRY(hipFuncSetAttribute((const void *)k_mip_tree<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    XPG_TRY(lds_limit((const void *)k_mip_tree<S>, ctx->device, lds));
     hipLaunchKernelGGL((k_mip_tree<S>), dim3(grid), dim3(threads), lds, ctx->stream, nb, (const S *)dt.p, (const S *)dl.p,
                        leq_rows, cols, is_max ? 1 : 0, is_bin ? 1 : 0, rmax, depth, (unsigned long long *)dws.p, ws_words,
                        (int32_t *)dst.p, (S *)dv.p, out_sol ? (S *)dsol.p : (S *)0, (int *)dn.p, (const int *)0, (const int *)0);
@@ -569,7 +569,7 @@ inline int dep_is_empty_batch(xpg_ctx * ctx, int nb, const R32 * mats, int rows,
             const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
             if (pass == 0) XPG_TRY(dws.alloc(ctx, (size_t)(cus * 32 < nb ? cus * 32 : nb) * ws_words * 8));   // the largest grid of either pass
             XPG_TRY(hipMemsetAsync(dn.p, 0, (size_t)nb * 4, ctx->stream));
-            XPG_TRY(hipFuncSetAttribute((const void *)k_mip_tree<R32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            XPG_TRY(lds_limit((const void *)k_mip_tree<R32>, ctx->device, lds));
             hipLaunchKernelGGL((k_mip_tree<R32>), dim3(grid), dim3(threads), lds, ctx->stream, nb, (const R32 *)dt.p, (const R32 *)dm.p,
                                rows, cols, is_max ? 1 : 0, 0, rmax, depth, (unsigned long long *)dws.p, ws_words,
                                (int32_t *)dst.p, (R32 *)dv.p, (R32 *)0, (int *)dn.p, (const int *)dk.p, (const int *)dact.p);

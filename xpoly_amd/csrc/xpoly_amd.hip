@@ -87,6 +87,7 @@ void xpg_destroy(xpg_ctx * ctx)
     if (ctx->st) (void)hipFree(ctx->st);
     if (ctx->stage) (void)hipFree(ctx->stage);
     if (ctx->hstage) (void)hipHostFree(ctx->hstage);
+    if (ctx->hpack) (void)hipHostFree(ctx->hpack);
     for (auto & b : ctx->dev_cache) (void)hipFree(b.first);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -734,6 +735,24 @@ int xpg_lineq_reduce_batch_rat32_dev(xpg_ctx * ctx, int nb, xpg_rat32 * d_mats, 
                                      int is_intersect, int32_t * d_out_rows, int32_t * d_out_ok)
 {
     XPG_BIND(ctx); return lineq_reduce_batch_dev(ctx, nb, (R32 *)d_mats, rows, cols, rhs_idx, 1, is_intersect, d_out_rows, d_out_ok); }
+int xpg_lineq_fme_batch_packed_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols, int rhs_idx, int u,
+                                     int darkshadow, int cap_rows, xpg_rat32 * outs, long long outs_cap_rows,
+                                     const xpg_rat32 ** out_view, long long * row_offsets, int32_t * out_ok)
+{
+    XPG_BIND(ctx);
+    return lineq_fme_batch_packed(ctx, nb, (const R32 *)mats, rows, cols, rhs_idx, u, darkshadow, cap_rows, (R32 *)outs,
+                                  outs_cap_rows, (const R32 **)out_view, row_offsets, out_ok);
+}
+int xpg_trim(xpg_ctx * ctx)
+{
+    XPG_BIND(ctx);
+    if (!ctx) return XPG_ERR_SHAPE;
+    XPG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto & b : ctx->dev_cache) (void)hipFree(b.first);
+    ctx->dev_cache.clear(); ctx->dev_cache_bytes = 0;
+    if (ctx->hpack) { (void)hipHostFree(ctx->hpack); ctx->hpack = 0; ctx->hpack_cap = 0; }
+    return 0;
+}
 int xpg_lineq_fme_batch_rat32_dev(xpg_ctx * ctx, int nb, const xpg_rat32 * d_mats, int rows, int cols, int rhs_idx,
                                   int u, int darkshadow, xpg_rat32 * d_outs, int cap_rows, int32_t * d_out_rows,
                                   int32_t * d_out_ok)

@@ -56,20 +56,45 @@ class Lineq:
                        "xpg_lineq_remove_iden_batch_rat32")
         return [a[b, : out_rows[b]].copy() for b in range(nb)]
 
-    def fme(self, mats, rhs_idx, u, darkshadow=False, cap_rows=None):
-        """Lineq::fme (linsys.cpp:656-774). Returns (ok[nb], [result of system b])."""
+    def fme(self, mats, rhs_idx, u, darkshadow=False, cap_rows=None, slots=False):
+        """Lineq::fme (linsys.cpp:656-774). Returns (ok[nb], [result of system b]). Through the packed entry point
+        (row offsets + live rows only); slots=True takes the cap_rows-slot entry point instead (A/B, tests)."""
         a = _stack(mats)
         nb, rows, cols = a.shape[:3]
-        cap = cap_rows or max(rows, rows * rows // 4 + rows + 1)
-        outs = np.zeros((nb, cap, cols, 2), dtype=np.int32)
-        out_rows = np.zeros(nb, dtype=np.int32); ok = np.zeros(nb, dtype=np.int32)
-        self.ctx.check(lib().xpg_lineq_fme_batch_rat32(self.ctx._h, C.c_int(nb), vp(a), C.c_int(rows), C.c_int(cols),
-                                                       C.c_int(rhs_idx), C.c_int(u), C.c_int(int(darkshadow)), vp(outs),
-                                                       C.c_int(cap), vp(out_rows), vp(ok)),
-                       "xpg_lineq_fme_batch_rat32")
-        if (out_rows < 0).any():
-            raise ValueError("fme result needs %d rows, cap_rows is %d" % (-out_rows.min(), cap))
-        return ok, [outs[b, : out_rows[b]].copy() for b in range(nb)]
+        if slots:
+            cap = cap_rows or max(rows, rows * rows // 4 + rows + 1)
+            outs = np.zeros((nb, cap, cols, 2), dtype=np.int32)
+            out_rows = np.zeros(nb, dtype=np.int32); ok = np.zeros(nb, dtype=np.int32)
+            self.ctx.check(lib().xpg_lineq_fme_batch_rat32(self.ctx._h, C.c_int(nb), vp(a), C.c_int(rows), C.c_int(cols),
+                                                           C.c_int(rhs_idx), C.c_int(u), C.c_int(int(darkshadow)), vp(outs),
+                                                           C.c_int(cap), vp(out_rows), vp(ok)),
+                           "xpg_lineq_fme_batch_rat32")
+            if (out_rows < 0).any():
+                raise ValueError("fme result needs %d rows, cap_rows is %d" % (-out_rows.min(), cap))
+            return ok, [outs[b, : out_rows[b]].copy() for b in range(nb)]
+        ok, off, packed = self.fme_packed(a, rhs_idx, u, darkshadow, cap_rows)
+        return ok, [packed[off[b]: off[b + 1]] for b in range(nb)]
+
+    def fme_packed(self, mats, rhs_idx, u, darkshadow=False, cap_rows=None, copy=True):
+        """xpg_lineq_fme_batch_packed_rat32: (ok[nb], row_offsets[nb + 1], rows[row_offsets[nb], cols, 2]).
+        copy=False returns the rows as a view of the handle's pinned buffer, valid until the next packed call
+        on this handle (what a C++ caller reads its results from)."""
+        a = _stack(mats)
+        nb, rows, cols = a.shape[:3]
+        off = np.zeros(nb + 1, dtype=np.int64); ok = np.zeros(nb, dtype=np.int32)
+        view = C.c_void_p()
+        self.ctx.check(lib().xpg_lineq_fme_batch_packed_rat32(
+            self.ctx._h, C.c_int(nb), vp(a), C.c_int(rows), C.c_int(cols), C.c_int(rhs_idx), C.c_int(u),
+            C.c_int(int(darkshadow)), C.c_int(cap_rows or 0), None, C.c_longlong(0), C.byref(view), vp(off), vp(ok)),
+            "xpg_lineq_fme_batch_packed_rat32")
+        total = int(off[nb])
+        if not copy and total:
+            buf = (C.c_int32 * (total * cols * 2)).from_address(view.value)
+            return ok, off, np.frombuffer(buf, dtype=np.int32).reshape(total, cols, 2)
+        packed = np.empty((total, cols, 2), dtype=np.int32)
+        if total:                                           # out of the handle's pinned buffer, before the next call reuses it
+            C.memmove(packed.ctypes.data, view.value, packed.nbytes)
+        return ok, off, packed
 
     def calcBound(self, mats, rhs_idx, cap_rows=None):
         """Lineq::calcBound (linsys.cpp:1047-1078): chained eliminations on the device.
