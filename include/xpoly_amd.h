@@ -259,6 +259,39 @@ int xpg_mip_batch_rat32_multi(int ndev, const int * devices, int nb, int is_max,
 int xpg_dep_is_empty_batch_rat32_multi(int ndev, const int * devices, int nb, const xpg_rat32 * mats,
                                        int rows, int cols, int32_t * out_empty, long long * out_nodes);
 
+/* ---- ragged batches: problems of different shapes in one call -------------------------------------------------
+ * What one SCoP hands the dependence analysis: DepPolyMgr::build emits polyhedra whose shape follows the
+ * statements' depths and the parameter count (src/eng/poly.cpp:1120-1224, :1009-1053) and DepGraph::rebuild tests
+ * each (poly.cpp:268-314, :530-573).  Padding to one shape is not parity-neutral, so shapes are per problem:
+ * rows[b], cols[b], and the CELL offset of problem b in the concatenated array (offsets[b]; tgtf / sol / v arrays of
+ * the LP form have their own offsets, cols[b] cells each).  The library sorts the problems into shape classes and
+ * runs the classes concurrently, each on its own stream of the handle's device; results come back in problem order.
+ * Semantics per problem are those of the uniform entry points above. */
+int xpg_six_batch_f64_ragged(xpg_ctx * ctx, int is_max, int nb, const double * tgtf, const double * leq,
+                             const int32_t * rows, const int32_t * cols, const long long * leq_offsets,
+                             const long long * tgtf_offsets, unsigned max_iter, int32_t * out_status,
+                             double * out_v, double * out_sol);
+int xpg_six_batch_rat32_ragged(xpg_ctx * ctx, int is_max, int nb, const xpg_rat32 * tgtf, const xpg_rat32 * leq,
+                               const int32_t * rows, const int32_t * cols, const long long * leq_offsets,
+                               const long long * tgtf_offsets, unsigned max_iter, int32_t * out_status,
+                               xpg_rat32 * out_v, xpg_rat32 * out_sol);
+/* DepPoly::is_empty (poly.cpp:530-573) on nb polyhedra of mixed shapes, constant in the last column of each. */
+int xpg_dep_is_empty_batch_ragged_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, const int32_t * rows,
+                                        const int32_t * cols, const long long * offsets, int32_t * out_empty,
+                                        long long * out_nodes);
+/* Lineq::reduce in place (system b keeps its rows[b] x cols[b] cells at offsets[b], the survivors packed at their
+ * front); rhs_idx[b] is its constant column (NULL: the last column of each). */
+int xpg_lineq_reduce_batch_ragged_rat32(xpg_ctx * ctx, int nb, xpg_rat32 * mats, const int32_t * rows,
+                                        const int32_t * cols, const long long * offsets, const int32_t * rhs_idx,
+                                        int is_intersect, int32_t * out_rows, int32_t * out_ok);
+/* Lineq::fme eliminating variable u[b] of system b.  Packed result: out_rows[b] rows of cols[b] cells starting at
+ * cell out_cell_offsets[b] of outs (out_cell_offsets[nb] = all cells).  outs NULL: a sizing call (returns 0);
+ * outs_cap_cells too small: XPG_ERR_SHAPE with out_rows / out_cell_offsets filled. */
+int xpg_lineq_fme_batch_ragged_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, const int32_t * rows,
+                                     const int32_t * cols, const long long * offsets, const int32_t * rhs_idx,
+                                     const int32_t * u, int darkshadow, xpg_rat32 * outs, long long outs_cap_cells,
+                                     long long * out_cell_offsets, int32_t * out_rows, int32_t * out_ok);
+
 /* ---- rational row elimination, batches of small systems (one wavefront each) -------------
  * mats is [nb][rows][cols] of xpg_rat32 on the host; rhs_idx is the constant column,
  * columns after it are constant symbols (src/com/linsys.h:64-70).

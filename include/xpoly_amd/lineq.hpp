@@ -118,5 +118,28 @@ public:
     }
 };
 
+// One SCoP's worth of dependence tests in ONE call: DepPoly::is_empty (src/eng/poly.cpp:530-573, called per polyhedron by
+// DepGraph::rebuild, poly.cpp:268-314) on polyhedra of whatever shapes DepPolyMgr::build produced (poly.cpp:1120-1224).
+// empty[k] = 1 / 0 as is_empty would return for *polys[k], XPG_ERR_REF_UNDEFINED where the reference is undefined.
+template <class RMatT>
+inline int dep_is_empty_all(const std::vector<RMatT *> & polys, std::vector<int32_t> & empty, xpg_ctx * c = 0)
+{
+    const int nb = (int)polys.size();
+    std::vector<int32_t> rows((size_t)nb), cols((size_t)nb);
+    std::vector<long long> off((size_t)nb + 1, 0);
+    for (int b = 0; b < nb; b++) {
+        rows[(size_t)b] = (int32_t)polys[(size_t)b]->get_row_size(); cols[(size_t)b] = (int32_t)polys[(size_t)b]->get_col_size();
+        off[(size_t)b + 1] = off[(size_t)b] + (long long)rows[(size_t)b] * cols[(size_t)b];
+    }
+    std::vector<xpg_rat32> flat((size_t)off[(size_t)nb]);
+    for (int b = 0; b < nb; b++)
+        if (rows[(size_t)b] * cols[(size_t)b])
+            std::memcpy((void *)(flat.data() + off[(size_t)b]), (const void *)polys[(size_t)b]->get_matrix(),
+                        sizeof(xpg_rat32) * (size_t)rows[(size_t)b] * cols[(size_t)b]);
+    empty.assign((size_t)nb, 0);
+    return xpg_dep_is_empty_batch_ragged_rat32(c ? c : detail::shared_context(), nb, flat.data(), rows.data(), cols.data(), off.data(),
+                                               empty.data(), (long long *)0);
+}
+
 } // namespace xpoly_amd
 #endif

@@ -27,6 +27,7 @@ struct xpg_ctx {
     void * stage; size_t stage_cap;   // grow-only device staging of the host-array batch entry points
     void * hstage; size_t hstage_cap; // its pinned host mirror (the MIP controller packs node batches into it)
     void * hpack = 0; size_t hpack_cap = 0;   // pinned host buffer of the packed-result entry points (the view they return)
+    std::vector<xpg_ctx *> lanes;             // extra handles on the same device, one per concurrent shape class of a ragged call
     std::vector<std::pair<void *, size_t> > dev_cache;   // device blocks between host-array row-elimination calls (DevBuf)
     size_t dev_cache_bytes = 0;
     int update_variant;     // tuning knob for the fp64 sweep (see launch_update_f64)

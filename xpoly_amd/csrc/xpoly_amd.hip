@@ -7,6 +7,8 @@
 #include <string.h>
 #include <atomic>
 #include <new>
+#include <map>
+#include <algorithm>
 #include <thread>
 #include <vector>
 #include "../../include/xpoly_amd.h"
@@ -88,6 +90,8 @@ void xpg_destroy(xpg_ctx * ctx)
     if (ctx->stage) (void)hipFree(ctx->stage);
     if (ctx->hstage) (void)hipHostFree(ctx->hstage);
     if (ctx->hpack) (void)hipHostFree(ctx->hpack);
+    for (xpg_ctx * l : ctx->lanes) xpg_destroy(l);
+    ctx->lanes.clear();
     for (auto & b : ctx->dev_cache) (void)hipFree(b.first);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -601,6 +605,206 @@ int xpg_dep_is_empty_batch_rat32_multi(int ndev, const int * devices, int nb, co
     });
     if (out_nodes) *out_nodes = nodes.load();
     return rc;
+}
+
+
+// ---- ragged batches: problems of DIFFERENT shapes in one call -----------------------------
+// The dependence analysis of one SCoP emits polyhedra whose shape follows the statements' depths and the number of
+// parameters (src/eng/poly.cpp:1120-1224, :1009-1053) and tests each (poly.cpp:268-314, :530-573); padding them to
+// one shape is not parity-neutral (extra 0 <= 0 rows change the bug-compatible pivot sequence). A ragged call takes
+// rows[nb], cols[nb] and the cell offsets of the concatenated systems, sorts the problems into shape classes and runs
+// the classes CONCURRENTLY -- each on a lane: an extra handle (stream, scratch) on the same device that the caller's
+// handle keeps, driven by a host thread for the duration of the call -- so that small classes share the chip instead
+// of each waiting for the deepest problem of the one before. Results are scattered back in problem order.
+} // extern "C"
+namespace {
+struct RaggedClass { int rows, cols; std::vector<int> idx; size_t work; };
+inline int ragged_lanes()
+{
+    static const int n = [] { const char * e = getenv("XPG_RAGGED_LANES"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 32 ? 32 : v); }();
+    return n;
+}
+// fn(lane_ctx, class) for every shape class; the first error wins.
+template <class F> int run_ragged(xpg_ctx * ctx, int nb, const int32_t * rows, const int32_t * cols, F fn)
+{
+    std::map<std::pair<int, int>, size_t> where;
+    std::vector<RaggedClass> cls;
+    for (int b = 0; b < nb; b++) {
+        if (rows[b] <= 0 || cols[b] < 2) return XPG_ERR_SHAPE;
+        const auto key = std::make_pair((int)rows[b], (int)cols[b]);
+        auto it = where.find(key);
+        if (it == where.end()) { it = where.insert(std::make_pair(key, cls.size())).first; cls.push_back(RaggedClass{rows[b], cols[b], {}, 0}); }
+        cls[it->second].idx.push_back(b);
+    }
+    for (auto & c : cls) c.work = c.idx.size() * (size_t)c.rows * c.cols;
+    std::sort(cls.begin(), cls.end(), [](const RaggedClass & a, const RaggedClass & b) { return a.work > b.work; });
+    const int nl = (int)cls.size() < ragged_lanes() ? (int)cls.size() : ragged_lanes();
+    while ((int)ctx->lanes.size() < nl - 1) {                       // lane 0 is the caller's handle
+        xpg_ctx * l = 0;
+        const int rc = xpg_create(&l, ctx->device);
+        if (rc) return rc;
+        ctx->lanes.push_back(l);
+    }
+    std::vector<std::vector<int> > mine((size_t)nl);               // longest class first, each to the least loaded lane
+    std::vector<size_t> load((size_t)nl, 0);
+    for (int k = 0; k < (int)cls.size(); k++) {
+        int best = 0;
+        for (int l = 1; l < nl; l++) if (load[(size_t)l] < load[(size_t)best]) best = l;
+        mine[(size_t)best].push_back(k); load[(size_t)best] += cls[(size_t)k].work;
+    }
+    std::vector<int> rcs((size_t)nl, 0);
+    auto lane_body = [&](int l) {
+        xpg_ctx * c = l == 0 ? ctx : ctx->lanes[(size_t)l - 1];
+        xpg::DeviceGuard bind(c->device);
+        for (int k : mine[(size_t)l]) { const int rc = fn(c, cls[(size_t)k]); if (rc) { rcs[(size_t)l] = rc; if (l) ctx->err = c->err; return; } }
+    };
+    std::vector<std::thread> th;
+    for (int l = 1; l < nl; l++) th.emplace_back(lane_body, l);
+    lane_body(0);
+    for (auto & t : th) t.join();
+    for (int rc : rcs) if (rc) return rc;
+    return 0;
+}
+template <class T> inline void ragged_gather(std::vector<T> & buf, const T * src, const long long * off, const RaggedClass & c, size_t per)
+{
+    buf.resize(c.idx.size() * per);
+    for (size_t k = 0; k < c.idx.size(); k++) memcpy((void *)(buf.data() + k * per), (const void *)(src + off[c.idx[k]]), per * sizeof(T));
+}
+} // namespace
+extern "C" {
+
+int xpg_dep_is_empty_batch_ragged_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, const int32_t * rows,
+                                        const int32_t * cols, const long long * offsets, int32_t * out_empty,
+                                        long long * out_nodes)
+{
+    XPG_BIND(ctx);
+    if (!ctx || nb < 0 || !mats || !rows || !cols || !offsets || !out_empty) return XPG_ERR_SHAPE;
+    std::atomic<long long> nodes(0);
+    const int rc = run_ragged(ctx, nb, rows, cols, [&](xpg_ctx * c, const RaggedClass & g) {
+        std::vector<R32> buf; std::vector<int32_t> emp(g.idx.size());
+        ragged_gather(buf, (const R32 *)mats, offsets, g, (size_t)g.rows * g.cols);
+        long n = 0;
+        const int r = dep_is_empty_batch(c, (int)g.idx.size(), buf.data(), g.rows, g.cols, g.cols - 1, (const R32 *)0, emp.data(), &n);
+        if (r) return r;
+        for (size_t k = 0; k < g.idx.size(); k++) out_empty[g.idx[k]] = emp[k];
+        nodes += n;
+        return 0;
+    });
+    if (out_nodes) *out_nodes = nodes.load();
+    return rc;
+}
+
+} // extern "C"
+namespace {
+template <class S>
+int six_batch_ragged(xpg_ctx * ctx, int is_max, int nb, const S * tgtf, const S * leq, const int32_t * rows, const int32_t * cols,
+                     const long long * leq_off, const long long * tg_off, unsigned max_iter, int32_t * out_status, S * out_v, S * out_sol)
+{
+    if (!ctx || nb < 0 || !tgtf || !leq || !rows || !cols || !leq_off || !tg_off || !out_status || !out_v || !out_sol) return XPG_ERR_SHAPE;
+    return run_ragged(ctx, nb, rows, cols, [&](xpg_ctx * c, const RaggedClass & g) {
+        const size_t ng = g.idx.size();
+        std::vector<S> bl, bt, bs(ng * (size_t)g.cols), bv(ng); std::vector<int32_t> st(ng);
+        ragged_gather(bl, leq, leq_off, g, (size_t)g.rows * g.cols);
+        ragged_gather(bt, tgtf, tg_off, g, (size_t)g.cols);
+        ragged_gather(bs, (const S *)out_sol, tg_off, g, (size_t)g.cols);     // (slots of unsolved LPs keep what they held)
+        const int r = batch_host<S>(c, is_max, (int)ng, bt.data(), bl.data(), g.rows, g.cols, max_iter, st.data(), bv.data(), bs.data());
+        if (r) return r;
+        for (size_t k = 0; k < ng; k++) {
+            const int b = g.idx[k];
+            out_status[b] = st[k]; out_v[b] = bv[k];
+            memcpy((void *)(out_sol + tg_off[b]), (const void *)(bs.data() + k * (size_t)g.cols), (size_t)g.cols * sizeof(S));
+        }
+        return 0;
+    });
+}
+} // namespace
+extern "C" {
+int xpg_six_batch_f64_ragged(xpg_ctx * ctx, int is_max, int nb, const double * tgtf, const double * leq, const int32_t * rows,
+                             const int32_t * cols, const long long * leq_offsets, const long long * tgtf_offsets,
+                             unsigned max_iter, int32_t * out_status, double * out_v, double * out_sol)
+{
+    XPG_BIND(ctx);
+    return six_batch_ragged<F64>(ctx, is_max, nb, (const F64 *)tgtf, (const F64 *)leq, rows, cols, leq_offsets, tgtf_offsets, max_iter,
+                                 out_status, (F64 *)out_v, (F64 *)out_sol);
+}
+int xpg_six_batch_rat32_ragged(xpg_ctx * ctx, int is_max, int nb, const xpg_rat32 * tgtf, const xpg_rat32 * leq, const int32_t * rows,
+                               const int32_t * cols, const long long * leq_offsets, const long long * tgtf_offsets,
+                               unsigned max_iter, int32_t * out_status, xpg_rat32 * out_v, xpg_rat32 * out_sol)
+{
+    XPG_BIND(ctx);
+    return six_batch_ragged<R32>(ctx, is_max, nb, (const R32 *)tgtf, (const R32 *)leq, rows, cols, leq_offsets, tgtf_offsets, max_iter,
+                                 out_status, (R32 *)out_v, (R32 *)out_sol);
+}
+// Lineq::reduce on systems of different shapes, in place (mats: the systems back to back, system b at cell
+// offsets[b]); rhs_idx[b] (NULL: the last column of each).
+int xpg_lineq_reduce_batch_ragged_rat32(xpg_ctx * ctx, int nb, xpg_rat32 * mats, const int32_t * rows, const int32_t * cols,
+                                        const long long * offsets, const int32_t * rhs_idx, int is_intersect,
+                                        int32_t * out_rows, int32_t * out_ok)
+{
+    XPG_BIND(ctx);
+    if (!ctx || nb < 0 || !mats || !rows || !cols || !offsets || !out_rows || !out_ok) return XPG_ERR_SHAPE;
+    // a class is (rows, cols, rhs): split the shape classes by constant column on the fly through the key of `cols`
+    std::vector<int32_t> key((size_t)nb);
+    for (int b = 0; b < nb; b++) {
+        const int r = rhs_idx ? rhs_idx[b] : cols[b] - 1;
+        if (cols[b] < 2 || cols[b] > 32767 || r < 0 || r >= cols[b]) return XPG_ERR_SHAPE;
+        key[(size_t)b] = cols[b] | (r << 16);
+    }
+    return run_ragged(ctx, nb, rows, key.data(), [&](xpg_ctx * c, const RaggedClass & g) {
+        const int gc = g.cols & 0xFFFF, rhs = g.cols >> 16;
+        const size_t per = (size_t)g.rows * gc, ng = g.idx.size();
+        std::vector<R32> buf; std::vector<int32_t> kr(ng), ko(ng);
+        ragged_gather(buf, (const R32 *)mats, offsets, g, per);
+        const int r = lineq_reduce_batch(c, (int)ng, buf.data(), g.rows, gc, rhs, 1, is_intersect, kr.data(), ko.data());
+        if (r) return r;
+        for (size_t k = 0; k < ng; k++) {
+            const int b = g.idx[k];
+            memcpy((void *)((R32 *)mats + offsets[b]), (const void *)(buf.data() + k * per), per * 8);
+            out_rows[b] = kr[k]; out_ok[b] = ko[k];
+        }
+        return 0;
+    });
+}
+// Lineq::fme on systems of different shapes, eliminating variable u[b] of system b. Packed result: system b's
+// rows (cols[b] wide) start at cell out_cell_offsets[b] of outs (out_cell_offsets[nb] = cells in all); outs may
+// be NULL or too small (outs_cap_cells): XPG_ERR_SHAPE with out_rows / out_cell_offsets filled.
+int xpg_lineq_fme_batch_ragged_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, const int32_t * rows, const int32_t * cols,
+                                     const long long * offsets, const int32_t * rhs_idx, const int32_t * u, int darkshadow,
+                                     xpg_rat32 * outs, long long outs_cap_cells, long long * out_cell_offsets,
+                                     int32_t * out_rows, int32_t * out_ok)
+{
+    XPG_BIND(ctx);
+    if (!ctx || nb < 0 || !mats || !rows || !cols || !offsets || !u || !out_cell_offsets || !out_rows || !out_ok) return XPG_ERR_SHAPE;
+    std::vector<int32_t> key((size_t)nb);
+    for (int b = 0; b < nb; b++) {
+        const int r = rhs_idx ? rhs_idx[b] : cols[b] - 1;
+        if (cols[b] < 2 || cols[b] > 255 || r < 1 || r >= cols[b] || u[b] < 0 || u[b] >= r) return XPG_ERR_SHAPE;
+        key[(size_t)b] = cols[b] | (r << 8) | (u[b] << 16);           // a class shares shape, constant column and variable
+    }
+    std::vector<std::vector<R32> > res((size_t)nb);
+    const int rc = run_ragged(ctx, nb, rows, key.data(), [&](xpg_ctx * c, const RaggedClass & g) {
+        const int gc = g.cols & 0xFF, rhs = (g.cols >> 8) & 0xFF, uu = g.cols >> 16;
+        const size_t per = (size_t)g.rows * gc, ng = g.idx.size();
+        std::vector<R32> buf; std::vector<int32_t> ko(ng); std::vector<long long> off(ng + 1);
+        ragged_gather(buf, (const R32 *)mats, offsets, g, per);
+        const R32 * view = 0;
+        const int r = lineq_fme_batch_packed(c, (int)ng, buf.data(), g.rows, gc, rhs, uu, darkshadow, 0, (R32 *)0, 0, &view, off.data(), ko.data());
+        if (r) return r;
+        for (size_t k = 0; k < ng; k++) {
+            const int b = g.idx[k];
+            out_rows[b] = (int32_t)(off[k + 1] - off[k]); out_ok[b] = ko[k];
+            res[(size_t)b].assign(view + off[k] * gc, view + off[k + 1] * gc);
+        }
+        return 0;
+    });
+    if (rc) return rc;
+    long long tot = 0;
+    for (int b = 0; b < nb; b++) { out_cell_offsets[b] = tot; tot += (long long)res[(size_t)b].size(); }
+    out_cell_offsets[nb] = tot;
+    if (!outs || outs_cap_cells < tot) return outs ? XPG_ERR_SHAPE : 0;
+    for (int b = 0; b < nb; b++)
+        if (!res[(size_t)b].empty()) memcpy((void *)((R32 *)outs + out_cell_offsets[b]), (const void *)res[(size_t)b].data(), res[(size_t)b].size() * 8);
+    return 0;
 }
 
 // ---- MIP / has_solution -------------------------------------------------------------------------

@@ -96,6 +96,37 @@ class Lineq:
             C.memmove(packed.ctypes.data, view.value, packed.nbytes)
         return ok, off, packed
 
+    def reduce_ragged(self, mats_list, rhs_idx=None, is_intersect=True):
+        """Lineq::reduce on systems of different shapes in one call: (ok[nb], [system b's surviving rows])."""
+        from .six import _ragged_pack
+        flat, off, parts = _ragged_pack(mats_list, RAT, 2)
+        nb = len(parts)
+        rows = np.array([p.shape[0] for p in parts], dtype=np.int32); cols = np.array([p.shape[1] for p in parts], dtype=np.int32)
+        rhs = None if rhs_idx is None else np.ascontiguousarray(rhs_idx, dtype=np.int32)
+        out_rows = np.zeros(nb, dtype=np.int32); ok = np.zeros(nb, dtype=np.int32)
+        self.ctx.check(lib().xpg_lineq_reduce_batch_ragged_rat32(self.ctx._h, C.c_int(nb), vp(flat), vp(rows), vp(cols), vp(off),
+                                                                 vp(rhs), C.c_int(int(is_intersect)), vp(out_rows), vp(ok)),
+                       "xpg_lineq_reduce_batch_ragged_rat32")
+        return ok, [flat[2 * int(off[b]): 2 * int(off[b]) + 2 * int(out_rows[b]) * int(cols[b])].reshape(int(out_rows[b]), int(cols[b]), 2).copy()
+                    for b in range(nb)]
+
+    def fme_ragged(self, mats_list, u, rhs_idx=None, darkshadow=False):
+        """Lineq::fme on systems of different shapes, eliminating variable u[b] of system b: (ok[nb], [result b])."""
+        from .six import _ragged_pack
+        flat, off, parts = _ragged_pack(mats_list, RAT, 2)
+        nb = len(parts)
+        rows = np.array([p.shape[0] for p in parts], dtype=np.int32); cols = np.array([p.shape[1] for p in parts], dtype=np.int32)
+        rhs = None if rhs_idx is None else np.ascontiguousarray(rhs_idx, dtype=np.int32)
+        uu = np.ascontiguousarray(u, dtype=np.int32)
+        out_rows = np.zeros(nb, dtype=np.int32); ok = np.zeros(nb, dtype=np.int32); ooff = np.zeros(nb + 1, dtype=np.int64)
+        call = lambda outs, capc: lib().xpg_lineq_fme_batch_ragged_rat32(
+            self.ctx._h, C.c_int(nb), vp(flat), vp(rows), vp(cols), vp(off), vp(rhs), vp(uu), C.c_int(int(darkshadow)), outs,
+            C.c_longlong(capc), vp(ooff), vp(out_rows), vp(ok))
+        self.ctx.check(call(None, 0), "xpg_lineq_fme_batch_ragged_rat32")          # sizing call
+        outs = np.zeros((int(ooff[nb]), 2), dtype=np.int32)
+        self.ctx.check(call(vp(outs), int(ooff[nb])), "xpg_lineq_fme_batch_ragged_rat32")
+        return ok, [outs[int(ooff[b]): int(ooff[b + 1])].reshape(int(out_rows[b]), int(cols[b]), 2) for b in range(nb)]
+
     def calcBound(self, mats, rhs_idx, cap_rows=None):
         """Lineq::calcBound (linsys.cpp:1047-1078): chained eliminations on the device.
         Returns (ok[nb], bounds[b][j] = rows x cols x 2 array bounding variable j alone)."""

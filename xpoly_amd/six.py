@@ -400,3 +400,52 @@ class SIX:
         out["trace"] = lp.trace()
         lp.close()
         return out
+
+
+# ---- ragged batches: problems of different shapes in one call (include/xpoly_amd.h, "ragged batches") ----------
+def _ragged_pack(arrays, kind, ndim):
+    """A list of per-problem arrays -> (flat concatenation, cell offsets[nb + 1]); cells are 8 bytes of either kind."""
+    parts = [np.ascontiguousarray(as_kind(a, kind, ndim)) for a in arrays]
+    cells = [int(np.prod(p.shape[:ndim])) for p in parts]
+    off = np.zeros(len(parts) + 1, dtype=np.int64)
+    off[1:] = np.cumsum(cells)
+    flat = np.concatenate([p.reshape(-1) for p in parts]) if parts else np.zeros(0, dtype=np.float64 if kind == F64 else np.int32)
+    return np.ascontiguousarray(flat), off, parts
+
+
+def six_batch_ragged(ctx, kind, is_max, tgtfs, leqs, max_iter=0xFFFFFFFF):
+    """SIX::maxm / minm (x >= 0, inequalities only) on LPs of DIFFERENT shapes in one call: leqs[b] is rows_b x cols_b,
+    tgtfs[b] has cols_b entries. Returns (status[nb], [v_b], [sol_b])."""
+    nb = len(leqs)
+    leq_flat, leq_off, lp = _ragged_pack(leqs, kind, 2)
+    tg_flat, tg_off, _ = _ragged_pack(tgtfs, kind, 1)
+    rows = np.array([p.shape[0] for p in lp], dtype=np.int32); cols = np.array([p.shape[1] for p in lp], dtype=np.int32)
+    assert np.array_equal(np.diff(tg_off), cols), "tgtfs[b] must have cols_b entries"
+    status = np.zeros(nb, dtype=np.int32)
+    v = empty_kind((nb,), kind)
+    sol = np.zeros_like(tg_flat)
+    fn = lib().xpg_six_batch_f64_ragged if kind == F64 else lib().xpg_six_batch_rat32_ragged
+    ctx.check(fn(ctx._h, C.c_int(int(is_max)), C.c_int(nb), vp(tg_flat), vp(leq_flat), vp(rows), vp(cols), vp(leq_off),
+                 vp(tg_off), C.c_uint(max_iter), vp(status), vp(v), vp(sol)), "xpg_six_batch_ragged")
+    esz = 1 if kind == F64 else 2
+    sols = [sol[int(tg_off[b]) * esz: int(tg_off[b + 1]) * esz].reshape((-1,) if kind == F64 else (-1, 2)) for b in range(nb)]
+    return status, v, sols
+
+
+def ragged_pack_rat(mats_list):
+    """(flat cells, rows[nb], cols[nb], cell offsets[nb + 1]) of a list of rational systems: the arrays the ragged C entry points take."""
+    flat, off, parts = _ragged_pack(mats_list, RAT, 2)
+    rows = np.array([p.shape[0] for p in parts], dtype=np.int32); cols = np.array([p.shape[1] for p in parts], dtype=np.int32)
+    return flat, rows, cols, off
+
+
+def dep_is_empty_ragged(ctx, mats_list=None, packed=None):
+    """DepPoly::is_empty (src/eng/poly.cpp:530-573) on dependence polyhedra of mixed shapes (constant in the last
+    column of each): (empty[nb], nodes). `packed` = ragged_pack_rat(...) of the list, for callers that keep it."""
+    flat, rows, cols, off = packed if packed is not None else ragged_pack_rat(mats_list)
+    nb = len(rows)
+    out = np.zeros(nb, dtype=np.int32)
+    nodes = C.c_longlong()
+    ctx.check(lib().xpg_dep_is_empty_batch_ragged_rat32(ctx._h, C.c_int(nb), vp(flat), vp(rows), vp(cols), vp(off), vp(out),
+                                                        C.byref(nodes)), "xpg_dep_is_empty_batch_ragged_rat32")
+    return out, nodes.value
