@@ -52,7 +52,7 @@ BATCH_M, BATCH_COLS = 32, 64
 PREWARM_SECONDS = 0.5
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "round2_pmc_hbm_traffic.json")
 PMC_BATCH = os.path.join(ROOT, "profiles", "round2_pmc_batch_issue.json")
-LEGS = ("pivots", "batched", "cfg2b", "rational", "mip", "lineq")
+LEGS = ("pivots", "batched", "sharded", "cfg2b", "rational", "mip", "lineq")
 LINEQ_NB = 16384                           # systems per row-elimination launch (the dependence tests' shapes)
 
 
@@ -287,7 +287,7 @@ def main():
         cpu = cpu_baselines(legs, a.no_ref_baseline)     # forks: before torch / HIP are initialised in this process
 
     import torch
-    from xpoly_amd.shard import gather_records, pack_records, shard_range
+    from xpoly_amd.shard import gather_records, pack_records, pack_records_i32, pack_records_rat, shard_range, unpack_records_rat
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -434,6 +434,7 @@ def main():
         lo, hi = shard_range(total, rank, world)
         nloc = hi - lo
         fams = {}
+        h2d_ms = {}
         for fam, name in ((1, "dep_test_like"), (0, "dense_positive")):
             if stub:
                 idx = torch.arange(lo, hi, dtype=torch.float64)
@@ -448,35 +449,48 @@ def main():
                     g_rec = golden("g8_large.json")["g3_large"][fam]
                     g_leq, g_tg = gen.small_lp_batch_f64(256, BATCH_M, BATCH_COLS, fam, seed=gen.XS_SEED + g_rec["seed_offset"])
                     b_leq[:256] = g_leq; b_tg[:256] = g_tg
+                torch.cuda.synchronize()
+                t_up = time.perf_counter()
                 d_leq = torch.from_numpy(b_leq).to(dev)
                 d_tg = torch.from_numpy(b_tg).to(dev)
+                torch.cuda.synchronize()
+                h2d_ms[name] = round((time.perf_counter() - t_up) * 1e3, 3)     # the shard's upload, once, outside the timed passes
                 d_st = torch.empty(nloc, dtype=torch.int32, device=dev)
                 d_v = torch.empty(nloc, dtype=torch.float64, device=dev)
                 d_sol = torch.zeros(nloc, BATCH_COLS, dtype=torch.float64, device=dev)
                 d_piv = torch.empty(nloc, dtype=torch.int32, device=dev)
 
+            tsplit = [0.0, 0.0]                            # seconds in the solve / in the gather, this rank
+
             def one_pass():
+                ta = time.perf_counter()
                 if not stub:
                     ctx.six_batch_dev(xpoly_amd.F64, True, nloc, d_tg.data_ptr(), d_leq.data_ptr(),
                                       BATCH_M, BATCH_COLS, d_st.data_ptr(), d_v.data_ptr(), d_sol.data_ptr(),
                                       d_piv.data_ptr())
                     ctx.sync()
+                tb = time.perf_counter()
+                tsplit[0] += tb - ta
                 if dist is None:
                     return None
                 # the only collective of the path: fixed-size (status, v, sol) records
                 full = gather_records(pack_records(d_st, d_v, d_sol), total, rank, world, dist)
                 if not stub:
                     torch.cuda.synchronize()
+                tsplit[1] += time.perf_counter() - tb
                 return full
 
             full = one_pass()
             barrier()
             reps = 3 if fam == 1 else 5
+            tsplit[0] = tsplit[1] = 0.0
             t0 = time.perf_counter()
             for _ in range(reps):
                 full = one_pass()
             barrier()
             bdt = max_over_ranks(time.perf_counter() - t0)
+            solve_ms = max_over_ranks(tsplit[0]) / reps * 1e3
+            gather_ms = max_over_ranks(tsplit[1]) / reps * 1e3
             if full is not None:
                 assert full.shape[0] == total
                 if stub:                                # the gathered order is the global LP order
@@ -488,7 +502,9 @@ def main():
             if rank == 0 and not stub and nloc >= 256:
                 checks.setdefault("batched", {})[name] = selfcheck_batched(fam, d_st, d_v, d_sol, full)
             fams[name] = dict(lps_per_s=round(total * reps / bdt, 1), pivots_per_s=round(piv * reps / bdt, 1),
-                              status_hist_rank0=hist, ms_per_pass=round(bdt / reps * 1e3, 3))
+                              status_hist_rank0=hist, ms_per_pass=round(bdt / reps * 1e3, 3),
+                              solve_ms=round(solve_ms, 3), gather_ms=round(gather_ms, 3),
+                              shard_h2d_ms_untimed=h2d_ms.get(name))
         batched = dict(metric="batched LPs/sec", value=fams["dep_test_like"]["lps_per_s"], unit="LPs/s",
                        headline_family="dep_test_like (entries in {-3..3} at density 0.25: the shape "
                                        "DepPoly::is_empty produces; the workload the kernel exists for)",
@@ -512,27 +528,42 @@ def main():
                                     wave_instructions_per_pivot=pb.get("dense_per_pivot")),
                 source="profiles/round2_pmc_batch_issue.json (rocprofv3 --pmc VALUBusy / SALUBusy / SQ_INSTS_* on "
                        "tools/lab/probe_batch.py; not collected in this run)")
-        if world == 1 and not stub:
-            # N = 1 reference point for STRONG scaling: the whole 65 536-LP batch of cfg 3 on one GPU
+        if not stub:
+            # STRONG scaling beside the weak figures above: the 65 536 LPs of BASELINE configs[2] in all, split over the
+            # ranks (65 536 / N each), same solve + one all_gather; at N = 1 this is the whole batch on one GPU
             full_n = BATCH_PER_GPU * 8
-            ref_pts = {}
+            slo, shi = shard_range(full_n, rank, world)
+            sn = shi - slo
+            strong = {}
             for fam, name in ((1, "dep_test_like"), (0, "dense_positive")):
-                f_leq, f_tg = gen.small_lp_batch_f64(full_n, BATCH_M, BATCH_COLS, fam, seed=gen.XS_SEED + 77 + fam)
+                f_leq, f_tg = gen.small_lp_batch_f64(sn, BATCH_M, BATCH_COLS, fam, seed=gen.XS_SEED + 77 + fam + 131 * rank)
                 d_leq = torch.from_numpy(f_leq).to(dev); d_tg = torch.from_numpy(f_tg).to(dev)
-                d_st = torch.empty(full_n, dtype=torch.int32, device=dev)
-                d_v = torch.empty(full_n, dtype=torch.float64, device=dev)
-                d_sol = torch.zeros(full_n, BATCH_COLS, dtype=torch.float64, device=dev)
-                ctx.sync()
-                t0 = time.perf_counter()
-                ctx.six_batch_dev(xpoly_amd.F64, True, full_n, d_tg.data_ptr(), d_leq.data_ptr(), BATCH_M, BATCH_COLS,
-                                  d_st.data_ptr(), d_v.data_ptr(), d_sol.data_ptr(), None)
-                ctx.sync()
-                ref_pts[name] = round(full_n / (time.perf_counter() - t0), 1)
+                d_st = torch.empty(sn, dtype=torch.int32, device=dev)
+                d_v = torch.empty(sn, dtype=torch.float64, device=dev)
+                d_sol = torch.zeros(sn, BATCH_COLS, dtype=torch.float64, device=dev)
+                best = None
+                for rep in range(2):
+                    barrier()
+                    t0 = time.perf_counter()
+                    ctx.six_batch_dev(xpoly_amd.F64, True, sn, d_tg.data_ptr(), d_leq.data_ptr(), BATCH_M, BATCH_COLS,
+                                      d_st.data_ptr(), d_v.data_ptr(), d_sol.data_ptr(), None)
+                    ctx.sync()
+                    if dist is not None:
+                        g = gather_records(pack_records(d_st, d_v, d_sol), full_n, rank, world, dist)
+                        torch.cuda.synchronize()
+                        assert g.shape[0] == full_n
+                    barrier()
+                    dt_s = max_over_ranks(time.perf_counter() - t0)
+                    best = dt_s if best is None else min(best, dt_s)
+                strong[name] = round(full_n / best, 1)
                 del d_leq, d_tg, d_st, d_v, d_sol, f_leq, f_tg
-            batched["n1_reference_points"] = dict(
-                weak="the `families` figures above (8192 LPs on this GPU)",
-                strong_65536_lps_on_one_gpu_lps_per_s=ref_pts)
+            batched["strong_scaling"] = dict(total_lps=full_n, lps_per_rank=sn, lps_per_s=strong,
+                                             note="fixed total of 65 536 LPs split over the ranks, solve + all_gather, better of two passes")
         out["batched"] = batched
+
+    # ---- leg 2b: the exact (rational) batches of BASELINE configs[4], sharded like leg 2 --------------------------
+    if "sharded" in legs:
+        out["sharded"] = leg_sharded(ctx, rank, world, dev, dist, stub, a.backend, barrier, max_over_ranks, sum_over_ranks)
 
     # ---- legs 3-5: the remaining BASELINE configs, rank 0 of an N = 1 run ---------------------------
     if world == 1 and not stub:
@@ -559,6 +590,89 @@ def main():
 
 
 # ---------------------------------------------------------------------------------------------------
+SH_MIP_PER_GPU, SH_DEP_PER_GPU = 1024, 4096
+
+
+def leg_sharded(ctx, rank, world, dev, dist, stub, backend, barrier, max_over_ranks, sum_over_ranks):
+    """BASELINE configs[4] as the north star states it -- independent exact problems sharded over the GPUs of the node,
+    no data-path collective, ONE gather of fixed-size records at the end -- for the two rational batch paths:
+      mip           0-1 knapsack MIPs (24 variables), xpg_mip_batch_rat32: each rank walks its own trees on its GPU;
+                    records (status, v num/den, sol num/den) gathered as int32 (exact: nothing goes through floats)
+      dep_is_empty  dependence polyhedra 12 x 5, xpg_dep_is_empty_batch_rat32: verdicts gathered as int32
+    Weak scaling: SH_MIP_PER_GPU / SH_DEP_PER_GPU problems per rank. Host arrays in and out on every rank (PCIe
+    included), as an xpoly caller at linsys.cpp:860-904 would use it. Solve and gather are timed separately."""
+    import torch
+    from xpoly_amd.shard import gather_records, pack_records_i32, pack_records_rat, shard_range, unpack_records_rat
+    res = {}
+    for what, per_gpu in (("mip", SH_MIP_PER_GPU), ("dep_is_empty", SH_DEP_PER_GPU)):
+        total = per_gpu * world
+        lo, hi = shard_range(total, rank, world)
+        nloc = hi - lo
+        if stub:
+            idx = np.arange(lo, hi, dtype=np.int64)
+        elif what == "mip":
+            from tools import gen
+            from xpoly_amd.six import mip_batch
+            leq, tgtf = gen.knapsack_batch_rat(nloc, MIP_NV, seed=gen.XS_SEED + 7919 * (rank + 1))
+        else:
+            from tools import gen
+            from xpoly_amd.six import dep_is_empty_batch
+            rng = np.random.default_rng(1000 + rank)
+            dm = np.stack([gen.random_system(rng, 12, 4) for _ in range(256)])
+            dm[..., 1] = 1
+            dm = np.ascontiguousarray(np.tile(dm, (nloc // 256 + 1, 1, 1, 1))[:nloc])
+
+        def solve():
+            if stub:
+                if what == "mip":
+                    st = (idx % 4).astype(np.int32)
+                    v = np.stack([idx * 3 + 1, np.ones_like(idx)], axis=1).astype(np.int32)
+                    sol = (idx[:, None, None] + np.arange(MIP_NV + 1)[None, :, None] * 2 + np.arange(2)[None, None, :]).astype(np.int32)
+                    return pack_records_rat(st, v, sol), int(nloc)
+                return pack_records_i32((idx % 3).astype(np.int32), (idx * 7 % 1000).astype(np.int32)), int(nloc)
+            if what == "mip":
+                st, v, sol, nodes = mip_batch(ctx, True, True, tgtf, leq)
+                return pack_records_rat(st, v, sol), int(nodes)
+            empty, nodes = dep_is_empty_batch(ctx, dm)
+            return pack_records_i32(empty), int(nodes)
+
+        def one_pass():
+            ta = time.perf_counter()
+            rec, nodes = solve()
+            tb = time.perf_counter()
+            full = None
+            if dist is not None:
+                rec = rec.to(dev)                           # the records go up (a few hundred KB), then ONE all_gather
+                full = gather_records(rec, total, rank, world, dist)
+                if not stub:
+                    torch.cuda.synchronize()
+            return rec, full, nodes, tb - ta, time.perf_counter() - tb
+        one_pass()
+        barrier()
+        t0 = time.perf_counter()
+        rec, full, nodes, ts, tg = one_pass()
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        if full is not None:
+            assert full.shape[0] == total and full.dtype == torch.int32
+            if stub:                                        # the gathered records are the global problem order, exactly
+                gi = torch.arange(total, dtype=torch.int64)
+                if what == "mip":
+                    st, v, sol = unpack_records_rat(full.cpu())
+                    assert torch.equal(st.to(torch.int64), gi % 4) and torch.equal(v[:, 0].to(torch.int64), gi * 3 + 1)
+                    assert torch.equal(sol[:, 5, 1].to(torch.int64), gi + 11)
+                else:
+                    assert torch.equal(full.cpu()[:, 0].to(torch.int64), gi % 3)
+        res[what] = dict(problems_total=total, problems_per_rank=nloc, problems_per_s=round(total / dt, 1),
+                         nodes_per_s=round(sum_over_ranks(float(nodes)) / dt, 1), wall_ms=round(dt * 1e3, 3),
+                         solve_ms=round(max_over_ranks(ts) * 1e3, 3), gather_ms=round(max_over_ranks(tg) * 1e3, 3),
+                         record_int32s=int(rec.shape[1]))
+    res["scaling"] = "weak (%d MIPs and %d polyhedra per GPU)" % (SH_MIP_PER_GPU, SH_DEP_PER_GPU)
+    res["collective"] = ("one all_gather_into_tensor of int32 records over %s, world size %d" % ("RCCL" if backend == "nccl" else backend, world)) if dist else "none (1 GPU)"
+    res["ranks"] = world
+    return res
+
+
 def leg_cfg2b(ctx, xpoly_amd, gen, m=4096, n=8192):
     """BASELINE configs[1] end to end: LP m=4096, n=8192 -> slack tableau 4096 x 12289 (lpsol.h:1406-1433).
     The SURVEY 8d recipe (b = n U(0.5,1)) reaches its optimum in a few dozen pivots, too few to time, so the

@@ -73,6 +73,52 @@ def test_gather_two_ranks_gloo(total):
         assert np.array_equal(got[r], want)
 
 
+def _worker_rat(rank, world, port, total, cols, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from xpoly_amd.shard import gather_records, pack_records_i32, pack_records_rat, shard_range, unpack_records_rat
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_range(total, rank, world)
+    idx = np.arange(lo, hi, dtype=np.int64)
+    st = (idx % 4).astype(np.int32)
+    v = np.stack([2147483647 - idx, idx + 1], axis=1).astype(np.int32)          # values no float64 column of a mixed record would keep apart from status
+    sol = (idx[:, None, None] * 3 + np.arange(cols)[None, :, None] * 2 + np.arange(2)[None, None, :]).astype(np.int32)
+    full = gather_records(pack_records_rat(st, v, sol), total, rank, world, dist)
+    verd = gather_records(pack_records_i32((idx % 3).astype(np.int32), (idx * 7).astype(np.int32)), total, rank, world, dist)
+    gst, gv, gsol = unpack_records_rat(full)
+    dist.barrier()
+    q.put((rank, gst.numpy().copy(), gv.numpy().copy(), gsol.numpy().copy(), verd.numpy().copy(), str(full.dtype)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [9, 64])
+def test_gather_exact_rational_records_two_ranks_gloo(total):
+    """The rational legs (MIP trees, dependence verdicts) gather int32 records: (status, v num/den, sol num/den) come back
+    in global problem order, bit for bit, on every rank; shards ragged by one."""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    cols = 5
+    procs = [ctx.Process(target=_worker_rat, args=(r, 2, port, total, cols, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    idx = np.arange(total, dtype=np.int64)
+    for rank, st, v, sol, verd, dtype in got:
+        assert dtype == "torch.int32"
+        assert np.array_equal(st, idx % 4)
+        assert np.array_equal(v, np.stack([2147483647 - idx, idx + 1], axis=1))
+        assert np.array_equal(sol, idx[:, None, None] * 3 + np.arange(cols)[None, :, None] * 2 + np.arange(2)[None, None, :])
+        assert np.array_equal(verd, np.stack([idx % 3, idx * 7], axis=1))
+
+
 def test_bench_spawns_its_own_ranks_and_gathers():
     """`python bench.py --gpus 2` starts two ranks by itself (torch.distributed.run on 127.0.0.1) and the
     batched leg's shard -> solve -> all_gather path runs in them; here with --backend gloo and a stub
@@ -81,7 +127,7 @@ def test_bench_spawns_its_own_ranks_and_gathers():
     import json
     import subprocess
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
-                        "--stub-solver", "--legs", "batched", "--steps", "1", "--warmup", "0"],
+                        "--stub-solver", "--legs", "batched,sharded", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -91,6 +137,12 @@ def test_bench_spawns_its_own_ranks_and_gathers():
     b = out["batched"]
     assert b["ranks"] == 2 and b["total_lps"] == 2 * 8192 and b["lps_per_rank"] == [8192, 8192]
     assert "world size 2" in b["collective"]
+    assert b["families"]["dep_test_like"]["gather_ms"] > 0
+    # the exact (int32-record) legs of BASELINE configs[4]: MIP trees and dependence verdicts, sharded the same way;
+    # the gathered order and every field are asserted inside bench.py (leg_sharded)
+    sh = out["sharded"]
+    assert sh["ranks"] == 2 and sh["mip"]["problems_total"] == 2 * 1024 and sh["dep_is_empty"]["problems_total"] == 2 * 4096
+    assert sh["mip"]["record_int32s"] == 3 + 2 * 25 and "world size 2" in sh["collective"]
 
 
 def test_bench_without_gpus_fails_loudly():

@@ -30,6 +30,33 @@ def pack_records(status, v, sol):
     return rec
 
 
+def pack_records_rat(status, v, sol):
+    """Exact rational results -> one int32 record per problem: [status, v.num, v.den, sol[0].num, sol[0].den, ...].
+    status [n] int32, v [n, 2] int32, sol [n, cols, 2] int32 (numpy or torch; what xpg_mip_batch_rat32 /
+    xpg_six_batch_rat32 return). Nothing is rounded on the way through the gather."""
+    import torch
+    status = torch.as_tensor(status); v = torch.as_tensor(v); sol = torch.as_tensor(sol)
+    n = status.shape[0]
+    rec = torch.empty(n, 3 + 2 * sol.shape[1], dtype=torch.int32, device=sol.device)
+    rec[:, 0] = status.to(torch.int32)
+    rec[:, 1:3] = v.reshape(n, 2).to(torch.int32)
+    rec[:, 3:] = sol.reshape(n, -1).to(torch.int32)
+    return rec
+
+
+def unpack_records_rat(rec):
+    """Inverse of pack_records_rat: (status [n], v [n, 2], sol [n, cols, 2]) as int32 tensors."""
+    n = rec.shape[0]
+    return rec[:, 0], rec[:, 1:3], rec[:, 3:].reshape(n, -1, 2)
+
+
+def pack_records_i32(*cols):
+    """Integer verdicts (e.g. DepPoly::is_empty answers, node counts) -> int32 records, one column per argument."""
+    import torch
+    cols = [torch.as_tensor(c).reshape(len(c), -1).to(torch.int32) for c in cols]
+    return torch.cat(cols, dim=1).contiguous()
+
+
 def gather_records(rec, total, rank, world, dist=None):
     """All-gathers per-rank record blocks (ragged by at most one row) into the global order.
 
