@@ -49,6 +49,8 @@ extern "C" {
 #define XPG_ERR_UNSUPPORTED  (-4)
 #define XPG_ERR_NO_DEVICE    (-5)
 #define XPG_ERR_REF_UNDEFINED (-7) /* the reference's behaviour is undefined on this input */
+#define XPG_ERR_CHAIN_STUCK  (-8)  /* a persistent launch of the blocked fp64 loop lost a worker AFTER its roll call (a
+                                      preempted queue); the handle's LP must be rebuilt (xpg_lp_begin / _two_stage) */
 
 typedef struct xpg_ctx xpg_ctx;   /* one device + one HIP stream + scratch; re-entrant per handle */
 typedef struct xpg_lp  xpg_lp;    /* one device-resident slack-form LP (tableau, objective, basis) */
@@ -113,6 +115,11 @@ int  xpg_lp_pivots_done(xpg_lp * lp, unsigned * out);
  * 16 staged pivots, and sweeps that applied fewer (the tail of an iterate budget, or a batch closed
  * early by a rare branch of SIX::solveSlackForm, src/com/lpsol.h:1138-1151).  Either may be NULL. */
 int  xpg_lp_counters(xpg_lp * lp, unsigned * sweeps_full, unsigned * sweeps_partial);
+/* Blocked fp64 loop, diagnostics: persistent chain launches of the current solve that were given up at their roll call
+ * because not every worker got a compute unit in time (the device is shared with other work), and whether the handle
+ * has switched this solve to launch-per-stage kernels because of it; runs (may be NULL) = the launches that passed.
+ * Results are the same either way. */
+int  xpg_lp_chain_aborts(xpg_lp * lp, unsigned * aborts, int * chain_off, unsigned * runs);
 /* OPT-IN, NON-PARITY (results are no longer the reference's bit for bit, and
  * nothing else in this header changes behaviour): before xpg_lp_begin / xpg_lp_two_stage,
  *   pricing = 1        Dantzig's rule -- the largest reduced cost enters -- instead of the reference's

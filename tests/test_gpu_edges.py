@@ -231,3 +231,32 @@ def test_batch_sizes_ragged_and_single(ctx, port):
             for b in range(nb):
                 want = port.six_solve(RAT, is_max, probs[b]["tgtf"], probs[b]["vc"], None, probs[b]["leq"])
                 assert status[b] == want[0] and np.array_equal(v[b], want[1])
+
+
+def test_wide_tableau_keeps_the_chain(port, monkeypatch):
+    """W >= 16 384 (here 1024 x 17 025: 267 prep workers, 268 partial slots -- two polling rounds per pick) used to drop
+    silently to the launch-per-stage kernels; the chain now runs there too, and its results are the serial loop's and
+    the oracle's bit for bit."""
+    import xpoly_amd
+    m, n, K = 1024, 16000, 160
+    leq, tg = gen.hard_lp_f64(m, n)
+    got = {}
+    for mode in ("block", "serial"):
+        monkeypatch.setenv("XPG_LOOP", mode)
+        c = xpoly_amd.Context(0)
+        lp = xpoly_amd.DeviceLP(c, F64, leq, tg)
+        lp.begin()
+        for k in (50, 110):
+            assert lp.iterate(k) == xpoly_amd.six.XPG_RUNNING
+        aborts, off = lp.chain_aborts()
+        got[mode] = (lp.read(), lp.trace().copy(), lp.pivots_done(), lp.chain_runs, aborts)
+        lp.close(); c.close()
+    a, ta, na, runs, aborts = got["block"]
+    b, tb, nb, _, _ = got["serial"]
+    assert runs >= 8 and aborts == 0, (runs, aborts)     # the persistent launch really ran (10 batches of 16)
+    assert na == nb == K and np.array_equal(ta, tb)
+    for k in ("tab", "tgtf"):
+        assert np.array_equal(a[k].view(np.uint64), b[k].view(np.uint64)), k
+    want = port.two_stage(F64, leq, tg, K)
+    assert np.array_equal(a["tab"].view(np.uint64), want["tab"].view(np.uint64))
+    assert np.array_equal(a["eq2bv"], want["eq2bv"])

@@ -8,7 +8,7 @@ SO_PATH = os.environ.get("XPG_SO_PATH") or os.path.join(HERE, "libxpoly_amd.so")
 
 XPG_RUNNING = -1000
 ERRORS = {-1: "XPG_ERR_HIP", -2: "XPG_ERR_ALLOC", -3: "XPG_ERR_SHAPE", -4: "XPG_ERR_UNSUPPORTED",
-          -5: "XPG_ERR_NO_DEVICE", -7: "XPG_ERR_REF_UNDEFINED"}
+          -5: "XPG_ERR_NO_DEVICE", -7: "XPG_ERR_REF_UNDEFINED", -8: "XPG_ERR_CHAIN_STUCK"}
 
 # every symbol include/xpoly_amd.h declares
 SYMBOLS = [
@@ -27,7 +27,7 @@ SYMBOLS = [
     "xpg_rat_rank_basis_batch", "xpg_rat_null_batch", "xpg_int_hnf_batch", "xpg_int_gcd_batch",
     "xpg_six_batch_f64_multi", "xpg_six_batch_rat32_multi", "xpg_mip_batch_rat32_multi",
     "xpg_dep_is_empty_batch_rat32_multi", "xpg_dep_is_empty_batch_ex_rat32", "xpg_lineq_move2var_batch_rat32", "xpg_mip_warm_f64",
-    "xpg_lineq_fme_batch_packed_rat32", "xpg_trim",
+    "xpg_lineq_fme_batch_packed_rat32", "xpg_trim", "xpg_lp_chain_aborts",
     "xpg_six_batch_f64_ragged", "xpg_six_batch_rat32_ragged", "xpg_dep_is_empty_batch_ragged_rat32",
     "xpg_lineq_reduce_batch_ragged_rat32", "xpg_lineq_fme_batch_ragged_rat32",
 ]

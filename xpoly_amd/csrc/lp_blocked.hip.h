@@ -436,6 +436,7 @@ __device__ __forceinline__ bool blk_prep_body(const LpView<F64> & v, int batch, 
         // the counters as they stand after it -- fields the chain itself never writes, so a late worker
         // of that launch reads what the early ones read
         if (t == 0) {
+            st->blk.ch_arrive = 0u;                            // (the previous batch's chain launch has completed: stream order)
             st->blk.ch_epoch = epoch;
             st->blk.ch_budget = generic_pivot ? budget : budget - 1;
             st->blk.ch_done = generic_pivot ? done : done + 1;

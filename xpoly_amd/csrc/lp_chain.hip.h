@@ -44,13 +44,25 @@
 // CLOSE records instead (budget spent, iteration limit, no eligible column), an empty first ratio pass is
 // seen by everyone in the records. The batch then has fewer than B staged pivots, the sweep applies them,
 // and the next batch starts with the launch-per-stage kernels, which own every rare branch.
-// A poll that does not complete within ~0.5 s flags ST_CHAIN_STUCK (XPG_ERR_HIP for the caller).
+// The protocol needs every worker RESIDENT at once (they poll each other). That is the rule when the handle has the
+// device to itself, and not guaranteed otherwise -- another stream of the host application or another process can hold
+// CUs for milliseconds. So a launch starts with a roll call: every worker counts itself in (one atomic add), the
+// committer waits for the count to reach the grid size and publishes GO in a decision granule; if the count is not
+// complete within CH_ARRIVE_TICKS (0.3 ms; a 200-workgroup grid starts within a microsecond on a free chip) it
+// publishes ABORT instead: every worker -- those present now and those that get a CU later -- leaves WITHOUT having
+// written any state, the batch is closed with the one pivot stage 0 staged, the sweep applies it, and the host, which
+// sees blk.ch_aborts move at its next status read, enqueues this LP's further batches as launch-per-stage kernels
+// (which need no co-residency). After GO every worker is resident and stays so, and a poll that still does not
+// complete within seconds flags ST_CHAIN_STUCK (XPG_ERR_CHAIN_STUCK for the caller): a preempted queue, not a state
+// this code recovers from.
 #pragma once
 #include "lp_blocked.hip.h"
 
 namespace xpg {
 
-enum { ST_CHAIN_STUCK = -1, CH_SPIN_LIMIT = 1 << 21, CH_CLOSE = 0x7FFFFFFF, CH_PART_BYTES = BLK_PART_INTS * 4 };
+enum { ST_CHAIN_STUCK = XPG_ERR_CHAIN_STUCK, CH_SPIN_LIMIT = 1 << 21, CH_CLOSE = 0x7FFFFFFF, CH_PART_BYTES = BLK_PART_INTS * 4,
+       CH_ARRIVE_TICKS = 30000,    // roll call: 0.3 ms of the 100 MHz clock
+       CH_GO = 1, CH_ABORT = 2 };
 typedef unsigned int ch_u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned long long ch_lo64(ch_u32x4 g) { return ((unsigned long long)g.y << 32) | g.x; }
@@ -284,8 +296,9 @@ __device__ unsigned long long g_ch_ts[4][16][8];            // [worker class][st
 #define CH_TS(pt_) do { } while (0)
 #endif
 
-// npick = ceil(m / 64) pick workers, nprep = ceil(W / 64) <= 255 prep workers; grid = max of the two, + 1.
-__global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int t0, int B, int npick, int nprep)
+// npick = ceil(m / 64) <= 256 pick workers, nprep = ceil(W / 64) <= 510 prep workers; grid = max of the two, + 1.
+// force_abort: test hook (XPG_CHAIN_TEST_ABORT=k makes every k-th chain launch fail its roll call).
+__global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int t0, int B, int npick, int nprep, int force_abort)
 {
     LoopState * st = v.st;
     const int w = (int)blockIdx.x, lane = (int)threadIdx.x;
@@ -293,7 +306,28 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
     if (st->blk.ch_epoch != blk_epoch(batch, t0 - 1) || st->status != ST_RUNNING || st->pricing != 0) return;
     unsigned budget = st->blk.ch_budget, done = st->blk.ch_done;
     const unsigned max_iter = st->max_iter;
-    if (w == (int)gridDim.x - 1) { ch_commit_loop(v, batch, t0, B, npick, nprep, budget, done, st->blk.ch_tp); return; }
+    // ---- roll call (see the header): count in; the committer decides GO / ABORT for everybody
+    char * const decision = (char *)v.blkP + (size_t)(nprep + 1) * CH_PART_BYTES;
+    const unsigned roll_tag = blk_epoch(batch, t0 - 1);
+    if (lane == 0) __hip_atomic_fetch_add(&st->blk.ch_arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (w == (int)gridDim.x - 1) {
+        const unsigned long long t_in = wall_clock64();
+        bool go = false;
+        for (;;) {
+            if (force_abort) break;
+            if (ch_ld(&st->blk.ch_arrive) >= gridDim.x) { go = true; break; }
+            if (wall_clock64() - t_in > (unsigned long long)CH_ARRIVE_TICKS) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (lane == 0) {
+            if (go) st->blk.ch_runs += 1u;
+            else { st->blk.closed = 1; st->blk.ch_aborts += 1u; }     // nothing of this launch has touched the state: close the batch at stage 0's pivot
+        }
+        ch_drain();
+        if (lane == 0) ch_store_granule(decision, (unsigned long long)(go ? CH_GO : CH_ABORT), (unsigned long long)roll_tag);
+        if (go) ch_commit_loop(v, batch, t0, B, npick, nprep, budget, done, st->blk.ch_tp);
+        return;
+    }
     const int m = v.m, W = v.W, rhs = v.rhs, ld = v.ld, lim = v.rhs - 1;
     const bool picker = w < npick, prepper = w < nprep;
     const int i = w * 64 + lane, j = w * 64 + lane;         // this lane's row (pick role) and column (prep role)
@@ -327,6 +361,16 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
         } else klast = ks;
     }
     int r_prev = st->blk.r[t0 - 1];                         // pivot row of stage t - 1 (for the constant's step)
+    // ---- the committer's decision (the loads above were in flight meanwhile)
+    {
+        unsigned spins = 0;
+        for (;;) {
+            const ch_u32x4 g = ch_load1(decision);
+            if (g.z == roll_tag) { if (g.x != (unsigned)CH_GO) return; break; }
+            if (++spins > CH_SPIN_LIMIT) { if (lane == 0) ch_st(&st->status, (int)ST_CHAIN_STUCK); return; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
 #ifdef XPG_STAMPS
     const int tsw = w == 0 ? 0 : (w == npick - 1 ? 1 : (w == npick ? 2 : (w == nprep - 1 ? 3 : -1)));
 #endif
@@ -337,18 +381,20 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
         CH_TS(0);
         // =========================== pick role =====================================================
         if (picker) {
-            // ---- poll the g0 granules of the partials of stage t-1 and the commit granule (slot nprep)
+            // ---- poll the g0 granules of the partials of stage t-1 and the commit granule (slot nprep): four slots per
+            // lane and round; beyond 256 slots (W >= 16 320: two rounds) up to 511
             int nf = INT_MAX;
-            {
-                const int k0 = lane, k1 = lane + 64, k2 = lane + 128, k3 = lane + 192;
-                const int kc = k0 <= nprep ? k0 : k0 % (nprep + 1);
+            for (int base = 0; base <= nprep; base += 256) {
+                const int k0 = base + lane, k1 = k0 + 64, k2 = k0 + 128, k3 = k0 + 192;
+                const int kc = k0 <= nprep ? k0 : base + (lane % (nprep + 1 - base));
+                const int j1 = k1 <= nprep ? k1 : kc, j2 = k2 <= nprep ? k2 : kc, j3 = k3 <= nprep ? k3 : kc;   // (no slot of its own: its first one again)
                 const void * p0 = parts + (size_t)kc * CH_PART_BYTES;
-                const void * p1 = parts + (size_t)(k1 <= nprep ? k1 : kc) * CH_PART_BYTES;   // (no slot of its own: its first one again)
-                const void * p2 = parts + (size_t)(k2 <= nprep ? k2 : kc) * CH_PART_BYTES;
-                const void * p3 = parts + (size_t)(k3 <= nprep ? k3 : kc) * CH_PART_BYTES;
+                const void * p1 = parts + (size_t)j1 * CH_PART_BYTES;
+                const void * p2 = parts + (size_t)j2 * CH_PART_BYTES;
+                const void * p3 = parts + (size_t)j3 * CH_PART_BYTES;
                 // (the commit of stage t0 - 1 was a launch of its own: no granule to wait for)
-                const bool x0 = kc == nprep && t == t0, x1 = (k1 <= nprep ? k1 : kc) == nprep && t == t0;
-                const bool x2 = (k2 <= nprep ? k2 : kc) == nprep && t == t0, x3 = (k3 <= nprep ? k3 : kc) == nprep && t == t0;
+                const bool x0 = kc == nprep && t == t0, x1 = j1 == nprep && t == t0;
+                const bool x2 = j2 == nprep && t == t0, x3 = j3 == nprep && t == t0;
                 ch_u32x4 g0, g1, g2, g3;
                 unsigned spins = 0;
                 for (;;) {

@@ -37,6 +37,7 @@ struct xpg_ctx {
     int loop_auto;          // XPG_LOOP unset: blocked loop where the sweep is what costs (large fp64 tableaux)
     int num_cus;            // compute units of the device
     int chain;              // blocked loop: stages 1.. of a batch in ONE persistent launch (lp_chain.hip.h); XPG_CHAIN=0 turns it off
+    int chain_test_abort = 0;   // test hook XPG_CHAIN_TEST_ABORT=k (read when the handle is created): every k-th chain launch fails its roll call
     // xpg_profile_begin/end: event pairs around each sweep launch
     std::vector<hipEvent_t> ev0, ev1;
     int prof_cap, prof_n, prof_stride, prof_seen;
@@ -165,8 +166,8 @@ template <> inline void launch_pipe_sweep<F64>(xpg_ctx * ctx, const LpView<F64> 
                            v, slot, colstride);
 }
 // One batch of the blocked loop: B x (pick, prep) -- the generic pick once after pick(0) -- and a sweep.
-template <class S> inline void launch_blk_batch(xpg_ctx *, const LpView<S> &, int, int, bool, bool) {}
-template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> & v, int batch, int B, bool ref_pricing, bool closes_often)
+template <class S> inline void launch_blk_batch(xpg_ctx *, const LpView<S> &, int, int, bool, bool, bool) {}
+template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> & v, int batch, int B, bool ref_pricing, bool closes_often, bool chain_off)
 {
     const int strips = (v.W + 511) / 512;
     // workgroup sizes of pick and prep: 64 = one wave per workgroup, no LDS round in the reductions
@@ -177,17 +178,20 @@ template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> &
     const int want_pick = (v.m + tp - 1) / tp;
     const int npick = want_pick < BLK_PICK_WGS ? want_pick : BLK_PICK_WGS;
     const dim3 gprep((v.W + tq - 1) / tq);
-    // Stages 1 .. B-1 in one persistent launch where every worker (one wave per 64 rows / 64 columns) can
-    // be resident at once -- they poll each other's records, so each needs a slot of its own; one per CU
-    // keeps that beyond doubt. Wider or taller tableaux, and the opt-in Dantzig pricing, take the
+    // Stages 1 .. B-1 in one persistent launch: one one-wave worker per 64 rows / 64 columns, all resident at once -- they
+    // poll each other's records. The launch checks that itself (roll call, lp_chain.hip.h) and falls back when the device
+    // cannot seat them all, so the shape limits here are only those of the hand-off areas: 256 records, 511 partial slots
+    // (W <= 32 640), and at most four workers per CU. Taller or wider tableaux, and the opt-in Dantzig pricing, take the
     // launch-per-stage path.
     const int cpick = (v.m + 63) / 64, cprep = (v.W + 63) / 64;
-    const bool chain = ctx->chain && ref_pricing && B > 1 && cpick < ctx->num_cus && cprep < ctx->num_cus &&
-                       cpick <= BLK_REC_MAX && cprep <= 255 &&
+    const bool chain = ctx->chain && !chain_off && ref_pricing && B > 1 &&
+                       cpick <= BLK_REC_MAX && cprep <= 510 && (cpick > cprep ? cpick : cprep) + 1 <= 4 * (ctx->num_cus > 0 ? ctx->num_cus : 1) &&
                        tpb_prep == 64;             // stage 0's prep leaves one look-ahead partial per 64 columns, as the chain's workers do
     for (int t = 0; t < B; t++) {
         if (t == 1 && chain) {
-            hipLaunchKernelGGL(k_blk_chain, dim3((cpick > cprep ? cpick : cprep) + 1), dim3(64), 0, ctx->stream, v, batch, 1, B, cpick, cprep);
+            const int test_abort = ctx->chain_test_abort;
+            hipLaunchKernelGGL(k_blk_chain, dim3((cpick > cprep ? cpick : cprep) + 1), dim3(64), 0, ctx->stream, v, batch, 1, B, cpick, cprep,
+                               test_abort > 0 && batch % test_abort == test_abort - 1 ? 1 : 0);
             break;
         }
         hipLaunchKernelGGL(k_blk_pick, dim3(npick), dim3(tp), 0, ctx->stream, v, batch, t, (int)gprep.x);
@@ -261,6 +265,8 @@ template <class S> struct Lp : LpBase {
     bool pipe_primed = false;
     int blk_batch = 0;      // blocked loop: id of the next batch since reset_loop
     bool closes_often = false;   // blocked loop: >= 5 % of this solve's sweeps so far were of a batch closed early
+    bool chain_off = false;      // blocked loop: a chain launch of this solve failed its roll call (the device is shared): launch per stage from here on
+    unsigned chain_aborts_seen = 0;
     int colstride = 0;      // elements per colbuf half
     int opt_pricing = 0;    // xpg_lp_set_options: 0 the reference's rule, 1 Dantzig (non-parity)
     double opt_feas_tol = 0.0;
@@ -369,6 +375,9 @@ template <class S> struct Lp : LpBase {
         XPG_HIP(ctx, hipMemcpyAsync(out, v.st, sizeof(LoopState), hipMemcpyDeviceToHost, ctx->stream));
         XPG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         closes_often = out->blk.sweeps_part >= 8 && out->blk.sweeps_part * 20u >= out->blk.sweeps_full + out->blk.sweeps_part;
+        if (out->blk.ch_aborts != chain_aborts_seen) { chain_aborts_seen = out->blk.ch_aborts; chain_off = true; }
+        if (out->status == XPG_ERR_CHAIN_STUCK)
+            ctx->err = "blocked loop: a worker of the persistent chain launch stopped answering after the roll call (preempted queue?); rebuild the LP";
         return 0;
     }
 
@@ -385,7 +394,7 @@ template <class S> struct Lp : LpBase {
     {
         hipLaunchKernelGGL((k_reset_loop<S>), dim3(1024), dim3(256), 0, ctx->stream, v, max_iter, opt_pricing,
                            opt_feas_tol);
-        pipe_t = 0; pipe_primed = false; blk_batch = 0; closes_often = false;
+        pipe_t = 0; pipe_primed = false; blk_batch = 0; closes_often = false; chain_off = false; chain_aborts_seen = 0;
     }
     void queue_pivot(int guarded, int counted)
     {
@@ -445,7 +454,7 @@ template <class S> struct Lp : LpBase {
             // the last batch of a budget that is not a multiple of B is enqueued at its own length, so its
             // sweep is the kernel specialised for that many stages (not the full-batch kernel's slow tail)
             const unsigned left = k - b * (unsigned)B;
-            launch_blk_batch(ctx, v, batch, left < (unsigned)B ? (int)left : B, opt_pricing == 0, closes_often);
+            launch_blk_batch(ctx, v, batch, left < (unsigned)B ? (int)left : B, opt_pricing == 0, closes_often, chain_off);
             if ((b & 7) == 7) {                         // throttle: at most 2 x 8 batches in flight
                 hipEvent_t e = throttle[(b >> 3) & 1];
                 if ((b >> 3) >= 2) (void)hipEventSynchronize(e);

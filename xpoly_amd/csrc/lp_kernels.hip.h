@@ -83,6 +83,9 @@ struct LoopState {
                                // pick), not the per-workgroup partials of the last prep
         unsigned ch_epoch;     // chain kernel ticket: epoch of the stage-0 prep that staged this batch's first pivot
         unsigned ch_budget, ch_done, ch_tp;   // budget / done / total_pivots after that stage
+        unsigned ch_arrive;    // chain kernel: workers of this batch's launch that have started (zeroed by stage 0's prep)
+        unsigned ch_aborts;    // chain launches given up before their first stage because not every worker got a CU in time
+        unsigned ch_runs;      // chain launches that passed their roll call
         unsigned sweeps_full;  // sweeps that applied a full batch of BLK_MAX pivots (xpg_lp_counters)
         unsigned sweeps_part;  // sweeps that applied fewer (budget ran out, or a pick closed the batch early)
         unsigned long long dbg[8];   // diagnostic builds (-DXPG_STAMPS): 100 MHz ticks between points of pick / prep
@@ -1126,6 +1129,7 @@ template <class S> __global__ void k_reset_loop(LpView<S> v, unsigned max_iter, 
         st->blk.want_generic = 0; st->blk.la_from_state = 1; st->blk.la_epoch = 0u;
         st->blk.sweeps_full = 0u; st->blk.sweeps_part = 0u;
         st->blk.ch_epoch = 0u; st->blk.ch_budget = 0u; st->blk.ch_done = 0u; st->blk.ch_tp = 0u;
+        st->blk.ch_arrive = 0u; st->blk.ch_aborts = 0u; st->blk.ch_runs = 0u;
         for (int k = 0; k < 8; k++) st->blk.dbg[k] = 0ull;
         for (int k = 0; k < BLK_REC_MAX; k++)                 // record tags
             for (int q = 1; q < 12; q += 2) v.blkR[(size_t)k * BLK_REC_WORDS + q] = 0ull;

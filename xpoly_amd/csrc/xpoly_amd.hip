@@ -63,6 +63,8 @@ int xpg_create(xpg_ctx ** out, int device)
     if (lm && lm[0] == 'p') c->loop_mode = 0;          // "pipe": always the pipelined loop
     const char * ch = getenv("XPG_CHAIN");               // "0": launch-per-stage chain, for A/B runs
     c->chain = ch ? atoi(ch) : 1;
+    const char * cta = getenv("XPG_CHAIN_TEST_ABORT");
+    c->chain_test_abort = cta ? atoi(cta) : 0;
     c->num_cus = 0;
     if (hipDeviceGetAttribute(&c->num_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) c->num_cus = 0;
     c->loop_auto = lm ? 0 : 1;                         // unset: blocked loop for large fp64 tableaux, else pipelined
@@ -361,6 +363,22 @@ int xpg_lp_counters(xpg_lp * lp, unsigned * sweeps_full, unsigned * sweeps_parti
     if (rc) return rc;
     if (sweeps_full) *sweeps_full = hs.blk.sweeps_full;
     if (sweeps_partial) *sweeps_partial = hs.blk.sweeps_part;
+    return 0;
+}
+
+int xpg_lp_chain_aborts(xpg_lp * lp, unsigned * aborts, int * chain_off, unsigned * runs)
+{
+    if (!lp || !lp->impl) return XPG_ERR_SHAPE;
+    XPG_BIND(lp->impl->ctx);
+    if (runs) *runs = 0;
+    if (lp->impl->kind != 0) { if (aborts) *aborts = 0; if (chain_off) *chain_off = 0; return 0; }
+    Lp<F64> * p = (Lp<F64> *)lp->impl;
+    LoopState hs;
+    const int rc = p->read_state(&hs);
+    if (rc) return rc;
+    if (aborts) *aborts = hs.blk.ch_aborts;
+    if (chain_off) *chain_off = p->chain_off ? 1 : 0;
+    if (runs) *runs = hs.blk.ch_runs;
     return 0;
 }
 

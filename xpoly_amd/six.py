@@ -232,6 +232,13 @@ class DeviceLP:
         self.ctx.check(lib().xpg_lp_counters(self._h, C.byref(f), C.byref(p)), "xpg_lp_counters")
         return f.value, p.value
 
+    def chain_aborts(self):
+        """(chain launches given up at their roll call in this solve, whether the solve switched to launch-per-stage)."""
+        n, off, runs = C.c_uint(), C.c_int(), C.c_uint()
+        self.ctx.check(lib().xpg_lp_chain_aborts(self._h, C.byref(n), C.byref(off), C.byref(runs)), "xpg_lp_chain_aborts")
+        self.chain_runs = runs.value
+        return n.value, bool(off.value)
+
     def shape(self):
         r, w, rhs = C.c_int(), C.c_int(), C.c_int()
         self.ctx.check(lib().xpg_lp_shape(self._h, C.byref(r), C.byref(w), C.byref(rhs)), "xpg_lp_shape")
