@@ -361,16 +361,21 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
         } else klast = ks;
     }
     int r_prev = st->blk.r[t0 - 1];                         // pivot row of stage t - 1 (for the constant's step)
-    // ---- the committer's decision (the loads above were in flight meanwhile)
-    {
+    // ---- the committer's decision. A worker must have it before its first WRITE: a pick worker therefore reads it only
+    // after the partial poll and the column gather of its first stage (read-only work that hides the hand-off), a worker
+    // without rows -- which would otherwise wait for records that an aborted launch never publishes -- right here.
+    bool decided = false;
+    auto wait_decision = [&]() -> bool {
+        if (decided) return true;
         unsigned spins = 0;
         for (;;) {
             const ch_u32x4 g = ch_load1(decision);
-            if (g.z == roll_tag) { if (g.x != (unsigned)CH_GO) return; break; }
-            if (++spins > CH_SPIN_LIMIT) { if (lane == 0) ch_st(&st->status, (int)ST_CHAIN_STUCK); return; }
+            if (g.z == roll_tag) { if (g.x != (unsigned)CH_GO) return false; decided = true; return true; }
+            if (++spins > CH_SPIN_LIMIT) { if (lane == 0) ch_st(&st->status, (int)ST_CHAIN_STUCK); return false; }
             __builtin_amdgcn_s_sleep(1);
         }
-    }
+    };
+    if (!picker && !wait_decision()) return;
 #ifdef XPG_STAMPS
     const int tsw = w == 0 ? 0 : (w == npick - 1 ? 1 : (w == npick ? 2 : (w == nprep - 1 ? 3 : -1)));
 #endif
@@ -411,10 +416,12 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
             }
             CH_TS(1);                                       // partials + commit granule seen
             const int first = wave_min_int(nf);
+
             // the fast path of blk_pick_body, or the end of the batch for everyone
             const bool fast = first >= 0 && first < rhs && done < max_iter && budget != 0;
             unsigned long long * rec = v.blkR + (size_t)w * BLK_REC_WORDS;
             if (!fast) {
+                if (!wait_decision()) return;
                 if (lane == 0) ch_store_granule3(rec, ~0u, ~0u, (unsigned)CH_CLOSE_ROW, tag);
                 return;
             }
@@ -457,6 +464,7 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
             klast = -a;                                                           // -a_i,nv (lpsol.h:1485)
 #pragma unroll
             for (int s = 0; s < BLK_MAX; s++) if (s == t) kreg[s] = klast;
+            if (!wait_decision()) return;                                         // (first stage only: nothing has been written so far)
             if (has_row) ch_st(&K[(size_t)i * BLK_MAX + t], klast);
             // findPivotBV's first pass (lpsol.h:553-663)
             unsigned long long key = ~0ull;
