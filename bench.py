@@ -50,7 +50,8 @@ PCIE_GBS = 63.0                            # MI355X_MICROARCH.md: host link PCIe
 BATCH_PER_GPU = 8192                       # 65 536 LPs over 8 GPUs (BASELINE.json configs[2])
 BATCH_M, BATCH_COLS = 32, 64
 PREWARM_SECONDS = 0.5
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "round2_pmc_hbm_traffic.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "round3_pmc_hbm_traffic_4096x8192.json")
+PMC_SUMMARY_2B = os.path.join(ROOT, "profiles", "round3_pmc_hbm_traffic_4096x12289.json")
 PMC_BATCH = os.path.join(ROOT, "profiles", "round2_pmc_batch_issue.json")
 LEGS = ("pivots", "batched", "sharded", "cfg2b", "rational", "mip", "lineq")
 LINEQ_NB = 16384                           # systems per row-elimination launch (the dependence tests' shapes)
@@ -407,7 +408,8 @@ def main():
             out["roofline"] = dict(
                 bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src,
-                kernel="k_blk_sweep_full<16,4>: one launch applies the 16 staged pivots of a batch to every cell",
+                kernel="k_blk_sweep_full<16,4>: one launch applies the 16 staged pivots of a batch to every cell (XCD-static "
+                       "tile map, alternate passes in opposite directions)",
                 algorithmic_bytes_per_launch=ALG_BYTES_PER_LAUNCH, launches_sampled=launches,
                 avg_launch_us=round(sweep_avg_s * 1e6, 2),
                 sweeps_in_region=dict(full=sweeps_full, partial=sweeps_part),
@@ -419,9 +421,11 @@ def main():
                     bytes_per_pivot=round(ALG_BYTES_PER_LAUNCH / ppl), us_per_pivot=round(per_pivot_s * 1e6, 3),
                     achieved=round(ALG_BYTES_PER_LAUNCH / ppl / per_pivot_s / 1e9, 1),
                     frac=round(ALG_BYTES_PER_LAUNCH / ppl / per_pivot_s / 1e9 / HBM_PEAK_GBS, 4)),
-                caveat="fraction of the 8 TB/s HBM peak; the 268 MB tableau nearly fits the 256 MiB Infinity Cache "
-                       "(MALL) and FETCH_SIZE counts its hits, so part of the stream is served by the MALL -- which is "
-                       "how `achieved` can exceed the ~6.3 TB/s a pure HBM copy reaches")
+                caveat="fraction of the 8 TB/s HBM peak; the 268 MB tableau is exactly the size of the 256 MiB Infinity Cache "
+                       "(MALL) and FETCH_SIZE counts its hits, so part of the stream is served by the MALL -- which is how "
+                       "`achieved` can exceed the ~6.3 TB/s a pure HBM copy reaches. The same kernel on a tableau 1.57 x the "
+                       "MALL is the `cfg2b.roofline` object of this line (0.79-0.82); a plain in-place copy with the same "
+                       "tiling runs at 0.86 / 0.79 of the peak at the two sizes (profiles/round3_sweep_lab.txt)")
         if rank == 0:
             out["self_check"] = {"pivots": selfcheck_bench_lp(lp)}      # outside the timed region
         lp.close()
@@ -716,6 +720,8 @@ def leg_cfg2b(ctx, xpoly_amd, gen, m=4096, n=8192):
             achieved=round(bytes_per_launch / avg / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
             frac=round(bytes_per_launch / avg / 1e9 / HBM_PEAK_GBS, 4), avg_launch_us=round(avg * 1e6, 2),
             launches_sampled=launches,
+            traffic=(round(json.load(open(PMC_SUMMARY_2B))["traffic_bytes_per_launch"]) if os.path.exists(PMC_SUMMARY_2B) else None),
+            traffic_source="profiles/round3_pmc_hbm_traffic_4096x12289.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of this leg; not collected in this run)",
             note="HIP events on the sweep launches of the timed pass; a plain in-place copy of this tableau with the same "
                  "tiling runs at 0.79 of the peak (tools/lab/sweep_lab2.hip, profiles/round3_sweep_lab.txt)")
     return out
