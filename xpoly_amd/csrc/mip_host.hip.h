@@ -336,7 +336,8 @@ template <class S> int run_mip_tasks(xpg_ctx * ctx, int kind, std::vector<MipTas
 template <class S> inline bool mip_device_fits(int leq_rows, int cols, bool is_bin);
 template <class S>
 int mip_batch_device(xpg_ctx * ctx, int nb, bool is_max, bool is_bin, const S * tgtf, const S * leq, int leq_rows,
-                     int cols, int32_t * out_status, S * out_v, S * out_sol, long long * out_nodes);
+                     int cols, int32_t * out_status, S * out_v, S * out_sol, long long * out_nodes,
+                     const uint8_t * allow_rational);
 
 // MIP::maxm / minm (lpsol.h:2636-2657, :2681-2702).
 template <class S>
@@ -347,9 +348,9 @@ int mip_solve(xpg_ctx * ctx, int kind, bool is_max, bool is_bin, const S * tgtf,
     if (!ctx || !tgtf || !vc || !out_v || cols < 2 || vc_rows != cols - 1 || eq_rows < 0 || leq_rows < 0 ||
         (eq_rows == 0 && leq_rows == 0) || (eq_rows > 0 && !eqs) || (leq_rows > 0 && !leq))
         return XPG_ERR_SHAPE;
-    // the plain case (x >= 0, inequalities only, no rational_indicator) is what the device tree walk takes
+    // the plain case (x >= 0, inequalities only; with or without a rational_indicator) is what the device tree walk takes
     static const bool on_device = [] { const char * e = getenv("XPG_MIP_DEVICE"); return !(e && e[0] == '0'); }();
-    if (on_device && eq_rows == 0 && !allow_rational && leq_rows > 0 && mip_device_fits<S>(leq_rows, cols, is_bin)) {
+    if (on_device && eq_rows == 0 && leq_rows > 0 && mip_device_fits<S>(leq_rows, cols, is_bin)) {
         bool plain = true;
         for (int i = 0; i < vc_rows && plain; i++)
             for (int j = 0; j < cols && plain; j++)
@@ -358,7 +359,7 @@ int mip_solve(xpg_ctx * ctx, int kind, bool is_max, bool is_bin, const S * tgtf,
             int32_t st = 0; long long nodes = 0;
             std::vector<S> sol((size_t)cols, zero<S>());
             if (out_sol) for (int j = 0; j < cols; j++) sol[(size_t)j] = out_sol[j];
-            const int rc = mip_batch_device<S>(ctx, 1, is_max, is_bin, tgtf, leq, leq_rows, cols, &st, out_v, sol.data(), &nodes);
+            const int rc = mip_batch_device<S>(ctx, 1, is_max, is_bin, tgtf, leq, leq_rows, cols, &st, out_v, sol.data(), &nodes, allow_rational);
             if (rc != XPG_ERR_UNSUPPORTED) {
                 if (rc) return rc;
                 if (st == XPG_IP_SUCC && out_sol) for (int j = 0; j < cols; j++) out_sol[j] = sol[(size_t)j];
@@ -408,7 +409,8 @@ template <class S> inline MipGeom mip_geom(const xpg_ctx * ctx, int nb, int rmax
 // host controller below.
 template <class S>
 int mip_batch_device(xpg_ctx * ctx, int nb, bool is_max, bool is_bin, const S * tgtf, const S * leq, int leq_rows,
-                     int cols, int32_t * out_status, S * out_v, S * out_sol, long long * out_nodes)
+                     int cols, int32_t * out_status, S * out_v, S * out_sol, long long * out_nodes,
+                     const uint8_t * allow_rational)
 {
     const int n = cols - 1;
     const int rmax = leq_rows + (is_bin ? 0 : n);         // integer branching appends one row per ancestor
@@ -419,7 +421,11 @@ int mip_batch_device(xpg_ctx * ctx, int nb, bool is_max, bool is_bin, const S * 
     const int threads = g.threads, grid = g.grid;
     const size_t ws_words = mip_ws_words(rmax, cols, depth);
     const size_t bl = (size_t)nb * leq_rows * cols * 8, bt = (size_t)nb * cols * 8;
-    DevBuf dl, dt, dws, dst, dv, dsol, dn;
+    DevBuf dl, dt, dws, dst, dv, dsol, dn, dal;
+    if (allow_rational) {
+        XPG_TRY(dal.alloc(ctx, (size_t)cols));
+        XPG_TRY(hipMemcpyAsync(dal.p, allow_rational, (size_t)cols, hipMemcpyHostToDevice, ctx->stream));
+    }
     XPG_TRY(dl.alloc(ctx, bl)); XPG_TRY(dt.alloc(ctx, bt)); XPG_TRY(dws.alloc(ctx, (size_t)grid * ws_words * 8));
     XPG_TRY(dst.alloc(ctx, (size_t)nb * 4)); XPG_TRY(dv.alloc(ctx, (size_t)nb * 8)); XPG_TRY(dsol.alloc(ctx, bt));
     XPG_TRY(dn.alloc(ctx, (size_t)nb * 4));
@@ -429,7 +435,8 @@ int mip_batch_device(xpg_ctx * ctx, int nb, bool is_max, bool is_bin, const S * 
     XPG_TRY(lds_limit((const void *)k_mip_tree<S>, ctx->device, lds));
     hipLaunchKernelGGL((k_mip_tree<S>), dim3(grid), dim3(threads), lds, ctx->stream, nb, (const S *)dt.p, (const S *)dl.p,
                        leq_rows, cols, is_max ? 1 : 0, is_bin ? 1 : 0, rmax, depth, (unsigned long long *)dws.p, ws_words,
-                       (int32_t *)dst.p, (S *)dv.p, out_sol ? (S *)dsol.p : (S *)0, (int *)dn.p, (const int *)0, (const int *)0);
+                       (int32_t *)dst.p, (S *)dv.p, out_sol ? (S *)dsol.p : (S *)0, (int *)dn.p, (const int *)0, (const int *)0,
+                       allow_rational ? (const uint8_t *)dal.p : (const uint8_t *)0);
     XPG_TRY(hipGetLastError());
     std::vector<int32_t> nodes((size_t)nb);
     XPG_TRY(hipMemcpyAsync(out_status, dst.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -451,7 +458,7 @@ int mip_batch(xpg_ctx * ctx, int kind, int nb, bool is_max, bool is_bin, const S
     // the whole tree walk on the device where the node LPs fit (XPG_MIP_DEVICE=0: the host controller, for A/B runs)
     static const bool on_device = [] { const char * e = getenv("XPG_MIP_DEVICE"); return !(e && e[0] == '0'); }();
     if (on_device) {
-        const int rc = mip_batch_device<S>(ctx, nb, is_max, is_bin, tgtf, leq, leq_rows, cols, out_status, out_v, out_sol, out_nodes);
+        const int rc = mip_batch_device<S>(ctx, nb, is_max, is_bin, tgtf, leq, leq_rows, cols, out_status, out_v, out_sol, out_nodes, (const uint8_t *)0);
         if (rc != XPG_ERR_UNSUPPORTED) return rc;
     }
     const int rhs = cols - 1;
@@ -572,7 +579,7 @@ inline int dep_is_empty_batch(xpg_ctx * ctx, int nb, const R32 * mats, int rows,
             XPG_TRY(lds_limit((const void *)k_mip_tree<R32>, ctx->device, lds));
             hipLaunchKernelGGL((k_mip_tree<R32>), dim3(grid), dim3(threads), lds, ctx->stream, nb, (const R32 *)dt.p, (const R32 *)dm.p,
                                rows, cols, is_max ? 1 : 0, 0, rmax, depth, (unsigned long long *)dws.p, ws_words,
-                               (int32_t *)dst.p, (R32 *)dv.p, (R32 *)0, (int *)dn.p, (const int *)dk.p, (const int *)dact.p);
+                               (int32_t *)dst.p, (R32 *)dv.p, (R32 *)0, (int *)dn.p, (const int *)dk.p, (const int *)dact.p, (const uint8_t *)0);
             XPG_TRY(hipGetLastError());
             XPG_TRY(hipMemcpyAsync(pass == 0 ? nodes_a.data() : nodes_b.data(), dn.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
             hipLaunchKernelGGL(k_dep_update, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, nb, (const int32_t *)dst.p,

@@ -12,7 +12,8 @@
 // never leaves its workgroup and the trees do not wait for each other.
 //
 // Scope: x >= 0, inequalities only at the root (xpg_mip_batch_*: the caller's vc is -I), binary or integer
-// branching, no rational_indicator. Anything else keeps the host controller.
+// branching, with or without a rational_indicator (lpsol.h:2369-2393; round 3). Equalities at the root and general
+// variable constraints keep the host controller.
 #pragma once
 #include "batch_kernels.hip.h"
 
@@ -130,7 +131,8 @@ template <class S> __device__ int mip_build_node(const MipWs<S> & w, const S * r
 
 // MipTask::on_lp: feeds the node's answer to the recursion and runs it until the next LP is needed (returns
 // false) or the tree ends (returns true, ctl[MC_FINAL] set). Thread 0 only.
-template <class S> __device__ bool mip_feed(const MipWs<S> & w, const S * tgtf, int cols, bool is_max, bool is_bin, int st)
+template <class S> __device__ bool mip_feed(const MipWs<S> & w, const S * tgtf, int cols, bool is_max, bool is_bin, int st,
+                                            const uint8_t * allow)
 {
     const int n0 = cols - 1;
     int top = w.ctl[MC_TOP];
@@ -154,8 +156,10 @@ template <class S> __device__ bool mip_feed(const MipWs<S> & w, const S * tgtf, 
             bool sat = true;                                 // MIP::is_satisfying (lpsol.h:2364-2408)
             for (int j = 0; j < cols; j++) {
                 S t = w.sol[j];
-                if (is_bin) { reduce(t); w.sol[j] = t; }
-                const bool bad = is_bin ? (ne(t, zero<S>()) && ne(t, one<S>())) : !is_int(t);
+                if (allow || is_bin) { reduce(t); w.sol[j] = t; }
+                bool bad;
+                if (allow) bad = !allow[j] && (!is_int(t) || (is_bin && ne(t, zero<S>()) && ne(t, one<S>())));   // lpsol.h:2369-2393
+                else bad = is_bin ? (ne(t, zero<S>()) && ne(t, one<S>())) : !is_int(t);
                 if (bad) { col = j; sat = false; break; }
             }
             const bool have_best = w.ctl[MC_HAVE_BEST] != 0;
@@ -226,8 +230,10 @@ template <class S> __device__ bool mip_feed(const MipWs<S> & w, const S * tgtf, 
 template <class S> __global__ __launch_bounds__(256, 2)
 void k_mip_tree(int nb, const S * tgtf_all, const S * leq_all, int leq_rows, int cols, int is_max, int is_bin, int rmax,
                 int depth, unsigned long long * ws_all, size_t ws_words, int32_t * out_status, S * out_v, S * out_sol,
-                int * out_nodes, const int * rows_of, const int * active)
+                int * out_nodes, const int * rows_of, const int * active, const uint8_t * allow)
 {
+    // allow (may be NULL): MIP's rational_indicator, one row of cols flags shared by the batch -- variables whose flag is
+    // set may stay fractional (lpsol.h:2369-2393).
     // rows_of (may be NULL): problem b has rows_of[b] of its leq_rows-row slot live (ragged batches: the systems
     // Lineq::reduce leaves); active (may be NULL): only problems whose entry is 1 are walked, the others' outputs
     // are left alone.
@@ -266,7 +272,7 @@ void k_mip_tree(int nb, const S * tgtf_all, const S * leq_all, int leq_rows, int
                 st = sm_solve_lp<S>(P, src, 10000u, /*raw_sol=*/1, w.y, (S *)&sh_v);
             }
             MIP_T(1)
-            if (threadIdx.x == 0) sh_ctl[0] = mip_feed<S>(w, tgtf, cols, is_max != 0, is_bin != 0, st) ? 1 : 0;
+            if (threadIdx.x == 0) sh_ctl[0] = mip_feed<S>(w, tgtf, cols, is_max != 0, is_bin != 0, st, allow) ? 1 : 0;
             __syncthreads();
             MIP_T(2)
             if (sh_ctl[0]) break;
