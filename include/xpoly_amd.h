@@ -120,6 +120,12 @@ int  xpg_lp_counters(xpg_lp * lp, unsigned * sweeps_full, unsigned * sweeps_part
  * has switched this solve to launch-per-stage kernels because of it; runs (may be NULL) = the launches that passed.
  * Results are the same either way. */
 int  xpg_lp_chain_aborts(xpg_lp * lp, unsigned * aborts, int * chain_off, unsigned * runs);
+/* Launch geometry, host-side views for tests (no device needed).  xpg_test_sweep_tile: the blocked sweep's workgroup ->
+ * tile map for a tableau of `strips` 512-column strips and `rowblocks` row blocks: lid < 0 returns the grid size, else
+ * 1 / 0 = workgroup lid has / has no tile, written to (*bx, *by).  xpg_test_pick_ld: the leading dimension a device
+ * tableau of W live columns gets. */
+int  xpg_test_sweep_tile(int strips, int rowblocks, int rev, int lid, int * bx, int * by);
+int  xpg_test_pick_ld(int W);
 /* OPT-IN, NON-PARITY (results are no longer the reference's bit for bit, and
  * nothing else in this header changes behaviour): before xpg_lp_begin / xpg_lp_two_stage,
  *   pricing = 1        Dantzig's rule -- the largest reduced cost enters -- instead of the reference's

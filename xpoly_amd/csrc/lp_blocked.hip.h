@@ -547,7 +547,7 @@ __host__ __device__ __forceinline__ int blk_sweep_grid(int strips, int rowblocks
 {
     return 8 * ((rowblocks + 7) / 8) * (8 * (strips >> 3) + (strips & 7));
 }
-__device__ __forceinline__ bool blk_sweep_tile(int lid, int strips, int rowblocks, int rev, int & bx, int & by)
+__host__ __device__ __forceinline__ bool blk_sweep_tile(int lid, int strips, int rowblocks, int rev, int & bx, int & by)
 {
     const int c = lid & 7, k = lid >> 3;
     const int nown = strips >> 3, L = strips & 7, per = 8 * nown + L;

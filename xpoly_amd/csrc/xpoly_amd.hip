@@ -366,6 +366,20 @@ int xpg_lp_counters(xpg_lp * lp, unsigned * sweeps_full, unsigned * sweeps_parti
     return 0;
 }
 
+// Host-side views of two pieces of launch geometry, for the CPU test suite (no device needed): the blocked sweep's
+// workgroup -> tile map (every tile of a strips x rowblocks tableau exactly once, whatever the shape) and the leading
+// dimension a device tableau of W live columns gets.
+int xpg_test_sweep_tile(int strips, int rowblocks, int rev, int lid, int * bx, int * by)
+{
+    if (!bx || !by || strips <= 0 || rowblocks <= 0) return XPG_ERR_SHAPE;
+    if (lid < 0) return blk_sweep_grid(strips, rowblocks);      // lid < 0: the grid size
+    int x = -1, y = -1;
+    const bool live = blk_sweep_tile(lid, strips, rowblocks, rev, x, y);
+    *bx = x; *by = y;
+    return live ? 1 : 0;
+}
+int xpg_test_pick_ld(int W) { return W > 0 ? pick_ld(W) : XPG_ERR_SHAPE; }
+
 int xpg_lp_chain_aborts(xpg_lp * lp, unsigned * aborts, int * chain_off, unsigned * runs)
 {
     if (!lp || !lp->impl) return XPG_ERR_SHAPE;
