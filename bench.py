@@ -581,7 +581,7 @@ def main():
             out["lineq"] = leg_lineq(ctx, xpoly_amd, gen)
 
     if rank == 0:
-        if checks or "self_check" in out:
+        if checks or "self_check" in out or "self_check" in out.get("mip", {}):
             out.setdefault("self_check", {}).update(checks)
             if "mip" in out and "self_check" in out["mip"]:
                 out["self_check"]["mip"] = out["mip"].pop("self_check")
