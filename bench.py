@@ -268,6 +268,9 @@ def main():
     ap.add_argument("--no-events", action="store_true", help="do not attach HIP events to sweep launches")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="gloo + --stub-solver: the rank-spawn / shard / gather path without GPUs (tests)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="test aid: every rank solves on cuda:0 and the collectives run over gloo on host tensors -- the real "
+                         "solver through the whole N > 1 path (shards, records, gather) on a box with ONE GPU")
     ap.add_argument("--stub-solver", action="store_true",
                     help="ranks fabricate their shard's records instead of solving (CPU test of the N > 1 path)")
     a = ap.parse_args()
@@ -293,12 +296,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if stub:
+        if a.same_device:
+            assert a.backend == "gloo", "--same-device needs --backend gloo (RCCL refuses two ranks on one GPU)"
+            local = 0
+        if stub or a.same_device:
             dist.init_process_group(backend=a.backend)
         else:
             torch.cuda.set_device(local)
             dist.init_process_group(backend=a.backend, device_id=torch.device("cuda", local))
     dev = torch.device("cpu") if stub else torch.device("cuda", local if world > 1 else 0)
+    cdev = torch.device("cpu") if (stub or a.backend == "gloo") else dev     # where the collectives' tensors live
     if not stub:
         torch.cuda.set_device(dev)
 
@@ -319,14 +326,14 @@ def main():
     def max_over_ranks(x):
         if dist is None:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     def sum_over_ranks(x):
         if dist is None:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device=cdev)
         dist.all_reduce(t)
         return float(t.item())
 
@@ -478,7 +485,7 @@ def main():
                 if dist is None:
                     return None
                 # the only collective of the path: fixed-size (status, v, sol) records
-                full = gather_records(pack_records(d_st, d_v, d_sol), total, rank, world, dist)
+                full = gather_records(pack_records(d_st, d_v, d_sol).to(cdev), total, rank, world, dist)
                 if not stub:
                     torch.cuda.synchronize()
                 tsplit[1] += time.perf_counter() - tb
@@ -553,7 +560,7 @@ def main():
                                       d_st.data_ptr(), d_v.data_ptr(), d_sol.data_ptr(), None)
                     ctx.sync()
                     if dist is not None:
-                        g = gather_records(pack_records(d_st, d_v, d_sol), full_n, rank, world, dist)
+                        g = gather_records(pack_records(d_st, d_v, d_sol).to(cdev), full_n, rank, world, dist)
                         torch.cuda.synchronize()
                         assert g.shape[0] == full_n
                     barrier()
@@ -567,7 +574,7 @@ def main():
 
     # ---- leg 2b: the exact (rational) batches of BASELINE configs[4], sharded like leg 2 --------------------------
     if "sharded" in legs:
-        out["sharded"] = leg_sharded(ctx, rank, world, dev, dist, stub, a.backend, barrier, max_over_ranks, sum_over_ranks)
+        out["sharded"] = leg_sharded(ctx, rank, world, cdev, dist, stub, a.backend, barrier, max_over_ranks, sum_over_ranks)
 
     # ---- legs 3-5: the remaining BASELINE configs, rank 0 of an N = 1 run ---------------------------
     if world == 1 and not stub:

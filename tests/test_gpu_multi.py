@@ -129,3 +129,25 @@ def test_sweep_counters_and_tail_batches(monkeypatch):
         lp.close(); c.close()
     assert np.array_equal(bits(out["block"]["tab"]), bits(out["serial"]["tab"]))
     assert np.array_equal(bits(out["block"]["tgtf"]), bits(out["serial"]["tgtf"]))
+
+
+def test_bench_two_ranks_real_solver_on_one_gpu():
+    """bench.py's whole N > 1 path with the REAL solver: two ranks started by bench.py itself, both on cuda:0
+    (--same-device: the collectives then run over gloo on host tensors, RCCL refuses two ranks per GPU): contiguous
+    shards, weak and strong batched legs, the exact int32-record legs, one all_gather each -- and bench.py's own
+    self-check of the gathered records against the reference fixture."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device",
+                        "--legs", "batched,sharded", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and "stub_solver" not in out
+    b = out["batched"]
+    assert b["ranks"] == 2 and b["total_lps"] == 16384 and b["families"]["dep_test_like"]["gather_ms"] > 0
+    assert b["strong_scaling"]["lps_per_rank"] == 32768
+    assert out["sharded"]["mip"]["problems_total"] == 2048 and out["sharded"]["dep_is_empty"]["problems_total"] == 8192
+    assert "identical" in out["self_check"]["batched"]["dep_test_like"]
