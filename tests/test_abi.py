@@ -80,3 +80,18 @@ def test_fma_canon_equals_the_two_reference_operations():
     subprocess.check_call(["hipcc", "-O2", "-ffp-contract=off", "-w", "-o", exe, os.path.join(ROOT, "tests", "cxx", "fma_canon_fuzz.cpp")])
     r = subprocess.run([exe, "2000000"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "fma_canon == add(mul)" in r.stdout, r.stdout + r.stderr
+
+
+def test_rational_inputs_outside_int32_are_refused():
+    """xpoly's Rational is int32 / int32 (rational.h:66-67): the Python mirror must not wrap wider integers silently."""
+    import numpy as np
+    import pytest
+    from xpoly_amd.six import RAT, as_kind
+    ok = as_kind(np.array([[1, -2], [2147483647, -2147483648]], dtype=np.int64), RAT, 2)
+    assert ok.dtype == np.int32 and ok.shape == (2, 2, 2) and ok[1, 0, 0] == 2147483647
+    with pytest.raises(ValueError):
+        as_kind(np.array([[1, 2147483648]], dtype=np.int64), RAT, 2)
+    with pytest.raises(ValueError):
+        as_kind(np.array([[[1, 1], [-2147483649, 1]]], dtype=np.int64), RAT, 2)
+    with pytest.raises(ValueError):
+        as_kind(np.array([[0.5, 1.0]]), RAT, 2)

@@ -2,6 +2,7 @@
 thread per shard inside the library), the per-handle device binding of every entry point, and the
 blocked loop's sweep counters."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest

@@ -222,8 +222,7 @@ class MipPool {
 public:
     MipPool()
     {
-        unsigned nt = std::thread::hardware_concurrency();
-        nt = 1;
+        unsigned nt = 1;                                    // the calling thread alone unless XPG_HOST_THREADS says otherwise (see above)
         if (const char * e = getenv("XPG_HOST_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) nt = (unsigned)v; }
         for (unsigned w = 1; w < nt; w++) th_.emplace_back([this, w] { worker((int)w); });
     }

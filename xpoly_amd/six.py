@@ -33,6 +33,13 @@ def as_kind(a, kind, ndim):
             raise ValueError("expected %d axes, got shape %s" % (ndim, a.shape))
         return a
     a = np.asarray(a)
+    if a.dtype != np.int32 and a.size and np.issubdtype(a.dtype, np.number):
+        # Rational is int32 / int32 (rational.h:66-67): a wider integer (or a float) that does not fit must not wrap silently
+        lim = np.iinfo(np.int32)
+        if (np.asarray(a) > lim.max).any() or (np.asarray(a) < lim.min).any():
+            raise ValueError("rational input holds values outside the int32 range of xpoly's Rational")
+        if not np.issubdtype(a.dtype, np.integer) and (np.asarray(a) != np.floor(a)).any():
+            raise ValueError("rational input must be integers, got fractional %s values" % a.dtype)
     if a.ndim == ndim + 1:
         if a.shape[-1] != 2 or not np.issubdtype(a.dtype, np.integer):
             raise ValueError("rational input must be integer (num, den) pairs [..., 2], got %s %s" % (a.dtype, a.shape))
