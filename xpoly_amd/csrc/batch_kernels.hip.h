@@ -13,6 +13,13 @@
 
 namespace xpg {
 
+#ifdef XPG_STAMPS
+__device__ unsigned long long g_fl[16];                  // diagnostic builds: sm_fast_loop counters / 100 MHz ticks (tools/lab/probe_fastloop.py)
+#define FL_ADD(k_, v_) atomicAdd(&g_fl[k_], (unsigned long long)(v_))
+#else
+#define FL_ADD(k_, v_) do { } while (0)
+#endif
+
 template <class S> struct Small {
     S * tab; int R, W, ld, rhs;     // R rows, W live columns, row stride ld
     S * obj; S * e; S * k; S * x;
@@ -255,6 +262,9 @@ template <class S> __device__ __forceinline__ void sm_findpair_wave0(Small<S> & 
                 mask &= mask - 1;
                 int b, cc; uint32_t w; S a;
                 const int row = sm_ratio_wave(P, cand, lane, b, w, cc, a);
+#ifdef XPG_STAMPS
+                if (lane == 0) FL_ADD(2, 1);
+#endif
                 if (row == INT_MAX) continue;
                 const int leave = __builtin_amdgcn_readlane(b, row);
                 const uint32_t wv = (uint32_t)__builtin_amdgcn_readlane((int)w, row);
@@ -297,18 +307,25 @@ template <class S> __device__ __forceinline__ void sm_findpair_wave0(Small<S> & 
 // Anything but "pivot chosen" leaves the loop with the tableau fully swept and the basis consistent, and the
 // generic code of sm_solve takes over exactly as it did behind sm_select_wave0. (Rotating the selecting wave over
 // the SIMDs with the workgroup index was tried: no difference.)
-template <class S> __device__ __forceinline__ int sm_fast_loop(Small<S> & P, unsigned max_iter, unsigned & done, bool preselected)
+// CR / CLD / CT: rows, row stride and workgroup size as compile-time constants (0: run-time values). The 32 x 64 LPs of
+// BASELINE configs[2] (R = 32, ld = 97, 256 threads) run the specialised instance: row offsets become immediates, loops
+// unroll, and the sweep takes the two-lanes-per-column form below (round 3: 1 040 -> 542 VALU, 521 -> 348 SALU, 263 -> 189 LDS
+// wave-instructions per pivot on the dense family, 1 055 / 507 / 264 -> 646 / 424 / 211 on the dependence-test-like one).
+template <class S, int CR, int CLD, int CT> __device__ __forceinline__ int sm_fast_loop(Small<S> & P, unsigned max_iter, unsigned & done, bool preselected)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const bool w0 = tid < 64;
-    const int st = tid - 64, nsw = (int)blockDim.x - 64;       // sweeper index / count
+    const int st = tid - 64, nsw = (CT ? CT : (int)blockDim.x) - 64;       // sweeper index / count
     const int nswaves = nsw >> 6, swave = st >> 6;
-    const int rhs = P.rhs, lim = rhs - 1, R = P.R, W = P.W, ld = P.ld;
+    const int rhs = P.rhs, lim = rhs - 1, R = CR ? CR : P.R, W = P.W, ld = CLD ? CLD : P.ld;
     if (!preselected) {                                         // the first pivot: nothing to overlap with
         if (w0) sm_select_wave0(P);
         __syncthreads();
     }
     for (;;) {
+#ifdef XPG_STAMPS
+        unsigned long long fl_t0 = wall_clock64();
+#endif
         int action = P.sh_w[0];
         if (action == ACT_FINDPAIR) {
             // every positive column is exhausted: findPivotNVandBVPair right here, on the tableau the barrier above
@@ -317,7 +334,15 @@ template <class S> __device__ __forceinline__ int sm_fast_loop(Small<S> & P, uns
             if (w0) sm_findpair_wave0(P);
             __syncthreads();
             action = P.sh_w[0] == ACT_PIVOT ? ACT_PIVOT : ACT_UNBOUND;
+#ifdef XPG_STAMPS
+            if (tid == 0) { FL_ADD(1, 1); FL_ADD(3, wall_clock64() - fl_t0); }
+#endif
         }
+#ifdef XPG_STAMPS
+        else if (tid == 0 && action == ACT_PIVOT) FL_ADD(0, 1);
+        if (action != ACT_PIVOT && tid == 0) FL_ADD(8 + (action % 7), 1);
+        unsigned long long fl_t1 = wall_clock64();
+#endif
         if (action != ACT_PIVOT) return action;
         const int enter = P.sh_w[1], leave = P.sh_w[2], r = P.sh_w[3];
         const S * park = (const S *)P.sh_c;
@@ -361,7 +386,14 @@ template <class S> __device__ __forceinline__ int sm_fast_loop(Small<S> & P, uns
             for (int j = st; j < W; j += nsw) P.e[j] = q_scaled(P.cn, P.tab[r * ld + j], s, smode);
             for (int i = st; i < R; i += nsw) P.k[i] = i != r ? neg(P.tab[i * ld + enter]) : zero<S>();
         }
+#ifdef XPG_STAMPS
+        if (tid == 0) FL_ADD(4, wall_clock64() - fl_t1);
+        if (tid == 64) FL_ADD(15, wall_clock64() - fl_t1);
+#endif
         __syncthreads();
+#ifdef XPG_STAMPS
+        unsigned long long fl_t2 = wall_clock64();
+#endif
         const int first = P.sh_w[5];
         const bool have_first = first != INT_MAX;
         // ---- stage C
@@ -424,6 +456,20 @@ template <class S> __device__ __forceinline__ int sm_fast_loop(Small<S> & P, uns
             // Four rows in flight while all four are in range, then the tail row by row; the pivot row goes through
             // the same a + k*e with k_r = 0 (staged so) and is then overwritten with e -- no clamp, select or range
             // test per cell (14 -> 7 instructions per cell on the fp64 ISA).
+            if (CR == 32 && CT == 256 && W == 96) {
+                // the 32 x 96 tableau on 192 sweeper lanes: two lanes per column, 16 rows each -- every lane busy, row
+                // offsets immediates, one -a_i,nv read per cell and no loop control (the generic form below walks
+                // 2 x 11 row steps per lane with half the lanes idle in the second column pass)
+                const int j = st < 96 ? st : st - 96, h = st < 96 ? 0 : 16;
+                if (!(j == rhs || (have_first && j == first))) {
+                    const S ej = P.e[j];
+                    S * c = P.tab + h * ld + j;
+                    const S * kk = P.k + h;
+#pragma unroll
+                    for (int n = 0; n < 16; n++) c[n * ld] = q_fma(P.cn, c[n * ld], kk[n], ej);
+                    if ((r & 16) == h) c[(r & 15) * ld] = ej;
+                }
+            } else
             for (int j = st & 63; j < W; j += 64) {
                 if (j == rhs || (have_first && j == first)) continue;
                 const S ej = P.e[j];
@@ -444,7 +490,14 @@ template <class S> __device__ __forceinline__ int sm_fast_loop(Small<S> & P, uns
         }
         P.pivots++;
         done++;
+#ifdef XPG_STAMPS
+        if (tid == 0) FL_ADD(5, wall_clock64() - fl_t2);
+        if (tid == 64) FL_ADD(6, wall_clock64() - fl_t2);
+#endif
         __syncthreads();
+#ifdef XPG_STAMPS
+        if (tid == 0) FL_ADD(7, wall_clock64() - fl_t0);
+#endif
     }
 }
 
@@ -463,7 +516,9 @@ template <class S> __device__ __forceinline__ int sm_solve(Small<S> & P, unsigne
     bool preselected = false;                                   // the generic code below has staged a pivot in sh_w
     while (done < max_iter) {
         if (overlapped) {
-            const int action = sm_fast_loop(P, max_iter, done, preselected);
+            const int action = (!is_f64<S>::value || P.R != 32 || P.ld != 97 || blockDim.x != 256)
+                                   ? sm_fast_loop<S, 0, 0, 0>(P, max_iter, done, preselected)
+                                   : sm_fast_loop<S, 32, 97, 256>(P, max_iter, done, preselected);
             preselected = false;
             if (action == ACT_TIMEOUT) return 4;
             if (action == ACT_UNBOUND) return 1;                // SIX_UNBOUND, lpsol.h:1138-1142

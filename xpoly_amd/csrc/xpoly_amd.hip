@@ -415,6 +415,15 @@ int xpg_lp_solve_debug(xpg_ctx * ctx, unsigned long long * out8)
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_lp_ticks), z, sizeof(z)) != hipSuccess) return XPG_ERR_HIP;
     return 0;
 }
+// diagnostic builds only: reads and clears sm_fast_loop's counters
+int xpg_fastloop_debug(xpg_ctx * ctx, unsigned long long * out16)
+{
+    XPG_BIND(ctx);
+    unsigned long long z[16] = {0};
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_fl), sizeof(z)) != hipSuccess) return XPG_ERR_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_fl), z, sizeof(z)) != hipSuccess) return XPG_ERR_HIP;
+    return 0;
+}
 // diagnostic builds only: reads and clears the phase tick sums of k_fme_batch
 int xpg_lineq_debug(xpg_ctx * ctx, unsigned long long * out16)
 {
