@@ -52,7 +52,7 @@ BATCH_M, BATCH_COLS = 32, 64
 PREWARM_SECONDS = 0.5
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "round3_pmc_hbm_traffic_4096x8192.json")
 PMC_SUMMARY_2B = os.path.join(ROOT, "profiles", "round3_pmc_hbm_traffic_4096x12289.json")
-PMC_BATCH = os.path.join(ROOT, "profiles", "round2_pmc_batch_issue.json")
+PMC_BATCH = os.path.join(ROOT, "profiles", "round3_pmc_batch_issue.json")
 LEGS = ("pivots", "batched", "sharded", "cfg2b", "rational", "mip", "lineq")
 LINEQ_NB = 16384                           # systems per row-elimination launch (the dependence tests' shapes)
 
@@ -530,14 +530,14 @@ def main():
         if os.path.exists(PMC_BATCH):                   # measured with rocprofv3 --pmc, not in this run
             pb = json.load(open(PMC_BATCH))
             batched["issue_rate"] = dict(
-                bound="instruction issue + dependent LDS rounds of the selection chain (HBM sees 16 KiB in / 0.5 KiB out per LP)",
+                bound="latency of the two-barrier pivot at 5 LPs per CU (LDS-limited: 30 KB per LP); VALU 27-30 % busy after the round-3 specialisation (HBM sees 16 KiB in / 0.5 KiB out per LP)",
                 dep_test_like=dict(valu_busy_percent=pb.get("dep_test_like_busy_percent", {}).get("VALUBusy"),
                                    salu_busy_percent=pb.get("dep_test_like_busy_percent", {}).get("SALUBusy"),
                                    wave_instructions_per_pivot=pb.get("dep_test_like_per_pivot")),
                 dense_positive=dict(valu_busy_percent=pb.get("dense_busy_percent", {}).get("VALUBusy"),
                                     salu_busy_percent=pb.get("dense_busy_percent", {}).get("SALUBusy"),
                                     wave_instructions_per_pivot=pb.get("dense_per_pivot")),
-                source="profiles/round2_pmc_batch_issue.json (rocprofv3 --pmc VALUBusy / SALUBusy / SQ_INSTS_* on "
+                source="profiles/round3_pmc_batch_issue.json (rocprofv3 --pmc VALUBusy / SALUBusy / SQ_INSTS_* on "
                        "tools/lab/probe_batch.py; not collected in this run)")
         if not stub:
             # STRONG scaling beside the weak figures above: the 65 536 LPs of BASELINE configs[2] in all, split over the

@@ -456,10 +456,11 @@ template <class S, int CR, int CLD, int CT> __device__ __forceinline__ int sm_fa
             // Four rows in flight while all four are in range, then the tail row by row; the pivot row goes through
             // the same a + k*e with k_r = 0 (staged so) and is then overwritten with e -- no clamp, select or range
             // test per cell (14 -> 7 instructions per cell on the fp64 ISA).
-            if (CR == 32 && CT == 256 && W == 96) {
-                // the 32 x 96 tableau on 192 sweeper lanes: two lanes per column, 16 rows each -- every lane busy, row
-                // offsets immediates, one -a_i,nv read per cell and no loop control (the generic form below walks
-                // 2 x 11 row steps per lane with half the lanes idle in the second column pass)
+            if (CR == 32 && CT == 256 && (W == 96 || W == 97)) {
+                // the 32 x 96 tableau (32 x 97 during phase one, whose last column is the constant one that wave 0 keeps)
+                // on 192 sweeper lanes: two lanes per column, 16 rows each -- every lane busy, row offsets immediates,
+                // one -a_i,nv read per cell and no loop control (the generic form below walks 2 x 11 row steps per lane
+                // with half the lanes idle in the second column pass)
                 const int j = st < 96 ? st : st - 96, h = st < 96 ? 0 : 16;
                 if (!(j == rhs || (have_first && j == first))) {
                     const S ej = P.e[j];
