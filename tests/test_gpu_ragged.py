@@ -113,3 +113,35 @@ def test_lineq_reduce_and_fme_ragged_match_oracle(ctx, port):
             wok, wres = port.fme(mats[k], mats[k].shape[1] - 1, us[k], dark)
             assert ok[k] == wok, (k, dark)
             assert (res[k].shape[0] == 0 and wres.shape[0] == 0) or (res[k].shape == wres.shape and np.array_equal(res[k], wres)), (k, dark)
+
+
+def test_ragged_and_packed_error_paths(ctx):
+    """Shapes the reference would only ASSERT on come back as XPG_ERR_SHAPE; a device slot too small for a result is
+    XPG_ERR_UNSUPPORTED with the rows needed; empty batches are no-ops."""
+    import ctypes as C
+    from xpoly_amd._capi import lib, vp
+    from xpoly_amd.six import dep_is_empty_ragged, ragged_pack_rat
+    rng = np.random.default_rng(3)
+    mats = [gen.random_system(rng, 6, 3), gen.random_system(rng, 9, 4)]
+    flat, rows, cols, off = ragged_pack_rat(mats)
+    out = np.zeros(2, dtype=np.int32)
+    bad_rows = rows.copy(); bad_rows[1] = 0
+    assert lib().xpg_dep_is_empty_batch_ragged_rat32(ctx._h, C.c_int(2), vp(flat), vp(bad_rows), vp(cols), vp(off), vp(out), None) == -3
+    bad_cols = cols.copy(); bad_cols[0] = 1
+    assert lib().xpg_dep_is_empty_batch_ragged_rat32(ctx._h, C.c_int(2), vp(flat), vp(rows), vp(bad_cols), vp(off), vp(out), None) == -3
+    assert lib().xpg_dep_is_empty_batch_ragged_rat32(ctx._h, C.c_int(0), vp(flat), vp(rows), vp(cols), vp(off), vp(out), None) == 0
+    assert lib().xpg_dep_is_empty_batch_ragged_rat32(ctx._h, C.c_int(2), None, vp(rows), vp(cols), vp(off), vp(out), None) == -3
+    # packed fme: a device slot of 2 rows cannot hold the result of a 10-row system with positive and negative rows
+    m = np.ascontiguousarray(np.stack([gen.random_system(rng, 10, 4) for _ in range(4)]))
+    offs = np.zeros(5, dtype=np.int64); ok = np.zeros(4, dtype=np.int32); view = C.c_void_p()
+    rc = lib().xpg_lineq_fme_batch_packed_rat32(ctx._h, C.c_int(4), vp(m), C.c_int(10), C.c_int(5), C.c_int(4), C.c_int(0), C.c_int(0),
+                                                C.c_int(10), None, C.c_longlong(0), C.byref(view), vp(offs), vp(ok))
+    assert rc in (0, -4)
+    if rc == -4:
+        assert offs[0] < 0                                  # -(rows the largest result needs)
+    rc = lib().xpg_lineq_fme_batch_packed_rat32(ctx._h, C.c_int(0), vp(m), C.c_int(10), C.c_int(5), C.c_int(4), C.c_int(0), C.c_int(0),
+                                                C.c_int(0), None, C.c_longlong(0), C.byref(view), vp(offs), vp(ok))
+    assert rc == 0 and offs[0] == 0
+    # and the handle still works
+    got, _ = dep_is_empty_ragged(ctx, mats)
+    assert got.shape == (2,)

@@ -677,6 +677,7 @@ template <class F> int run_ragged(xpg_ctx * ctx, int nb, const int32_t * rows, c
         if (it == where.end()) { it = where.insert(std::make_pair(key, cls.size())).first; cls.push_back(RaggedClass{rows[b], cols[b], {}, 0}); }
         cls[it->second].idx.push_back(b);
     }
+    if (cls.empty()) return 0;                                      // nb == 0
     for (auto & c : cls) c.work = c.idx.size() * (size_t)c.rows * c.cols;
     std::sort(cls.begin(), cls.end(), [](const RaggedClass & a, const RaggedClass & b) { return a.work > b.work; });
     const int nl = (int)cls.size() < ragged_lanes() ? (int)cls.size() : ragged_lanes();
