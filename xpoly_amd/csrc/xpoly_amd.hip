@@ -698,13 +698,17 @@ template <class F> int run_ragged(xpg_ctx * ctx, int nb, const int32_t * rows, c
     auto lane_body = [&](int l) {
         xpg_ctx * c = l == 0 ? ctx : ctx->lanes[(size_t)l - 1];
         xpg::DeviceGuard bind(c->device);
-        for (int k : mine[(size_t)l]) { const int rc = fn(c, cls[(size_t)k]); if (rc) { rcs[(size_t)l] = rc; if (l) ctx->err = c->err; return; } }
+        for (int k : mine[(size_t)l]) { const int rc = fn(c, cls[(size_t)k]); if (rc) { rcs[(size_t)l] = rc; return; } }
     };
     std::vector<std::thread> th;
     for (int l = 1; l < nl; l++) th.emplace_back(lane_body, l);
     lane_body(0);
     for (auto & t : th) t.join();
-    for (int rc : rcs) if (rc) return rc;
+    for (int l = 0; l < nl; l++)
+        if (rcs[(size_t)l]) {                                        // the first failing lane's code and message (after the join: no race)
+            if (l) ctx->err = ctx->lanes[(size_t)l - 1]->err;
+            return rcs[(size_t)l];
+        }
     return 0;
 }
 template <class T> inline void ragged_gather(std::vector<T> & buf, const T * src, const long long * off, const RaggedClass & c, size_t per)
