@@ -137,14 +137,9 @@ template <class S> __device__ __forceinline__ void sm_select_wave0(Small<S> & P)
     const int cc = P.colcnt[b];
     const bool open = lane < R && !((w >> (b & 31)) & 1u) && cc < lim;
     const bool nonzero = open && !eq(a, zero<S>());
-    Cand<S> c; c.q = nonzero ? q_div(P.cn, bc, a) : zero<S>();
-    c.idx = (nonzero && !le(a, zero<S>())) ? lane : INT_MAX;
-    Cand<S> best = wave_argmin(c);
-    if (best.idx == INT_MAX) {                                       // relaxed second pass: a != 0
-        c.idx = nonzero ? lane : INT_MAX;
-        best = wave_argmin(c);
-    }
-    const int row = __builtin_amdgcn_readfirstlane(best.idx);
+    const S qr = nonzero ? q_div(P.cn, bc, a) : zero<S>();
+    int row = wave_argmin_row(qr, nonzero && !le(a, zero<S>()), lane);
+    if (row == INT_MAX) row = wave_argmin_row(qr, nonzero, lane);    // relaxed second pass: a != 0
     if (row == INT_MAX) {
         if (lane == 0) { P.sh_w[0] = ACT_CLOSE; P.sh_w[1] = first; P.sh_w[2] = -1; P.sh_w[3] = -1; }
         return;
@@ -232,14 +227,10 @@ template <class S> __device__ __forceinline__ int sm_ratio_wave(const Small<S> &
     cc = P.colcnt[b];
     const bool open = lane < R && !((w >> (b & 31)) & 1u) && cc < lim;
     const bool nonzero = open && !eq(a, zero<S>());
-    Cand<S> c; c.q = nonzero ? q_div(P.cn, bc, a) : zero<S>();
-    c.idx = (nonzero && !le(a, zero<S>())) ? lane : INT_MAX;
-    Cand<S> best = wave_argmin(c);
-    if (best.idx == INT_MAX) {                                  // relaxed second pass: a != 0
-        c.idx = nonzero ? lane : INT_MAX;
-        best = wave_argmin(c);
-    }
-    return __builtin_amdgcn_readfirstlane(best.idx);
+    const S qr = nonzero ? q_div(P.cn, bc, a) : zero<S>();
+    int row = wave_argmin_row(qr, nonzero && !le(a, zero<S>()), lane);
+    if (row == INT_MAX) row = wave_argmin_row(qr, nonzero, lane);           // relaxed second pass: a != 0
+    return row;
 }
 
 // SIX::findPivotNVandBVPair (lpsol.h:671-773) by wave 0 alone: candidates 64 per ballot in ascending order, positive
@@ -420,14 +411,9 @@ template <class S, int CR, int CLD, int CT> __device__ __forceinline__ int sm_fa
                 const int cc = P.colcnt[b];
                 const bool open = lane < R && !((w >> (b & 31)) & 1u) && cc < lim;
                 const bool nonzero = open && !eq(a, zero<S>());
-                Cand<S> c; c.q = nonzero ? q_div(P.cn, bc, a) : zero<S>();
-                c.idx = (nonzero && !le(a, zero<S>())) ? lane : INT_MAX;
-                Cand<S> best = wave_argmin(c);
-                if (best.idx == INT_MAX) {                      // relaxed second pass: a != 0
-                    c.idx = nonzero ? lane : INT_MAX;
-                    best = wave_argmin(c);
-                }
-                const int row = __builtin_amdgcn_readfirstlane(best.idx);
+                const S qr = nonzero ? q_div(P.cn, bc, a) : zero<S>();
+                int row = wave_argmin_row(qr, nonzero && !le(a, zero<S>()), lane);
+                if (row == INT_MAX) row = wave_argmin_row(qr, nonzero, lane);       // relaxed second pass: a != 0
                 if (row == INT_MAX) {
                     if (lane == 0) { P.sh_w[0] = ACT_CLOSE; P.sh_w[1] = first; P.sh_w[2] = -1; P.sh_w[3] = -1; }
                 } else {
@@ -925,8 +911,12 @@ int batch_dev(xpg_ctx * ctx, int is_max, int nb, const S * tgtf, const S * leq, 
     if (nb == 0) return 0;
     const int n = cols - 1;
     const int R = is_max ? m : n, V = is_max ? n : m;
-    const size_t lds = small_lds_bytes<S>(R, V);
+    size_t lds = small_lds_bytes<S>(R, V);
     if (lds > 160 * 1024) return XPG_ERR_UNSUPPORTED;     // one LP must fit one CU's LDS
+    if (const char * pad = getenv("XPG_BATCH_LDS_KB")) {  // A/B aid: request more LDS per LP = fewer LPs per CU (occupancy scaling curve)
+        const size_t want = (size_t)atoi(pad) * 1024;
+        if (want > lds && want <= 160 * 1024) lds = want;
+    }
     // measured on MI355X (32x64 LPs): 64 / 128 / 256 threads -> 61k / 91k / 118k LPs/s
     const int cells = R * (V + R + 2);
     int threads = cells >= 2048 ? 256 : (cells >= 1024 ? 128 : 64);

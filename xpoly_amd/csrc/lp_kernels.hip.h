@@ -201,6 +201,53 @@ template <class S> __device__ __forceinline__ Cand<S> wave_argmin(Cand<S> c)
     return better(better(read_lane(c, 15), read_lane(c, 31)), better(read_lane(c, 47), read_lane(c, 63)));
 }
 
+// fp64 ratio tests, the cheap form: the ratio as a 64-bit key whose UNSIGNED order is better()'s order on ratios that are
+// not NaN (-0 and +0 are one value, then the usual monotone map of IEEE doubles), reduced by four DPP steps on 64-bit
+// integers, the lowest lane among the minima by ballot -- a third of the instructions of the Cand<F64> tree (three
+// registers through every step, two fp64 compares and an index compare per step). A NaN ratio compares "equal" to
+// everything in better() (both `>` are false), which no key can mimic: if any candidate ratio of the wave is a NaN the
+// Cand tree decides, as before.
+__device__ __forceinline__ unsigned long long ratio_key_f64(double q)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, q + 0.0);   // (-0) + (+0) = +0
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+template <int CTRL> __device__ __forceinline__ unsigned long long u64_min_step(unsigned long long x)
+{
+    const unsigned lo = (unsigned)dpp_row_shr<CTRL>((int)(unsigned)x), hi = (unsigned)dpp_row_shr<CTRL>((int)(unsigned)(x >> 32));
+    const unsigned long long t = ((unsigned long long)hi << 32) | lo;
+    return t < x ? t : x;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64_dpp(unsigned long long x)
+{
+    x = u64_min_step<0x111>(x); x = u64_min_step<0x112>(x); x = u64_min_step<0x114>(x); x = u64_min_step<0x118>(x);
+    unsigned long long r[4];
+    for (int k = 0; k < 4; k++) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, 16 * k + 15);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), 16 * k + 15);
+        r[k] = ((unsigned long long)hi << 32) | lo;
+    }
+    const unsigned long long ab = r[0] < r[1] ? r[0] : r[1], cd = r[2] < r[3] ? r[2] : r[3];
+    return ab < cd ? ab : cd;
+}
+// The row (= lane) of the least ratio among the lanes with `valid`, lowest row on ties; INT_MAX if there is none.
+__device__ __forceinline__ int wave_argmin_row(F64 q, bool valid, int lane)
+{
+    if (__ballot(valid && q.v != q.v) != 0ull) {                // a NaN among the candidates: better()'s own rules
+        Cand<F64> c; c.q = q; c.idx = valid ? lane : INT_MAX;
+        return __builtin_amdgcn_readfirstlane(wave_argmin(c).idx);
+    }
+    const unsigned long long key = valid ? ratio_key_f64(q.v) : ~0ull;
+    const unsigned long long kmin = wave_min_u64_dpp(key);
+    if (kmin == ~0ull) return INT_MAX;
+    return __ffsll((long long)__ballot(key == kmin)) - 1;
+}
+template <class S> __device__ __forceinline__ int wave_argmin_row(S q, bool valid, int lane)   // Rational: the Cand tree
+{
+    Cand<S> c; c.q = q; c.idx = valid ? lane : INT_MAX;
+    return __builtin_amdgcn_readfirstlane(wave_argmin(c).idx);
+}
+
 // Wave-wide integer minimum the same way.
 __device__ __forceinline__ int wave_min_int(int x)
 {
