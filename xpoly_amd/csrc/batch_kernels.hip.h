@@ -302,7 +302,7 @@ template <class S> __device__ __forceinline__ void sm_findpair_wave0(Small<S> & 
 // BASELINE configs[2] (R = 32, ld = 97, 256 threads) run the specialised instance: row offsets become immediates, loops
 // unroll, and the sweep takes the two-lanes-per-column form below (round 3: 1 040 -> 542 VALU, 521 -> 348 SALU, 263 -> 189 LDS
 // wave-instructions per pivot on the dense family, 1 055 / 507 / 264 -> 646 / 424 / 211 on the dependence-test-like one).
-template <class S, int CR, int CLD, int CT> __device__ __forceinline__ int sm_fast_loop(Small<S> & P, unsigned max_iter, unsigned & done, bool preselected)
+template <class S, int CR, int CLD, int CT> __device__ __forceinline__ int sm_fast_loop_body(Small<S> & P, unsigned max_iter, unsigned & done, bool preselected)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const bool w0 = tid < 64;
@@ -485,6 +485,23 @@ template <class S, int CR, int CLD, int CT> __device__ __forceinline__ int sm_fa
 #ifdef XPG_STAMPS
         if (tid == 0) FL_ADD(7, wall_clock64() - fl_t0);
 #endif
+    }
+}
+
+template <class S, int CR, int CLD, int CT> __device__ __forceinline__ void sm_carve_fwd(Small<S> & P, unsigned char * lds);
+template <class S, int CR, int CLD, int CT> __device__ __forceinline__ int sm_fast_loop(Small<S> & P0, unsigned max_iter, unsigned & done, bool preselected)
+{
+    if constexpr (CR != 0) {
+        // the specialised instance re-derives every LDS array from ONE base with compile-time offsets (the carve of a
+        // 32-row, 63-variable LP is a set of constants): the twenty pointers of Small<S> stop competing for scalar
+        // registers -- the run-time form spills them to VGPR lanes and pays v_readlane / v_writelane in the pivot loop
+        Small<S> P = P0;
+        sm_carve_fwd<S, CR, CLD, CT>(P, (unsigned char *)P0.tab);
+        const int action = sm_fast_loop_body<S, CR, CLD, CT>(P, max_iter, done, preselected);
+        P0.pivots = P.pivots; P0.closes = P.closes;
+        return action;
+    } else {
+        return sm_fast_loop_body<S, 0, 0, 0>(P0, max_iter, done, preselected);
     }
 }
 
@@ -806,6 +823,10 @@ template <class S> __device__ __forceinline__ void sm_carve(Small<S> & P, unsign
     P.nv = (uint8_t *)p; p += (size_t)((nmax + 3) & ~3);
     P.bv = (uint8_t *)p;
     P.ld = Wmax;
+}
+template <class S, int CR, int CLD, int CT> __device__ __forceinline__ void sm_carve_fwd(Small<S> & P, unsigned char * lds)
+{
+    sm_carve(P, lds, CR, CLD - CR - 2);                          // (ld = V + 1 + R + 1)
 }
 
 // One LP by the whole workgroup: SIX::maxm / minm of an x >= 0, inequality-only problem (src: m rows, cols - 1
