@@ -20,6 +20,14 @@
  * All buffers are caller-owned; the library never frees caller memory.
  * Functions with a _dev suffix take DEVICE pointers; the others take HOST
  * pointers and stage through HBM themselves.
+ *
+ * Threading: a handle (xpg_ctx, and every xpg_lp made from it) is used by ONE host
+ * thread at a time -- it owns one HIP stream, grow-only staging areas and a small
+ * cache of device blocks (xpg_trim returns them), none of which is locked.  Different
+ * handles, on the same device or on different ones, may be used from different
+ * threads concurrently (the _multi and _ragged entry points do exactly that inside
+ * the library).  The reference itself is single-threaded with per-instance state
+ * (lpsol.h:205-209).
  */
 #ifndef XPOLY_AMD_H
 #define XPOLY_AMD_H
