@@ -922,6 +922,50 @@ template <class S> __global__ __launch_bounds__(256, 4) void k_batch(int nb, con
     }
 }
 
+// The same kernel for LPs of DIFFERENT shapes in one launch (round 3): LP lp is rows[lp] x cols[lp], its inequalities at
+// cell leq_off[lp] of leq, its objective -- and its solution slot -- at cell tg_off[lp] of tgtf / out_sol. The LDS
+// arrays are carved per LP; the launch reserves the LDS of the largest one.
+template <class S> __global__ __launch_bounds__(256, 4) void k_batch_ragged(int nb, const S * tgtf, const S * leq, const int * rows,
+                                           const int * cols_of, const long long * leq_off, const long long * tg_off,
+                                           int is_max, unsigned max_iter, int32_t * out_status, S * out_v, S * out_sol, int raw_sol)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    for (int lp = blockIdx.x; lp < nb; lp += gridDim.x) {
+        const int m = rows[lp], cols = cols_of[lp], n = cols - 1;
+        Small<S> P;
+        sm_carve(P, lds, is_max ? m : n, is_max ? n : m);
+        Source<S> src;
+        src.leq = leq + leq_off[lp]; src.tgtf = tgtf + tg_off[lp];
+        src.m = m; src.cols = cols; src.is_max = is_max;
+        const int status = sm_solve_lp<S>(P, src, max_iter, raw_sol, out_sol + tg_off[lp], out_v + lp);
+        if (threadIdx.x == 0) out_status[lp] = status;
+        __syncthreads();
+    }
+}
+// Device arrays in and out, enqueue only. max_rows / max_cols: the largest shape of the batch (sizes the LDS request).
+template <class S>
+int batch_dev_ragged(xpg_ctx * ctx, int is_max, int nb, const S * tgtf, const S * leq, const int * d_rows, const int * d_cols,
+                     const long long * d_leq_off, const long long * d_tg_off, int max_R, int max_V, unsigned max_iter,
+                     int32_t * out_status, S * out_v, S * out_sol)
+{
+    if (!ctx || nb < 0 || !tgtf || !leq || !d_rows || !d_cols || !d_leq_off || !d_tg_off || max_R <= 0 || max_V <= 0 ||
+        !out_status || !out_v || !out_sol)
+        return XPG_ERR_SHAPE;
+    if (nb == 0) return 0;
+    const size_t lds = small_lds_bytes<S>(max_R, max_V);
+    if (lds > 160 * 1024) return XPG_ERR_UNSUPPORTED;
+    const int cells = max_R * (max_V + max_R + 2);
+    int threads = cells >= 2048 ? 256 : (cells >= 1024 ? 128 : 64);
+    const int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
+    int grid = 256 * (per_cu > 16 ? 16 : per_cu) * 64;
+    if (grid > nb) grid = nb;
+    XPG_HIP(ctx, lds_limit((const void *)k_batch_ragged<S>, ctx->device, lds));
+    hipLaunchKernelGGL((k_batch_ragged<S>), dim3(grid), dim3(threads), lds, ctx->stream, nb, tgtf, leq, d_rows, d_cols, d_leq_off,
+                       d_tg_off, is_max ? 1 : 0, max_iter, out_status, out_v, out_sol, 0);
+    XPG_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
 template <class S>
 int batch_dev(xpg_ctx * ctx, int is_max, int nb, const S * tgtf, const S * leq, int m, int cols,
               unsigned max_iter, int32_t * out_status, S * out_v, S * out_sol, uint32_t * out_pivots,

@@ -747,6 +747,42 @@ int six_batch_ragged(xpg_ctx * ctx, int is_max, int nb, const S * tgtf, const S 
                      const long long * leq_off, const long long * tg_off, unsigned max_iter, int32_t * out_status, S * out_v, S * out_sol)
 {
     if (!ctx || nb < 0 || !tgtf || !leq || !rows || !cols || !leq_off || !tg_off || !out_status || !out_v || !out_sol) return XPG_ERR_SHAPE;
+    if (nb == 0) return 0;
+    // ONE launch of the LDS-resident kernel with per-LP shapes (k_batch_ragged): the concatenated arrays go up as they
+    // are, the LDS request is that of the largest LP. (Classes on concurrent lanes -- run_ragged, what the other ragged
+    // entry points do -- remain the fallback for a batch whose largest LP does not fit one CU's LDS.)
+    int max_R = 0, max_V = 0;
+    long long leq_cells = 0, tg_cells = 0;
+    for (int b = 0; b < nb; b++) {
+        if (rows[b] <= 0 || cols[b] < 2 || leq_off[b] < 0 || tg_off[b] < 0) return XPG_ERR_SHAPE;
+        const int n = cols[b] - 1, R = is_max ? rows[b] : n, V = is_max ? n : rows[b];
+        max_R = R > max_R ? R : max_R; max_V = V > max_V ? V : max_V;
+        const long long le = leq_off[b] + (long long)rows[b] * cols[b], te = tg_off[b] + cols[b];
+        leq_cells = le > leq_cells ? le : leq_cells; tg_cells = te > tg_cells ? te : tg_cells;
+    }
+    if (small_lds_bytes<S>(max_R, max_V) <= 160 * 1024) {
+        const size_t bl = (size_t)leq_cells * 8, bt = (size_t)tg_cells * 8;
+        DevBuf dl, dt, ds, dv, dst, dr, dc, dlo, dto;
+        XPG_TRY(dl.alloc(ctx, bl)); XPG_TRY(dt.alloc(ctx, bt)); XPG_TRY(ds.alloc(ctx, bt)); XPG_TRY(dv.alloc(ctx, (size_t)nb * 8));
+        XPG_TRY(dst.alloc(ctx, (size_t)nb * 4)); XPG_TRY(dr.alloc(ctx, (size_t)nb * 4)); XPG_TRY(dc.alloc(ctx, (size_t)nb * 4));
+        XPG_TRY(dlo.alloc(ctx, (size_t)nb * 8)); XPG_TRY(dto.alloc(ctx, (size_t)nb * 8));
+        XPG_TRY(hipMemcpyAsync(dl.p, leq, bl, hipMemcpyHostToDevice, ctx->stream));
+        XPG_TRY(hipMemcpyAsync(dt.p, tgtf, bt, hipMemcpyHostToDevice, ctx->stream));
+        XPG_TRY(hipMemcpyAsync(ds.p, out_sol, bt, hipMemcpyHostToDevice, ctx->stream));     // (slots of unsolved LPs keep what they held)
+        XPG_TRY(hipMemcpyAsync(dr.p, rows, (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream));
+        XPG_TRY(hipMemcpyAsync(dc.p, cols, (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream));
+        XPG_TRY(hipMemcpyAsync(dlo.p, leq_off, (size_t)nb * 8, hipMemcpyHostToDevice, ctx->stream));
+        XPG_TRY(hipMemcpyAsync(dto.p, tg_off, (size_t)nb * 8, hipMemcpyHostToDevice, ctx->stream));
+        const int rc = batch_dev_ragged<S>(ctx, is_max, nb, (const S *)dt.p, (const S *)dl.p, (const int *)dr.p, (const int *)dc.p,
+                                           (const long long *)dlo.p, (const long long *)dto.p, max_R, max_V, max_iter,
+                                           (int32_t *)dst.p, (S *)dv.p, (S *)ds.p);
+        if (rc) return rc;
+        XPG_TRY(hipMemcpyAsync(out_status, dst.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+        XPG_TRY(hipMemcpyAsync(out_v, dv.p, (size_t)nb * 8, hipMemcpyDeviceToHost, ctx->stream));
+        XPG_TRY(hipMemcpyAsync(out_sol, ds.p, bt, hipMemcpyDeviceToHost, ctx->stream));
+        XPG_TRY(hipStreamSynchronize(ctx->stream));
+        return 0;
+    }
     return run_ragged(ctx, nb, rows, cols, [&](xpg_ctx * c, const RaggedClass & g) {
         const size_t ng = g.idx.size();
         std::vector<S> bl, bt, bs(ng * (size_t)g.cols), bv(ng); std::vector<int32_t> st(ng);
