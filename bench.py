@@ -588,10 +588,12 @@ def main():
             out["lineq"] = leg_lineq(ctx, xpoly_amd, gen)
 
     if rank == 0:
-        if checks or "self_check" in out or "self_check" in out.get("mip", {}):
+        if checks or "self_check" in out or "self_check" in out.get("mip", {}) or "self_check" in out.get("cfg2b", {}):
             out.setdefault("self_check", {}).update(checks)
             if "mip" in out and "self_check" in out["mip"]:
                 out["self_check"]["mip"] = out["mip"].pop("self_check")
+            if "cfg2b" in out and "self_check" in out["cfg2b"]:
+                out["self_check"]["cfg2b"] = out["cfg2b"].pop("self_check")
         out["cpu_baseline"] = cpu
         print(json.dumps(out))
     if ctx is not None:
@@ -711,6 +713,18 @@ def leg_cfg2b(ctx, xpoly_amd, gen, m=4096, n=8192):
             pers.append((t2 - t1) / 1024.0)
     per = min(pers)
     f, p = lp.counters()
+    # self-check, outside the timing: the state the last pass left (256 + 1024 pivots) against the real reference
+    check = None
+    recs = [r for r in golden("g11_bench_lp.json").get("cfg2b_lp", []) if r["K"] == 1280]
+    if recs and (m, n) == (4096, 8192):
+        got = lp.read()
+        bad = [k for k, ok in (("tableau", checksum(got["tab"]) == recs[0]["tab"]), ("objective row", checksum(got["tgtf"]) == recs[0]["tgtf"]),
+                               ("basis", checksum(got["eq2bv"].astype(np.int32)) == recs[0]["eq2bv"])) if not ok]
+        if bad:
+            sys.exit("bench.py self-check FAILED: cfg2b after 1280 pivots, %s differ(s) from tests/golden/g11_bench_lp.json" % ", ".join(bad))
+        check = ("tableau 4096x12289 (CRC-32 + sum + xor), objective row, basis after the last pass's 1280 pivots = the real reference's "
+                 "TwoStageMethod(max_iter=1280) on this LP (tests/golden/g11_bench_lp.json cfg2b_lp): bit-identical")
+        del got
     lp.close()
     bytes_per_launch = 2 * m * W * 8
     out = dict(metric="simplex pivots/sec, LP m=4096 n=8192 (tableau 4096x12289 fp64)", value=round(1.0 / per, 1),
@@ -720,6 +734,8 @@ def leg_cfg2b(ctx, xpoly_amd, gen, m=4096, n=8192):
                loop_effective_gbs=round(bytes_per_launch / BLOCK / per / 1e9, 1),
                loop_effective_frac=round(bytes_per_launch / BLOCK / per / 1e9 / HBM_PEAK_GBS, 4),
                sample="(t[K=1280] - t[K=256]) / 1024 on one LP, device-resident blocked loop, better of two passes")
+    if check:
+        out["self_check"] = check
     if launches:
         avg = sweep_ms / 1e3 / launches
         out["roofline"] = dict(

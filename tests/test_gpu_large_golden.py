@@ -206,3 +206,22 @@ def test_chain_under_a_busy_device_stays_bit_exact():
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     print("chain under a busy device: roll calls failed %d, switched to launch-per-stage: %s" % (out["aborts"], out["chain_off"]))
     assert out["tab"] == rec["tab"] and out["tgtf"] == rec["tgtf"] and out["eq2bv"] == rec["eq2bv"]
+
+
+def test_cfg2b_bench_lp_against_the_reference(ctx):
+    """The LP bench.py's cfg2b leg times -- gen.hard_lp_f64(4096, 8192), slack tableau 4096 x 12289 (403 MB, ld 12352) --
+    after the 256 + 1024 pivots of one pass: whole tableau, objective row and basis are what the real reference's
+    TwoStageMethod(max_iter = 1280) leaves (tests/golden/g11_bench_lp.json cfg2b_lp, tools/gen_golden_bench.py cfg2b)."""
+    import xpoly_amd
+    recs = GOLD_BENCH.get("cfg2b_lp", [])
+    assert recs, "fixture missing: run tools/gen_golden_bench.py cfg2b in the authoring container"
+    rec = recs[0]
+    leq, tgtf = gen.hard_lp_f64(4096, 8192)
+    lp = xpoly_amd.DeviceLP(ctx, F64, leq, tgtf)
+    del leq
+    lp.begin()
+    assert lp.iterate(256) == xpoly_amd.six.XPG_RUNNING
+    assert lp.iterate(rec["K"] - 256) == xpoly_amd.six.XPG_RUNNING
+    assert lp.pivots_done() == rec["K"]
+    check_bench_lp_state(lp.read(), rec)
+    lp.close()

@@ -26,16 +26,41 @@ OUT = os.path.join(ROOT, "tests", "golden", "g11_bench_lp.json")
 M, N = 4096, 4095
 
 
-def record(r, K):
-    return dict(generator="gen.hard_lp_f64(%d, %d)" % (M, N), K=K, status=int(r["status"]), rhs=int(r["rhs"]),
+def record(r, K, m=M, n=N):
+    return dict(generator="gen.hard_lp_f64(%d, %d)" % (m, n), K=K, status=int(r["status"]), rhs=int(r["rhs"]),
                 tab_shape=list(r["tab"].shape), tab=checksum(r["tab"]), tgtf=checksum(r["tgtf"]),
                 obj_const=float(r["tgtf"][r["rhs"]]).hex(), eq2bv=checksum(r["eq2bv"].astype(np.int32)),
                 eq2bv_head=[int(x) for x in r["eq2bv"][:32]],
                 bv2eq=checksum(r["bv2eq"].astype(np.int32)),
-                entered_count=int(np.sum(r["eq2bv"] < N)))
+                entered_count=int(np.sum(r["eq2bv"] < n)))
+
+
+def main_cfg2b():
+    """The LP of bench.py's cfg2b leg: gen.hard_lp_f64(4096, 8192), slack tableau 4096 x 12289, K = 1280 (where that leg's
+    timed pass ends)."""
+    ref, port = Ref(), Port()
+    m, n, K = 4096, 8192, 1280
+    leq, tgtf = gen.hard_lp_f64(m, n)
+    t0 = time.time()
+    r = ref.two_stage(F64, leq, tgtf, K)
+    t1 = time.time()
+    rec = record(r, K, m, n)
+    del r
+    p = port.two_stage(F64, leq, tgtf, K)
+    t2 = time.time()
+    prec = record(p, K, m, n)
+    del p
+    print("cfg2b K", K, "reference %.1f s, restatement %.1f s" % (t1 - t0, t2 - t1), "agree" if prec == rec else "DIFFER", flush=True)
+    assert prec == rec, (prec, rec)
+    out = json.load(open(OUT)) if os.path.exists(OUT) else {}
+    out["cfg2b_lp"] = [rec]
+    json.dump(out, open(OUT, "w"), indent=1)
+    print("written", OUT)
 
 
 def main():
+    if sys.argv[1:] == ["cfg2b"]:
+        return main_cfg2b()
     ks = [int(x) for x in sys.argv[1:]] or [1024, 2048, 3840]
     ref, port = Ref(), Port()
     leq, tgtf = gen.hard_lp_f64(M, N)
