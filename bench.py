@@ -588,12 +588,13 @@ def main():
             out["lineq"] = leg_lineq(ctx, xpoly_amd, gen)
 
     if rank == 0:
-        if checks or "self_check" in out or "self_check" in out.get("mip", {}) or "self_check" in out.get("cfg2b", {}):
+        if checks or "self_check" in out or any("self_check" in out.get(leg, {}) for leg in ("mip", "cfg2b", "rational")):
             out.setdefault("self_check", {}).update(checks)
             if "mip" in out and "self_check" in out["mip"]:
                 out["self_check"]["mip"] = out["mip"].pop("self_check")
-            if "cfg2b" in out and "self_check" in out["cfg2b"]:
-                out["self_check"]["cfg2b"] = out["cfg2b"].pop("self_check")
+            for leg in ("cfg2b", "rational"):
+                if leg in out and "self_check" in out[leg]:
+                    out["self_check"][leg] = out[leg].pop("self_check")
         out["cpu_baseline"] = cpu
         print(json.dumps(out))
     if ctx is not None:
@@ -770,6 +771,13 @@ def leg_rational(ctx, xpoly_amd, gen):
         assert st == RUNNING
         if rep > 0:
             best = dt if best is None else min(best, dt)
+    # self-check, outside the timing: the state the last run left (K = 16) against the real reference's fixture
+    rec = [r for r in golden("g8_large.json")["g4_large"] if r["K"] == RAT_K][0]
+    got = lp.read()
+    if (checksum(got["tab"]) != rec["tab"] or checksum(got["tgtf"]) != rec["tgtf"] or
+            checksum(got["eq2bv"].astype(np.int32)) != rec["eq2bv"] or got["tgtf"][got["rhs"]].tolist() != rec["obj_const"]):
+        sys.exit("bench.py self-check FAILED: rational tableau after %d pivots differs from tests/golden/g8_large.json (g4_large)" % RAT_K)
+    del got
     lp.close()
     W = RAT_N + RAT_M + 1
     alg = 2 * RAT_M * W * 8
@@ -778,6 +786,8 @@ def leg_rational(ctx, xpoly_amd, gen):
                 bound="integer ALU (gcd / appro per cell), not HBM",
                 algorithmic_bytes_per_pivot=alg, achieved_gbs=round(alg * RAT_K / best / 1e9, 1),
                 hbm_frac=round(alg * RAT_K / best / 1e9 / HBM_PEAK_GBS, 4),
+                self_check="tableau 1024x2048 (CRC-32 + sum + xor of all (num, den) cells), objective row, basis after the last run's 16 pivots = "
+                           "the real reference's (tests/golden/g8_large.json g4_large, %d appro calls on the way): bit-identical" % rec["appro_calls"],
                 sample="best of %d runs of xpg_lp_begin + xpg_lp_iterate(16)" % (reps - 1))
 
 
