@@ -31,3 +31,8 @@ for k, s in stacks.items():
 uni = np.stack([gen.random_system(rng, 12, 4) for _ in range(256)]); uni[..., 1] = 1
 uni = np.ascontiguousarray(np.tile(uni, (16, 1, 1, 1)))
 print("uniform 4096 x (12 x 5)         %.2f ms" % t(lambda: dep_is_empty_batch(ctx, uni)))
+big = [polys[k % 4096] for k in range(65536)]
+pb = ragged_pack_rat(big)
+print("ragged 65536 polyhedra of 8 shapes   %.2f ms" % t(lambda: dep_is_empty_ragged(ctx, packed=pb), 2))
+uni16 = np.ascontiguousarray(np.tile(uni, (16, 1, 1, 1)))
+print("uniform 65536 x (12 x 5)             %.2f ms" % t(lambda: dep_is_empty_batch(ctx, uni16), 2))

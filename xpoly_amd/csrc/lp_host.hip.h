@@ -235,10 +235,10 @@ template <> inline void launch_update<R32>(xpg_ctx * ctx, const LpView<R32> & v,
 {
     const bool timed = prof_open(ctx);
     static const int rows = [] { const char * s = getenv("XPG_R32_ROWS"); return s ? atoi(s) : 1; }();   // A/B knob: 8 / 4 / 2 / 1 rows per thread measured 15.6 / 16.5 / 16.8 / 17.2 k pivots/s at 1024 x 2048
-    if (rows <= 1) hipLaunchKernelGGL((k_update_r32<1>), dim3((v.W + 255) / 256, v.m), dim3(256), 0, ctx->stream, v, guarded);
-    else if (rows == 2) hipLaunchKernelGGL((k_update_r32<2>), dim3((v.W + 255) / 256, (v.m + 1) / 2), dim3(256), 0, ctx->stream, v, guarded);
-    else if (rows == 4) hipLaunchKernelGGL((k_update_r32<4>), dim3((v.W + 255) / 256, (v.m + 3) / 4), dim3(256), 0, ctx->stream, v, guarded);
-    else hipLaunchKernelGGL((k_update_r32<8>), dim3((v.W + 255) / 256, (v.m + 7) / 8), dim3(256), 0, ctx->stream, v, guarded);
+    if (rows <= 1) hipLaunchKernelGGL((k_update_r32<1>), dim3(v.m, (v.W + 255) / 256), dim3(256), 0, ctx->stream, v, guarded);
+    else if (rows == 2) hipLaunchKernelGGL((k_update_r32<2>), dim3((v.m + 1) / 2, (v.W + 255) / 256), dim3(256), 0, ctx->stream, v, guarded);
+    else if (rows == 4) hipLaunchKernelGGL((k_update_r32<4>), dim3((v.m + 3) / 4, (v.W + 255) / 256), dim3(256), 0, ctx->stream, v, guarded);
+    else hipLaunchKernelGGL((k_update_r32<8>), dim3((v.m + 7) / 8, (v.W + 255) / 256), dim3(256), 0, ctx->stream, v, guarded);
     if (timed) prof_close(ctx);
 }
 
