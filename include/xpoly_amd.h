@@ -134,6 +134,12 @@ int  xpg_lp_chain_aborts(xpg_lp * lp, unsigned * aborts, int * chain_off, unsign
  * tableau of W live columns gets. */
 int  xpg_test_sweep_tile(int strips, int rowblocks, int rev, int lid, int * bx, int * by);
 int  xpg_test_pick_ld(int W);
+/* The device's canonical rational forms on n host triples (tests: the sweep's fused a + k * e and the ratio test's
+ * b / a must equal the reference's two operations, src/com/rational.cpp:273-397, for canonical operands -- lowest
+ * terms, den > 0, below the appro threshold; anything else in the inputs returns XPG_ERR_SHAPE):
+ * out_fma[i] = a[i] + k[i] * e[i], out_div[i] = a[i] / k[i] (k[i] = 0: 0/1). Either output may be NULL. */
+int  xpg_test_canon_ops_rat32(xpg_ctx * ctx, int n, const xpg_rat32 * a, const xpg_rat32 * k, const xpg_rat32 * e,
+                              xpg_rat32 * out_fma, xpg_rat32 * out_div);
 /* OPT-IN, NON-PARITY (results are no longer the reference's bit for bit, and
  * nothing else in this header changes behaviour): before xpg_lp_begin / xpg_lp_two_stage,
  *   pricing = 1        Dantzig's rule -- the largest reduced cost enters -- instead of the reference's

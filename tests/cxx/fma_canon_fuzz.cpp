@@ -43,6 +43,14 @@ static int check_division_helpers(long n)
         if (by(q32 * g) != q32) { printf("MISMATCH ExactDiv32 q=%u g=%u\n", q32, g); return 1; }
         const unsigned long long q64 = rnd() % (0xffffffffffffffffull / g);
         if (by.wide(q64 * g) != q64) { printf("MISMATCH ExactDiv32::wide q=%llu g=%u\n", q64, g); return 1; }
+        // the fp64 forms the canonical operations use (g < 2^31 there; dividends below 2^63)
+        const DivFp fp(g);
+        if (fp(q32 * g) != q32) { printf("MISMATCH DivFp q=%u g=%u\n", q32, g); return 1; }
+        if (fp.mod(x) != (uint32_t)(x % g)) { printf("MISMATCH DivFp::mod x=%llu g=%u\n", x, g); return 1; }
+        const unsigned long long q63 = rnd() % (0x7fffffffffffffffull / g + 1);
+        if (fp.wide(q63 * g) != q63) { printf("MISMATCH DivFp::wide q=%llu g=%u\n", q63, g); return 1; }
+        const unsigned long long top = (0x7fffffffffffffffull / g) * g;      // the largest multiple below 2^63
+        if (fp.wide(top) != top / g || fp.mod(top + (g > 1 ? g - 1 : 0)) != (g > 1 ? g - 1 : 0)) { printf("MISMATCH DivFp at the top, g=%u\n", g); return 1; }
     }
     return 0;
 }

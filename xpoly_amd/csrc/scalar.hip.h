@@ -3,8 +3,9 @@
 // The solver must replay the reference's arithmetic exactly:
 //   * Float   = one fp64 (src/com/flty.h:45-62); '*' then '+' are two roundings
 //               (flty.cpp:97-116), so this translation unit is compiled with
-//               -ffp-contract=off and carries the pragma below: v_fma_f64 must
-//               never appear in a kernel that includes this header.
+//               -ffp-contract=off and carries the pragma below: the compiler must
+//               never contract a Float product and sum (the only v_fma_f64 in these
+//               kernels are the explicit ones of the integer quotients, DivFp below).
 //   * Rational = int32/int32 with int64 intermediates, gcd reduction and the
 //               float32 "appro" rescue (src/com/rational.cpp:163-397).
 // Both are written as overloads on two POD types so that every kernel is a
@@ -159,19 +160,28 @@ XPG_HD R32 neg(R32 a) { return R32(-a.num, a.den); }
 //   * the zero cases: k*0 = 0/1 (rational.cpp:276-281) and a + 0/1 = squeeze(a.num, a.den) = a.
 // The tail of squeeze (second-reduce and appro thresholds, rational.cpp:294-309) is applied to the same
 // lowest-terms pair the reference applies it to.
-// Binary gcd (the value is the Euclidean one; ~7 instructions per step against ~30 for a 32-bit remainder on
-// gfx950, and the step counts of the lanes of a wave lie closer together).
+// Binary gcd (the value is the Euclidean one; the step counts of the lanes of a wave lie closer together than
+// Euclid's). Both operands are kept odd, so a step is min, |x - y|, test, count-trailing-zeros, shift: five VALU
+// instructions on the device (v_sad_u32 spelled out -- the compiler's max - min form and its register copy made it
+// seven) against ~30 for a 32-bit remainder on gfx950.
 XPG_HD uint32_t gcd32(uint32_t x, uint32_t y)
 {
     if (x == 0) return y;
     if (y == 0) return x;
     const int sh = __builtin_ctz(x | y);
     x >>= __builtin_ctz(x);
-    do {
-        y >>= __builtin_ctz(y);
-        const uint32_t lo = x < y ? x : y, hi = x < y ? y : x;
-        x = lo; y = hi - lo;
-    } while (y != 0);
+    y >>= __builtin_ctz(y);
+    for (;;) {
+        uint32_t d;
+#ifdef __HIP_DEVICE_COMPILE__
+        asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(x), "v"(y));
+#else
+        d = x < y ? y - x : x - y;
+#endif
+        x = x < y ? x : y;
+        if (d == 0) break;
+        y = d >> __builtin_ctz(d);
+    }
     return x << sh;
 }
 // Division without a divide (gfx950 has none: a 32-bit quotient costs ~30 instructions, a 64-bit one far more, and
@@ -212,6 +222,59 @@ XPG_HD uint32_t mod_u64_u32(unsigned long long x, uint32_t g)
     if ((unsigned long long)r >= (unsigned long long)g) return (uint32_t)(x % g);   // never (kept as the definition)
     return (uint32_t)r;
 }
+// The same quotients and remainders through fp64 (the canonical forms below use these; the modular-inverse forms
+// above stay for the 64-bit generic operations and as the cross-check of tests/cxx/fma_canon_fuzz.cpp). gfx950's
+// 32-bit integer multiplies are quarter rate and an inverse costs seven of them; fp64 FMAs are full rate:
+//  * r = 1/g from v_rcp_f64 and two Newton steps (relative error ~2^-52 whatever the seed's; the host divides);
+//  * x / g for a multiple x < 2^32 of g: trunc(x * r + 1/2) -- the product is within 2^-19 of the integer;
+//  * floor and remainder of an integer |x| < 2^52: q = floor(x * r) is at most one off, x - q * g is exact in
+//    an FMA, two conditional corrections;
+//  * x mod g for x < 2^63: reduce the high word first (t < g), then t * 2^32 (exact) through one more quotient
+//    estimate, whose error (< 2^12 units) leaves an exact integer remainder below 2^44; add the low word, reduce;
+//  * x / g for a multiple x < 2^63 of g: floor-divide the high word, the rest (r1 * 2^32 + lo) / g is below 2^32
+//    and exact, so the rounded product finds it.
+// Every result is an exact integer independent of the reciprocal's last bits, so host and device agree.
+XPG_HD double rcp_int(double g)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+    double r = __builtin_amdgcn_rcp(g);
+    r = __builtin_fma(__builtin_fma(-g, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-g, r, 1.0), r, r);
+    return r;
+#else
+    return 1.0 / g;
+#endif
+}
+struct DivFp {
+    double g, r;
+    XPG_HD explicit DivFp(uint32_t gi) : g((double)gi), r(rcp_int((double)gi)) {}
+    XPG_HD uint32_t operator()(uint32_t x) const { return (uint32_t)__builtin_fma((double)x, r, 0.5); }
+    XPG_HD double floor_rem(double x, double & q) const
+    {
+        double qq = __builtin_floor(x * r);
+        double m = __builtin_fma(-qq, g, x);
+        if (m < 0.0) { m += g; qq -= 1.0; }
+        if (m >= g) { m -= g; qq += 1.0; }
+        q = qq;
+        return m;
+    }
+    XPG_HD unsigned long long wide(unsigned long long x) const
+    {
+        const double hi = (double)(uint32_t)(x >> 32), lo = (double)(uint32_t)x;
+        double q1;
+        const double r1 = floor_rem(hi, q1);
+        const uint32_t q0 = (uint32_t)__builtin_fma(__builtin_fma(r1, 4294967296.0, lo), r, 0.5);
+        return ((unsigned long long)(uint32_t)q1 << 32) | q0;
+    }
+    XPG_HD uint32_t mod(unsigned long long x) const
+    {
+        const double hi = (double)(uint32_t)(x >> 32), lo = (double)(uint32_t)x;
+        double q;
+        const double xh = floor_rem(hi, q) * 4294967296.0;
+        const double m = __builtin_fma(-__builtin_floor(xh * r), g, xh) + lo;
+        return (uint32_t)floor_rem(m, q);
+    }
+};
 XPG_HD bool canonical(R32 a)
 {
     if (a.den <= 0) return false;
@@ -235,7 +298,7 @@ XPG_HD void appro_lowest(long long & n, long long & d)
     else { m = 0; t = 1; }
     if (m == 0) { n = 0; d = 1; return; }
     const uint32_t g = gcd32(m, t);
-    if (g != 1) { const ExactDiv32 by(g); m = by(m); t = by(t); }
+    if (g != 1) { const DivFp by(g); m = by(m); t = by(t); }
     n = (long long)m; d = (long long)t;
 }
 XPG_HD R32 squeeze_lowest(long long n, long long d)            // squeeze() for a pair already in lowest terms, d > 0
@@ -252,7 +315,7 @@ XPG_HD R32 mul_canon(R32 a, R32 b)                             // == mul(a, b) f
     if (a.num == 0 || b.num == 0) return R32(0, 1);
     const uint32_t an = a.num < 0 ? (uint32_t)(-(long long)a.num) : (uint32_t)a.num;
     const uint32_t bn = b.num < 0 ? (uint32_t)(-(long long)b.num) : (uint32_t)b.num;
-    const ExactDiv32 by1(gcd32(an, (uint32_t)b.den)), by2(gcd32(bn, (uint32_t)a.den));
+    const DivFp by1(gcd32(an, (uint32_t)b.den)), by2(gcd32(bn, (uint32_t)a.den));
     const long long mag = (long long)by1(an) * (long long)by2(bn);
     const long long den = (long long)by2((uint32_t)a.den) * (long long)by1((uint32_t)b.den);
     return squeeze_lowest(((a.num < 0) != (b.num < 0)) ? -mag : mag, den);
@@ -269,15 +332,18 @@ XPG_HD R32 div_canon(R32 a, R32 b)                             // == div(a, b) f
 XPG_HD R32 add_lowest(R32 a, R32 p)
 {
     const uint32_t g = gcd32((uint32_t)a.den, (uint32_t)p.den);
-    const ExactDiv32 by(g);
+    const DivFp by(g);
     const uint32_t A = by((uint32_t)a.den), P = by((uint32_t)p.den);
     const long long n = (long long)a.num * (long long)P + (long long)p.num * (long long)A;
     if (n == 0) return R32(0, 1);
     unsigned long long nm = n < 0 ? (unsigned long long)(-n) : (unsigned long long)n;
     unsigned long long d = (unsigned long long)A * (unsigned long long)(uint32_t)p.den;
     if (g != 1) {
-        const uint32_t h = gcd32(mod_u64_u32(nm, g), g);
-        if (h != 1) { const ExactDiv32 byh(h); nm = byh.wide(nm); d = byh.wide(d); }
+        const uint32_t h = gcd32(by.mod(nm), g);
+        if (h != 1) {                                          // h divides g, and g divides p.den
+            const DivFp byh(h);
+            nm = byh.wide(nm); d = (unsigned long long)A * (unsigned long long)byh((uint32_t)p.den);
+        }
     }
     return squeeze_lowest(n < 0 ? -(long long)nm : (long long)nm, (long long)d);
 }
@@ -292,7 +358,7 @@ XPG_HD R32 fma_canon(R32 a, R32 k, R32 e)
     if (k.num == 0 || e.num == 0) return a;
     const uint32_t kn = k.num < 0 ? (uint32_t)(-(long long)k.num) : (uint32_t)k.num;
     const uint32_t en = e.num < 0 ? (uint32_t)(-(long long)e.num) : (uint32_t)e.num;
-    const ExactDiv32 by1(gcd32(kn, (uint32_t)e.den)), by2(gcd32(en, (uint32_t)k.den));
+    const DivFp by1(gcd32(kn, (uint32_t)e.den)), by2(gcd32(en, (uint32_t)k.den));
     const long long pmag = (long long)by1(kn) * (long long)by2(en);
     const long long pden = (long long)by2((uint32_t)k.den) * (long long)by1((uint32_t)e.den);
     const R32 p = squeeze_lowest(((k.num < 0) != (e.num < 0)) ? -pmag : pmag, pden);

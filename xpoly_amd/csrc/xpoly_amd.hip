@@ -379,6 +379,39 @@ int xpg_test_sweep_tile(int strips, int rowblocks, int rev, int lid, int * bx, i
     return live ? 1 : 0;
 }
 int xpg_test_pick_ld(int W) { return W > 0 ? pick_ld(W) : XPG_ERR_SHAPE; }
+} // extern "C"
+namespace xpg { namespace {
+__global__ __launch_bounds__(256) void k_test_canon_ops(int n, const R32 * a, const R32 * k, const R32 * e, R32 * out_fma, R32 * out_div)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (out_fma) out_fma[i] = fma_canon(a[i], k[i], e[i]);
+    if (out_div) out_div[i] = k[i].num == 0 ? R32(0, 1) : div_canon(a[i], k[i]);
+}
+} }
+extern "C" {
+int xpg_test_canon_ops_rat32(xpg_ctx * ctx, int n, const xpg_rat32 * a, const xpg_rat32 * k, const xpg_rat32 * e,
+                             xpg_rat32 * out_fma, xpg_rat32 * out_div)
+{
+    if (!ctx || n < 0 || !a || !k || !e) return XPG_ERR_SHAPE;
+    XPG_BIND(ctx);
+    if (n == 0) return 0;
+    const R32 * in[3] = { (const R32 *)a, (const R32 *)k, (const R32 *)e };
+    for (int t = 0; t < 3; t++)
+        for (int i = 0; i < n; i++)
+            if (!canonical(in[t][i])) { ctx->err = "xpg_test_canon_ops_rat32: operand not canonical"; return XPG_ERR_SHAPE; }
+    const size_t bytes = (size_t)n * sizeof(R32);
+    DevBuf d;
+    XPG_HIP(ctx, d.alloc(ctx, 5 * bytes));
+    R32 * base = (R32 *)d.p;
+    for (int t = 0; t < 3; t++) XPG_HIP(ctx, hipMemcpyAsync(base + (size_t)t * n, in[t], bytes, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_test_canon_ops, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, base, base + n, base + 2 * (size_t)n,
+                       out_fma ? base + 3 * (size_t)n : (R32 *)0, out_div ? base + 4 * (size_t)n : (R32 *)0);
+    if (out_fma) XPG_HIP(ctx, hipMemcpyAsync(out_fma, base + 3 * (size_t)n, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_div) XPG_HIP(ctx, hipMemcpyAsync(out_div, base + 4 * (size_t)n, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    XPG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
 
 int xpg_lp_chain_aborts(xpg_lp * lp, unsigned * aborts, int * chain_off, unsigned * runs)
 {
