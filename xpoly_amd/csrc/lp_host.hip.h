@@ -165,6 +165,13 @@ template <> inline void launch_pipe_sweep<F64>(xpg_ctx * ctx, const LpView<F64> 
         hipLaunchKernelGGL(k_pipe_pick, dim3(strips < PICK_MAX_WGS ? strips : PICK_MAX_WGS), dim3(256), 0, ctx->stream,
                            v, slot, colstride);
 }
+template <> inline void launch_pipe_sweep<R32>(xpg_ctx * ctx, const LpView<R32> & v, int slot, int colstride, bool sample)
+{
+    const bool timed = sample && prof_open(ctx);
+    const int N = (v.m + 255) / 256 < PICK_MAX_WGS ? (v.m + 255) / 256 : PICK_MAX_WGS;
+    hipLaunchKernelGGL(k_pipe_sweep_r32, dim3(v.m > N ? v.m : N, 1 + (v.W + 255) / 256), dim3(256), 0, ctx->stream, v, slot, colstride, N);
+    if (timed) prof_close(ctx);
+}
 // One batch of the blocked loop: B x (pick, prep) -- the generic pick once after pick(0) -- and a sweep.
 template <class S> inline void launch_blk_batch(xpg_ctx *, const LpView<S> &, int, int, bool, bool, bool) {}
 template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> & v, int batch, int B, bool ref_pricing, bool closes_often, bool chain_off)
@@ -415,17 +422,21 @@ template <class S> struct Lp : LpBase {
         const bool blocked = std::is_same<S, F64>::value &&
                              (ctx->loop_mode == 3 || (ctx->loop_auto && (size_t)v.m * v.W * 16 >= ((size_t)16 << 20)));
         if (blocked) { queue_blocked(k); return; }
-        const bool pipelined = std::is_same<S, F64>::value && ctx->loop_mode != 1;
+        // (the rational scalar: XPG_R32_LOOP=serial keeps the three-launch loop for A/B runs)
+        static const bool r32_serial = [] { const char * s = getenv("XPG_R32_LOOP"); return s && !strcmp(s, "serial"); }();
+        const bool pipelined = ctx->loop_mode != 1 && (std::is_same<S, F64>::value || !r32_serial);
         if (pipelined && k > 0 && !pipe_primed) {
-            // the first pivot is chosen by a sweep launch that has nothing to sweep (pd[1].row < 0)
-            launch_pipe_sweep(ctx, v, 1, colstride, false);
+            // the first pivot is chosen by a launch that has nothing to sweep (pd[1].row < 0): fp64 the sweep launch's
+            // pick workgroup, Rational the prep launch's first workgroup
+            if (std::is_same<S, F64>::value) launch_pipe_sweep(ctx, v, 1, colstride, false);
+            else hipLaunchKernelGGL((k_pipe_prep<S>), dim3(1), dim3(256), 0, ctx->stream, v, 1, colstride);
             pipe_primed = true;
         }
         for (unsigned t = 0; t < k; t++) {
             if (pipelined) {
                 // two launches per pivot; the next pivot is chosen inside the sweep launch
                 const int slot = (int)(pipe_t++ & 1u);
-                hipLaunchKernelGGL((k_pipe_prep<S>), dim3((v.W + 255) / 256), dim3(256), 0, ctx->stream, v, slot);
+                hipLaunchKernelGGL((k_pipe_prep<S>), dim3((v.W + 255) / 256), dim3(256), 0, ctx->stream, v, slot, colstride);
                 launch_pipe_sweep(ctx, v, slot, colstride, true);
             } else {
                 hipLaunchKernelGGL((k_pick<S>), dim3(1), dim3(1024), 0, ctx->stream, v);

@@ -729,12 +729,17 @@ void k_update_f64(double * __restrict__ tab, int m, int W, int ld,
 // inside the launch are the pick workgroups' 32-byte ratio-test records (pipe_pick_f64 below);
 // launch boundaries order everything else. pd[].stop defers a final status by one launch so
 // that the sweep in flight completes.
-template <class S> __global__ __launch_bounds__(256) void k_pipe_prep(LpView<S> v, int slot)
+// What the first workgroup does when the descriptor has no pivot to stage: nothing (fp64: the sweep launch's pick
+// workgroup runs the generic pick) or that generic pick itself (Rational, lp_pipe_r32.hip.h).
+template <class S> __device__ inline void prep_idle(const LpView<S> &, int, int) {}
+template <> __device__ inline void prep_idle<R32>(const LpView<R32> & v, int slot, int colstride);
+template <class S> __global__ __launch_bounds__(256) void k_pipe_prep(LpView<S> v, int slot, int colstride)
 {
     LoopState * st = v.st;
     PipeDesc & D = st->pd[slot];
     // every scalar this kernel branches on is loaded before the first branch: one round trip
     const int status = st->status, pricing = st->pricing;
+    const bool canon = !is_f64<S>::value && st->noncanon == 0;  // Rational: the canonical forms (scalar.hip.h)
     const int stop = D.stop, r = D.row, enter = D.col, leave = D.leave, zu = D.zero_upto;
     const unsigned long long piv_bits = D.piv_bits, cnv_bits = D.cnv_bits;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
@@ -749,7 +754,10 @@ template <class S> __global__ __launch_bounds__(256) void k_pipe_prep(LpView<S> 
         }
         return;
     }
-    if (r < 0) return;
+    if (r < 0) {
+        if (blockIdx.x == 0) prep_idle<S>(v, slot, colstride);
+        return;
+    }
     if (gid == 0) v.pickrec[PICK_CTR_OFF + 16 * slot] = 0ull;  // arrival counter of this iteration's pick
     const S s = div(one<S>(), from_bits<S>(piv_bits));        // 1/(eq.get(eqnum, nv)), :1471
     const int smode = scale_mode(s);
@@ -764,13 +772,13 @@ template <class S> __global__ __launch_bounds__(256) void k_pipe_prep(LpView<S> 
         S oj = v.obj[j];
         const bool nvj = j < v.rhs && v.nv[j] != 0;            // basis BEFORE this pivot's swap
         const int rcj = v.rowcnt[j < v.rhs ? j : 0];
-        S e = scaled(a, s, smode);
+        S e = scaled_c(a, s, smode, canon);
         v.rowbuf[j] = e;
-        S t = mul(e, minus_one<S>());                          // nvexp.mul(-1), :1496
+        S t = mul_c(e, minus_one<S>(), canon);                          // nvexp.mul(-1), :1496
         if (j >= v.rhs) t = neg(t);                            // :1497-1499
-        t = scaled(t, cnv, cmode);                             // nvexp.mul(tgtf(nv)), :1500
+        t = scaled_c(t, cnv, cmode, canon);                             // nvexp.mul(tgtf(nv)), :1500
         if (j < zu && !nvj) oj = zero<S>();                    // lpsol.h:1055-1060, deferred by the pick
-        const S o = add(t, oj);                                // addRowToRow, :1501
+        const S o = add_c(t, oj, canon);                                // addRowToRow, :1501
         v.obj[j] = o;
         // look-ahead pricing of the next iteration, on the basis AFTER the swap
         const bool nv_next = j == enter ? false : (j == leave ? true : nvj);

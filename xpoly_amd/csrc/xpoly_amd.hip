@@ -14,6 +14,7 @@
 #include "../../include/xpoly_amd.h"
 #include "scalar.hip.h"
 #include "lp_kernels.hip.h"
+#include "lp_pipe_r32.hip.h"
 #include "lp_host.hip.h"
 #include "six_host.hip.h"
 #include "batch_kernels.hip.h"
