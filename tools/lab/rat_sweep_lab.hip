@@ -59,7 +59,7 @@ struct DivOld {
     XPG_HD unsigned long long wide(unsigned long long x) const { return by.wide(x); }
     XPG_HD uint32_t mod(unsigned long long x) const { return mod_u64_u32(x, g); }
 };
-XPG_HD double rcp_int(double g)                            // 1/g for an integer 1 <= g < 2^32, relative error ~2^-52
+XPG_HD double lab_rcp_int(double g)                            // 1/g for an integer 1 <= g < 2^32, relative error ~2^-52
 {
 #ifdef __HIP_DEVICE_COMPILE__
     double r = __builtin_amdgcn_rcp(g);
@@ -70,9 +70,9 @@ XPG_HD double rcp_int(double g)                            // 1/g for an integer
     return 1.0 / g;
 #endif
 }
-struct DivFp {
+struct LabDivFp {
     double g, r;
-    XPG_HD explicit DivFp(uint32_t gi) : g((double)gi), r(rcp_int((double)gi)) {}
+    XPG_HD explicit LabDivFp(uint32_t gi) : g((double)gi), r(lab_rcp_int((double)gi)) {}
     XPG_HD uint32_t q(uint32_t x) const { return (uint32_t)__builtin_fma((double)x, r, 0.5); }     // g divides x
     XPG_HD double floor_rem(double x, double & qo) const       // x an integer, |x| < 2^52: x mod g in [0, g), qo = floor(x / g)
     {
@@ -197,16 +197,16 @@ int main(int argc, char ** argv)
         run("product fma_canon, loads first", k_sweep<FmaProduct, 1>);
         run("old gcd, old div (template)", k_sweep<FmaT<GcdOld, DivOld>, 0>);
         run("new gcd, old div", k_sweep<FmaT<GcdNew, DivOld>, 0>);
-        run("old gcd, fp64 div", k_sweep<FmaT<GcdOld, DivFp>, 0>);
-        run("new gcd, fp64 div", k_sweep<FmaT<GcdNew, DivFp>, 0>);
-        run("new gcd, fp64 div, loads first", k_sweep<FmaT<GcdNew, DivFp>, 1>);
+        run("old gcd, fp64 div", k_sweep<FmaT<GcdOld, LabDivFp>, 0>);
+        run("new gcd, fp64 div", k_sweep<FmaT<GcdNew, LabDivFp>, 0>);
+        run("new gcd, fp64 div, loads first", k_sweep<FmaT<GcdNew, LabDivFp>, 1>);
         run("asm gcd, old div", k_sweep<FmaT<GcdAsm, DivOld>, 0>);
-        run("asm gcd, fp64 div", k_sweep<FmaT<GcdAsm, DivFp>, 0>);
+        run("asm gcd, fp64 div", k_sweep<FmaT<GcdAsm, LabDivFp>, 0>);
         for (int kb : {24, 32, 48, 64}) {                        // dynamic LDS as an occupancy limiter: 160 KB per CU
             char nm[96]; snprintf(nm, 96, "asm gcd, fp64 div, %d workgroups per CU", 160 / kb);
             lds_bytes = (size_t)kb * 1024;
-            CK(hipFuncSetAttribute((const void *)k_sweep<FmaT<GcdAsm, DivFp>, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            run(nm, k_sweep<FmaT<GcdAsm, DivFp>, 0>);
+            CK(hipFuncSetAttribute((const void *)k_sweep<FmaT<GcdAsm, LabDivFp>, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            run(nm, k_sweep<FmaT<GcdAsm, LabDivFp>, 0>);
         }
         lds_bytes = 0;
         hipFree(dT); hipFree(d0); hipFree(dE); hipFree(dK);

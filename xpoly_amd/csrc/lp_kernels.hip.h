@@ -519,6 +519,28 @@ template <class S> __device__ __forceinline__ S add_c(S a, S b, bool) { return a
 template <> __device__ __forceinline__ R32 add_c<R32>(R32 a, R32 b, bool canon) { return canon ? add_canon(a, b) : add_any(a, b); }
 template <class S> __device__ __forceinline__ S scaled_c(S cell, S x, int mode, bool canon)
 { return mode == SCALE_KEEP ? cell : (mode == SCALE_ZERO ? zero<S>() : mul_c(cell, x, canon)); }
+// The objective row's update (lpsol.h:1496-1501): t = e * -1 (negated back beyond rhs), t *= c_nv, obj += t. For
+// canonical Rational operands e * -1 is the negation (same magnitude: no gcd, no appro), and scale-then-add is the
+// sweep's fused operation (mul and add of canonical operands are symmetric in their operands).
+template <class S> __device__ __forceinline__ S obj_update_c(S e, bool beyond_rhs, S cnv, int cmode, S oj, bool canon)
+{
+    S t = mul_c(e, minus_one<S>(), canon);                     // nvexp.mul(-1), :1496
+    if (beyond_rhs) t = neg(t);                                // :1497-1499
+    t = scaled_c(t, cnv, cmode, canon);                        // nvexp.mul(tgtf(nv)), :1500
+    return add_c(t, oj, canon);                                // addRowToRow, :1501
+}
+template <> __device__ __forceinline__ R32 obj_update_c<R32>(R32 e, bool beyond_rhs, R32 cnv, int cmode, R32 oj, bool canon)
+{
+    if (!canon) {
+        R32 t = mul_any(e, minus_one<R32>());
+        if (beyond_rhs) t = neg(t);
+        t = cmode == SCALE_KEEP ? t : (cmode == SCALE_ZERO ? zero<R32>() : mul_any(t, cnv));
+        return add_any(t, oj);
+    }
+    const R32 t = beyond_rhs ? e : neg(e);                     // (e.num == 0: 0/1 either way)
+    if (cmode == SCALE_MUL) return fma_canon(oj, cnv, t);
+    return add_canon(cmode == SCALE_KEEP ? t : zero<R32>(), oj);
+}
 
 template <class S> __global__ __launch_bounds__(256)
 void k_prep(LpView<S> v, int guarded, int counted, int bookkeeping, int lookahead)
@@ -774,11 +796,8 @@ template <class S> __global__ __launch_bounds__(256) void k_pipe_prep(LpView<S> 
         const int rcj = v.rowcnt[j < v.rhs ? j : 0];
         S e = scaled_c(a, s, smode, canon);
         v.rowbuf[j] = e;
-        S t = mul_c(e, minus_one<S>(), canon);                          // nvexp.mul(-1), :1496
-        if (j >= v.rhs) t = neg(t);                            // :1497-1499
-        t = scaled_c(t, cnv, cmode, canon);                             // nvexp.mul(tgtf(nv)), :1500
         if (j < zu && !nvj) oj = zero<S>();                    // lpsol.h:1055-1060, deferred by the pick
-        const S o = add_c(t, oj, canon);                                // addRowToRow, :1501
+        const S o = obj_update_c(e, j >= v.rhs, cnv, cmode, oj, canon);   // lpsol.h:1496-1501
         v.obj[j] = o;
         // look-ahead pricing of the next iteration, on the basis AFTER the swap
         const bool nv_next = j == enter ? false : (j == leave ? true : nvj);

@@ -282,24 +282,32 @@ XPG_HD bool canonical(R32 a)
     const uint32_t mag = a.num < 0 ? (uint32_t)(-(long long)a.num) : (uint32_t)a.num;
     return gcd32(mag, (uint32_t)a.den) == 1 && mag < 0x7fffFFFFu && a.den < 0x7fffFFFF;
 }
-// appro64 (rational.cpp:189-226) for n, d > 0: the same float32 operations, then its reduce64 on the 32-bit pair
-// they leave (n < 2^31, d a power of ten <= 10^6) with the binary gcd and the exact division above.
+// appro64 (rational.cpp:189-226) for n, d > 0: the same float32 operations, then the lowest terms of the pair they
+// leave -- m < 2^31 over 10^k, k <= 6 -- which its reduce64 reaches with a Euclid loop. The denominator is
+// 2^k 5^k: the common twos are a count of trailing zeros, and a multiple of five is recognised and divided in one
+// multiplication by 5^-1 mod 2^32 (m * 0xCCCCCCCD <= 0x33333333 exactly when 5 divides m, and the product is m / 5).
 XPG_HD void appro_lowest(long long & n, long long & d)
 {
     float q = (float)n / (float)d;
-    uint32_t m, t;
-    if (q < 100.0) { q = q * 1000000.0f; m = (uint32_t)(int)q; t = 1000000; }
-    else if (q < 1000.0) { q = q * 100000.0f; m = (uint32_t)(int)q; t = 100000; }
-    else if (q < 100000.0) { q = q * 10000.0f; m = (uint32_t)(int)q; t = 10000; }
-    else if (q < 1000000.0) { q = q * 1000.0f; m = (uint32_t)(int)q; t = 1000; }
-    else if (q < 10000000.0) { q = q * 100.0f; m = (uint32_t)(int)q; t = 100; }
-    else if (q < 100000000.0) { q = q * 10.0f; m = (uint32_t)(int)q; t = 10; }
-    else if (q < 2147483647.0) { m = (uint32_t)(int)q; t = 1; }
-    else { m = 0; t = 1; }
+    uint32_t m, t5; int k;
+    if (q < 100.0) { q = q * 1000000.0f; m = (uint32_t)(int)q; k = 6; t5 = 15625u; }
+    else if (q < 1000.0) { q = q * 100000.0f; m = (uint32_t)(int)q; k = 5; t5 = 3125u; }
+    else if (q < 100000.0) { q = q * 10000.0f; m = (uint32_t)(int)q; k = 4; t5 = 625u; }
+    else if (q < 1000000.0) { q = q * 1000.0f; m = (uint32_t)(int)q; k = 3; t5 = 125u; }
+    else if (q < 10000000.0) { q = q * 100.0f; m = (uint32_t)(int)q; k = 2; t5 = 25u; }
+    else if (q < 100000000.0) { q = q * 10.0f; m = (uint32_t)(int)q; k = 1; t5 = 5u; }
+    else if (q < 2147483647.0) { m = (uint32_t)(int)q; k = 0; t5 = 1u; }
+    else { m = 0; k = 0; t5 = 1u; }
     if (m == 0) { n = 0; d = 1; return; }
-    const uint32_t g = gcd32(m, t);
-    if (g != 1) { const DivFp by(g); m = by(m); t = by(t); }
-    n = (long long)m; d = (long long)t;
+    const int z = __builtin_ctz(m);
+    const int z2 = z < k ? z : k;
+    m >>= z2;
+    for (int i = 0; i < k; i++) {
+        const uint32_t fifth = m * 0xCCCCCCCDu;
+        if (fifth > 0x33333333u) break;
+        m = fifth; t5 *= 0xCCCCCCCDu;
+    }
+    n = (long long)m; d = (long long)(t5 << (k - z2));
 }
 XPG_HD R32 squeeze_lowest(long long n, long long d)            // squeeze() for a pair already in lowest terms, d > 0
 {
