@@ -783,7 +783,7 @@ def leg_rational(ctx, xpoly_amd, gen):
     alg = 2 * RAT_M * W * 8
     return dict(metric="exact rational simplex pivots/sec (tableau 1024x2048, K=16)", value=round(RAT_K / best, 1),
                 unit="pivots/s", us_per_pivot=round(best / RAT_K * 1e6, 2), tableau=[RAT_M, W], dtype="int32 num/den",
-                bound="integer ALU (gcd / appro per cell), not HBM",
+                bound="integer issue (gcd / appro per cell; pipelined loop: prep launch + sweep launch with the next pick inside), not HBM",
                 algorithmic_bytes_per_pivot=alg, achieved_gbs=round(alg * RAT_K / best / 1e9, 1),
                 hbm_frac=round(alg * RAT_K / best / 1e9 / HBM_PEAK_GBS, 4),
                 self_check="tableau 1024x2048 (CRC-32 + sum + xor of all (num, den) cells), objective row, basis after the last run's 16 pivots = "
