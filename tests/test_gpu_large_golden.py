@@ -225,3 +225,66 @@ def test_cfg2b_bench_lp_against_the_reference(ctx):
     assert lp.pivots_done() == rec["K"]
     check_bench_lp_state(lp.read(), rec)
     lp.close()
+
+
+def signed_lp_rat(m, n, seed):
+    """Signed integer data with repeated ratios (ties, relaxed ratio passes, disabled columns) and a feasible origin."""
+    rng = np.random.default_rng(seed)
+    A = rng.integers(-3, 7, size=(m, n)).astype(np.int32)
+    A[rng.random((m, n)) < 0.5] = 0
+    b = (rng.integers(1, 4, size=m) * 6).astype(np.int32)
+    c = rng.integers(-2, 5, size=n).astype(np.int32)
+    return gen.to_rat(np.concatenate([A, b[:, None]], axis=1)), gen.to_rat(np.concatenate([c, [0]]).astype(np.int32))
+
+
+@pytest.mark.parametrize("m,n,seed", [(300, 200, 1), (520, 130, 2), (700, 90, 3), (257, 600, 4)])
+def test_rational_pipelined_loop_with_several_pick_workgroups(ctx, port, m, n, seed):
+    """The pipelined rational loop on tableaux of more than 256 rows: the sweep launch carries 2-3 pick workgroups
+    whose records the last adder combines (lp_pipe_r32.hip.h). States after 1, 7, 33 pivots and at the end (optimum
+    or 100 iterations) against the oracle, dense positive data and signed data with ties and deferred branches."""
+    import xpoly_amd
+    six = xpoly_amd.SIX(ctx, RAT)
+    for fam in (0, 1):
+        leq, tg = gen.int_lp_rat(m, n, seed=gen.XS_SEED + seed) if fam == 0 else signed_lp_rat(m, n, seed)
+        for K in (1, 7, 33, 100):
+            want = port.two_stage(RAT, leq, tg, K)
+            six.set_param(0, K)
+            got = six.TwoStageMethod(leq, tg)
+            assert got["status"] == want["status"], (fam, K, got["status"], want["status"])
+            for k in ("tab", "tgtf", "nvset", "bvset", "bv2eq", "eq2bv"):
+                assert np.array_equal(got[k], want[k]), (fam, K, k)
+            if want["status"] == 0:
+                assert np.array_equal(got["maxv"], want["maxv"]) and np.array_equal(got["sol"], want["sol"])
+
+
+SERIAL_R32_SCRIPT = r"""
+import json, sys, zlib
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import xpoly_amd
+from tools import gen
+ctx = xpoly_amd.Context(0)
+leq, tgtf = gen.int_lp_rat(1024, 1023)
+six = xpoly_amd.SIX(ctx, 1)
+six.set_param(0, 16)
+got = six.TwoStageMethod(leq, tgtf)
+def checksum(x):
+    x = np.ascontiguousarray(x)
+    v = x.view(np.uint64).reshape(-1) if x.dtype.itemsize == 8 else x.view(np.uint32).reshape(-1).astype(np.uint64)
+    return dict(crc32="%08x" % (zlib.crc32(x.tobytes()) & 0xFFFFFFFF), sum="%016x" % int(v.sum(dtype=np.uint64)), xor="%016x" % int(np.bitwise_xor.reduce(v)))
+print(json.dumps(dict(tab=checksum(got["tab"]), tgtf=checksum(got["tgtf"]), eq2bv=checksum(got["eq2bv"].astype(np.int32)))))
+"""
+
+
+def test_cfg4_rational_serial_loop_against_the_reference():
+    """XPG_R32_LOOP=serial (the three-launch pick -> prep -> sweep loop kept for A/B runs) reaches the same state as the
+    real reference on the 1024 x 2048 LP after 16 pivots. The switch is read once per process, hence a process of its own."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rec = [r for r in GOLD["g4_large"] if r["K"] == 16][0]
+    env = dict(os.environ, XPG_R32_LOOP="serial")
+    r = subprocess.run([sys.executable, "-c", SERIAL_R32_SCRIPT, root], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["tab"] == rec["tab"] and out["tgtf"] == rec["tgtf"] and out["eq2bv"] == rec["eq2bv"]
