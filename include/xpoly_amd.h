@@ -218,6 +218,9 @@ int xpg_six_batch_rat32_multi(int ndev, const int * devices, int is_max, int nb,
  * node is a from-scratch SIX solve (max_iter 10000, lpsol.h:2441) on the GPU; is_bin
  * selects 0-1 programming; rational_indicator (cols bytes, may be NULL) marks entries
  * allowed to stay fractional (lpsol.h:2369-2393).  Returns XPG_IP_* or XPG_ERR_*.
+ * With vc = -I (x >= 0; what the reference's caller PolyTran::FeaSchedule passes, src/eng/poly.cpp:5118-5130), with
+ * or without equalities, and node LPs within 64 KB of LDS the whole tree walk runs on the device in one launch;
+ * any other vc is walked by the host controller (node LPs on the device, lock-step rounds): same results.
  * (The reference cannot instantiate MIP<FloatMat,Float>, lpsol.h:2242-2254; the f64
  * flavour follows the same template text.) */
 int xpg_mip_maxm_rat32(xpg_ctx * ctx, const xpg_rat32 * tgtf, const xpg_rat32 * vc, int vc_rows,

@@ -231,3 +231,42 @@ def test_mip_batch_bench_shape_matches_the_reference_fixture(ctx):
         assert [int(v[b][0]), int(v[b][1])] == want["v"], b
         if want["status"] == 0:
             assert [int(x) for x in sol[b].reshape(-1)] == want["sol"], b
+
+
+@pytest.mark.parametrize("kind", [RAT, F64])
+def test_mip_with_root_equalities_on_the_device_matches_oracle(ctx, port, kind):
+    """Equalities at the root (MIP::maxm's `eq`, what PolyTran::FeaSchedule passes) through the device tree walk:
+    convertEq2Ineq's substitution of the root's and the branches' equalities per node, leftovers as pairs."""
+    from mip_eq_cases import run
+    compared, seen = run(ctx, port, kind, 4242 + kind, 120)
+    print("MIPs with equalities compared:", compared, "status histogram:", seen)
+    assert compared > 120 and 0 in seen and len(seen) >= 2
+
+
+HOST_MIP_SCRIPT = r"""
+import json, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import xpoly_amd
+from oracle.checker import Port
+from mip_eq_cases import run
+ctx = xpoly_amd.Context(0)
+port = Port()
+out = {}
+for kind in (1, 0):
+    compared, seen = run(ctx, port, kind, 4242 + kind, 60)
+    out[str(kind)] = compared
+print(json.dumps(out))
+"""
+
+
+def test_mip_with_root_equalities_on_the_host_controller_matches_oracle():
+    """The same problems with XPG_MIP_DEVICE=0: the host controller (mip_host.hip.h run_mip_tasks) that still serves
+    general variable constraints and problems beyond the LDS budget. The switch is read once per process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, XPG_MIP_DEVICE="0")
+    r = subprocess.run([sys.executable, "-c", HOST_MIP_SCRIPT, root], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["1"] > 60 and out["0"] > 60

@@ -332,11 +332,11 @@ template <class S> int run_mip_tasks(xpg_ctx * ctx, int kind, std::vector<MipTas
     }
 }
 
-template <class S> inline bool mip_device_fits(int leq_rows, int cols, bool is_bin);
+template <class S> inline bool mip_device_fits(int leq_rows, int cols, bool is_bin, int eq_rows = 0);
 template <class S>
 int mip_batch_device(xpg_ctx * ctx, int nb, bool is_max, bool is_bin, const S * tgtf, const S * leq, int leq_rows,
                      int cols, int32_t * out_status, S * out_v, S * out_sol, long long * out_nodes,
-                     const uint8_t * allow_rational);
+                     const uint8_t * allow_rational, const S * eqs, int eq_rows);
 
 // MIP::maxm / minm (lpsol.h:2636-2657, :2681-2702).
 template <class S>
@@ -347,9 +347,10 @@ int mip_solve(xpg_ctx * ctx, int kind, bool is_max, bool is_bin, const S * tgtf,
     if (!ctx || !tgtf || !vc || !out_v || cols < 2 || vc_rows != cols - 1 || eq_rows < 0 || leq_rows < 0 ||
         (eq_rows == 0 && leq_rows == 0) || (eq_rows > 0 && !eqs) || (leq_rows > 0 && !leq))
         return XPG_ERR_SHAPE;
-    // the plain case (x >= 0, inequalities only; with or without a rational_indicator) is what the device tree walk takes
+    // x >= 0 (vc = -I) with inequalities and / or equalities at the root, with or without a rational_indicator, is what
+    // the device tree walk takes; free or otherwise bounded variables stay with the host controller
     static const bool on_device = [] { const char * e = getenv("XPG_MIP_DEVICE"); return !(e && e[0] == '0'); }();
-    if (on_device && eq_rows == 0 && leq_rows > 0 && mip_device_fits<S>(leq_rows, cols, is_bin)) {
+    if (on_device && mip_device_fits<S>(leq_rows, cols, is_bin, eq_rows)) {
         bool plain = true;
         for (int i = 0; i < vc_rows && plain; i++)
             for (int j = 0; j < cols && plain; j++)
@@ -358,7 +359,7 @@ int mip_solve(xpg_ctx * ctx, int kind, bool is_max, bool is_bin, const S * tgtf,
             int32_t st = 0; long long nodes = 0;
             std::vector<S> sol((size_t)cols, zero<S>());
             if (out_sol) for (int j = 0; j < cols; j++) sol[(size_t)j] = out_sol[j];
-            const int rc = mip_batch_device<S>(ctx, 1, is_max, is_bin, tgtf, leq, leq_rows, cols, &st, out_v, sol.data(), &nodes, allow_rational);
+            const int rc = mip_batch_device<S>(ctx, 1, is_max, is_bin, tgtf, leq, leq_rows, cols, &st, out_v, sol.data(), &nodes, allow_rational, eqs, eq_rows);
             if (rc != XPG_ERR_UNSUPPORTED) {
                 if (rc) return rc;
                 if (st == XPG_IP_SUCC && out_sol) for (int j = 0; j < cols; j++) out_sol[j] = sol[(size_t)j];
@@ -380,9 +381,19 @@ int mip_solve(xpg_ctx * ctx, int kind, bool is_max, bool is_bin, const S * tgtf,
 }
 
 // Whether the node LPs of the deepest path fit the device tree walk's LDS budget, maximising and minimising.
-template <class S> inline bool mip_device_fits(int leq_rows, int cols, bool is_bin)
+// Rows of the largest node LP: the root's inequalities, one bound row per ancestor under integer branching, and -- with
+// equalities at the root -- two rows for every equality convertEq2Ineq may leave unsubstituted (the root's, and under
+// 0-1 branching one per ancestor).
+inline int mip_rmax(int leq_rows, int eq_rows, int n, bool is_bin)
 {
-    const int n = cols - 1, rmax = leq_rows + (is_bin ? 0 : n);
+    int r = leq_rows + (is_bin ? 0 : n);
+    if (eq_rows > 0) r += 2 * (eq_rows + (is_bin ? n : 0));
+    return r;
+}
+template <class S> inline bool mip_device_fits(int leq_rows, int cols, bool is_bin, int eq_rows)
+{
+    const int n = cols - 1, rmax = mip_rmax(leq_rows, eq_rows, n, is_bin);
+    if (rmax <= 0 || eq_rows + n + 2 > MIP_EQ_MAX) return false;
     return small_lds_bytes<S>(rmax, n) <= 64 * 1024 && small_lds_bytes<S>(n, rmax) <= 64 * 1024;
 }
 // Launch shape of k_mip_tree for nb trees whose node LPs have at most rmax rows and n variables.
@@ -409,18 +420,22 @@ template <class S> inline MipGeom mip_geom(const xpg_ctx * ctx, int nb, int rmax
 template <class S>
 int mip_batch_device(xpg_ctx * ctx, int nb, bool is_max, bool is_bin, const S * tgtf, const S * leq, int leq_rows,
                      int cols, int32_t * out_status, S * out_v, S * out_sol, long long * out_nodes,
-                     const uint8_t * allow_rational)
+                     const uint8_t * allow_rational, const S * eqs, int eq_rows)
 {
     const int n = cols - 1;
-    const int rmax = leq_rows + (is_bin ? 0 : n);         // integer branching appends one row per ancestor
+    const int rmax = mip_rmax(leq_rows, eq_rows, n, is_bin);
     const int depth = n + 2;
     const MipGeom g = mip_geom<S>(ctx, nb, rmax, n, is_max);
     if (g.lds > 64 * 1024) return XPG_ERR_UNSUPPORTED;
     const size_t lds = g.lds;
     const int threads = g.threads, grid = g.grid;
     const size_t ws_words = mip_ws_words(rmax, cols, depth);
-    const size_t bl = (size_t)nb * leq_rows * cols * 8, bt = (size_t)nb * cols * 8;
-    DevBuf dl, dt, dws, dst, dv, dsol, dn, dal;
+    const size_t bl = (size_t)nb * leq_rows * cols * 8, bt = (size_t)nb * cols * 8, be = (size_t)nb * eq_rows * cols * 8;
+    DevBuf dl, dt, dws, dst, dv, dsol, dn, dal, de;
+    if (eq_rows > 0) {
+        XPG_TRY(de.alloc(ctx, be));
+        XPG_TRY(hipMemcpyAsync(de.p, eqs, be, hipMemcpyHostToDevice, ctx->stream));
+    }
     if (allow_rational) {
         XPG_TRY(dal.alloc(ctx, (size_t)cols));
         XPG_TRY(hipMemcpyAsync(dal.p, allow_rational, (size_t)cols, hipMemcpyHostToDevice, ctx->stream));
@@ -428,14 +443,14 @@ int mip_batch_device(xpg_ctx * ctx, int nb, bool is_max, bool is_bin, const S * 
     XPG_TRY(dl.alloc(ctx, bl)); XPG_TRY(dt.alloc(ctx, bt)); XPG_TRY(dws.alloc(ctx, (size_t)grid * ws_words * 8));
     XPG_TRY(dst.alloc(ctx, (size_t)nb * 4)); XPG_TRY(dv.alloc(ctx, (size_t)nb * 8)); XPG_TRY(dsol.alloc(ctx, bt));
     XPG_TRY(dn.alloc(ctx, (size_t)nb * 4));
-    XPG_TRY(hipMemcpyAsync(dl.p, leq, bl, hipMemcpyHostToDevice, ctx->stream));
+    if (bl) XPG_TRY(hipMemcpyAsync(dl.p, leq, bl, hipMemcpyHostToDevice, ctx->stream));
     XPG_TRY(hipMemcpyAsync(dt.p, tgtf, bt, hipMemcpyHostToDevice, ctx->stream));
     if (out_sol) XPG_TRY(hipMemcpyAsync(dsol.p, out_sol, bt, hipMemcpyHostToDevice, ctx->stream));
     XPG_TRY(lds_limit((const void *)k_mip_tree<S>, ctx->device, lds));
     hipLaunchKernelGGL((k_mip_tree<S>), dim3(grid), dim3(threads), lds, ctx->stream, nb, (const S *)dt.p, (const S *)dl.p,
                        leq_rows, cols, is_max ? 1 : 0, is_bin ? 1 : 0, rmax, depth, (unsigned long long *)dws.p, ws_words,
                        (int32_t *)dst.p, (S *)dv.p, out_sol ? (S *)dsol.p : (S *)0, (int *)dn.p, (const int *)0, (const int *)0,
-                       allow_rational ? (const uint8_t *)dal.p : (const uint8_t *)0);
+                       allow_rational ? (const uint8_t *)dal.p : (const uint8_t *)0, eq_rows > 0 ? (const S *)de.p : (const S *)0, eq_rows);
     XPG_TRY(hipGetLastError());
     std::vector<int32_t> nodes((size_t)nb);
     XPG_TRY(hipMemcpyAsync(out_status, dst.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -457,7 +472,7 @@ int mip_batch(xpg_ctx * ctx, int kind, int nb, bool is_max, bool is_bin, const S
     // the whole tree walk on the device where the node LPs fit (XPG_MIP_DEVICE=0: the host controller, for A/B runs)
     static const bool on_device = [] { const char * e = getenv("XPG_MIP_DEVICE"); return !(e && e[0] == '0'); }();
     if (on_device) {
-        const int rc = mip_batch_device<S>(ctx, nb, is_max, is_bin, tgtf, leq, leq_rows, cols, out_status, out_v, out_sol, out_nodes, (const uint8_t *)0);
+        const int rc = mip_batch_device<S>(ctx, nb, is_max, is_bin, tgtf, leq, leq_rows, cols, out_status, out_v, out_sol, out_nodes, (const uint8_t *)0, (const S *)0, 0);
         if (rc != XPG_ERR_UNSUPPORTED) return rc;
     }
     const int rhs = cols - 1;
@@ -578,7 +593,8 @@ inline int dep_is_empty_batch(xpg_ctx * ctx, int nb, const R32 * mats, int rows,
             XPG_TRY(lds_limit((const void *)k_mip_tree<R32>, ctx->device, lds));
             hipLaunchKernelGGL((k_mip_tree<R32>), dim3(grid), dim3(threads), lds, ctx->stream, nb, (const R32 *)dt.p, (const R32 *)dm.p,
                                rows, cols, is_max ? 1 : 0, 0, rmax, depth, (unsigned long long *)dws.p, ws_words,
-                               (int32_t *)dst.p, (R32 *)dv.p, (R32 *)0, (int *)dn.p, (const int *)dk.p, (const int *)dact.p, (const uint8_t *)0);
+                               (int32_t *)dst.p, (R32 *)dv.p, (R32 *)0, (int *)dn.p, (const int *)dk.p, (const int *)dact.p, (const uint8_t *)0,
+                               (const R32 *)0, 0);
             XPG_TRY(hipGetLastError());
             XPG_TRY(hipMemcpyAsync(pass == 0 ? nodes_a.data() : nodes_b.data(), dn.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
             hipLaunchKernelGGL(k_dep_update, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, nb, (const int32_t *)dst.p,

@@ -11,9 +11,10 @@
 // LPs (1024 knapsacks of 24 variables: 22-29 ms, against 13 ms for the reference arithmetic restated on all 256 host cores). Here a tree
 // never leaves its workgroup and the trees do not wait for each other.
 //
-// Scope: x >= 0, inequalities only at the root (xpg_mip_batch_*: the caller's vc is -I), binary or integer
-// branching, with or without a rational_indicator (lpsol.h:2369-2393; round 3). Equalities at the root and general
-// variable constraints keep the host controller.
+// Scope: x >= 0 (the caller's vc is -I: what xpg_mip_batch_* and the reference's own caller, PolyTran::FeaSchedule,
+// src/eng/poly.cpp:5118-5130, pass), inequalities and -- round 3 -- equalities at the root, binary or integer
+// branching, with or without a rational_indicator (lpsol.h:2369-2393). General variable constraints (free
+// variables, bounds other than x >= 0) keep the host controller.
 #pragma once
 #include "batch_kernels.hip.h"
 
@@ -75,13 +76,31 @@ __device__ __forceinline__ bool mip_int_cast_ok(R32 a) { return a.den != 0; }
 // inequalities column by column (fold_eq of six_host.hip.h; every branch equality has one variable, so each is
 // "the only nonzero of its column" and none is left to become a pair of inequalities). All threads; returns the
 // row count, or a negative status where the reference's behaviour is undefined.
-template <class S> __device__ int mip_build_node(const MipWs<S> & w, const S * root_leq, int leq_rows, int cols, bool is_bin,
-                                                  int top, int * sh_flag)
+template <class S> __device__ int mip_build_node_eq(const MipWs<S> & w, const S * root_eq, int eq_rows, int cols, bool is_bin,
+                                                     int top, int rows, int * sh_flag);
+template <class S> __device__ int mip_build_node(const MipWs<S> & w, const S * root_leq, int leq_rows, const S * root_eq, int eq_rows,
+                                                  int cols, bool is_bin, int top, int * sh_flag)
 {
     const int rhs0 = cols - 1;
     for (int t = threadIdx.x; t < leq_rows * cols; t += blockDim.x) w.L[t] = root_leq[t];
     if (threadIdx.x == 0) *sh_flag = 0;
     int rows = leq_rows;
+    if (eq_rows > 0) {                                       // equalities at the root: the general convertEq2Ineq
+        if (!is_bin)
+            for (int f = 0; f < top; f++) {
+                const int * fr = w.frame + f * 6;
+                const bool ceiling = fr[MF_STAGE] == 2;
+                for (int j = threadIdx.x; j < cols; j += blockDim.x) {
+                    S val = zero<S>();
+                    if (j == fr[MF_COL]) val = ceiling ? minus_one<S>() : one<S>();
+                    if (j == rhs0) val = S::from_int(ceiling ? -fr[MF_HI] : fr[MF_LO]);
+                    w.L[(size_t)rows * cols + j] = val;
+                }
+                rows++;
+            }
+        __syncthreads();
+        return mip_build_node_eq<S>(w, root_eq, eq_rows, cols, is_bin, top, rows, sh_flag);
+    }
     if (!is_bin) {
         for (int f = 0; f < top; f++) {                      // frame f's child row (lpsol.h:2514-2520, :2555-2559)
             const int * fr = w.frame + f * 6;
@@ -127,6 +146,100 @@ template <class S> __device__ int mip_build_node(const MipWs<S> & w, const S * r
     }
     __syncthreads();
     return *sh_flag ? XPG_ERR_REF_UNDEFINED : rows;
+}
+
+// The same with equalities at the root (MipTask::push_branch + fold_eq of six_host.hip.h = SIX::convertEq2Ineq,
+// lpsol.h:1197-1278, on the node's equality list: the root's rows, then -- 0-1 branching -- one x_col = b row per
+// ancestor). Columns are visited in order; a column in which exactly ONE not-yet-used equality has a nonzero is
+// substituted into every inequality that mentions it (the reference reads the equality's leading entry at the
+// INEQUALITY's row index, lpsol.h:1232: reproduced, refused once it would leave the row), and the equalities left
+// over become pairs of opposite inequalities below the others. Wave 0 finds the next (column, equality) with
+// ballots over the equality rows; the substitution runs over the inequality rows in parallel. MIP_EQ_MAX bounds the
+// equality list (root rows + depth).
+enum { MIP_EQ_MAX = 256 };
+template <class S> __device__ __forceinline__ S mip_eq_cell(const S * root_eq, int eq_rows, int cols, const int * frame, int i, int k)
+{
+    if (i < eq_rows) return root_eq[(size_t)i * cols + k];
+    const int * fr = frame + (i - eq_rows) * 6;              // a branch equality: 1 in its column, b in the constant column
+    if (k == fr[MF_COL]) return one<S>();
+    if (k == cols - 1) return S::from_int(fr[MF_STAGE] == 2 ? fr[MF_HI] : fr[MF_LO]);   // lpsol.h:2506-2512, :2548-2553
+    return zero<S>();
+}
+template <class S> __device__ int mip_build_node_eq(const MipWs<S> & w, const S * root_eq, int eq_rows, int cols, bool is_bin,
+                                                     int top, int rows, int * sh_flag)
+{
+    __shared__ unsigned char sh_used[MIP_EQ_MAX];
+    __shared__ short sh_left[MIP_EQ_MAX];
+    __shared__ int sh_pick[3];                               // column, equality, equalities left over
+    const int rhs0 = cols - 1, lane = threadIdx.x & 63;
+    const int ne_rows = eq_rows + (is_bin ? top : 0);
+    for (int i = threadIdx.x; i < ne_rows; i += blockDim.x) sh_used[i] = 0;
+    __syncthreads();
+    int from = 0;
+    while (rows > 0) {                                       // (no inequality at all: nothing to substitute into)
+        if (threadIdx.x < 64) {
+            int fj = -1, fat = -1;
+            for (int j = from; j < rhs0 && fj < 0; j++) {
+                int hits = 0, at = -1;
+                for (int base = 0; base < ne_rows; base += 64) {
+                    const int i = base + lane;
+                    const bool nz = i < ne_rows && !sh_used[i] && ne(mip_eq_cell<S>(root_eq, eq_rows, cols, w.frame, i, j), zero<S>());
+                    const unsigned long long bal = __ballot(nz);
+                    hits += __popcll(bal);
+                    if (bal) at = base + 63 - __clzll((long long)bal);
+                }
+                if (hits == 1) { fj = j; fat = at; }
+            }
+            if (lane == 0) { sh_pick[0] = fj; sh_pick[1] = fat; if (fat >= 0) sh_used[fat] = 1; }
+        }
+        __syncthreads();
+        const int j = sh_pick[0], at = sh_pick[1];
+        if (j < 0) break;
+        for (int q = threadIdx.x; q < rows; q += blockDim.x) {
+            S * Lq = w.L + (size_t)q * cols;
+            const S coef = Lq[j];
+            if (eq(coef, zero<S>())) continue;
+            if (q >= cols) { *sh_flag = 1; continue; }       // the reference reads the equality at the ROW's index
+            const S lead = mip_eq_cell<S>(root_eq, eq_rows, cols, w.frame, at, q);
+            const bool rescale = ne(lead, one<S>());
+            const S x1 = rescale ? q_div(false, one<S>(), lead) : one<S>();
+            const int m1 = rescale ? scale_mode(x1) : SCALE_KEEP, m2 = scale_mode(coef);
+            Lq[j] = zero<S>();
+            for (int k = 0; k < cols; k++) {
+                S t = mip_eq_cell<S>(root_eq, eq_rows, cols, w.frame, at, k);
+                t = q_scaled(false, t, x1, m1);
+                t = q_scaled(false, t, coef, m2);
+                if (k >= rhs0) t = neg(t);
+                Lq[k] = q_add(false, t, Lq[k]);
+            }
+        }
+        __syncthreads();
+        from = j + 1;
+    }
+    // the equalities left over, in order: -row then +row (lpsol.h:1264-1277)
+    if (threadIdx.x < 64) {
+        int left = 0;
+        for (int base = 0; base < ne_rows; base += 64) {
+            const int i = base + lane;
+            const bool open = i < ne_rows && !sh_used[i];
+            const unsigned long long bal = __ballot(open);
+            if (open) sh_left[left + __popcll(bal & ((1ull << lane) - 1ull))] = (short)i;
+            left += __popcll(bal);
+        }
+        if (lane == 0) sh_pick[2] = left;
+    }
+    __syncthreads();
+    const int left = sh_pick[2];
+    for (int t = threadIdx.x; t < left * cols; t += blockDim.x) {
+        const int u = t / cols, k = t - u * cols;
+        const S c = mip_eq_cell<S>(root_eq, eq_rows, cols, w.frame, sh_left[u], k);
+        w.L[(size_t)(rows + 2 * u) * cols + k] = q_mul(false, c, minus_one<S>());
+        w.L[(size_t)(rows + 2 * u + 1) * cols + k] = c;
+    }
+    rows += 2 * left;
+    __syncthreads();
+    if (*sh_flag) return XPG_ERR_REF_UNDEFINED;
+    return rows > 0 ? rows : XPG_ERR_SHAPE;
 }
 
 // MipTask::on_lp: feeds the node's answer to the recursion and runs it until the next LP is needed (returns
@@ -230,8 +343,9 @@ template <class S> __device__ bool mip_feed(const MipWs<S> & w, const S * tgtf, 
 template <class S> __global__ __launch_bounds__(256, 2)
 void k_mip_tree(int nb, const S * tgtf_all, const S * leq_all, int leq_rows, int cols, int is_max, int is_bin, int rmax,
                 int depth, unsigned long long * ws_all, size_t ws_words, int32_t * out_status, S * out_v, S * out_sol,
-                int * out_nodes, const int * rows_of, const int * active, const uint8_t * allow)
+                int * out_nodes, const int * rows_of, const int * active, const uint8_t * allow, const S * eq_all, int eq_rows)
 {
+    // eq_all / eq_rows (may be NULL / 0): eq_rows equalities per problem at the root.
     // allow (may be NULL): MIP's rational_indicator, one row of cols flags shared by the batch -- variables whose flag is
     // set may stay fractional (lpsol.h:2369-2393).
     // rows_of (may be NULL): problem b has rows_of[b] of its leq_rows-row slot live (ragged batches: the systems
@@ -246,6 +360,7 @@ void k_mip_tree(int nb, const S * tgtf_all, const S * leq_all, int leq_rows, int
         if (active && active[b] != 1) continue;
         const S * tgtf = tgtf_all + (size_t)b * cols;
         const S * root = leq_all + (size_t)b * leq_rows * cols;
+        const S * root_eq = eq_rows > 0 ? eq_all + (size_t)b * eq_rows * cols : (const S *)0;
         const int my_rows = rows_of ? rows_of[b] : leq_rows;
         const MipWs<S> w = mip_ws_carve<S>(ws_all + (size_t)blockIdx.x * ws_words, rmax, cols, depth);
         // MipTask::start
@@ -263,7 +378,7 @@ void k_mip_tree(int nb, const S * tgtf_all, const S * leq_all, int leq_rows, int
             __syncthreads();
             if (threadIdx.x == 0) w.ctl[MC_NODES] += 1;
             MIP_T0
-            int st = mip_build_node<S>(w, root, my_rows, cols, is_bin != 0, top, &sh_ctl[1]);
+            int st = mip_build_node<S>(w, root, my_rows, root_eq, eq_rows, cols, is_bin != 0, top, &sh_ctl[1]);
             MIP_T(0)
             if (st >= 0) {
                 Source<S> src;
