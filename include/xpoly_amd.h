@@ -140,6 +140,11 @@ int  xpg_test_pick_ld(int W);
  * out_fma[i] = a[i] + k[i] * e[i], out_div[i] = a[i] / k[i] (k[i] = 0: 0/1). Either output may be NULL. */
 int  xpg_test_canon_ops_rat32(xpg_ctx * ctx, int n, const xpg_rat32 * a, const xpg_rat32 * k, const xpg_rat32 * e,
                               xpg_rat32 * out_fma, xpg_rat32 * out_div);
+/* The device's GENERIC rational forms (any numerators, any denominators above INT32_MIN, zero and negative ones
+ * included -- what a problem whose cells are not canonical runs on): out_mul[i] = a[i] * b[i], out_add[i] = a[i] + b[i],
+ * out_div[i] = a[i] / b[i] as src/com/rational.cpp:273-397 computes them. Outputs may be NULL. */
+int  xpg_test_any_ops_rat32(xpg_ctx * ctx, int n, const xpg_rat32 * a, const xpg_rat32 * b,
+                            xpg_rat32 * out_mul, xpg_rat32 * out_add, xpg_rat32 * out_div);
 /* OPT-IN, NON-PARITY (results are no longer the reference's bit for bit, and
  * nothing else in this header changes behaviour): before xpg_lp_begin / xpg_lp_two_stage,
  *   pricing = 1        Dantzig's rule -- the largest reduced cost enters -- instead of the reference's

@@ -82,3 +82,35 @@ def test_canonical_forms_refuse_other_operands(ctx):
     out = np.empty_like(A)
     p = lambda x: x.ctypes.data_as(C.c_void_p)
     assert lib().xpg_test_canon_ops_rat32(ctx._h, C.c_int(1), p(A), p(K), p(K), p(out), None) != 0
+
+
+def test_generic_forms_equal_the_reference_operations(ctx, port):
+    """mul / add / div on arbitrary (num, den) pairs -- small and large numerators, denominators that are zero,
+    negative or not coprime (what MIP's substituted nodes and unreduced inputs hold) -- through the device's generic
+    forms (32-bit gcd and fp64 quotients when both sides of a result fit 32 bits, 64-bit binary gcd otherwise)."""
+    from xpoly_amd._capi import lib
+    rng = np.random.default_rng(77)
+    n = 60000
+    caps = [1, 3, 10, 1000, 1000000, 0x3FFFFFFF, 0x7FFFFFFF]
+
+    def draw_any():
+        out = np.empty((n, 2), dtype=np.int64)
+        for i in range(n):
+            cn, cd = caps[int(rng.integers(7))], caps[int(rng.integers(7))]
+            num, den = int(rng.integers(-cn, cn + 1)), int(rng.integers(-cd, cd + 1))
+            r = rng.random()
+            if r < 0.25:
+                den = 1
+            elif r < 0.34:
+                den = 0
+            out[i] = (num, den)
+        return out.astype(np.int32)
+    A, B = draw_any(), draw_any()
+    outs = [np.empty_like(A) for _ in range(3)]
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    ctx.check(lib().xpg_test_any_ops_rat32(ctx._h, C.c_int(n), p(A), p(B), p(outs[0]), p(outs[1]), p(outs[2])), "xpg_test_any_ops_rat32")
+    for i in range(n):
+        a, b = (int(A[i, 0]), int(A[i, 1])), (int(B[i, 0]), int(B[i, 1]))
+        for op, got in ((MUL, outs[0]), (ADD, outs[1]), (DIV, outs[2])):
+            want = port.rat_op(op, a, b)
+            assert tuple(got[i]) == want, "op %d on %s, %s: device %s, reference %s" % (op, a, b, tuple(got[i]), want)

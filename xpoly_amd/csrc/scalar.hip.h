@@ -410,9 +410,15 @@ XPG_HD R32 squeeze_any(long long n, long long d)               // == squeeze(n, 
     const bool minus = n < 0;
     unsigned long long un = minus ? 0ull - (unsigned long long)n : (unsigned long long)n, ud = (unsigned long long)d;
     if (un == 0) ud = 1;                                       // reduce64: n == 0 -> d = 1
-    else {
+    else if (((un | ud) >> 32) == 0) {                         // both below 2^32 (small data: MIP nodes, dependence systems): the 32-bit forms
+        const uint32_t g = gcd32((uint32_t)un, (uint32_t)ud);  // (ud == 0: g = un, the pair becomes 1 / 0 as with gcd_u64)
+        if (g != 1) { const DivFp by(g); un = by((uint32_t)un); ud = by((uint32_t)ud); }
+    } else {
         const unsigned long long g = gcd_u64(un, ud);
-        if (g != 1) { un = exact_div_u64(un, g); ud = exact_div_u64(ud, g); }
+        if (g != 1) {
+            if ((g >> 32) == 0 && (un >> 63) == 0 && (ud >> 63) == 0) { const DivFp by((uint32_t)g); un = by.wide(un); ud = by.wide(ud); }
+            else { un = exact_div_u64(un, g); ud = exact_div_u64(ud, g); }
+        }
     }
     long long mag = (long long)un, dd = (long long)ud;
     if (mag >= (imax >> 2) || dd >= (imax >> 2)) {

@@ -389,8 +389,36 @@ __global__ __launch_bounds__(256) void k_test_canon_ops(int n, const R32 * a, co
     if (out_fma) out_fma[i] = fma_canon(a[i], k[i], e[i]);
     if (out_div) out_div[i] = k[i].num == 0 ? R32(0, 1) : div_canon(a[i], k[i]);
 }
+__global__ __launch_bounds__(256) void k_test_any_ops(int n, const R32 * a, const R32 * b, R32 * out_mul, R32 * out_add, R32 * out_div)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (out_mul) out_mul[i] = mul_any(a[i], b[i]);
+    if (out_add) out_add[i] = add_any(a[i], b[i]);
+    if (out_div) out_div[i] = div_any(a[i], b[i]);
+}
 } }
 extern "C" {
+int xpg_test_any_ops_rat32(xpg_ctx * ctx, int n, const xpg_rat32 * a, const xpg_rat32 * b, xpg_rat32 * out_mul, xpg_rat32 * out_add,
+                           xpg_rat32 * out_div)
+{
+    if (!ctx || n < 0 || !a || !b) return XPG_ERR_SHAPE;
+    XPG_BIND(ctx);
+    if (n == 0) return 0;
+    const size_t bytes = (size_t)n * sizeof(R32);
+    DevBuf d;
+    XPG_HIP(ctx, d.alloc(ctx, 5 * bytes));
+    R32 * base = (R32 *)d.p;
+    XPG_HIP(ctx, hipMemcpyAsync(base, a, bytes, hipMemcpyHostToDevice, ctx->stream));
+    XPG_HIP(ctx, hipMemcpyAsync(base + n, b, bytes, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_test_any_ops, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, base, base + n,
+                       out_mul ? base + 2 * (size_t)n : (R32 *)0, out_add ? base + 3 * (size_t)n : (R32 *)0, out_div ? base + 4 * (size_t)n : (R32 *)0);
+    if (out_mul) XPG_HIP(ctx, hipMemcpyAsync(out_mul, base + 2 * (size_t)n, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_add) XPG_HIP(ctx, hipMemcpyAsync(out_add, base + 3 * (size_t)n, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_div) XPG_HIP(ctx, hipMemcpyAsync(out_div, base + 4 * (size_t)n, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    XPG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
 int xpg_test_canon_ops_rat32(xpg_ctx * ctx, int n, const xpg_rat32 * a, const xpg_rat32 * k, const xpg_rat32 * e,
                              xpg_rat32 * out_fma, xpg_rat32 * out_div)
 {
