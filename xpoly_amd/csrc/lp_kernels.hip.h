@@ -295,7 +295,7 @@ template <class S> __device__ int ratio_test(const LpView<S> & v, int nv, Cand<S
                 if (i >= v.m) continue;
                 if (pass == 0 ? le(a[u], zero<S>()) : eq(a[u], zero<S>())) continue;
                 if (((w[u] >> (b[u] & 31)) & 1u) || cc[u] >= lim) continue;
-                Cand<S> c; c.q = q_div(cn, bb[u], a[u]); c.idx = i;
+                Cand<S> c; c.q = l_div(cn, bb[u], a[u]); c.idx = i;
                 best = better(best, c);
             }
         }
@@ -514,9 +514,9 @@ template <class S> __global__ __launch_bounds__(1024) void k_pick(LpView<S> v)
 // (the forced pivots of phase 1 are neither, lpsol.h:906-908, :939).
 // canonical-operand forms of the rational operations (scalar.hip.h), selected where every operand is known canonical
 template <class S> __device__ __forceinline__ S mul_c(S a, S b, bool) { return mul(a, b); }
-template <> __device__ __forceinline__ R32 mul_c<R32>(R32 a, R32 b, bool canon) { return canon ? mul_canon(a, b) : mul_any(a, b); }
+template <> __device__ __forceinline__ R32 mul_c<R32>(R32 a, R32 b, bool canon) { return canon ? mul_canon(a, b) : mul_any_ol(a, b); }
 template <class S> __device__ __forceinline__ S add_c(S a, S b, bool) { return add(a, b); }
-template <> __device__ __forceinline__ R32 add_c<R32>(R32 a, R32 b, bool canon) { return canon ? add_canon(a, b) : add_any(a, b); }
+template <> __device__ __forceinline__ R32 add_c<R32>(R32 a, R32 b, bool canon) { return canon ? add_canon(a, b) : add_any_ol(a, b); }
 template <class S> __device__ __forceinline__ S scaled_c(S cell, S x, int mode, bool canon)
 { return mode == SCALE_KEEP ? cell : (mode == SCALE_ZERO ? zero<S>() : mul_c(cell, x, canon)); }
 // The objective row's update (lpsol.h:1496-1501): t = e * -1 (negated back beyond rhs), t *= c_nv, obj += t. For
@@ -532,10 +532,10 @@ template <class S> __device__ __forceinline__ S obj_update_c(S e, bool beyond_rh
 template <> __device__ __forceinline__ R32 obj_update_c<R32>(R32 e, bool beyond_rhs, R32 cnv, int cmode, R32 oj, bool canon)
 {
     if (!canon) {
-        R32 t = mul_any(e, minus_one<R32>());
+        R32 t = mul_any_ol(e, minus_one<R32>());
         if (beyond_rhs) t = neg(t);
-        t = cmode == SCALE_KEEP ? t : (cmode == SCALE_ZERO ? zero<R32>() : mul_any(t, cnv));
-        return add_any(t, oj);
+        t = cmode == SCALE_KEEP ? t : (cmode == SCALE_ZERO ? zero<R32>() : mul_any_ol(t, cnv));
+        return add_any_ol(t, oj);
     }
     const R32 t = beyond_rhs ? e : neg(e);                     // (e.num == 0: 0/1 either way)
     if (cmode == SCALE_MUL) return fma_canon(oj, cnv, t);
@@ -654,7 +654,7 @@ void k_update_r32(LpView<R32> v, int guarded)
         const int i = i0 + ii;
         if (i >= v.m) break;
         R32 * p = v.tab + (size_t)i * v.ld + j;
-        const R32 o = (i == r) ? e : (canon ? fma_canon(*p, v.colbuf[i], e) : add_any(*p, mul_any(v.colbuf[i], e)));
+        const R32 o = (i == r) ? e : l_fma(canon, *p, v.colbuf[i], e);
         *p = o;
         if (ex_col) v.nextcol[i] = o;
         if (ex_b) v.bcol[i] = o;

@@ -101,13 +101,13 @@ __device__ inline void pipe_pick_r32(const LpView<R32> & v, int slot, int colstr
             const R32 e0 = rb[xc];
             for (int i = p * 256 + tid; i < m; i += stride) {
                 R32 * q = tab + (size_t)i * ld + xc;
-                const R32 n0 = (i == r) ? e0 : q_fma(cn, *q, cb[i], e0);
+                const R32 n0 = (i == r) ? e0 : l_fma(cn, *q, cb[i], e0);
                 *q = n0;
                 nextcol[i] = n0;
             }
         }
         for (int i = p * 256 + tid; i < m; i += stride)
-            bcol[i] = (i == r) ? eb : q_fma(cn, bcol[i], cb[i], eb);
+            bcol[i] = (i == r) ? eb : l_fma(cn, bcol[i], cb[i], eb);
         if (p == 0 && tid == 0) {
             if (done_now >= max_iter)                  // while (cnt < m_max_iter), lpsol.h:1039
                 write_desc(O, -1, 0, 0, first, anypos, 4, xc, 0, done_now, total_now, 0ull, 0ull);
@@ -132,7 +132,7 @@ __device__ inline void pipe_pick_r32(const LpView<R32> & v, int slot, int colstr
         if (i == r) bi = ienter;                       // the commit above, seen without waiting for it
         const uint32_t w = v.ppt[(size_t)xc * v.pw + (bi >> 5)];
         const int cc = v.colcnt[bi];
-        R32 nb = q_fma(cn, bo, k, eb), a = q_fma(cn, c0, k, e0);               // the sweep's a + k*e
+        R32 nb = l_fma(cn, bo, k, eb), a = l_fma(cn, c0, k, e0);               // the sweep's a + k*e
         if (i == r) { nb = eb; a = e0; }
         bcol[i] = nb;
         *q = a;
@@ -140,7 +140,7 @@ __device__ inline void pipe_pick_r32(const LpView<R32> & v, int slot, int colstr
         cbo[i] = neg(a);                                                       // -column, lpsol.h:1485
         if (le(a, zero<R32>())) continue;                                      // findPivotBV, lpsol.h:553-663
         if (((w >> (bi & 31)) & 1u) || cc >= lim) continue;
-        Cand<R32> c; c.q = q_div(cn, nb, a); c.idx = i;
+        Cand<R32> c; c.q = l_div(cn, nb, a); c.idx = i;
         const Cand<R32> nbest = better(best, c);
         if (nbest.idx != best.idx) { best_a = a; best_b = bi; best_cc = cc; best_w = w; }
         best = nbest;
@@ -221,7 +221,7 @@ void k_pipe_sweep_r32(LpView<R32> v, int slot, int colstride, int N)
         return;
     }
     const R32 k = v.colbuf[(size_t)slot * colstride + i];
-    *p = (i == r) ? e : q_fma(canon, *p, k, e);
+    *p = (i == r) ? e : l_fma(canon, *p, k, e);
 }
 
 } // namespace xpg
