@@ -8,7 +8,7 @@ from tools import gen
 ctx = xpoly_amd.Context(0)
 dev = torch.device("cuda", 0)
 for fam in (1, 0):
-    for nb in (1280, 2560, 5120, 8192, 16384, 32768, 65536):
+    for nb in ([int(a) for a in sys.argv[1:]] or [1280, 2560, 5120, 8192, 16384, 32768, 65536]):
         leq, tg = gen.small_lp_batch_f64(nb, 32, 64, fam)
         d_leq = torch.from_numpy(leq).to(dev); d_tg = torch.from_numpy(tg).to(dev)
         d_st = torch.empty(nb, dtype=torch.int32, device=dev); d_v = torch.empty(nb, dtype=torch.float64, device=dev)

@@ -19,6 +19,15 @@ __device__ unsigned long long g_fl[16];                  // diagnostic builds: s
 #else
 #define FL_ADD(k_, v_) do { } while (0)
 #endif
+#ifdef XPG_LIFE
+// diagnostic builds (-DXPG_LIFE, tools/lab/probe_batch_life.py): 100 MHz time of every 256th pivot of the first 4096 LPs
+__device__ unsigned long long g_life[4096 * 32];
+#define LIFE_MARK(lp_, piv_) do { if (threadIdx.x == 0 && (lp_) < 4096 && ((piv_) & 255) == 0 && ((piv_) >> 8) < 31) g_life[(lp_) * 32 + ((piv_) >> 8)] = wall_clock64(); } while (0)
+#define LIFE_END(lp_) do { if (threadIdx.x == 0 && (lp_) < 4096) g_life[(lp_) * 32 + 31] = wall_clock64(); } while (0)
+#else
+#define LIFE_MARK(lp_, piv_) do { } while (0)
+#define LIFE_END(lp_) do { } while (0)
+#endif
 
 template <class S> struct Small {
     S * tab; int R, W, ld, rhs;     // R rows, W live columns, row stride ld
@@ -217,20 +226,31 @@ template <class S> __device__ __forceinline__ void sm_pivot_fast(Small<S> & P, i
 // SIX::findPivotBV (lpsol.h:553-663) for column nv by one wavefront (R <= 64, lane = row): both passes, DPP
 // arg-min, no workgroup barrier. Returns the pivot row or INT_MAX; b / w / cc are this lane's basic variable, pair
 // word and counter (the caller fetches the winner's by v_readlane).
-template <class S> __device__ __forceinline__ int sm_ratio_wave(const Small<S> & P, int nv, int lane, int & b, uint32_t & w, int & cc, S & a)
+// (b, cc, bc -- this lane's basic variable, its pair counter and its constant-column entry -- do not depend on the column:
+// a caller that tries many columns in a row fetches them once)
+template <class S> __device__ __forceinline__ int sm_ratio_wave_with(const Small<S> & P, int nv, int lane, int b, int cc, S bc, uint32_t & w, S & a)
 {
     const int lim = P.rhs - 1, R = P.R, li = lane < R ? lane : 0;
     a = P.tab[li * P.ld + nv];
-    const S bc = P.tab[li * P.ld + P.rhs];
-    b = P.eq2bv[li];
     w = P.ppt[nv * P.pw + (b >> 5)];
-    cc = P.colcnt[b];
     const bool open = lane < R && !((w >> (b & 31)) & 1u) && cc < lim;
     const bool nonzero = open && !eq(a, zero<S>());
+    // no open row with a nonzero entry: both passes fail, and findPivotNVandBVPair's scan meets many such columns
+    // late in a long LP (an LP of the dependence-test family was measured at 12 us per pivot after 5 000 pivots, ~50
+    // failed candidates each) -- they leave before the quotient and the two arg-min chains
+    if (__ballot(nonzero) == 0ull) return INT_MAX;
     const S qr = nonzero ? q_div(P.cn, bc, a) : zero<S>();
     int row = wave_argmin_row(qr, nonzero && !le(a, zero<S>()), lane);
     if (row == INT_MAX) row = wave_argmin_row(qr, nonzero, lane);           // relaxed second pass: a != 0
     return row;
+}
+template <class S> __device__ __forceinline__ int sm_ratio_wave(const Small<S> & P, int nv, int lane, int & b, uint32_t & w, int & cc, S & a)
+{
+    const int li = lane < P.R ? lane : 0;
+    const S bc = P.tab[li * P.ld + P.rhs];
+    b = P.eq2bv[li];
+    cc = P.colcnt[b];
+    return sm_ratio_wave_with(P, nv, lane, b, cc, bc, w, a);
 }
 
 // SIX::findPivotNVandBVPair (lpsol.h:671-773) by wave 0 alone: candidates 64 per ballot in ascending order, positive
@@ -239,6 +259,9 @@ template <class S> __device__ __forceinline__ int sm_ratio_wave(const Small<S> &
 template <class S> __device__ __forceinline__ void sm_findpair_wave0(Small<S> & P)
 {
     const int lane = threadIdx.x, rhs = P.rhs, lim = rhs - 1;
+    const int li = lane < P.R ? lane : 0;
+    const int b = P.eq2bv[li], cc = P.colcnt[b];               // nothing the candidates share changes before one succeeds
+    const S bc = P.tab[li * P.ld + rhs];
     for (int pass = 0; pass < 2; pass++)
         for (int base = 0; base < rhs; base += 64) {
             const int i = base + lane;
@@ -251,8 +274,8 @@ template <class S> __device__ __forceinline__ void sm_findpair_wave0(Small<S> & 
             while (mask) {
                 const int cand = base + __ffsll((long long)mask) - 1;
                 mask &= mask - 1;
-                int b, cc; uint32_t w; S a;
-                const int row = sm_ratio_wave(P, cand, lane, b, w, cc, a);
+                uint32_t w; S a;
+                const int row = sm_ratio_wave_with(P, cand, lane, b, cc, bc, w, a);
 #ifdef XPG_STAMPS
                 if (lane == 0) FL_ADD(2, 1);
 #endif
@@ -477,6 +500,7 @@ template <class S, int CR, int CLD, int CT> __device__ __forceinline__ int sm_fa
         }
         P.pivots++;
         done++;
+        LIFE_MARK((int)blockIdx.x, P.pivots);
 #ifdef XPG_STAMPS
         if (tid == 0) FL_ADD(5, wall_clock64() - fl_t2);
         if (tid == 64) FL_ADD(6, wall_clock64() - fl_t2);
@@ -913,7 +937,9 @@ template <class S> __global__ __launch_bounds__(256, 4) void k_batch(int nb, con
         Source<S> src;
         src.leq = leq + (size_t)lp * m * cols; src.tgtf = tgtf + (size_t)lp * cols;
         src.m = m; src.cols = cols; src.is_max = is_max;
+        LIFE_MARK(lp, 0);
         const int status = sm_solve_lp<S>(P, src, max_iter, raw_sol, out_sol + (size_t)lp * cols, out_v + lp);
+        LIFE_END(lp);
         if (threadIdx.x == 0) {
             out_status[lp] = status;
             if (out_pivots) out_pivots[lp] = getenv_closes ? P.closes : P.pivots;

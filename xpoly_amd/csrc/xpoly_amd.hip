@@ -458,6 +458,17 @@ int xpg_lp_chain_aborts(xpg_lp * lp, unsigned * aborts, int * chain_off, unsigne
     return 0;
 }
 
+#ifdef XPG_LIFE
+// diagnostic builds (-DXPG_LIFE) only: the per-LP pivot time marks of k_batch (4096 LPs x 32 marks), cleared on read
+int xpg_life_debug(xpg_ctx * ctx, unsigned long long * out)
+{
+    XPG_BIND(ctx);
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_life), sizeof(unsigned long long) * 4096 * 32) != hipSuccess) return XPG_ERR_HIP;
+    std::vector<unsigned long long> z(4096 * 32, 0ull);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_life), z.data(), sizeof(unsigned long long) * 4096 * 32) != hipSuccess) return XPG_ERR_HIP;
+    return 0;
+}
+#endif
 #ifdef XPG_STAMPS
 // diagnostic builds only: reads and clears the tick sums of k_mip_tree (build, solve, feed)
 int xpg_mip_debug(xpg_ctx * ctx, unsigned long long * out4)
