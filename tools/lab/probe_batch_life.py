@@ -13,7 +13,7 @@ fam = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 L = lib()
 L.xpg_life_debug.argtypes = [C.c_void_p, C.c_void_p]
 buf = np.zeros(4096 * 32, dtype=np.uint64)
-for nb in (768,):
+for nb in ([int(a) for a in sys.argv[2:]] or [768]):
     leq, tg = gen.small_lp_batch_f64(nb, 32, 64, fam)
     d_leq = torch.from_numpy(leq).to(dev); d_tg = torch.from_numpy(tg).to(dev)
     d_st = torch.empty(nb, dtype=torch.int32, device=dev); d_v = torch.empty(nb, dtype=torch.float64, device=dev)
@@ -22,13 +22,15 @@ for nb in (768,):
         ctx.six_batch_dev(0, True, nb, d_tg.data_ptr(), d_leq.data_ptr(), 32, 64, d_st.data_ptr(), d_v.data_ptr(), d_sol.data_ptr(), d_piv.data_ptr())
         ctx.sync()
         assert L.xpg_life_debug(ctx._h, buf.ctypes.data_as(C.c_void_p)) == 0
-    t = buf.reshape(4096, 32)[:nb].astype(np.float64) / 100.0          # us
-    piv = d_piv.cpu().numpy()
+    nbm = min(nb, 4096)                                                 # the marks cover the first 4096 LPs
+    t = buf.reshape(4096, 32)[:nbm].astype(np.float64) / 100.0         # us
+    piv = d_piv.cpu().numpy()[:nbm]
+    nb_all, nb = nb, nbm
     t0 = t[:, 0].min()
     seg = []
     for k in range(1, 24):
         ok = (t[:, k] > 0) & (t[:, k - 1] > 0)
-        seg.append((t[ok, k] - t[ok, k - 1]).mean() / 256.0 if ok.sum() > nb // 4 else float("nan"))
+        seg.append((t[ok, k] - t[ok, k - 1]).mean() / 256.0 if ok.sum() > nb // 16 else float("nan"))
     # head: start -> first mark (pivot 256); tail: last mark -> end, against the pivots left after that mark
     last_k = np.array([max([k for k in range(1, 31) if t[b, k] > 0] or [0]) for b in range(nb)])
     tail = t[np.arange(nb), 31] - t[np.arange(nb), last_k]
