@@ -923,7 +923,11 @@ template <class S> __device__ __forceinline__ int sm_solve_lp(Small<S> & P, Sour
     return status;
 }
 
-template <class S> __global__ __launch_bounds__(256, 4) void k_batch(int nb, const S * tgtf, const S * leq, int m, int cols,
+// WAVES: waves per SIMD the kernel's registers allow = workgroups of 256 threads per CU. Five where five LPs fit a CU's
+// LDS (the 32 x 64 LPs of BASELINE configs[2]: 30 KB each): 96 registers and 336 bytes of scratch instead of 128 and 208,
+// and the fifth LP more than pays for the spills (8192 LPs: 92.9 k -> 98.3 k dependence-test, 252.9 k -> 286.4 k dense
+// LPs/s) -- the pivot is a latency chain, and what a CU lacks is LPs in flight. Four where LDS seats fewer anyway.
+template <class S, int WAVES> __global__ __launch_bounds__(256, WAVES) void k_batch(int nb, const S * tgtf, const S * leq, int m, int cols,
                                            int is_max, unsigned max_iter, int32_t * out_status,
                                            S * out_v, S * out_sol, uint32_t * out_pivots, int raw_sol)
 {
@@ -1020,9 +1024,16 @@ int batch_dev(xpg_ctx * ctx, int is_max, int nb, const S * tgtf, const S * leq, 
     int grid = 256 * (per_cu > 16 ? 16 : per_cu) * 64;
     if (const char * g = getenv("XPG_BATCH_GRID_X")) { const int v = atoi(g); if (v >= 1) grid = 256 * (per_cu > 16 ? 16 : per_cu) * v; }
     if (grid > nb) grid = nb;
-    XPG_HIP(ctx, lds_limit((const void *)k_batch<S>, ctx->device, lds));
-    hipLaunchKernelGGL((k_batch<S>), dim3(grid), dim3(threads), lds, ctx->stream, nb, tgtf, leq, m, cols,
-                       is_max ? 1 : 0, max_iter, out_status, out_v, out_sol, out_pivots, raw_sol);
+    static const int waves_env = [] { const char * e = getenv("XPG_BATCH_WAVES"); return e ? atoi(e) : 0; }();   // A/B: 4 or 5
+    if ((per_cu >= 5 && waves_env != 4) || waves_env == 5) {
+        XPG_HIP(ctx, lds_limit((const void *)k_batch<S, 5>, ctx->device, lds));
+        hipLaunchKernelGGL((k_batch<S, 5>), dim3(grid), dim3(threads), lds, ctx->stream, nb, tgtf, leq, m, cols,
+                           is_max ? 1 : 0, max_iter, out_status, out_v, out_sol, out_pivots, raw_sol);
+    } else {
+        XPG_HIP(ctx, lds_limit((const void *)k_batch<S, 4>, ctx->device, lds));
+        hipLaunchKernelGGL((k_batch<S, 4>), dim3(grid), dim3(threads), lds, ctx->stream, nb, tgtf, leq, m, cols,
+                           is_max ? 1 : 0, max_iter, out_status, out_v, out_sol, out_pivots, raw_sol);
+    }
     XPG_HIP(ctx, hipGetLastError());
     return 0;
 }
