@@ -270,3 +270,30 @@ def test_mip_with_root_equalities_on_the_host_controller_matches_oracle():
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["1"] > 60 and out["0"] > 60
+
+
+def test_has_solution_with_equalities_matches_oracle(ctx, port):
+    """Lineq::has_solution (src/com/linsys.cpp:830-906) with an equality system beside the inequalities: the integer
+    and the rational question, unique or not, on systems whose equalities pass through a lattice point or miss it.
+    The integer question is MIP::maxm / minm with equalities at the root -- the device tree walk since round 3."""
+    from xpoly_amd.six import has_solution
+    rng = np.random.default_rng(909)
+    seen = {}
+    for it in range(80):
+        nv = int(rng.integers(2, 6))
+        leq, vc = gen.random_feas(rng, int(rng.integers(1, 7)), nv)
+        xs = rng.integers(0, 4, size=nv)
+        me = int(rng.integers(1, 3))
+        Ae = rng.integers(-2, 3, size=(me, nv))
+        be = Ae @ xs + (rng.integers(0, 2, size=me) if rng.random() < 0.25 else 0)
+        eq = gen.to_rat(np.concatenate([Ae, np.asarray(be).reshape(me, 1)], axis=1).astype(np.int32))
+        for ii in (True, False):
+            for uu in (True, False):
+                want = port.has_solution(leq, eq, vc, nv, ii, uu)
+                if want == -7:
+                    continue
+                got = has_solution(ctx, leq, eq, vc, nv, ii, uu)
+                assert got == want, (it, ii, uu, got, want)
+                seen[want] = seen.get(want, 0) + 1
+    print("has_solution with equalities:", seen)
+    assert set(seen) == {0, 1}

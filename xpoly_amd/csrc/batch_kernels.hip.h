@@ -80,6 +80,7 @@ template <class S> __device__ __forceinline__ void sm_pivot(Small<S> & P, int nv
     if (threadIdx.x == 0) {
         P.nv[nv] = 0; P.nv[bv] = 1; P.bv[nv] = 1; P.bv[bv] = 0;
         P.eq2bv[r] = nv; P.bv2eq[nv] = r; P.bv2eq[bv] = -1;
+        XPG_TRACE_PIVOT("lds", nv, bv, r);
     }
     P.pivots++;
     __syncthreads();
@@ -91,15 +92,36 @@ template <class S> __device__ __forceinline__ int sm_ratio(const Small<S> & P, i
     const int lim = P.rhs - 1;
     for (int pass = 0; pass < 2; pass++) {
         Cand<S> best; best.q = zero<S>(); best.idx = INT_MAX;
+        bool weird = false;
         for (int i = threadIdx.x; i < P.R; i += blockDim.x) {
             const S a = P.tab[i * P.ld + nv];
             if (pass == 0 ? le(a, zero<S>()) : eq(a, zero<S>())) continue;
             const int b = P.eq2bv[i];
             if (sm_seen(P, nv, b) || P.colcnt[b] >= lim) continue;
             Cand<S> c; c.q = q_div(P.cn, P.tab[i * P.ld + P.rhs], a); c.idx = i;
+            weird |= unordered_value(c.q);
             best = better(best, c);
         }
         best = block_argmin(best, P.sh_c);
+        if (__syncthreads_or(weird ? 1 : 0)) {                  // a quotient with den <= 0: the reference's scan itself (lp_kernels.hip.h)
+            if (threadIdx.x < 64) {
+                const int lane = threadIdx.x;
+                int sbest = INT_MAX; S sq = zero<S>();
+                for (int base = 0; base < P.R; base += 64) {
+                    const int i = min(base + lane, P.R - 1);
+                    const S a = P.tab[i * P.ld + nv];
+                    const int b = P.eq2bv[i];
+                    bool ok = base + lane < P.R && !(pass == 0 ? le(a, zero<S>()) : eq(a, zero<S>()));
+                    ok = ok && !(sm_seen(P, nv, b) || P.colcnt[b] >= lim);
+                    const S q = ok ? q_div(P.cn, P.tab[i * P.ld + P.rhs], a) : zero<S>();
+                    scan_step_in_order(q, ok, base, sbest, sq);
+                }
+                if (lane == 0) P.sh_i[0] = sbest;
+            }
+            __syncthreads();
+            best.idx = P.sh_i[0];
+            __syncthreads();
+        }
         if (best.idx != INT_MAX) return P.eq2bv[best.idx];
     }
     return -1;
@@ -218,6 +240,7 @@ template <class S> __device__ __forceinline__ void sm_pivot_fast(Small<S> & P, i
     if (threadIdx.x == 0) {
         P.nv[nv] = 0; P.nv[bv] = 1; P.bv[nv] = 1; P.bv[bv] = 0;
         P.eq2bv[r] = nv; P.bv2eq[nv] = r; P.bv2eq[bv] = -1;
+        XPG_TRACE_PIVOT("lds", nv, bv, r);
     }
     P.pivots++;
     __syncthreads();
@@ -415,6 +438,7 @@ template <class S, int CR, int CLD, int CT> __device__ __forceinline__ int sm_fa
             if (lane == 0) {                                    // lpsol.h:1504-1510
                 P.nv[enter] = 0; P.nv[leave] = 1; P.bv[enter] = 1; P.bv[leave] = 0;
                 P.eq2bv[r] = enter; P.bv2eq[enter] = r; P.bv2eq[leave] = -1;
+                XPG_TRACE_PIVOT("lds-fast", enter, leave, r);
             }
             const int li = lane < R ? lane : 0;
             const int fc = have_first ? first : rhs;
@@ -727,6 +751,23 @@ template <class S> __device__ __forceinline__ int sm_phase_one(Small<S> & P, con
         best = better(best, c);
     }
     best = block_argmin(best, P.sh_c);
+    {
+        bool weird = false;
+        for (int i = threadIdx.x; i < P.R; i += blockDim.x) weird |= unordered_value(P.tab[i * P.ld + P.rhs]);
+        if (__syncthreads_or(weird ? 1 : 0)) {                  // lpsol.h:894-904 as written: row = 0; if (b[row] > b[i]) row = i
+            if (threadIdx.x < 64) {
+                int sbest = INT_MAX; S sq = zero<S>();
+                for (int base = 0; base < P.R; base += 64) {
+                    const int i = min(base + (int)threadIdx.x, P.R - 1);
+                    scan_step_in_order(P.tab[i * P.ld + P.rhs], base + (int)threadIdx.x < P.R, base, sbest, sq);
+                }
+                if (threadIdx.x == 0) P.sh_i[0] = sbest;
+            }
+            __syncthreads();
+            best.idx = P.sh_i[0];
+            __syncthreads();
+        }
+    }
     sm_pivot(P, xa, P.eq2bv[best.idx]);
     S top;
     if (sm_solve<S>(P, max_iter, top) != 0) return 0;

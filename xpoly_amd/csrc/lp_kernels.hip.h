@@ -242,8 +242,34 @@ __device__ __forceinline__ int wave_argmin_row(F64 q, bool valid, int lane)
     if (kmin == ~0ull) return INT_MAX;
     return __ffsll((long long)__ballot(key == kmin)) - 1;
 }
+// Rational comparisons order by cross-multiplication (rational.h: a.num * b.den < a.den * b.num), which is a strict
+// weak order only while every denominator is positive. The reference's own operations can leave den = 0 behind
+// (convertEq2Ineq divides by an equality's entry at the INEQUALITY's row index, lpsol.h:1232, which may be 0; MIP's
+// substituted nodes), and then +n/0 > 5 > -n/0 while +n/0 and -n/0 compare "equal": the winner of a scan depends on the
+// order the candidates are met in, and only the reference's own order -- rows ascending, `if (best > q) best = q` --
+// reproduces it. Every arg-min over Rational candidates therefore checks for such a candidate and, if there is one,
+// replays the sequential scan (64 rows per step: the lanes fetch, one scalar loop combines them in row order).
+template <class S> __device__ __forceinline__ bool unordered_value(S) { return false; }
+template <> __device__ __forceinline__ bool unordered_value<R32>(R32 q) { return q.den <= 0; }
+// One step of that scan over the 64 candidates of a wave (lane l = candidate base + l): best / bestq carry over.
+template <class S> __device__ __forceinline__ void scan_step_in_order(S q, bool valid, int base, int & best, S & bestq)
+{
+    unsigned long long m = __ballot(valid);
+    Cand<S> c; c.q = q; c.idx = 0;
+    while (m) {
+        const int l = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const S ql = read_lane(c, l).q;
+        if (best == INT_MAX || gt(bestq, ql)) { bestq = ql; best = base + l; }
+    }
+}
 template <class S> __device__ __forceinline__ int wave_argmin_row(S q, bool valid, int lane)   // Rational: the Cand tree
 {
+    if (__ballot(valid && unordered_value(q)) != 0ull) {         // not an order: the reference's scan itself
+        int best = INT_MAX; S bestq = zero<S>();
+        scan_step_in_order(q, valid, 0, best, bestq);
+        return best;
+    }
     Cand<S> c; c.q = q; c.idx = valid ? lane : INT_MAX;
     return __builtin_amdgcn_readfirstlane(wave_argmin(c).idx);
 }
@@ -276,6 +302,7 @@ template <class S> __device__ int ratio_test(const LpView<S> & v, int nv, Cand<S
     const bool cn = !is_f64<S>::value && v.st->noncanon == 0;      // Rational: the canonical quotient (rat_ops.hip.h)
     for (int pass = pass0 == -1 ? 1 : 0; pass < 2; pass++) {
         Cand<S> best; best.q = zero<S>(); best.idx = INT_MAX;
+        bool weird = false;
         // every load of a row is issued before the first test (two dependent rounds per U rows
         // instead of four per row): this workgroup is latency-bound, not bandwidth-bound
         for (int i0 = threadIdx.x; i0 < v.m; i0 += U * T) {
@@ -296,10 +323,35 @@ template <class S> __device__ int ratio_test(const LpView<S> & v, int nv, Cand<S
                 if (pass == 0 ? le(a[u], zero<S>()) : eq(a[u], zero<S>())) continue;
                 if (((w[u] >> (b[u] & 31)) & 1u) || cc[u] >= lim) continue;
                 Cand<S> c; c.q = l_div(cn, bb[u], a[u]); c.idx = i;
+                weird |= unordered_value(c.q);
                 best = better(best, c);
             }
         }
         best = block_argmin(best, sh);
+        if (__syncthreads_or(weird ? 1 : 0)) {
+            // a candidate quotient with den <= 0: replay the reference's scan of this pass (wave 0, rows in order)
+            __shared__ int sh_seq;
+            if (threadIdx.x < 64) {
+                const int lane = threadIdx.x;
+                int sbest = INT_MAX; S sq = zero<S>();
+                for (int base = 0; base < v.m; base += 64) {
+                    const int i = min(base + lane, v.m - 1);
+                    const S a = col_cached ? v.nextcol[i] : v.tab[(size_t)i * v.ld + nv];
+                    const S bb = b_cached ? v.bcol[i] : v.tab[(size_t)i * v.ld + v.rhs];
+                    const int b = v.eq2bv[i];
+                    const uint32_t w = v.ppt[(size_t)nv * v.pw + (b >> 5)];
+                    const int cc = v.colcnt[b];
+                    bool ok = base + lane < v.m && !(pass == 0 ? le(a, zero<S>()) : eq(a, zero<S>()));
+                    ok = ok && !(((w >> (b & 31)) & 1u) || cc >= lim);
+                    const S q = ok ? l_div(cn, bb, a) : zero<S>();
+                    scan_step_in_order(q, ok, base, sbest, sq);
+                }
+                if (lane == 0) sh_seq = sbest;
+            }
+            __syncthreads();
+            best.idx = sh_seq;
+            __syncthreads();
+        }
         if (best.idx != INT_MAX) return v.eq2bv[best.idx];
     }
     return -1;
@@ -399,6 +451,7 @@ template <class S> __device__ void pick_commit(const LpView<S> & v, int r, int e
     LoopState * st = v.st;
     v.nv[enter] = 0; v.nv[leave] = 1; v.bv[enter] = 1; v.bv[leave] = 0;   // lpsol.h:1504-1510
     v.eq2bv[r] = enter; v.bv2eq[enter] = r; v.bv2eq[leave] = -1;
+    XPG_TRACE_PIVOT("hbm-pick", enter, leave, r);
     const unsigned t = st->total_pivots;
     if ((int)t < v.trace_cap) { v.trace[2 * t] = enter; v.trace[2 * t + 1] = leave; }
     st->total_pivots = t + 1;
@@ -584,6 +637,7 @@ void k_prep(LpView<S> v, int guarded, int counted, int bookkeeping, int lookahea
         const int leave = st->leave;                           // :1504-1510
         v.nv[c] = 0; v.nv[leave] = 1; v.bv[c] = 1; v.bv[leave] = 0;
         v.eq2bv[r] = c; v.bv2eq[c] = r; v.bv2eq[leave] = -1;
+        XPG_TRACE_PIVOT("hbm-prep", c, leave, r);
         const unsigned t = st->total_pivots;
         if ((int)t < v.trace_cap) { v.trace[2 * t] = c; v.trace[2 * t + 1] = leave; }
         st->total_pivots = t + 1;
@@ -1250,6 +1304,21 @@ template <class S> __global__ __launch_bounds__(1024) void k_force_pivot(LpView<
         best = better(best, c);
     }
     best = block_argmin(best, sh);
+    bool weird = false;
+    for (int i = threadIdx.x; i < v.m; i += blockDim.x) weird |= unordered_value(v.tab[(size_t)i * v.ld + v.rhs]);
+    if (__syncthreads_or(weird ? 1 : 0)) {                      // lpsol.h:894-904 as written: row = 0; if (b[row] > b[i]) row = i
+        __shared__ int sh_seq;
+        if (threadIdx.x < 64) {
+            int sbest = INT_MAX; S sq = zero<S>();
+            for (int base = 0; base < v.m; base += 64) {
+                const int i = min(base + (int)threadIdx.x, v.m - 1);
+                scan_step_in_order(v.tab[(size_t)i * v.ld + v.rhs], base + (int)threadIdx.x < v.m, base, sbest, sq);
+            }
+            if (threadIdx.x == 0) sh_seq = sbest;
+        }
+        __syncthreads();
+        best.idx = sh_seq;
+    }
     if (threadIdx.x == 0) {
         LoopState * st = v.st;
         const int r = best.idx;

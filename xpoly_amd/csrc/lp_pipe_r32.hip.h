@@ -86,6 +86,7 @@ __device__ inline void pipe_pick_r32(const LpView<R32> & v, int slot, int colstr
     if (p == 0 && tid == 0) {                          // commit this iteration's pivot (lpsol.h:1504-1510)
         v.nv[ienter] = 0; v.nv[ileave] = 1; v.bv[ienter] = 1; v.bv[ileave] = 0;
         v.eq2bv[r] = ienter; v.bv2eq[ienter] = r; v.bv2eq[ileave] = -1;
+        XPG_TRACE_PIVOT("hbm-pipe", ienter, ileave, r);
         const unsigned t = total_now - 1;
         if ((int)t < v.trace_cap) { v.trace[2 * t] = ienter; v.trace[2 * t + 1] = ileave; }
         st->total_pivots = total_now; st->done = done_now;
@@ -125,6 +126,7 @@ __device__ inline void pipe_pick_r32(const LpView<R32> & v, int slot, int colstr
     if (tid == 0) { cnv_bits = to_bits(v.obj[xc]); rc_enter = v.rowcnt[xc]; }   // for the last adder's tail
     Cand<R32> best; best.q = zero<R32>(); best.idx = INT_MAX;
     R32 best_a = zero<R32>(); int best_b = 0, best_cc = 0; uint32_t best_w = 0;
+    bool weird = false;                                // a quotient with den <= 0: no order to reduce by (lp_kernels.hip.h)
     for (int i = p * 256 + tid; i < m; i += stride) {
         R32 * q = tab + (size_t)i * ld + xc;
         const R32 k = cb[i], bo = bcol[i], c0 = *q;    // every load of the row in flight before the first use
@@ -141,11 +143,13 @@ __device__ inline void pipe_pick_r32(const LpView<R32> & v, int slot, int colstr
         if (le(a, zero<R32>())) continue;                                      // findPivotBV, lpsol.h:553-663
         if (((w >> (bi & 31)) & 1u) || cc >= lim) continue;
         Cand<R32> c; c.q = l_div(cn, nb, a); c.idx = i;
+        weird |= unordered_value(c.q);
         const Cand<R32> nbest = better(best, c);
         if (nbest.idx != best.idx) { best_a = a; best_b = bi; best_cc = cc; best_w = w; }
         best = nbest;
     }
     const Cand<R32> wbest = block_argmin(best, sh_c);
+    const int wg_weird = __syncthreads_or(weird ? 1 : 0);
     // one lane publishes this workgroup's record: the owner of the winning row, else lane 0
     const bool publisher = wbest.idx != INT_MAX ? (best.idx == wbest.idx) : (tid == 0);
     if (tid == 0) { sh_cnv = cnv_bits; sh_rc = rc_enter; }
@@ -157,7 +161,7 @@ __device__ inline void pipe_pick_r32(const LpView<R32> & v, int slot, int colstr
     __hip_atomic_store(rec + 1, to_bits(best_a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(rec + 2, ((unsigned long long)(unsigned)wbest.idx << 32) | (unsigned)best_b, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(rec + 3, ((unsigned long long)best_w << 32) | (unsigned)best_cc, __ATOMIC_RELAXED,
+    __hip_atomic_store(rec + 3, ((unsigned long long)best_w << 32) | (unsigned)best_cc | (wg_weird ? 0x80000000u : 0u), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long arrived = __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -165,6 +169,7 @@ __device__ inline void pipe_pick_r32(const LpView<R32> & v, int slot, int colstr
     // ---- last adder: combine the records in workgroup order (ties: lowest row, lpsol.h:604-611)
     Cand<R32> g; g.q = zero<R32>(); g.idx = INT_MAX;
     R32 g_a = zero<R32>(); int g_b = 0, g_cc = 0; uint32_t g_w = 0;
+    bool any_weird = false;
     for (int k = 0; k < N; k++) {
         const unsigned long long * rk = v.pickrec + (size_t)k * PICK_REC_WORDS;
         const unsigned long long w0 = __hip_atomic_load(rk + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -172,11 +177,13 @@ __device__ inline void pipe_pick_r32(const LpView<R32> & v, int slot, int colstr
         const unsigned long long w2 = __hip_atomic_load(rk + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long w3 = __hip_atomic_load(rk + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         Cand<R32> c; c.q = from_bits<R32>(w0); c.idx = (int)(unsigned)(w2 >> 32);
+        any_weird |= ((unsigned)w3 & 0x80000000u) != 0u;
         const Cand<R32> ng = better(g, c);
-        if (ng.idx != g.idx) { g_a = from_bits<R32>(w1); g_b = (int)(unsigned)w2; g_w = (uint32_t)(w3 >> 32); g_cc = (int)(unsigned)w3; }
+        if (ng.idx != g.idx) { g_a = from_bits<R32>(w1); g_b = (int)(unsigned)w2; g_w = (uint32_t)(w3 >> 32); g_cc = (int)((unsigned)w3 & 0x7fffffffu); }
         g = ng;
     }
-    if (g.idx == INT_MAX) {                            // first pass empty: second pass / disableNV next launch
+    if (g.idx == INT_MAX || any_weird) {               // first pass empty (second pass / disableNV), or candidates that only the
+                                                       // reference's own scan order decides: the generic pick of the next launch
         write_desc(O, -1, 0, 0, first, anypos, 0, xc, 0, done_now, total_now, 0ull, 0ull);
         return;
     }

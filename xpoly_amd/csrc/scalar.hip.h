@@ -18,6 +18,13 @@
 
 #define XPG_HD __host__ __device__ __forceinline__
 
+// diagnostic builds (-DXPG_TRACE): every committed pivot of workgroup 0 is printed (entering, leaving, row)
+#if defined(XPG_TRACE) && defined(__HIP_DEVICE_COMPILE__)
+#define XPG_TRACE_PIVOT(tag_, e_, l_, r_) do { if (blockIdx.x == 0 && blockIdx.y == 0) printf("%s: enter %d leave %d row %d\n", tag_, (int)(e_), (int)(l_), (int)(r_)); } while (0)
+#else
+#define XPG_TRACE_PIVOT(tag_, e_, l_, r_) do { } while (0)
+#endif
+
 namespace xpg {
 
 // ---- fp64 --------------------------------------------------------------------
