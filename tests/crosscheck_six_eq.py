@@ -9,7 +9,7 @@ from tools import gen
 from oracle.checker import Port
 ctx = xpoly_amd.Context(0); port = Port()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 400
-bad = 0; total = 0; undefined = 0
+bad = 0; total = 0; undefined = 0; bad_by_kind = {0: 0, 1: 0}
 for kind in (1, 0):
     rng = np.random.default_rng(5150 + kind)
     six = SIX(ctx, kind)
@@ -31,7 +31,7 @@ for kind in (1, 0):
             same_v = np.array_equal(np.asarray(got[1]), np.asarray(want[1])) or (kind == 0 and np.asarray(got[1]).tobytes() == np.asarray(want[1]).tobytes())
             ok = got[0] == want[0] and same_v and (want[0] != 0 or np.array_equal(got[2], want[2]) or (kind == 0 and np.asarray(got[2]).tobytes() == np.asarray(want[2]).tobytes()))
             if not ok:
-                bad += 1
+                bad += 1; bad_by_kind[kind] += 1
                 if bad <= 5: print("MISMATCH kind", kind, "it", it, "max", is_max, "gpu", got[0], np.asarray(got[1]).tolist(), "oracle", want[0], np.asarray(want[1]).tolist(), "\n  leq", leq[..., 0].tolist() if kind else leq.tolist(), "\n  eq", eq[..., 0].tolist() if kind else eq.tolist(), "tg", tg[..., 0].tolist() if kind else tg.tolist())
         if kind == 1:
             for ii in (True, False):
@@ -42,4 +42,4 @@ for kind in (1, 0):
                     if got != want:
                         bad += 1
                         if bad <= 5: print("MISMATCH has_solution it", it, ii, uu, got, want)
-print("compared", total, "mismatches", bad, "reference-undefined skipped", undefined)
+print("compared", total, "mismatches", bad, "(fp64 %d, rational %d in SIX)" % (bad_by_kind[0], bad_by_kind[1]), "reference-undefined skipped", undefined)

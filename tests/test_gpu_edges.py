@@ -260,3 +260,47 @@ def test_wide_tableau_keeps_the_chain(port, monkeypatch):
     want = port.two_stage(F64, leq, tg, K)
     assert np.array_equal(a["tab"].view(np.uint64), want["tab"].view(np.uint64))
     assert np.array_equal(a["eq2bv"], want["eq2bv"])
+
+
+def test_fp64_loop_on_tableaux_with_inf_and_nan_cells(ctx, port):
+    """A Float tableau may hold inf / NaN (convertEq2Ineq divides by an equality entry that can be 0, lpsol.h:1232).
+    The reference then carries NaN through is_feasible's row sums (a nonbasic inf times an exact 0) and meets NaN
+    ratios in findPivotBV's scan, where only its own row order decides: statuses at every iteration limit, tableau,
+    objective row and basis must still be the oracle's (NaN = NaN: their signs and payloads differ between x86 and
+    the GPU). Regression test of round 3: k_rowcheck skipped nonbasic terms whatever they held."""
+    import xpoly_amd
+    F64 = 0
+    six = xpoly_amd.SIX(ctx, F64)
+    rng = np.random.default_rng(3)
+
+    def same(a, b):
+        a, b = np.asarray(a), np.asarray(b)
+        if a.shape != b.shape:
+            return False
+        if a.dtype != np.float64:
+            return a.tobytes() == b.tobytes()
+        na, nb = np.isnan(a), np.isnan(b)
+        return np.array_equal(na, nb) and a[~na].tobytes() == b[~nb].tobytes()
+    seen = set()
+    for it in range(60):
+        m, n = int(rng.integers(2, 8)), int(rng.integers(2, 7))
+        A = rng.integers(-3, 6, size=(m, n)).astype(np.float64)
+        A[rng.random((m, n)) < 0.3] = 0
+        b = rng.integers(-2, 9, size=m).astype(np.float64)
+        c = rng.integers(-2, 5, size=n).astype(np.float64)
+        leq = np.concatenate([A, b[:, None]], axis=1)
+        tg = np.concatenate([c, [0.0]])
+        for _ in range(int(rng.integers(1, 3))):
+            leq[int(rng.integers(0, m)), int(rng.integers(0, n + 1))] = rng.choice([np.inf, -np.inf, np.nan])
+        for K in (0, 1, 2, 3, 5, 1000):
+            want = port.two_stage(F64, leq, tg, K)
+            if want["status"] == -7:
+                continue
+            six.set_param(0, K)
+            got = six.TwoStageMethod(leq, tg)
+            assert got["status"] == want["status"], (it, K, got["status"], want["status"])
+            seen.add(want["status"])
+            if want["status"] != 2:
+                for k in ("tab", "tgtf", "eq2bv"):
+                    assert same(got[k], want[k]), (it, K, k)
+    assert len(seen) >= 3

@@ -205,8 +205,8 @@ template <class S> __device__ __forceinline__ Cand<S> wave_argmin(Cand<S> c)
 // not NaN (-0 and +0 are one value, then the usual monotone map of IEEE doubles), reduced by four DPP steps on 64-bit
 // integers, the lowest lane among the minima by ballot -- a third of the instructions of the Cand<F64> tree (three
 // registers through every step, two fp64 compares and an index compare per step). A NaN ratio compares "equal" to
-// everything in better() (both `>` are false), which no key can mimic: if any candidate ratio of the wave is a NaN the
-// Cand tree decides, as before.
+// everything in better() (both `>` are false), which no key -- and no tree -- can mimic: if any candidate ratio of the wave
+// is a NaN the rows are scanned in the reference's order (scan_step_in_order below is the same loop).
 __device__ __forceinline__ unsigned long long ratio_key_f64(double q)
 {
     const unsigned long long b = __builtin_bit_cast(unsigned long long, q + 0.0);   // (-0) + (+0) = +0
@@ -233,9 +233,17 @@ __device__ __forceinline__ unsigned long long wave_min_u64_dpp(unsigned long lon
 // The row (= lane) of the least ratio among the lanes with `valid`, lowest row on ties; INT_MAX if there is none.
 __device__ __forceinline__ int wave_argmin_row(F64 q, bool valid, int lane)
 {
-    if (__ballot(valid && q.v != q.v) != 0ull) {                // a NaN among the candidates: better()'s own rules
-        Cand<F64> c; c.q = q; c.idx = valid ? lane : INT_MAX;
-        return __builtin_amdgcn_readfirstlane(wave_argmin(c).idx);
+    if (__ballot(valid && q.v != q.v) != 0ull) {                // a NaN among the candidates: no order, the reference's scan itself
+        int best = INT_MAX; F64 bestq = F64(0.0);
+        unsigned long long m = __ballot(valid);
+        Cand<F64> c; c.q = q; c.idx = 0;
+        while (m) {
+            const int l = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const F64 ql = read_lane(c, l).q;
+            if (best == INT_MAX || gt(bestq, ql)) { bestq = ql; best = l; }
+        }
+        return best;
     }
     const unsigned long long key = valid ? ratio_key_f64(q.v) : ~0ull;
     const unsigned long long kmin = wave_min_u64_dpp(key);
@@ -251,6 +259,7 @@ __device__ __forceinline__ int wave_argmin_row(F64 q, bool valid, int lane)
 // replays the sequential scan (64 rows per step: the lanes fetch, one scalar loop combines them in row order).
 template <class S> __device__ __forceinline__ bool unordered_value(S) { return false; }
 template <> __device__ __forceinline__ bool unordered_value<R32>(R32 q) { return q.den <= 0; }
+template <> __device__ __forceinline__ bool unordered_value<F64>(F64 q) { return q.v != q.v; }   // a NaN ratio (inf / inf, 0 * inf upstream): `>` is false both ways
 // One step of that scan over the 64 candidates of a wave (lane l = candidate base + l): best / bestq carry over.
 template <class S> __device__ __forceinline__ void scan_step_in_order(S q, bool valid, int base, int & best, S & bestq)
 {
@@ -995,6 +1004,7 @@ __device__ inline void pipe_pick_f64(const LpView<F64> & v, int slot, int colstr
     constexpr int U = 2;
     Cand<F64> best; best.q = zero<F64>(); best.idx = INT_MAX;
     double best_a = 0.0; int best_b = 0, best_cc = 0; uint32_t best_w = 0;
+    bool weird = false;                                // a NaN ratio: only the reference's scan order decides (unordered_value)
     for (int i0 = p * 256 + tid; i0 < m; i0 += stride * U) {
         double k[U], bo[U], c0[U], c1[U];
         int bi[U], cc[U]; uint32_t w[U];
@@ -1027,12 +1037,14 @@ __device__ inline void pipe_pick_f64(const LpView<F64> & v, int slot, int colstr
             if (le(F64(a), zero<F64>())) continue;                            // findPivotBV, lpsol.h:553-663
             if (((w[u] >> (bi[u] & 31)) & 1u) || cc[u] >= lim) continue;
             Cand<F64> c; c.q = div(F64(nb), F64(a)); c.idx = i;
+            weird |= c.q.v != c.q.v;
             const Cand<F64> nbest = better(best, c);
             if (nbest.idx != best.idx) { best_a = a; best_b = bi[u]; best_cc = cc[u]; best_w = w[u]; }
             best = nbest;
         }
     }
     const Cand<F64> wbest = block_argmin(best, sh_c);
+    const int wg_weird = __syncthreads_or(weird ? 1 : 0);
     // one lane publishes this workgroup's record: the owner of the winning row, else lane 0
     const bool publisher = wbest.idx != INT_MAX ? (best.idx == wbest.idx) : (tid == 0);
     __shared__ unsigned long long sh_cnv; __shared__ int sh_rc;
@@ -1045,7 +1057,7 @@ __device__ inline void pipe_pick_f64(const LpView<F64> & v, int slot, int colstr
     __hip_atomic_store(rec + 1, to_bits(F64(best_a)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(rec + 2, ((unsigned long long)(unsigned)wbest.idx << 32) | (unsigned)best_b, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(rec + 3, ((unsigned long long)best_w << 32) | (unsigned)best_cc, __ATOMIC_RELAXED,
+    __hip_atomic_store(rec + 3, ((unsigned long long)best_w << 32) | (unsigned)best_cc | (wg_weird ? 0x80000000u : 0u), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long arrived = __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1053,6 +1065,7 @@ __device__ inline void pipe_pick_f64(const LpView<F64> & v, int slot, int colstr
     // ---- last adder: combine the records in workgroup order (ties: lowest row, lpsol.h:604-611)
     Cand<F64> g; g.q = zero<F64>(); g.idx = INT_MAX;
     double g_a = 0.0; int g_b = 0, g_cc = 0; uint32_t g_w = 0;
+    bool any_weird = false;
     for (int k = 0; k < N; k++) {
         const unsigned long long * rk = v.pickrec + (size_t)k * PICK_REC_WORDS;
         const unsigned long long w0 = __hip_atomic_load(rk + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1060,11 +1073,12 @@ __device__ inline void pipe_pick_f64(const LpView<F64> & v, int slot, int colstr
         const unsigned long long w2 = __hip_atomic_load(rk + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long w3 = __hip_atomic_load(rk + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         Cand<F64> c; c.q = from_bits<F64>(w0); c.idx = (int)(unsigned)(w2 >> 32);
+        any_weird |= ((unsigned)w3 & 0x80000000u) != 0u;
         const Cand<F64> ng = better(g, c);
-        if (ng.idx != g.idx) { g_a = from_bits<F64>(w1).v; g_b = (int)(unsigned)w2; g_w = (uint32_t)(w3 >> 32); g_cc = (int)(unsigned)w3; }
+        if (ng.idx != g.idx) { g_a = from_bits<F64>(w1).v; g_b = (int)(unsigned)w2; g_w = (uint32_t)(w3 >> 32); g_cc = (int)((unsigned)w3 & 0x7fffffffu); }
         g = ng;
     }
-    if (g.idx == INT_MAX) {                            // first pass empty: second pass / disableNV next launch
+    if (g.idx == INT_MAX || any_weird) {               // first pass empty (second pass / disableNV), or NaN ratios: next launch, generic pick
         write_desc(O, -1, 0, 0, first, anypos, 0, xc, 0, done_now, total_now, 0ull, 0ull);
         return;
     }
@@ -1177,8 +1191,12 @@ template <class S> __global__ void k_solution(LpView<S> v)
     }
 }
 // One thread per row; the sum runs over j ascending exactly as the reference
-// does, skipping nonbasic j whose x_j is an exact zero (adding a*0 leaves the
-// running sum unchanged for finite a).
+// does, skipping nonbasic j whose x_j is an exact zero where that term cannot change the sum: a * 0 is a zero for
+// a finite Float a (and an inf or NaN a -- what convertEq2Ineq's division by a zero entry leaves in a tableau -- makes
+// it NaN, which the reference's sum then carries into "optimal but infeasible": those terms stay); Rational's
+// a * 0 is 0/1 whatever a holds, and sum + 0/1 re-squeezes a sum that every earlier step already squeezed.
+__device__ __forceinline__ bool rowcheck_term_is_noop(F64 a) { return fabs(a.v) <= 1.7976931348623157e308; }
+__device__ __forceinline__ bool rowcheck_term_is_noop(R32) { return true; }
 template <class S> __global__ void k_rowcheck(LpView<S> v)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1186,7 +1204,7 @@ template <class S> __global__ void k_rowcheck(LpView<S> v)
     S sum = zero<S>();
     const S * row = v.tab + (size_t)i * v.ld;
     for (int j = 0; j < v.rhs; j++)
-        if (v.bv[j]) sum = add(sum, mul(row[j], v.x[j]));
+        if (v.bv[j] || !rowcheck_term_is_noop(row[j])) sum = add(sum, mul(row[j], v.x[j]));
     reduce(sum);
     S b = row[v.rhs];
     reduce(b);
