@@ -269,6 +269,7 @@ template <class S> struct Lp : LpBase {
     int final_status;
     hipEvent_t throttle[2] = {nullptr, nullptr};
     unsigned pipe_t = 0;    // pipelined loop: iteration counter since reset_loop (slot = pipe_t & 1)
+    bool irregular = false, irregular_known = false;   // fp64: the input held an inf / NaN (read back once per build)
     bool pipe_primed = false;
     int blk_batch = 0;      // blocked loop: id of the next batch since reset_loop
     bool closes_often = false;   // blocked loop: >= 5 % of this solve's sweeps so far were of a batch closed early
@@ -394,6 +395,7 @@ template <class S> struct Lp : LpBase {
         v.rhs = v.W - 1;
         // (a tableau that may grow -- warm-started branch and bound appends rows and slack columns -- keeps the allocation's)
         v.ld = row_cap == m ? pick_ld(v.W) : ld_cap;
+        irregular_known = false;
         hipLaunchKernelGGL((k_build<S>), dim3(2048), dim3(256), 0, ctx->stream, v, d_leq, d_tgtf, n0, with_xa);
         hipLaunchKernelGGL((k_init_basis<S>), dim3(64), dim3(256), 0, ctx->stream, v, n0 + (with_xa ? 1 : 0));
     }
@@ -419,8 +421,14 @@ template <class S> struct Lp : LpBase {
         unsigned blk = 0;
         // blocked loop: chosen explicitly, or by default where one sweep moves >= 16 MB (it trades
         // launches for HBM traffic; on small tableaux the pipelined loop's two launches per pivot win)
-        const bool blocked = std::is_same<S, F64>::value &&
-                             (ctx->loop_mode == 3 || (ctx->loop_auto && (size_t)v.m * v.W * 16 >= ((size_t)16 << 20)));
+        bool blocked = std::is_same<S, F64>::value &&
+                       (ctx->loop_mode == 3 || (ctx->loop_auto && (size_t)v.m * v.W * 16 >= ((size_t)16 << 20)));
+        if (blocked && !irregular_known) {                 // once per build: did k_build meet an inf or a NaN? (LoopState::noncanon)
+            LoopState hs;
+            if (read_state(&hs) == 0) irregular = hs.noncanon != 0;
+            irregular_known = true;
+        }
+        if (blocked && irregular) blocked = false;          // NaN ratios need the generic pick's scan order: the pipelined loop has it
         if (blocked) { queue_blocked(k); return; }
         // (the rational scalar: XPG_R32_LOOP=serial keeps the three-launch loop for A/B runs)
         static const bool r32_serial = [] { const char * s = getenv("XPG_R32_LOOP"); return s && !strcmp(s, "serial"); }();

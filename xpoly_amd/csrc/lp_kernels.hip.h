@@ -1222,7 +1222,10 @@ template <class S> __global__ void k_finish(LpView<S> v, S * maxv)
 
 // ---- slack-form construction (SIX::slack, lpsol.h:1406-1433; the xa column
 // of constructBasicFeasibleSolution, lpsol.h:860-868) straight into HBM.
-__device__ __forceinline__ bool is_canonical_cell(F64) { return true; }
+// (Float: a finite cell. A tableau that starts with an inf or a NaN meets NaN ratios, which only the reference's scan order
+// decides -- unordered_value above; the blocked loop's record hand-offs have no such path, so the host keeps an LP whose
+// input is not finite on the pipelined loop, whose picks defer those ratio tests to the generic pick.)
+__device__ __forceinline__ bool is_canonical_cell(F64 a) { return fabs(a.v) <= 1.7976931348623157e308; }
 __device__ __forceinline__ bool is_canonical_cell(R32 a) { return canonical(a); }
 template <class S> __global__ void k_build(LpView<S> v, const S * leq, const S * tgtf,
                                            int n, int with_xa)
