@@ -47,6 +47,37 @@ for rows, nv in ((5, 2), (12, 4), (16, 6), (30, 9)):
         if rk[b] != port.rat_rank(mats[b]):
             bad += 1
             if bad <= 5: print("rank mismatch", rows, nv, b, mats[b].tolist())
+    for unit in (False, True):
+        rk2, bas = lq.rankBasis(mats, unit)
+        for b in range(nb):
+            wr, wb = port.rat_rank_basis(mats[b], unit)
+            if rk2[b] != wr or not same(bas[b], wb):
+                bad += 1
+                if bad <= 5: print("rankBasis mismatch", rows, nv, unit, b, mats[b].tolist())
+    nl = lq.null(mats)
+    for b in range(nb):
+        if not np.array_equal(nl[b], port.rat_null(mats[b])):
+            bad += 1
+            if bad <= 5: print("null mismatch", rows, nv, b, mats[b].tolist())
+    mv = lq.move2var(np.concatenate([mats, mats[:, :, :2]], axis=2), nv, nv + 1, nv + 2)
+    for b in range(0, nb, 8):
+        if not np.array_equal(mv[b], port.move2var(np.concatenate([mats[b], mats[b][:, :2]], axis=1), nv, nv + 1, nv + 2)):
+            bad += 1
+            if bad <= 5: print("move2var mismatch", rows, nv, b)
+    if rows <= 12:
+        okb, bnd = lq.calcBound(mats[:64], nv, cap_rows=4 * rows * rows)
+        for b in range(64):
+            try:
+                wok, wb = port.calc_bound(mats[b], nv)
+            except RuntimeError:
+                continue
+            gok, gb = okb[b], bnd[b]
+            while gok < 0:                                     # an intermediate system outgrew the slots: -rows needed (of the step that overflowed); ask again
+                o2, b2 = lq.calcBound(mats[b:b + 1], nv, cap_rows=2 * int(-gok) + 64)
+                gok, gb = o2[0], b2[0]
+            if gok != wok or (wok and any(not same(gb[j], wb[j]) for j in range(nv))):
+                bad += 1
+                if bad <= 5: print("calcBound mismatch", rows, nv, b, mats[b].tolist())
     print("shape %dx%d: %d systems checked, %d mismatches so far" % (rows, nv + 1, nb, bad), flush=True)
 for n in (3, 4, 7):
     sq = np.stack([gen.random_square(rng, n) for _ in range(nb // 2)])
