@@ -103,7 +103,7 @@ template <class S> __device__ __forceinline__ int sm_ratio(const Small<S> & P, i
             best = better(best, c);
         }
         best = block_argmin(best, P.sh_c);
-        if (__syncthreads_or(weird ? 1 : 0)) {                  // a quotient with den <= 0: the reference's scan itself (lp_kernels.hip.h)
+        if (__builtin_expect(__syncthreads_or(weird ? 1 : 0), 0)) {   // an unordered quotient: the reference's scan itself (lp_kernels.hip.h)
             if (threadIdx.x < 64) {
                 const int lane = threadIdx.x;
                 int sbest = INT_MAX; S sq = zero<S>();
@@ -754,7 +754,7 @@ template <class S> __device__ __forceinline__ int sm_phase_one(Small<S> & P, con
     {
         bool weird = false;
         for (int i = threadIdx.x; i < P.R; i += blockDim.x) weird |= unordered_value(P.tab[i * P.ld + P.rhs]);
-        if (__syncthreads_or(weird ? 1 : 0)) {                  // lpsol.h:894-904 as written: row = 0; if (b[row] > b[i]) row = i
+        if (__builtin_expect(__syncthreads_or(weird ? 1 : 0), 0)) {   // lpsol.h:894-904 as written: row = 0; if (b[row] > b[i]) row = i
             if (threadIdx.x < 64) {
                 int sbest = INT_MAX; S sq = zero<S>();
                 for (int base = 0; base < P.R; base += 64) {

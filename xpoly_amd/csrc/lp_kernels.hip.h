@@ -233,7 +233,7 @@ __device__ __forceinline__ unsigned long long wave_min_u64_dpp(unsigned long lon
 // The row (= lane) of the least ratio among the lanes with `valid`, lowest row on ties; INT_MAX if there is none.
 __device__ __forceinline__ int wave_argmin_row(F64 q, bool valid, int lane)
 {
-    if (__ballot(valid && q.v != q.v) != 0ull) {                // a NaN among the candidates: no order, the reference's scan itself
+    if (__builtin_expect(__ballot(valid && q.v != q.v) != 0ull, 0)) {   // a NaN among the candidates: no order, the reference's scan itself
         int best = INT_MAX; F64 bestq = F64(0.0);
         unsigned long long m = __ballot(valid);
         Cand<F64> c; c.q = q; c.idx = 0;
@@ -274,7 +274,7 @@ template <class S> __device__ __forceinline__ void scan_step_in_order(S q, bool 
 }
 template <class S> __device__ __forceinline__ int wave_argmin_row(S q, bool valid, int lane)   // Rational: the Cand tree
 {
-    if (__ballot(valid && unordered_value(q)) != 0ull) {         // not an order: the reference's scan itself
+    if (__builtin_expect(__ballot(valid && unordered_value(q)) != 0ull, 0)) {   // not an order: the reference's scan itself
         int best = INT_MAX; S bestq = zero<S>();
         scan_step_in_order(q, valid, 0, best, bestq);
         return best;
@@ -337,7 +337,7 @@ template <class S> __device__ int ratio_test(const LpView<S> & v, int nv, Cand<S
             }
         }
         best = block_argmin(best, sh);
-        if (__syncthreads_or(weird ? 1 : 0)) {
+        if (__builtin_expect(__syncthreads_or(weird ? 1 : 0), 0)) {
             // a candidate quotient with den <= 0: replay the reference's scan of this pass (wave 0, rows in order)
             __shared__ int sh_seq;
             if (threadIdx.x < 64) {
@@ -1327,7 +1327,7 @@ template <class S> __global__ __launch_bounds__(1024) void k_force_pivot(LpView<
     best = block_argmin(best, sh);
     bool weird = false;
     for (int i = threadIdx.x; i < v.m; i += blockDim.x) weird |= unordered_value(v.tab[(size_t)i * v.ld + v.rhs]);
-    if (__syncthreads_or(weird ? 1 : 0)) {                      // lpsol.h:894-904 as written: row = 0; if (b[row] > b[i]) row = i
+    if (__builtin_expect(__syncthreads_or(weird ? 1 : 0), 0)) {  // lpsol.h:894-904 as written: row = 0; if (b[row] > b[i]) row = i
         __shared__ int sh_seq;
         if (threadIdx.x < 64) {
             int sbest = INT_MAX; S sq = zero<S>();
