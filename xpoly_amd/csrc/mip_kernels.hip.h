@@ -259,10 +259,8 @@ template <class S> __device__ __forceinline__ void mip_feed_products(const MipWs
 
 // MipTask::on_lp: feeds the node's answer to the recursion and runs it until the next LP is needed (returns
 // false) or the tree ends (returns true, ctl[MC_FINAL] set). Thread 0 only.
-template <class S> __device__ bool mip_feed(const MipWs<S> & w, const S * tgtf, int cols, bool is_max, bool is_bin, int st,
-                                            const uint8_t * allow)
+template <class S> __device__ bool mip_feed(const MipWs<S> & w, int cols, bool is_max, bool is_bin, int st, const uint8_t * allow)
 {
-    const int n0 = cols - 1;
     int top = w.ctl[MC_TOP];
     S v = zero<S>();
     int ret;
@@ -400,7 +398,7 @@ void k_mip_tree(int nb, const S * tgtf_all, const S * leq_all, int leq_rows, int
             }
             MIP_T(1)
             if (st == XPG_SIX_SUCC) mip_feed_products<S>(w, tgtf, cols);       // (st is the same in every thread)
-            if (threadIdx.x == 0) sh_ctl[0] = mip_feed<S>(w, tgtf, cols, is_max != 0, is_bin != 0, st, allow) ? 1 : 0;
+            if (threadIdx.x == 0) sh_ctl[0] = mip_feed<S>(w, cols, is_max != 0, is_bin != 0, st, allow) ? 1 : 0;
             __syncthreads();
             MIP_T(2)
             if (sh_ctl[0]) break;
