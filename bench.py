@@ -531,7 +531,7 @@ def main():
         if os.path.exists(PMC_BATCH):                   # measured with rocprofv3 --pmc, not in this run
             pb = json.load(open(PMC_BATCH))
             batched["issue_rate"] = dict(
-                bound="latency of the two-barrier pivot at 5 LPs per CU (LDS: 30 KB per LP; the kernel is held to 96 registers to seat the fifth); VALU 33-42 % busy (HBM sees 16 KiB in / 0.5 KiB out per LP)",
+                bound="latency of the two-barrier pivot at 5 LPs per CU (LDS: 30 KB per LP; the pivot loop is a function of its own on 88 registers, the kernel is held to 96 to seat the fifth LP); VALU 35-46 % busy (HBM sees 16 KiB in / 0.5 KiB out per LP)",
                 dep_test_like=dict(valu_busy_percent=pb.get("dep_test_like_busy_percent", {}).get("VALUBusy"),
                                    salu_busy_percent=pb.get("dep_test_like_busy_percent", {}).get("SALUBusy"),
                                    wave_instructions_per_pivot=pb.get("dep_test_like_per_pivot")),
