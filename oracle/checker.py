@@ -128,7 +128,8 @@ class _Lib:
                     eq2bv=eq2bv[:r].copy(), rhs=rhs, maxv=maxv[0], sol=sol[:c].copy())
 
     # ---- MIP::maxm / minm (lpsol.h:2636 / :2681) -------------------------
-    def mip_solve(self, kind, is_max, is_bin, tgtf, vc, eq, leq, rat_ind=None):
+    def mip_solve(self, kind, is_max, is_bin, tgtf, vc, eq, leq, rat_ind=None, stats=None):
+        """stats: a dict that receives {"nodes", "max_leq_rows"} of the tree walk."""
         tgtf = as_kind(tgtf, kind, 1)
         cols = tgtf.shape[-1] if kind == F64 else tgtf.shape[-2]
         vc = as_kind(vc, kind, 2)
@@ -139,12 +140,20 @@ class _Lib:
         ind = None if rat_ind is None else np.ascontiguousarray(rat_ind, dtype=np.uint8)
         v = empty_kind((1,), kind)
         sol = empty_kind((cols,), kind)
-        fn = self._f("mip_solve")
-        fn.restype = C.c_int
-        st = fn(C.c_int(kind), C.c_int(int(is_max)), C.c_int(int(is_bin)),
+        args = [C.c_int(kind), C.c_int(int(is_max)), C.c_int(int(is_bin)),
                 _vp(tgtf), _vp(vc), C.c_int(vc.shape[0]), _vp(eq_a),
                 C.c_int(eq_rows), _vp(leq_a), C.c_int(leq_rows), C.c_int(cols),
-                _vp(ind), _vp(v), _vp(sol))
+                _vp(ind), _vp(v), _vp(sol)]
+        if stats is None:
+            fn = self._f("mip_solve")
+            fn.restype = C.c_int
+            st = fn(*args)
+        else:
+            fn = self._f("mip_solve_stats")
+            fn.restype = C.c_int
+            nodes, rows = C.c_long(0), C.c_int(0)
+            st = fn(*args, C.byref(nodes), C.byref(rows))
+            stats["nodes"], stats["max_leq_rows"] = nodes.value, rows.value
         return st, v[0], sol
 
     # ---- Rational / Float scalars ----------------------------------------

@@ -105,11 +105,11 @@ int t_two_stage(const void * leq, int m, int cols, const void * vc, const void *
 template <class S>
 int t_mip_solve(int is_max, int is_bin, const void * tgtf, const void * vc, int vc_rows,
                 const void * eq, int eq_rows, const void * leq, int leq_rows, int cols,
-                const uint8_t * rat_ind, void * out_v, void * out_sol, long * nodes)
+                const uint8_t * rat_ind, void * out_v, void * out_sol, long * nodes, int * max_leq_rows = 0)
 {
     Problem<S> Q = load_problem<S>(tgtf, vc, vc_rows, eq, eq_rows, leq, leq_rows, cols);
     S v; std::vector<S> sol;
-    int st = mip_solve(Q, is_max != 0, is_bin != 0, rat_ind, v, sol, nodes);
+    int st = mip_solve(Q, is_max != 0, is_bin != 0, rat_ind, v, sol, nodes, max_leq_rows);
     Raw<S>::put(out_v, 0, v);
     if (st == IP_SUCC && (int)sol.size() == cols) store(sol, out_sol);
     return st;
@@ -171,6 +171,19 @@ int orc_mip_solve(int kind, int is_max, int is_bin, const void * tgtf, const voi
                                 cols, rat_ind, out_v, out_sol, 0);
     return t_mip_solve<R32>(is_max, is_bin, tgtf, vc, vc_rows, eq, eq_rows, leq, leq_rows,
                             cols, rat_ind, out_v, out_sol, 0);
+}
+
+// the same solve with tree statistics (how many nodes, the most inequality rows a node LP had): for tests that must
+// know a tree went deep enough to reach a particular kernel path
+int orc_mip_solve_stats(int kind, int is_max, int is_bin, const void * tgtf, const void * vc,
+                        int vc_rows, const void * eq, int eq_rows, const void * leq, int leq_rows,
+                        int cols, const uint8_t * rat_ind, void * out_v, void * out_sol, long * nodes, int * max_leq_rows)
+{
+    if (kind == 0)
+        return t_mip_solve<F64>(is_max, is_bin, tgtf, vc, vc_rows, eq, eq_rows, leq, leq_rows,
+                                cols, rat_ind, out_v, out_sol, nodes, max_leq_rows);
+    return t_mip_solve<R32>(is_max, is_bin, tgtf, vc, vc_rows, eq, eq_rows, leq, leq_rows,
+                            cols, rat_ind, out_v, out_sol, nodes, max_leq_rows);
 }
 
 void orc_rat_op(int op, int32_t an, int32_t ad, int32_t bn, int32_t bd, int32_t * rn,

@@ -23,6 +23,10 @@ int orc_two_stage_trace(int kind, const void * leq, int m, int cols, const void 
 int orc_mip_solve(int kind, int is_max, int is_bin, const void * tgtf, const void * vc,
                   int vc_rows, const void * eq, int eq_rows, const void * leq, int leq_rows,
                   int cols, const uint8_t * rat_ind, void * out_v, void * out_sol);
+int orc_mip_solve_stats(int kind, int is_max, int is_bin, const void * tgtf, const void * vc,
+                        int vc_rows, const void * eq, int eq_rows, const void * leq, int leq_rows,
+                        int cols, const uint8_t * rat_ind, void * out_v, void * out_sol, long * nodes,
+                        int * max_leq_rows);
 void orc_rat_op(int op, int32_t an, int32_t ad, int32_t bn, int32_t bd, int32_t * rn,
                 int32_t * rd);
 int orc_rat_cmp(int cmp, int32_t an, int32_t ad, int32_t bn, int32_t bd);

@@ -564,7 +564,8 @@ template <class S> struct Mip {
     const uint8_t * allow_rational;   // 1 x cols or null
     int rhs0;
     long nodes;
-    Mip() : have_best(false), allow_rational(0), rhs0(0), nodes(0) {}
+    int max_leq_rows;                 // the most inequality rows any node LP had (test statistics only)
+    Mip() : have_best(false), allow_rational(0), rhs0(0), nodes(0), max_leq_rows(0) {}
 
     bool all_int(const std::vector<S> & s, int & col) const               // xmat.cpp:603-616, :1523-1536
     {
@@ -604,6 +605,7 @@ template <class S> struct Mip {
              S & v, std::vector<S> & sol)                                  // lpsol.h:2427-2612
     {
         nodes++;
+        if (Q.leq.r > max_leq_rows) max_leq_rows = Q.leq.r;
         int st = is_max ? six_maxm(Q, 10000u, v, sol) : six_minm(Q, 10000u, v, sol);
         if (st < 0) return st;
         if (st != SIX_SUCC) {
@@ -661,7 +663,7 @@ template <class S> struct Mip {
 
 template <class S>
 int mip_solve(const Problem<S> & Q, bool is_max, bool is_bin, const uint8_t * allow_rational,
-              S & v, std::vector<S> & sol, long * nodes = 0)
+              S & v, std::vector<S> & sol, long * nodes = 0, int * max_leq_rows = 0)
 {
     Mip<S> M;
     M.allow_rational = allow_rational;
@@ -670,6 +672,7 @@ int mip_solve(const Problem<S> & Q, bool is_max, bool is_bin, const uint8_t * al
     v = S(0);
     int st = M.node(Q, is_max, is_bin, forks, v, sol);
     if (nodes) *nodes = M.nodes;
+    if (max_leq_rows) *max_leq_rows = M.max_leq_rows;
     return st;
 }
 

@@ -297,3 +297,37 @@ def test_has_solution_with_equalities_matches_oracle(ctx, port):
                 seen[want] = seen.get(want, 0) + 1
     print("has_solution with equalities:", seen)
     assert set(seen) == {0, 1}
+
+
+def test_f64_mip_whose_nodes_pass_32_rows_in_a_block_carved_for_more(ctx, port):
+    """25 inequalities, 35 integer variables, maximising: the tree's LDS block is carved for rmax = 60 rows with row
+    stride 97, the walk runs 256 threads, and at depth 7 a node LP has exactly 32 live rows and stride 97 -- the shape
+    the specialised pivot loop of the 32 x 64 batch kernel is compiled for, in a block laid out differently (its
+    objective row sits 60 rows behind the tableau base, not 32). The trees must match the oracle's all the way down
+    (round-3 advisor finding; lpsol.h:2427-2612)."""
+    from xpoly_amd.six import MIP, mip_batch
+    rng = np.random.default_rng(41)
+    vc = gen.vc_nonneg(35, True)
+    probs, wants, deep = [], [], 0
+    while len(probs) < 12:
+        leq, tg = gen.interval_mip_f64(rng, 25, 35, int(rng.choice([3, 6, 12])))
+        st = {}
+        w = port.mip_solve(F64, True, False, tg, vc, None, leq, stats=st)
+        if w[0] < 0:
+            continue
+        deep += st["max_leq_rows"] >= 32
+        probs.append((leq, tg)); wants.append(w)
+    assert deep >= 6                                       # most of these trees do pass through 32 rows
+    mip = MIP(ctx, F64)
+    for (leq, tg), want in zip(probs, wants):              # one tree per call (xpg_mip_maxm_f64)
+        got = mip.maxm(tg, vc, None, leq, False, None)
+        assert got[0] == want[0]
+        assert np.array_equal(np.atleast_1d(got[1]), np.atleast_1d(want[1]))
+        if want[0] == 0:
+            assert np.array_equal(got[2].reshape(-1), want[2].reshape(-1))
+    st, v, sol, nodes = mip_batch(ctx, True, False, np.stack([p[1] for p in probs]), np.stack([p[0] for p in probs]), kind=F64)
+    for b, want in enumerate(wants):                       # and as one batch (xpg_mip_batch_f64)
+        assert st[b] == want[0], b
+        assert np.array_equal(np.atleast_1d(v[b]), np.atleast_1d(want[1])), b
+        if want[0] == 0:
+            assert np.array_equal(sol[b].reshape(-1), want[2].reshape(-1)), b

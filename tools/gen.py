@@ -256,3 +256,25 @@ def knapsack_batch_rat(nb, nv, seed=XS_SEED):
     leq = np.concatenate([cap, np.broadcast_to(ub, (nb, nv, nv + 1))], axis=1)
     tgtf = np.concatenate([c, np.zeros((nb, 1), dtype=np.int32)], axis=1)
     return to_rat(np.ascontiguousarray(leq)), to_rat(tgtf)
+
+
+def interval_mip_f64(rng, m=25, nv=35, maxlen=6):
+    """An integer program whose fp64 arithmetic is exact and whose tree goes deep: consecutive-ones rows (totally
+    unimodular), half-integer right-hand sides, so every basic solution is a multiple of 1/2 and the walk branches
+    on one variable after the other (up to nv bound rows on top of the m inequalities). Returns (leq, tgtf)."""
+    A = np.zeros((m, nv), dtype=np.int64)
+    starts = np.linspace(0, nv, 13).astype(int)     # the first 12 rows tile the columns: every variable is bounded
+    r = 0
+    for k in range(12):
+        A[r, starts[k]:starts[k + 1]] = 1
+        r += 1
+    while r < m:
+        a = int(rng.integers(0, nv - 1))
+        L = int(rng.integers(2, maxlen + 1))
+        A[r, a:min(nv, a + L)] = 1
+        r += 1
+    b = rng.integers(1, 6, size=m) + 0.5
+    c = rng.integers(1, 9, size=nv)
+    leq = np.concatenate([A, b[:, None]], axis=1).astype(np.float64)
+    tgtf = np.concatenate([c, [0]]).astype(np.float64)
+    return leq, tgtf

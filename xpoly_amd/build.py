@@ -2,21 +2,39 @@
 
 -ffp-contract=off is part of the numerical contract, not a tuning flag: the
 reference rounds after the multiply and again after the add (lpsol.h:1485-1489).
+
+csrc/xpoly_amd.hip is compiled four times in parallel (-DXPG_PART=0..3, each part
+holding the entry points of one subsystem and including only the kernel headers
+they launch) and the objects are linked into one shared object: the device code
+of all kernels in one translation unit took 4.7 minutes, the parts take about
+the time of the largest. XPG_BUILD_MONOLITHIC=1 builds the single-TU form.
 """
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "xpoly_amd.hip")
 OUT = os.path.join(HERE, "libxpoly_amd.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
+OBJ = os.path.join(HERE, "csrc", "_obj")
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17"]
+PARTS = 4
+# headers each part includes (directly or not): a part is recompiled when one of them, or xpoly_amd.hip, is newer than
+# its object
+COMMON = ["xpoly_amd.hip", "scalar.hip.h", "ctx.hip.h", "rat_ops.hip.h", "../../include/xpoly_amd.h"]
+DEPS = {
+    0: ["lp_kernels.hip.h", "lp_pipe_r32.hip.h", "lp_host.hip.h", "lp_blocked.hip.h", "lp_chain.hip.h", "warm_mip.hip.h"],
+    1: ["lp_kernels.hip.h", "six_host.hip.h", "batch_kernels.hip.h"],
+    2: ["lp_kernels.hip.h", "six_host.hip.h", "batch_kernels.hip.h", "lineq_shared.hip.h", "mip_host.hip.h", "mip_kernels.hip.h"],
+    3: ["lineq_shared.hip.h", "lineq_host.hip.h", "lineq_kernels.hip.h"],
+}
 
 
 def sources():
     d = os.path.join(HERE, "csrc")
     inc = os.path.join(HERE, "..", "include", "xpoly_amd.h")
-    return [os.path.join(d, f) for f in sorted(os.listdir(d))] + [inc]
+    return [os.path.join(d, f) for f in sorted(os.listdir(d)) if os.path.isfile(os.path.join(d, f))] + [inc]
 
 
 def stale():
@@ -26,11 +44,37 @@ def stale():
     return any(os.path.getmtime(s) > t for s in sources())
 
 
-def build(force=False):
+def build(force=False, extra=()):
     if not force and not stale():
         return OUT
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    subprocess.check_call([hipcc] + FLAGS + ["-o", OUT, SRC])
+    extra = list(extra) + os.environ.get("XPG_BUILD_FLAGS", "").split()
+    if os.environ.get("XPG_BUILD_MONOLITHIC") == "1":
+        subprocess.check_call([hipcc] + CFLAGS + extra + ["-shared", "-o", OUT, SRC])
+        return OUT
+    os.makedirs(OBJ, exist_ok=True)
+    objs = [os.path.join(OBJ, "part%d.o" % p) for p in range(PARTS)]
+
+    flags_key = " ".join(CFLAGS + extra)
+    key_file = os.path.join(OBJ, "flags.txt")
+    same_flags = os.path.exists(key_file) and open(key_file).read() == flags_key
+
+    def part_stale(p):
+        if not same_flags or not os.path.exists(objs[p]):
+            return True
+        t = os.path.getmtime(objs[p])
+        d = os.path.join(HERE, "csrc")
+        return any(os.path.getmtime(os.path.join(d, f)) > t for f in COMMON + DEPS[p])
+
+    def one(p):
+        if part_stale(p):
+            subprocess.check_call([hipcc] + CFLAGS + extra + ["-DXPG_PART=%d" % p, "-c", SRC, "-o", objs[p]])
+
+    with ThreadPoolExecutor(max_workers=PARTS) as ex:
+        list(ex.map(one, range(PARTS)))
+    with open(key_file, "w") as f:
+        f.write(flags_key)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", OUT] + objs)
     return OUT
 
 

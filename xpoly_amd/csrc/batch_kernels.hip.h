@@ -590,7 +590,11 @@ template <class S> __device__ __forceinline__ int sm_solve(Small<S> & P, unsigne
     while (done < max_iter) {
         if (overlapped) {
             int action;
-            if (!is_f64<S>::value || P.R != 32 || P.ld != 97 || blockDim.x != 256) action = sm_fast_loop<S, 0, 0, 0>(P, max_iter, done, preselected);
+            // the specialised loop re-derives every array from the tableau base as sm_carve(32, 63) lays them out: the LDS
+            // must really have been carved for 32 rows (a MIP node with 32 live rows in a block carved for rmax = 60 has
+            // R == 32 and ld == 97 too, and its objective row sits 60 rows behind the base, not 32)
+            const bool carved_32x63 = (const unsigned char *)P.obj - (const unsigned char *)P.tab == (ptrdiff_t)32 * 97 * 8;
+            if (!is_f64<S>::value || P.R != 32 || P.ld != 97 || blockDim.x != 256 || !carved_32x63) action = sm_fast_loop<S, 0, 0, 0>(P, max_iter, done, preselected);
             else {
                 const FastLoopRet fr = sm_fast_loop_32x97x256<S>((__attribute__((address_space(3))) unsigned char *)P.tab, P.W, P.rhs, P.cn, P.pivots,
                                                                  P.closes, max_iter, done, preselected);

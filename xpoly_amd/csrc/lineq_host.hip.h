@@ -3,82 +3,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <chrono>
-#include "lp_host.hip.h"
+#include "ctx.hip.h"
 #include "lineq_kernels.hip.h"
 
 namespace xpg {
 
-// Device scratch of one host-array call. The blocks come from, and go back to, a small cache the handle owns
-// (freed with it): a caller that eliminates one system per call -- the drop-in adapter does -- would otherwise pay
-// four hipMalloc / hipFree pairs per call, more than the kernel.
-struct DevBuf {
-    void * p; size_t cap; xpg_ctx * owner;
-    DevBuf() : p(0), cap(0), owner(0) {}
-    ~DevBuf()
-    {
-        if (!p) return;
-        if (!owner || cap > ((size_t)1 << 30)) { (void)hipFree(p); return; }
-        // park the block; when the cache is full (16 blocks / 1 GiB) the LARGEST parked blocks go first, so that the
-        // small blocks of one-system callers are not crowded out by what a large batch left behind
-        while (!owner->dev_cache.empty() && (owner->dev_cache.size() >= 16 || owner->dev_cache_bytes + cap > ((size_t)1 << 30))) {
-            size_t big = 0;
-            for (size_t i = 1; i < owner->dev_cache.size(); i++) if (owner->dev_cache[i].second > owner->dev_cache[big].second) big = i;
-            (void)hipFree(owner->dev_cache[big].first);
-            owner->dev_cache_bytes -= owner->dev_cache[big].second;
-            owner->dev_cache.erase(owner->dev_cache.begin() + (long)big);
-        }
-        owner->dev_cache.push_back(std::make_pair(p, cap));
-        owner->dev_cache_bytes += cap;
-    }
-    hipError_t alloc(xpg_ctx * ctx, size_t bytes)
-    {
-        if (bytes < 256) bytes = 256;
-        owner = ctx;
-        int best = -1;                                   // the smallest cached block that is large enough
-        for (size_t i = 0; i < ctx->dev_cache.size(); i++)
-            if (ctx->dev_cache[i].second >= bytes && (best < 0 || ctx->dev_cache[i].second < ctx->dev_cache[(size_t)best].second)) best = (int)i;
-        if (best >= 0 && ctx->dev_cache[(size_t)best].second <= 2 * bytes + 4096) {
-            p = ctx->dev_cache[(size_t)best].first; cap = ctx->dev_cache[(size_t)best].second;
-            ctx->dev_cache_bytes -= cap;
-            ctx->dev_cache.erase(ctx->dev_cache.begin() + best);
-            return hipSuccess;
-        }
-        cap = bytes;
-        hipError_t e = hipMalloc(&p, bytes);
-        if (e != hipSuccess) {                           // make room: drop the cache and try once more
-            for (auto & b : ctx->dev_cache) (void)hipFree(b.first);
-            ctx->dev_cache.clear(); ctx->dev_cache_bytes = 0;
-            e = hipMalloc(&p, bytes);
-        }
-        if (e != hipSuccess) { p = 0; cap = 0; }
-        return e;
-    }
-};
-
-inline int lineq_grid(int nb) { return nb < 256 * 16 ? nb : 256 * 16; }
-// Lanes per system: the smallest of 16 / 32 / 64 that covers `width` (the columns for the column-parallel Gauss
-// kernels; columns AND rows for reduce, whose duplicate-row and classification passes run one lane per row; fme
-// always takes the whole wave for its P x N result rows); a wave then carries 64 / L systems -- as long as their
-// LDS slices fit the 64 KB a workgroup gets by default. Groups of one wave that take different branches run one
-// after the other, so packing pays where the control flow is mostly shared (measured: DESIGN.md section 4).
-struct LineqGeom { int L, G; size_t lds; dim3 block; int grid; int sys_lds; };
-inline LineqGeom lineq_geom(int nb, int width, size_t sys_lds)
-{
-    LineqGeom q;
-    q.L = width <= 16 ? 16 : (width <= 32 ? 32 : 64);
-    if (const char * e = getenv("XPG_LINEQ_LANES")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) q.L = v > q.L ? v : q.L; }
-    sys_lds = (sys_lds + 15) & ~(size_t)15;
-    while (q.L < 64 && sys_lds * (size_t)(64 / q.L) > 64 * 1024) q.L *= 2;
-    q.G = 64 / q.L;
-    q.sys_lds = (int)sys_lds;
-    q.lds = sys_lds * (size_t)q.G;
-    q.block = dim3((unsigned)q.L, (unsigned)q.G);
-    const int wgs = (nb + q.G - 1) / q.G;
-    q.grid = lineq_grid(wgs);
-    return q;
-}
-
-#define XPG_TRY(e_) do { hipError_t err_ = (e_); if (err_ != hipSuccess) { ctx->err = std::string(#e_) + ": " + hipGetErrorString(err_); return XPG_ERR_HIP; } } while (0)
 
 // mode 0: removeIdenRow, 1: reduce -- in place on mats[nb][rows][cols]. The *_dev forms take device arrays and
 // only enqueue (the caller synchronises the handle's stream); the host-array forms stage through them.
@@ -427,5 +356,7 @@ inline int int_gcd_batch(xpg_ctx * ctx, int nb, int32_t * mats, int rows, int co
     XPG_TRY(hipStreamSynchronize(ctx->stream));
     return 0;
 }
+
+
 
 } // namespace xpg

@@ -16,6 +16,7 @@
 #pragma once
 #include "scalar.hip.h"
 #include "rat_ops.hip.h"
+#include "lineq_shared.hip.h"
 #include <limits.h>
 
 namespace xpg {
@@ -361,12 +362,7 @@ __device__ inline WScratch carve_scratch(unsigned char * p, int cap)
     s.drop = p;
     return s;
 }
-__host__ __device__ inline size_t lineq_lds_bytes(int cap, int cols)
-{
-    size_t b = (size_t)cap * cols * 8;
-    b += (size_t)(cap + 1) * 4 + 16 + (size_t)((cap + 1) & ~1) * 4 + (size_t)((cap + 3) & ~3);
-    return (b + 15) & ~(size_t)15;
-}
+// (lineq_lds_bytes, the LDS bytes of one system with this carve: lineq_shared.hip.h)
 
 // mode 0: removeIdenRow, 1: reduce. One wave per system; in/out [nb][rows][cols] in place.
 __global__ __launch_bounds__(64) void k_reduce_batch(int nb, R32 * mats, int rows, int cols, int rhs,

@@ -14,92 +14,12 @@
 #include <vector>
 #include <stdio.h>
 #include "../../include/xpoly_amd.h"
+#include "ctx.hip.h"
 #include "lp_kernels.hip.h"
 #include "lp_blocked.hip.h"
 #include "lp_chain.hip.h"
 
-struct xpg_ctx {
-    int device;
-    hipStream_t stream;
-    std::string err;
-    // scratch of the one-shot K1 entry points (xpg_pivot_*_dev)
-    void * rowbuf; void * colbuf; xpg::LoopState * st; size_t row_cap, col_cap;
-    void * stage; size_t stage_cap;   // grow-only device staging of the host-array batch entry points
-    void * hstage; size_t hstage_cap; // its pinned host mirror (the MIP controller packs node batches into it)
-    void * hpack = 0; size_t hpack_cap = 0;   // pinned host buffer of the packed-result entry points (the view they return)
-    std::vector<xpg_ctx *> lanes;             // extra handles on the same device, one per concurrent shape class of a ragged call
-    std::vector<std::pair<void *, size_t> > dev_cache;   // device blocks between host-array row-elimination calls (DevBuf)
-    size_t dev_cache_bytes = 0;
-    int update_variant;     // tuning knob for the fp64 sweep (see launch_update_f64)
-    int loop_mode;          // 0: pipelined fp64 loop (2 launches per pivot), 1: serial pick/prep/update
-    int zigzag;             // pipelined sweep alternates its tile order (Infinity Cache reuse)
-    int block_len;          // blocked loop (loop_mode 3): pivots staged per sweep, 1..16
-    int loop_auto;          // XPG_LOOP unset: blocked loop where the sweep is what costs (large fp64 tableaux)
-    int num_cus;            // compute units of the device
-    int chain;              // blocked loop: stages 1.. of a batch in ONE persistent launch (lp_chain.hip.h); XPG_CHAIN=0 turns it off
-    int chain_test_abort = 0;   // test hook XPG_CHAIN_TEST_ABORT=k (read when the handle is created): every k-th chain launch fails its roll call
-    // xpg_profile_begin/end: event pairs around each sweep launch
-    std::vector<hipEvent_t> ev0, ev1;
-    int prof_cap, prof_n, prof_stride, prof_seen;
-};
-
-#define XPG_HIP(ctx, call)                                                         \
-    do {                                                                           \
-        hipError_t e_ = (call);                                                    \
-        if (e_ != hipSuccess) {                                                    \
-            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);        \
-            return XPG_ERR_HIP;                                                    \
-        }                                                                          \
-    } while (0)
-
 namespace xpg {
-
-// Every extern "C" entry point binds the handle's device for its own duration and puts the caller's
-// current device back: allocations, function attributes and launches of a handle created on device A
-// must not land on whatever device the calling thread (or its host framework) selected last.
-struct DeviceGuard {
-    int prev = -1, mine = -1;
-    explicit DeviceGuard(int device) : mine(device)
-    {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        if (device >= 0 && prev != device) (void)hipSetDevice(device);
-    }
-    ~DeviceGuard() { if (prev >= 0 && mine >= 0 && prev != mine) (void)hipSetDevice(prev); }
-    DeviceGuard(const DeviceGuard &) = delete;
-    DeviceGuard & operator=(const DeviceGuard &) = delete;
-};
-#define XPG_BIND(ctx_) xpg::DeviceGuard xpg_bind_guard_((ctx_) ? (ctx_)->device : -1)
-
-inline int round_up(int x, int a) { return (x + a - 1) / a * a; }
-
-// hipFuncAttributeMaxDynamicSharedMemorySize is one value per (function, device): two host threads -- two handles,
-// or the _multi entry points given the same device twice -- setting "exactly what this launch needs" could lower
-// it between the other thread's set and its launch. So the limit is only ever RAISED, under a mutex.
-inline hipError_t lds_limit(const void * fn, int device, size_t bytes)
-{
-    static std::mutex mu;
-    static std::map<std::pair<const void *, int>, size_t> cur;
-    std::lock_guard<std::mutex> g(mu);
-    size_t & c = cur[std::make_pair(fn, device)];
-    if (bytes <= c) return hipSuccess;
-    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e == hipSuccess) c = bytes;
-    return e;
-}
-
-// Leading dimension of a device tableau of W live columns. Always a multiple of 16 elements: rows start on 128-byte
-// lines, every 16-byte access is aligned, and a thread whose first column is live owns a whole pair. A width that is
-// itself a multiple of 16 is kept (4096 x 8192 runs best at ld = 8192: 78 us per blocked sweep against 82 at 8208);
-// any other goes to the next multiple of 64 (rows on 512-byte boundaries: 4096 x 12289 126 us at 12352 against 131
-// at 12304), stepping over the row strides the sweep was measured to run 10-20 % slower at (tools/lab/sweep_lab2.hip
-// ldscan, profiles/round3_sweep_lab.txt: k * (32 KiB + 128 B) -- 8224, 12336, 16448 elements -- and 32 KiB - 128 B).
-inline int pick_ld(int W)
-{
-    static const int align = [] { const char * s = getenv("XPG_LD_ALIGN"); const int a = s ? atoi(s) : 64; return a >= 16 && a % 16 == 0 ? a : 64; }();
-    int ld = W % 16 == 0 ? W : round_up(W, align);
-    if (ld % 4112 == 0 || (ld + 16) % 4096 == 0) ld += 16;
-    return ld;
-}
 
 // fp64 sweep launch. Variants are (rows per workgroup, rows in flight); the
 // default is what measured best on MI355X (profiles/), the others stay
@@ -162,7 +82,7 @@ template <> inline void launch_pipe_sweep<F64>(xpg_ctx * ctx, const LpView<F64> 
                           (const double *)v.colbuf + (size_t)slot * colstride, ctx->zigzag ? (slot & 1) : 0);
     if (timed) ctx->prof_n++;
     if (!fused)
-        hipLaunchKernelGGL(k_pipe_pick, dim3(strips < PICK_MAX_WGS ? strips : PICK_MAX_WGS), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL((k_pipe_pick<0>), dim3(strips < PICK_MAX_WGS ? strips : PICK_MAX_WGS), dim3(256), 0, ctx->stream,
                            v, slot, colstride);
 }
 template <> inline void launch_pipe_sweep<R32>(xpg_ctx * ctx, const LpView<R32> & v, int slot, int colstride, bool sample)

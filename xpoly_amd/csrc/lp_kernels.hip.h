@@ -1092,7 +1092,7 @@ __device__ inline void pipe_pick_f64(const LpView<F64> & v, int slot, int colstr
 }
 
 // A/B aid (XPG_LOOP=split): the pick as a launch of its own after a sweep launched without it.
-__global__ __launch_bounds__(256) void k_pipe_pick(LpView<F64> v, int slot, int colstride)
+template <int UNUSED = 0> __global__ __launch_bounds__(256) void k_pipe_pick(LpView<F64> v, int slot, int colstride)
 {
     if (v.st->status != ST_RUNNING) return;
     pipe_pick_f64(v, slot, colstride, blockIdx.x, gridDim.x);

@@ -22,7 +22,7 @@
 #include <thread>
 #include <vector>
 #include "six_host.hip.h"
-#include "lineq_host.hip.h"
+#include "lineq_shared.hip.h"
 #include "mip_kernels.hip.h"
 
 namespace xpg {
@@ -533,21 +533,6 @@ inline int has_solution(xpg_ctx * ctx, const R32 * leq, int leq_rows, const R32 
     return 0;
 }
 
-// Lineq::move2var (src/com/linsys.cpp:1177-1200) for one system: the constant symbols first_sym..last_sym become
-// variables in front of the constant column rhs_idx -- taken out, multiplied by -1 with the scalar's own '*'
-// (Matrix::mul, matt.h:1331-1348: 2/4 comes back as -1/2) and inserted before column rhs_idx. Shape unchanged.
-inline void move2var_one(const R32 * in, R32 * out, int rows, int cols, int rhs_idx, int first_sym, int last_sym)
-{
-    for (int i = 0; i < rows; i++) {
-        const R32 * src = in + (size_t)i * cols;
-        R32 * dst = out + (size_t)i * cols;
-        int c = 0;
-        for (int j = 0; j < rhs_idx; j++) dst[c++] = src[j];
-        for (int j = first_sym; j <= last_sym; j++) dst[c++] = mul(src[j], R32(-1, 1));
-        for (int j = rhs_idx; j < cols; j++)
-            if (j < first_sym || j > last_sym) dst[c++] = src[j];
-    }
-}
 
 // DepPoly::is_empty(keepit, vc) (src/eng/poly.cpp:530-573) for nb dependence polyhedra of one shape: the constant
 // is column rhs_idx, columns after it are constant symbols. move2var (when there are symbols) -> Lineq::reduce at
@@ -575,7 +560,8 @@ inline int dep_is_empty_batch(xpg_ctx * ctx, int nb, const R32 * mats, int rows,
         XPG_TRY(dok.alloc(ctx, (size_t)nb * 4)); XPG_TRY(dact.alloc(ctx, (size_t)nb * 4)); XPG_TRY(demp.alloc(ctx, (size_t)nb * 4));
         XPG_TRY(dst.alloc(ctx, (size_t)nb * 4)); XPG_TRY(dv.alloc(ctx, (size_t)nb * 8)); XPG_TRY(dn.alloc(ctx, (size_t)nb * 4));
         XPG_TRY(hipMemcpyAsync(dm.p, mats, bm, hipMemcpyHostToDevice, ctx->stream));
-        int rc = lineq_reduce_batch_dev(ctx, nb, (R32 *)dm.p, rows, cols, last, 1, 1, (int32_t *)dk.p, (int32_t *)dok.p);
+        // Lineq::reduce on the device arrays (the C ABI entry: its kernels live in the row-elimination translation unit)
+        int rc = xpg_lineq_reduce_batch_rat32_dev(ctx, nb, (xpg_rat32 *)dm.p, rows, cols, last, 1, (int32_t *)dk.p, (int32_t *)dok.p);
         if (rc) return rc;
         hipLaunchKernelGGL(k_dep_prepare, dim3((nb + 3) / 4), dim3(64, 4), 0, ctx->stream, nb, (const R32 *)dm.p, rows, cols,
                            (const int *)dk.p, (const int *)dok.p, (R32 *)dt.p, (int *)dact.p, (int32_t *)demp.p);
@@ -613,7 +599,7 @@ inline int dep_is_empty_batch(xpg_ctx * ctx, int nb, const R32 * mats, int rows,
         work.assign(mats, mats + (size_t)nb * rows * cols);
     }
     std::vector<int32_t> kept(nb), ok(nb);
-    int rc = lineq_reduce_batch(ctx, nb, work.data(), rows, cols, last, 1, 1, kept.data(), ok.data());
+    int rc = xpg_lineq_reduce_batch_rat32(ctx, nb, (xpg_rat32 *)work.data(), rows, cols, last, 1, kept.data(), ok.data());
     if (rc) return rc;
     const int nv = rhs_idx;
     std::vector<R32> vc((size_t)nv * (nv + 1), R32(0, 1));

@@ -7,7 +7,7 @@
 #pragma once
 #include <vector>
 #include <stdlib.h>
-#include "lp_host.hip.h"
+#include "ctx.hip.h"
 #include "batch_kernels.hip.h"
 
 namespace xpg {

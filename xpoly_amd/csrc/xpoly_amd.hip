@@ -12,21 +12,56 @@
 #include <thread>
 #include <vector>
 #include "../../include/xpoly_amd.h"
+// The library is ONE shared object built from this file compiled four times in parallel (-DXPG_PART=0..3, build.py):
+// the device code of all kernels together takes four minutes in one translation unit, and every part only includes
+// the kernel headers its entry points launch. XPG_PART undefined = everything in one translation unit.
+//   part 0  handle, K1 pivot, the device-resident LP (every loop of lp_*.hip.h), warm-started MIP, test and debug hooks
+//   part 1  SIX::maxm / minm, the LDS-resident LP batches (k_batch), their multi-device and ragged forms
+//   part 2  MIP (device tree walk + host controller), has_solution, DepPoly::is_empty front end
+//   part 3  rational / integer row elimination (Lineq, rank / det / inv / null, hnf, gcd)
+#ifndef XPG_PART
+#define XPG_PART (-1)
+#endif
+#define XPG_IN(p_) (XPG_PART < 0 || XPG_PART == (p_))
 #include "scalar.hip.h"
+#include "ctx.hip.h"
+#if XPG_IN(0)
 #include "lp_kernels.hip.h"
 #include "lp_pipe_r32.hip.h"
 #include "lp_host.hip.h"
+#include "warm_mip.hip.h"
+#endif
+#if XPG_IN(1) || XPG_IN(2)
 #include "six_host.hip.h"
 #include "batch_kernels.hip.h"
+#endif
+#if XPG_IN(3)
 #include "lineq_host.hip.h"
+#endif
+#if XPG_IN(2)
 #include "mip_host.hip.h"
-#include "warm_mip.hip.h"
+#endif
 
 using namespace xpg;
+
+// batch_dev<S> launches k_batch<S>: part 1 compiles it, part 2 (the MIP controller's node batches, has_solution's
+// LPs) calls part 1's instance
+#if XPG_PART == 2
+namespace xpg {
+extern template int batch_dev<F64>(xpg_ctx *, int, int, const F64 *, const F64 *, int, int, unsigned, int32_t *, F64 *, F64 *, uint32_t *, int);
+extern template int batch_dev<R32>(xpg_ctx *, int, int, const R32 *, const R32 *, int, int, unsigned, int32_t *, R32 *, R32 *, uint32_t *, int);
+}
+#elif XPG_PART == 1
+namespace xpg {
+template int batch_dev<F64>(xpg_ctx *, int, int, const F64 *, const F64 *, int, int, unsigned, int32_t *, F64 *, F64 *, uint32_t *, int);
+template int batch_dev<R32>(xpg_ctx *, int, int, const R32 *, const R32 *, int, int, unsigned, int32_t *, R32 *, R32 *, uint32_t *, int);
+}
+#endif
 
 static_assert(sizeof(F64) == 8 && sizeof(R32) == 8, "both scalars are 8 bytes");
 static_assert(sizeof(xpg_rat32) == sizeof(R32), "ABI layout of a rational");
 
+#if XPG_IN(0)
 struct xpg_lp { LpBase * impl; };
 
 extern "C" {
@@ -573,6 +608,39 @@ int xpg_lp_trace(xpg_lp * lp, int32_t * pairs, int cap_pairs, int * n_pairs)
     return 0;
 }
 
+int xpg_trim(xpg_ctx * ctx)
+{
+    XPG_BIND(ctx);
+    if (!ctx) return XPG_ERR_SHAPE;
+    XPG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto & b : ctx->dev_cache) (void)hipFree(b.first);
+    ctx->dev_cache.clear(); ctx->dev_cache_bytes = 0;
+    if (ctx->hpack) { (void)hipHostFree(ctx->hpack); ctx->hpack = 0; ctx->hpack_cap = 0; }
+    return 0;
+}
+
+int xpg_mip_warm_f64(xpg_ctx * ctx, int is_max, const double * tgtf, const double * leq, int leq_rows, int cols, int is_bin,
+                     double * out_v, double * out_sol, long long * out_stats)
+{
+    XPG_BIND(ctx);
+    if (!ctx || !tgtf || !leq || leq_rows <= 0 || cols < 2 || !out_v) return XPG_ERR_SHAPE;
+    std::vector<double> obj(tgtf, tgtf + cols);
+    if (!is_max) for (int j = 0; j < cols; j++) obj[(size_t)j] = -obj[(size_t)j];       // min c.x = -max (-c).x
+    WarmMip W(ctx);
+    WarmStats S;
+    double v = 0.0;
+    const int st = W.solve(obj.data(), leq, leq_rows, cols, is_bin != 0, &v, out_sol, S);
+    if (out_stats) { out_stats[0] = S.nodes; out_stats[1] = S.dual_pivots; out_stats[2] = S.root_pivots; out_stats[3] = S.max_depth; }
+    if (st == XPG_IP_SUCC) *out_v = is_max ? v : -v;
+    else *out_v = 0.0;
+    return st;
+}
+
+} // extern "C"
+#endif // part 0
+
+#if XPG_IN(1)
+extern "C" {
 // ---- SIX::maxm / minm ---------------------------------------------------------------------
 int xpg_six_maxm_f64(xpg_ctx * ctx, const double * tgtf, const double * vc, int vc_rows,
                      const double * eq, int eq_rows, const double * leq, int leq_rows, int cols,
@@ -642,8 +710,10 @@ int xpg_six_batch_rat32(xpg_ctx * ctx, int is_max, int nb, const xpg_rat32 * tgt
                            out_status, (R32 *)out_v, (R32 *)out_sol);
 }
 
-// ---- the same batches over several devices: one context + host thread per shard ------------------
 } // extern "C"
+#endif // part 1
+// ---- the same batches over several devices: one context + host thread per shard ------------------
+#if XPG_IN(1) || XPG_IN(2)
 namespace {
 // fn(ctx, lo, hi) runs shard [lo, hi) on its own context; the first error wins.
 template <class F> int run_sharded(int ndev, const int * devices, int nb, F fn)
@@ -668,6 +738,8 @@ template <class F> int run_sharded(int ndev, const int * devices, int nb, F fn)
     return 0;
 }
 } // namespace
+#endif
+#if XPG_IN(1)
 extern "C" {
 
 int xpg_six_batch_f64_multi(int ndev, const int * devices, int is_max, int nb, const double * tgtf, const double * leq,
@@ -689,6 +761,10 @@ int xpg_six_batch_rat32_multi(int ndev, const int * devices, int is_max, int nb,
                                    max_iter, out_status + lo, out_v + lo, out_sol + (size_t)lo * cols);
     });
 }
+} // extern "C"
+#endif
+#if XPG_IN(2)
+extern "C" {
 int xpg_mip_batch_rat32_multi(int ndev, const int * devices, int nb, int is_max, int is_bin, const xpg_rat32 * tgtf,
                               const xpg_rat32 * leq, int leq_rows, int cols, int32_t * out_status, xpg_rat32 * out_v,
                               xpg_rat32 * out_sol, long long * out_nodes)
@@ -731,6 +807,8 @@ int xpg_dep_is_empty_batch_rat32_multi(int ndev, const int * devices, int nb, co
 // handle keeps, driven by a host thread for the duration of the call -- so that small classes share the chip instead
 // of each waiting for the deepest problem of the one before. Results are scattered back in problem order.
 } // extern "C"
+#endif
+#if XPG_IN(1) || XPG_IN(2) || XPG_IN(3)
 namespace {
 struct RaggedClass { int rows, cols; std::vector<int> idx; size_t work; };
 inline int ragged_lanes()
@@ -790,6 +868,8 @@ template <class T> inline void ragged_gather(std::vector<T> & buf, const T * src
     for (size_t k = 0; k < c.idx.size(); k++) memcpy((void *)(buf.data() + k * per), (const void *)(src + off[c.idx[k]]), per * sizeof(T));
 }
 } // namespace
+#endif
+#if XPG_IN(2)
 extern "C" {
 
 int xpg_dep_is_empty_batch_ragged_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, const int32_t * rows,
@@ -797,15 +877,28 @@ int xpg_dep_is_empty_batch_ragged_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 *
                                         long long * out_nodes)
 {
     XPG_BIND(ctx);
-    if (!ctx || nb < 0 || !mats || !rows || !cols || !offsets || !out_empty) return XPG_ERR_SHAPE;
+    if (out_nodes) *out_nodes = 0;
+    if (!ctx || nb < 0) return XPG_ERR_SHAPE;
+    if (nb == 0) return 0;                                          // an empty SCoP: nothing to answer (mats may be null)
+    if (!rows || !cols || !offsets || !out_empty) return XPG_ERR_SHAPE;
+    // DepPoly::is_empty answers true for a polyhedron without rows before it looks at anything else (poly.cpp:533-535):
+    // those are answered here and left out of the shape classes
+    std::vector<int32_t> lrows, lcols; std::vector<long long> loff; std::vector<int> lidx;
+    for (int b = 0; b < nb; b++) {
+        if (rows[b] < 0) return XPG_ERR_SHAPE;
+        if (rows[b] == 0) { out_empty[b] = 1; continue; }
+        lrows.push_back(rows[b]); lcols.push_back(cols[b]); loff.push_back(offsets[b]); lidx.push_back(b);
+    }
+    if (lidx.empty()) return 0;
+    if (!mats) return XPG_ERR_SHAPE;
     std::atomic<long long> nodes(0);
-    const int rc = run_ragged(ctx, nb, rows, cols, [&](xpg_ctx * c, const RaggedClass & g) {
+    const int rc = run_ragged(ctx, (int)lidx.size(), lrows.data(), lcols.data(), [&](xpg_ctx * c, const RaggedClass & g) {
         std::vector<R32> buf; std::vector<int32_t> emp(g.idx.size());
-        ragged_gather(buf, (const R32 *)mats, offsets, g, (size_t)g.rows * g.cols);
+        ragged_gather(buf, (const R32 *)mats, loff.data(), g, (size_t)g.rows * g.cols);
         long n = 0;
         const int r = dep_is_empty_batch(c, (int)g.idx.size(), buf.data(), g.rows, g.cols, g.cols - 1, (const R32 *)0, emp.data(), &n);
         if (r) return r;
-        for (size_t k = 0; k < g.idx.size(); k++) out_empty[g.idx[k]] = emp[k];
+        for (size_t k = 0; k < g.idx.size(); k++) out_empty[lidx[(size_t)g.idx[k]]] = emp[k];
         nodes += n;
         return 0;
     });
@@ -814,6 +907,8 @@ int xpg_dep_is_empty_batch_ragged_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 *
 }
 
 } // extern "C"
+#endif
+#if XPG_IN(1)
 namespace {
 template <class S>
 int six_batch_ragged(xpg_ctx * ctx, int is_max, int nb, const S * tgtf, const S * leq, const int32_t * rows, const int32_t * cols,
@@ -890,6 +985,10 @@ int xpg_six_batch_rat32_ragged(xpg_ctx * ctx, int is_max, int nb, const xpg_rat3
     return six_batch_ragged<R32>(ctx, is_max, nb, (const R32 *)tgtf, (const R32 *)leq, rows, cols, leq_offsets, tgtf_offsets, max_iter,
                                  out_status, (R32 *)out_v, (R32 *)out_sol);
 }
+} // extern "C"
+#endif
+#if XPG_IN(3)
+extern "C" {
 // Lineq::reduce on systems of different shapes, in place (mats: the systems back to back, system b at cell
 // offsets[b]); rhs_idx[b] (NULL: the last column of each).
 int xpg_lineq_reduce_batch_ragged_rat32(xpg_ctx * ctx, int nb, xpg_rat32 * mats, const int32_t * rows, const int32_t * cols,
@@ -962,6 +1061,10 @@ int xpg_lineq_fme_batch_ragged_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * ma
     return 0;
 }
 
+} // extern "C"
+#endif
+#if XPG_IN(2)
+extern "C" {
 // ---- MIP / has_solution -------------------------------------------------------------------------
 int xpg_mip_maxm_rat32(xpg_ctx * ctx, const xpg_rat32 * tgtf, const xpg_rat32 * vc, int vc_rows,
                        const xpg_rat32 * eq, int eq_rows, const xpg_rat32 * leq, int leq_rows, int cols,
@@ -1004,23 +1107,6 @@ int xpg_has_solution_rat32(xpg_ctx * ctx, const xpg_rat32 * leq, int leq_rows, c
                         rhs_idx, is_int_sol != 0, is_unique_sol != 0);
 }
 
-int xpg_mip_warm_f64(xpg_ctx * ctx, int is_max, const double * tgtf, const double * leq, int leq_rows, int cols, int is_bin,
-                     double * out_v, double * out_sol, long long * out_stats)
-{
-    XPG_BIND(ctx);
-    if (!ctx || !tgtf || !leq || leq_rows <= 0 || cols < 2 || !out_v) return XPG_ERR_SHAPE;
-    std::vector<double> obj(tgtf, tgtf + cols);
-    if (!is_max) for (int j = 0; j < cols; j++) obj[(size_t)j] = -obj[(size_t)j];       // min c.x = -max (-c).x
-    WarmMip W(ctx);
-    WarmStats S;
-    double v = 0.0;
-    const int st = W.solve(obj.data(), leq, leq_rows, cols, is_bin != 0, &v, out_sol, S);
-    if (out_stats) { out_stats[0] = S.nodes; out_stats[1] = S.dual_pivots; out_stats[2] = S.root_pivots; out_stats[3] = S.max_depth; }
-    if (st == XPG_IP_SUCC) *out_v = is_max ? v : -v;
-    else *out_v = 0.0;
-    return st;
-}
-
 int xpg_mip_batch_rat32(xpg_ctx * ctx, int nb, int is_max, int is_bin, const xpg_rat32 * tgtf, const xpg_rat32 * leq,
                         int leq_rows, int cols, int32_t * out_status, xpg_rat32 * out_v, xpg_rat32 * out_sol,
                         long long * out_nodes)
@@ -1054,6 +1140,10 @@ int xpg_dep_is_empty_batch_ex_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mat
     if (out_nodes) *out_nodes = n;
     return rc;
 }
+} // extern "C"
+#endif
+#if XPG_IN(3)
+extern "C" {
 int xpg_lineq_move2var_batch_rat32(xpg_ctx * ctx, int nb, xpg_rat32 * mats, int rows, int cols, int rhs_idx,
                                    int first_sym, int last_sym)
 {
@@ -1102,16 +1192,6 @@ int xpg_lineq_fme_batch_packed_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * ma
     return lineq_fme_batch_packed(ctx, nb, (const R32 *)mats, rows, cols, rhs_idx, u, darkshadow, cap_rows, (R32 *)outs,
                                   outs_cap_rows, (const R32 **)out_view, row_offsets, out_ok);
 }
-int xpg_trim(xpg_ctx * ctx)
-{
-    XPG_BIND(ctx);
-    if (!ctx) return XPG_ERR_SHAPE;
-    XPG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (auto & b : ctx->dev_cache) (void)hipFree(b.first);
-    ctx->dev_cache.clear(); ctx->dev_cache_bytes = 0;
-    if (ctx->hpack) { (void)hipHostFree(ctx->hpack); ctx->hpack = 0; ctx->hpack_cap = 0; }
-    return 0;
-}
 int xpg_lineq_fme_batch_rat32_dev(xpg_ctx * ctx, int nb, const xpg_rat32 * d_mats, int rows, int cols, int rhs_idx,
                                   int u, int darkshadow, xpg_rat32 * d_outs, int cap_rows, int32_t * d_out_rows,
                                   int32_t * d_out_ok)
@@ -1152,3 +1232,4 @@ int xpg_int_gcd_batch(xpg_ctx * ctx, int nb, int32_t * mats, int rows, int cols)
     XPG_BIND(ctx); return int_gcd_batch(ctx, nb, mats, rows, cols); }
 
 } // extern "C"
+#endif // part 3
