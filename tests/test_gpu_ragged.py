@@ -125,11 +125,22 @@ def test_ragged_and_packed_error_paths(ctx):
     mats = [gen.random_system(rng, 6, 3), gen.random_system(rng, 9, 4)]
     flat, rows, cols, off = ragged_pack_rat(mats)
     out = np.zeros(2, dtype=np.int32)
-    bad_rows = rows.copy(); bad_rows[1] = 0
+    # a polyhedron without rows is EMPTY for DepPoly::is_empty (poly.cpp:533-535): answered, not an error, and the other
+    # systems of the call get their own answers
+    want, _ = dep_is_empty_ragged(ctx, mats)
+    no_rows = rows.copy(); no_rows[1] = 0
+    out[:] = -9
+    assert lib().xpg_dep_is_empty_batch_ragged_rat32(ctx._h, C.c_int(2), vp(flat), vp(no_rows), vp(cols), vp(off), vp(out), None) == 0
+    assert out[1] == 1 and out[0] == want[0]
+    no_rows[0] = 0
+    assert lib().xpg_dep_is_empty_batch_ragged_rat32(ctx._h, C.c_int(2), None, vp(no_rows), vp(cols), vp(off), vp(out), None) == 0
+    assert out.tolist() == [1, 1]
+    bad_rows = rows.copy(); bad_rows[1] = -1
     assert lib().xpg_dep_is_empty_batch_ragged_rat32(ctx._h, C.c_int(2), vp(flat), vp(bad_rows), vp(cols), vp(off), vp(out), None) == -3
     bad_cols = cols.copy(); bad_cols[0] = 1
     assert lib().xpg_dep_is_empty_batch_ragged_rat32(ctx._h, C.c_int(2), vp(flat), vp(rows), vp(bad_cols), vp(off), vp(out), None) == -3
     assert lib().xpg_dep_is_empty_batch_ragged_rat32(ctx._h, C.c_int(0), vp(flat), vp(rows), vp(cols), vp(off), vp(out), None) == 0
+    assert lib().xpg_dep_is_empty_batch_ragged_rat32(ctx._h, C.c_int(0), None, None, None, None, None, None) == 0     # an empty SCoP
     assert lib().xpg_dep_is_empty_batch_ragged_rat32(ctx._h, C.c_int(2), None, vp(rows), vp(cols), vp(off), vp(out), None) == -3
     # packed fme: a device slot of 2 rows cannot hold the result of a 10-row system with positive and negative rows
     m = np.ascontiguousarray(np.stack([gen.random_system(rng, 10, 4) for _ in range(4)]))

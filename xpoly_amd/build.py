@@ -44,19 +44,22 @@ def stale():
     return any(os.path.getmtime(s) > t for s in sources())
 
 
-def build(force=False, extra=()):
-    if not force and not stale():
+def build(force=False, extra=(), out=None, obj=None):
+    """out / obj: another library path and object directory (diagnostic builds: -DXPG_STAMPS, -DXPG_LIFE)."""
+    if out is None and not force and not stale():
         return OUT
+    OUT_ = out or OUT
+    OBJ_ = obj or OBJ
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     extra = list(extra) + os.environ.get("XPG_BUILD_FLAGS", "").split()
     if os.environ.get("XPG_BUILD_MONOLITHIC") == "1":
-        subprocess.check_call([hipcc] + CFLAGS + extra + ["-shared", "-o", OUT, SRC])
-        return OUT
-    os.makedirs(OBJ, exist_ok=True)
-    objs = [os.path.join(OBJ, "part%d.o" % p) for p in range(PARTS)]
+        subprocess.check_call([hipcc] + CFLAGS + extra + ["-shared", "-o", OUT_, SRC])
+        return OUT_
+    os.makedirs(OBJ_, exist_ok=True)
+    objs = [os.path.join(OBJ_, "part%d.o" % p) for p in range(PARTS)]
 
     flags_key = " ".join(CFLAGS + extra)
-    key_file = os.path.join(OBJ, "flags.txt")
+    key_file = os.path.join(OBJ_, "flags.txt")
     same_flags = os.path.exists(key_file) and open(key_file).read() == flags_key
 
     def part_stale(p):
@@ -74,8 +77,8 @@ def build(force=False, extra=()):
         list(ex.map(one, range(PARTS)))
     with open(key_file, "w") as f:
         f.write(flags_key)
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", OUT] + objs)
-    return OUT
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", OUT_] + objs)
+    return OUT_
 
 
 if __name__ == "__main__":

@@ -14,14 +14,14 @@
 namespace xpg {
 
 #ifdef XPG_STAMPS
-__device__ unsigned long long g_fl[16];                  // diagnostic builds: sm_fast_loop counters / 100 MHz ticks (tools/lab/probe_fastloop.py)
+static __device__ unsigned long long g_fl[16];                  // diagnostic builds: sm_fast_loop counters / 100 MHz ticks (tools/lab/probe_fastloop.py)
 #define FL_ADD(k_, v_) atomicAdd(&g_fl[k_], (unsigned long long)(v_))
 #else
 #define FL_ADD(k_, v_) do { } while (0)
 #endif
 #ifdef XPG_LIFE
 // diagnostic builds (-DXPG_LIFE, tools/lab/probe_batch_life.py): 100 MHz time of every 256th pivot of the first 4096 LPs
-__device__ unsigned long long g_life[4096 * 32];
+static __device__ unsigned long long g_life[4096 * 32];
 #define LIFE_MARK(lp_, piv_) do { if (threadIdx.x == 0 && (lp_) < 4096 && ((piv_) & 255) == 0 && ((piv_) >> 8) < 31) g_life[(lp_) * 32 + ((piv_) >> 8)] = wall_clock64(); } while (0)
 #define LIFE_END(lp_) do { if (threadIdx.x == 0 && (lp_) < 4096) g_life[(lp_) * 32 + 31] = wall_clock64(); } while (0)
 #else
@@ -893,7 +893,7 @@ template <class S> __host__ __device__ inline size_t small_lds_bytes(int R, int 
 }
 
 #ifdef XPG_STAMPS
-__device__ unsigned long long g_lp_ticks[8];     // diagnostic builds: ticks in phase one / plain build / main solve, pivots, counts
+static __device__ unsigned long long g_lp_ticks[8];     // diagnostic builds: ticks in phase one / plain build / main solve, pivots, counts
 #endif
 // The LDS arrays of one LP with at most R rows and V variables (small_lds_bytes is their size).
 template <class S> __device__ __forceinline__ void sm_carve(Small<S> & P, unsigned char * lds, int R, int V)

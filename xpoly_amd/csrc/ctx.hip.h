@@ -35,6 +35,7 @@ struct xpg_ctx {
     int loop_auto;          // XPG_LOOP unset: blocked loop where the sweep is what costs (large fp64 tableaux)
     int num_cus;            // compute units of the device
     int chain;              // blocked loop: stages 1.. of a batch in ONE persistent launch (lp_chain.hip.h); XPG_CHAIN=0 turns it off
+    int chain_local = 1;        // the chain's workers all on ONE XCD, hand-offs through its L2 (XPG_CHAIN_XCD=0: spread over the chip, sc1 stores)
     int chain_test_abort = 0;   // test hook XPG_CHAIN_TEST_ABORT=k (read when the handle is created): every k-th chain launch fails its roll call
     // xpg_profile_begin/end: event pairs around each sweep launch
     std::vector<hipEvent_t> ev0, ev1;

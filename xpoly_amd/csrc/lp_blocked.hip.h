@@ -76,10 +76,11 @@ __device__ __forceinline__ BlkLook blk_lookahead(const LpView<F64> & v, unsigned
     int nf = INT_MAX, any = 0;
     unsigned long long key = 0;
     for (int k = lane; k < nparts; k += 64) {
-        const int * P = v.blkP + (size_t)k * BLK_PART_INTS;
-        const bool ok = (unsigned)P[2] == want_epoch;       // layout: the partial store of blk_prep_body
+        const int * P = v.blkP + (size_t)k * 4;             // layout: lp_kernels.hip.h, the partial store of blk_prep_body
+        const int * Q = v.blkP + BLK_PART_PAY + (size_t)k * BLK_PART_PAY_INTS;
+        const bool ok = (unsigned)P[2] == want_epoch;
         const int pn = P[0], pa = P[1];
-        const unsigned long long pk = ((unsigned long long)(unsigned)P[17] << 32) | (unsigned)P[16];
+        const unsigned long long pk = ((unsigned long long)(unsigned)Q[13] << 32) | (unsigned)Q[12];
         if (ok) { nf = min(nf, pn); any |= pa; key = pk > key ? pk : key; }
     }
     for (int o = 32; o > 0; o >>= 1) { nf = min(nf, __shfl_xor(nf, o)); any |= __shfl_xor(any, o); }
@@ -393,23 +394,25 @@ __device__ __forceinline__ bool blk_prep_body(const LpView<F64> & v, int batch, 
     if ((threadIdx.x & 63) == 0) { sh_nf[threadIdx.x >> 6] = nf; sh_any[threadIdx.x >> 6] = any; sh_key[threadIdx.x >> 6] = key; }
     __syncthreads();
     for (int k = 0; k < (int)(blockDim.x >> 6); k++) { nf = min(nf, sh_nf[k]); any |= sh_any[k]; key = sh_key[k] > key ? sh_key[k] : key; }
-    // The partial, in the granule layout the chain kernel polls (lp_chain.hip.h): g0 {nf, any, epoch, 0},
-    // g1 {e_t[nf], epoch}, g2 {objective entry of nf, epoch}, g3 {e_t[rhs], epoch} (the workgroup that owns the
-    // constant column), then the Dantzig key. g1..g3 are what the chain's first stage needs fresh of this one.
+    // The partial, in the granule layout the chain kernel polls (lp_kernels.hip.h): g0 {nf, any, epoch, 0} in the dense
+    // array, and in this workgroup's payload g1 {e_t[nf], epoch}, g2 {objective entry of nf, epoch}, g3 {e_t[rhs], epoch}
+    // (the workgroup that owns the constant column), then the Dantzig key. g1..g3 are what the chain's first stage
+    // needs fresh of this one.
     {
-        int * P = v.blkP + (size_t)p * BLK_PART_INTS;
+        int * P = v.blkP + (size_t)p * 4;
+        int * Q = v.blkP + BLK_PART_PAY + (size_t)p * BLK_PART_PAY_INTS;
         if (my_j >= 0 && my_j == nf) {
             const unsigned long long eb_ = to_bits(my_e), ob_ = to_bits(my_o);
-            P[4] = (int)(unsigned)eb_; P[5] = (int)(unsigned)(eb_ >> 32); P[6] = (int)epoch; P[7] = 0;
-            P[8] = (int)(unsigned)ob_; P[9] = (int)(unsigned)(ob_ >> 32); P[10] = (int)epoch; P[11] = 0;
+            Q[0] = (int)(unsigned)eb_; Q[1] = (int)(unsigned)(eb_ >> 32); Q[2] = (int)epoch; Q[3] = 0;
+            Q[4] = (int)(unsigned)ob_; Q[5] = (int)(unsigned)(ob_ >> 32); Q[6] = (int)epoch; Q[7] = 0;
         }
         if (my_j == rhs) {
             const unsigned long long eb_ = to_bits(my_e);
-            P[12] = (int)(unsigned)eb_; P[13] = (int)(unsigned)(eb_ >> 32); P[14] = (int)epoch; P[15] = 0;
+            Q[8] = (int)(unsigned)eb_; Q[9] = (int)(unsigned)(eb_ >> 32); Q[10] = (int)epoch; Q[11] = 0;
         }
         if (threadIdx.x == 0) {
+            Q[12] = (int)(unsigned)key; Q[13] = (int)(unsigned)(key >> 32);
             P[0] = nf; P[1] = any; P[2] = (int)epoch; P[3] = 0;
-            P[16] = (int)(unsigned)key; P[17] = (int)(unsigned)(key >> 32);
         }
     }
     // -column from the generic pick's colbuf when it chose this pivot
@@ -436,7 +439,7 @@ __device__ __forceinline__ bool blk_prep_body(const LpView<F64> & v, int batch, 
         // the counters as they stand after it -- fields the chain itself never writes, so a late worker
         // of that launch reads what the early ones read
         if (t == 0) {
-            st->blk.ch_arrive = 0u;                            // (the previous batch's chain launch has completed: stream order)
+            for (int x = 0; x < 8; x++) st->blk.ch_arrive[x] = 0u;   // (the previous batch's chain launch has completed: stream order)
             st->blk.ch_epoch = epoch;
             st->blk.ch_budget = generic_pivot ? budget : budget - 1;
             st->blk.ch_done = generic_pivot ? done : done + 1;
@@ -561,11 +564,11 @@ __host__ __device__ __forceinline__ bool blk_sweep_tile(int lid, int strips, int
     return true;
 }
 
-template <int ROWS, int U> __global__ __launch_bounds__(256)
+template <int ROWS, int U, int NB> __global__ __launch_bounds__(256)
 void k_blk_sweep_full(double * __restrict__ tab, int m, int W, int ld, const double * __restrict__ E,
                       const double * __restrict__ K, LoopState * __restrict__ st, int batch, int only_full, int rev)
 {
-    constexpr int NB = BLK_MAX;
+    static_assert(NB <= BLK_MAX, "a full batch is at most BLK_MAX pivots");
     static_assert(ROWS % (2 * U) == 0, "a row block holds whole ping-pong pairs");
     int bx, by;
     if (!blk_sweep_tile((int)blockIdx.x, (W + 511) / 512, (m + ROWS - 1) / ROWS, rev, bx, by)) return;
@@ -689,14 +692,14 @@ void k_blk_sweep_full(double * __restrict__ tab, int m, int W, int ld, const dou
 // The batch length as a template switch (block lengths below 16, and the A/B switch XPG_BLK_ROWS=1).
 template <int ROWS, int UNROLL, int BCAP> __global__ __launch_bounds__(256)
 void k_blk_sweep(double * __restrict__ tab, int m, int W, int ld, const double * __restrict__ E,
-                 const double * __restrict__ K, LoopState * __restrict__ st, int batch, int skip_full)
+                 const double * __restrict__ K, LoopState * __restrict__ st, int batch, int skip_full, int full_n)
 {
     const int status = st->status;
     const int n = (st->blk.batch == batch) ? st->blk.n : 0;
     if (status != ST_RUNNING || n == 0) return;
-    if (skip_full && n == BLK_MAX) return;              // the full-batch kernel launched just before did this one
+    if (skip_full && n == skip_full) return;            // the full-batch kernel launched just before did this one (skip_full = its length)
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {     // xpg_lp_counters
-        if (n == BLK_MAX) st->blk.sweeps_full += 1u; else st->blk.sweeps_part += 1u;
+        if (n == full_n) st->blk.sweeps_full += 1u; else st->blk.sweeps_part += 1u;
     }
     // only the row blocks that hold one of the pivot rows pay for the "row r := e" test per cell
     bool hasr = false;
@@ -713,6 +716,26 @@ void k_blk_sweep(double * __restrict__ tab, int m, int W, int ld, const double *
         XPG_BLK_CASE(9) XPG_BLK_CASE(10) XPG_BLK_CASE(11) XPG_BLK_CASE(12)
         XPG_BLK_CASE(13) XPG_BLK_CASE(14) XPG_BLK_CASE(15) XPG_BLK_CASE(16)
         default: break;
+    }
+    if (n > BCAP) {
+        // a batch longer than the switch is compiled for (17 .. 31 staged pivots: a batch of 32 closed early, or the tail
+        // of an iteration budget): stage count and row list read at run time, e_s re-read from the cache per row
+        const int j = blockIdx.x * 512 + threadIdx.x * 2;
+        if (j >= W) return;
+        const int i0 = blockIdx.y * ROWS, iend = min(i0 + ROWS, m);
+        for (int i = i0; i < iend; i++) {
+            double * p = tab + (size_t)i * ld + j;
+            double ax = p[0], ay = p[1];
+            for (int s = 0; s < n; s++) {
+                const double k = K[(size_t)i * BLK_MAX + s];
+                const double ex = E[(size_t)s * ld + j], ey = E[(size_t)s * ld + j + 1];
+                const double p0 = k * ex, p1 = k * ey;
+                const bool piv = st->blk.r[s] == i;
+                ax = piv ? ex : ax + p0;
+                ay = piv ? ey : ay + p1;
+            }
+            p[0] = ax; p[1] = ay;
+        }
     }
 #undef XPG_BLK_CASE
 }

@@ -60,7 +60,7 @@
 
 namespace xpg {
 
-enum { ST_CHAIN_STUCK = XPG_ERR_CHAIN_STUCK, CH_SPIN_LIMIT = 1 << 21, CH_CLOSE = 0x7FFFFFFF, CH_PART_BYTES = BLK_PART_INTS * 4,
+enum { ST_CHAIN_STUCK = XPG_ERR_CHAIN_STUCK, CH_SPIN_LIMIT = 1 << 21, CH_CLOSE = 0x7FFFFFFF,
        CH_ARRIVE_TICKS = 30000,    // roll call: 0.3 ms of the 100 MHz clock
        CH_GO = 1, CH_ABORT = 2 };
 typedef unsigned int ch_u32x4 __attribute__((ext_vector_type(4)));
@@ -109,17 +109,26 @@ __device__ __forceinline__ ch_u32x4 ch_load1(const void * p)
 // bytes reads its data registers after issue, the hardware does not interlock a VALU write to them in the next
 // cycles, and the compiler's hazard recogniser cannot see a store inside inline asm (seen without it: the next
 // granule's tag move landed in this granule's data).
-__device__ __forceinline__ void ch_store_granule(void * p, unsigned long long lo, unsigned long long hi)
+// LOCAL (every worker of the launch on ONE XCD, see k_blk_chain): a PLAIN store -- it writes through the CU's L1 into the
+// XCD's L2 and stays there, where the consumers' sc1 loads (which bypass their own L1 only) find it at L2 latency. An sc1
+// store drops the line from the L2 and every reader pays the fabric again (tools/lab/xcd_handoff_lab.hip: an
+// all-to-all step of 129 workers 2.90 us spread / sc1, 3.74 us on one XCD / sc1, 1.85 us on one XCD / plain).
+template <bool LOCAL> __device__ __forceinline__ void ch_store_u32x4(void * p, ch_u32x4 g)
+{
+    if (LOCAL) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 3" :: "v"(p), "v"(g) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 3" :: "v"(p), "v"(g) : "memory");
+}
+template <bool LOCAL> __device__ __forceinline__ void ch_store_granule(void * p, unsigned long long lo, unsigned long long hi)
 {
     ch_u32x4 g;
     g.x = (unsigned)lo; g.y = (unsigned)(lo >> 32); g.z = (unsigned)hi; g.w = (unsigned)(hi >> 32);
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 3" :: "v"(p), "v"(g) : "memory");
+    ch_store_u32x4<LOCAL>(p, g);
 }
-__device__ __forceinline__ void ch_store_granule3(void * p, unsigned x, unsigned y, unsigned z, unsigned tag)
+template <bool LOCAL> __device__ __forceinline__ void ch_store_granule3(void * p, unsigned x, unsigned y, unsigned z, unsigned tag)
 {
     ch_u32x4 g;
     g.x = x; g.y = y; g.z = z; g.w = tag;
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 3" :: "v"(p), "v"(g) : "memory");
+    ch_store_u32x4<LOCAL>(p, g);
 }
 __device__ __forceinline__ void ch_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -136,6 +145,21 @@ template <class T> __device__ __forceinline__ T ch_ld(const T * p)      // agent
         T r; __builtin_memcpy(&r, &u, 8); return r;
     }
 }
+// LOCAL: a plain store (kept in the XCD's L2, see ch_store_u32x4); the readers are sc1 loads on the same XCD
+template <class T> __device__ __forceinline__ void ch_st_plain(T * p, T x)
+{
+    if constexpr (sizeof(T) == 1) {
+        unsigned char u; __builtin_memcpy(&u, &x, 1);
+        __hip_atomic_store((unsigned char *)p, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    } else if constexpr (sizeof(T) == 4) {
+        unsigned u; __builtin_memcpy(&u, &x, 4);
+        __hip_atomic_store((unsigned *)p, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    } else {
+        static_assert(sizeof(T) == 8, "1-, 4- or 8-byte objects");
+        unsigned long long u; __builtin_memcpy(&u, &x, 8);
+        __hip_atomic_store((unsigned long long *)p, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+}
 template <class T> __device__ __forceinline__ void ch_st(T * p, T x)    // agent-scope (sc1, write-through) store
 {
     if constexpr (sizeof(T) == 1) {
@@ -149,6 +173,13 @@ template <class T> __device__ __forceinline__ void ch_st(T * p, T x)    // agent
         unsigned long long u; __builtin_memcpy(&u, &x, 8);
         __hip_atomic_store((unsigned long long *)p, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+template <bool LOCAL, class T> __device__ __forceinline__ void ch_stl(T * p, T x) { if (LOCAL) ch_st_plain(p, x); else ch_st(p, x); }
+__device__ __forceinline__ int ch_xcc_id()                               // which of the 8 XCDs this wave runs on
+{
+    int x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x));
+    return x & 7;
 }
 __device__ __forceinline__ double ch_readlane_f64(double x, int lane)
 {
@@ -189,19 +220,24 @@ __device__ __forceinline__ unsigned long long ch_wave_min_u64(unsigned long long
 struct ChWinner { int r, enter, leave, qstar, cc; uint32_t w; double a; unsigned long long cnv; };
 enum { CH_CLOSE_ROW = 0x7FFFFFFE };
 
-// Poll g0 {key, row, tag} of the <= 256 records of stage `tag` (lane l polls l, l + 64, ...) and find the winner.
-// Returns the winner's record index (>= 0), -1 on CLOSE, -2 when the first ratio pass was empty everywhere, -3 on
-// a stuck poll; W.r is set.
-__device__ __forceinline__ int ch_poll_records(const unsigned long long * blkR, int npick, unsigned tag, int lane, ChWinner & W)
+// addresses in the hand-off areas (layout: lp_kernels.hip.h)
+__device__ __forceinline__ char * ch_rec_g0(const LpView<F64> & v, int w) { return (char *)(v.blkR + BLK_REC_G0) + (size_t)w * 16; }
+__device__ __forceinline__ char * ch_rec_pay(const LpView<F64> & v, int w) { return (char *)(v.blkR + BLK_REC_PAY) + (size_t)w * (BLK_REC_PAY_WORDS * 8); }
+__device__ __forceinline__ char * ch_part_g0(const LpView<F64> & v, int w) { return (char *)v.blkP + (size_t)w * 16; }
+__device__ __forceinline__ char * ch_part_pay(const LpView<F64> & v, int w) { return (char *)(v.blkP + BLK_PART_PAY) + (size_t)w * (BLK_PART_PAY_INTS * 4); }
+
+// Poll g0 {key, row, tag} of the <= 256 records of stage `tag` (lane l polls l, l + 64, ...: 64 granules = eight lines per
+// load) and find the winner. Returns the winner's record index (>= 0), -1 on CLOSE, -2 when the first ratio pass was
+// empty everywhere, -3 on a stuck poll; W.r is set.
+__device__ __forceinline__ int ch_poll_records(const LpView<F64> & v, int npick, unsigned tag, int lane, ChWinner & W)
 {
     const int nu = (npick + 63) >> 6;                           // records per lane, wave-uniform
     const int k0 = lane, k1 = lane + 64, k2 = lane + 128, k3 = lane + 192;
     // (a lane without a record of its own re-reads one it shares with another lane of the same line: no hot spot)
-    const char * base = (const char *)blkR;
-    const void * p0 = base + (size_t)(k0 < npick ? k0 : k0 % npick) * (BLK_REC_WORDS * 8);
-    const void * p1 = base + (size_t)(k1 < npick ? k1 : k0 % npick) * (BLK_REC_WORDS * 8);
-    const void * p2 = base + (size_t)(k2 < npick ? k2 : k0 % npick) * (BLK_REC_WORDS * 8);
-    const void * p3 = base + (size_t)(k3 < npick ? k3 : k0 % npick) * (BLK_REC_WORDS * 8);
+    const void * p0 = ch_rec_g0(v, k0 < npick ? k0 : k0 % npick);
+    const void * p1 = ch_rec_g0(v, k1 < npick ? k1 : k0 % npick);
+    const void * p2 = ch_rec_g0(v, k2 < npick ? k2 : k0 % npick);
+    const void * p3 = ch_rec_g0(v, k3 < npick ? k3 : k0 % npick);
     ch_u32x4 g0, g1, g2, g3;
     unsigned spins = 0;
     for (;;) {
@@ -230,13 +266,13 @@ __device__ __forceinline__ int ch_poll_records(const unsigned long long * blkR, 
     return __builtin_amdgcn_readlane(rec, __ffsll((long long)hit) - 1);
 }
 // g1..g3 of the winner's record (the asm block's wait also completes whatever loads the caller has in flight)
-__device__ __forceinline__ bool ch_load_winner(const unsigned long long * blkR, int widx, unsigned tag, ChWinner & W)
+__device__ __forceinline__ bool ch_load_winner(const LpView<F64> & v, int widx, unsigned tag, ChWinner & W)
 {
-    const char * p = (const char *)blkR + (size_t)widx * (BLK_REC_WORDS * 8);
+    const char * p = ch_rec_pay(v, widx);
     ch_u32x4 g1, g2, g3;
     unsigned spins = 0;
     for (;;) {
-        ch_load3(p + 16, p + 32, p + 48, g1, g2, g3);
+        ch_load3(p, p + 16, p + 32, g1, g2, g3);
         if (__all(g1.w == tag && g2.w == tag && g3.w == tag)) break;     // (every lane loads the same granules)
         if (++spins > CH_SPIN_LIMIT) return false;
         __builtin_amdgcn_s_sleep(1);
@@ -248,16 +284,16 @@ __device__ __forceinline__ bool ch_load_winner(const unsigned long long * blkR, 
 }
 
 // ---- the committer: one extra worker that owns the basis arrays --------------------------------------
-__device__ __forceinline__ void ch_commit_loop(const LpView<F64> & v, int batch, int t0, int B, int npick, int nprep,
-                                               unsigned budget, unsigned done, unsigned tp)
+template <bool LOCAL> __device__ __forceinline__ void ch_commit_loop(const LpView<F64> & v, int batch, int t0, int B, int npick, int nprep,
+                                                                     unsigned budget, unsigned done, unsigned tp)
 {
     LoopState * st = v.st;
     const int lane = (int)threadIdx.x;
     for (int t = t0; t < B; t++) {
         const unsigned tag = blk_epoch(batch, t);
         ChWinner g;
-        const int widx = ch_poll_records(v.blkR, npick, tag, lane, g);
-        if (widx == -3 || (widx >= 0 && !ch_load_winner(v.blkR, widx, tag, g))) { if (lane == 0) ch_st(&st->status, (int)ST_CHAIN_STUCK); return; }
+        const int widx = ch_poll_records(v, npick, tag, lane, g);
+        if (widx == -3 || (widx >= 0 && !ch_load_winner(v, widx, tag, g))) { if (lane == 0) ch_st(&st->status, (int)ST_CHAIN_STUCK); return; }
         if (widx < 0) {
             // CLOSE with budget left, or an empty first ratio pass: the batch takes no more pivots (blk_pick_body /
             // blk_prep_body set `closed` in the same cases); with the budget spent it just ends
@@ -267,13 +303,16 @@ __device__ __forceinline__ void ch_commit_loop(const LpView<F64> & v, int batch,
         if (lane == 0) {
             const int enter = g.enter, leave = g.leave, r = g.r;
             if (!((g.w >> (leave & 31)) & 1u)) {                // genPair, lpsol.h:100-104
-                ch_st(&v.ppt[(size_t)enter * v.pw + (leave >> 5)], g.w | (1u << (leave & 31)));
-                __hip_atomic_fetch_add(&v.rowcnt[enter], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ch_st(&v.colcnt[leave], g.cc + 1);
+                ch_stl<LOCAL>(&v.ppt[(size_t)enter * v.pw + (leave >> 5)], g.w | (1u << (leave & 31)));
+                // (this lane is the only writer of the counters while the launch runs; LOCAL: a plain read-modify-write,
+                // so that the line stays in the L2 the prep workers read it from)
+                if (LOCAL) ch_st_plain(&v.rowcnt[enter], ch_ld(&v.rowcnt[enter]) + 1);
+                else __hip_atomic_fetch_add(&v.rowcnt[enter], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ch_stl<LOCAL>(&v.colcnt[leave], g.cc + 1);
             }
-            ch_st(&v.nv[enter], (uint8_t)0); ch_st(&v.nv[leave], (uint8_t)1);          // lpsol.h:1504-1510
-            ch_st(&v.bv[enter], (uint8_t)1); ch_st(&v.bv[leave], (uint8_t)0);
-            ch_st(&v.eq2bv[r], enter); ch_st(&v.bv2eq[enter], r); ch_st(&v.bv2eq[leave], -1);
+            ch_stl<LOCAL>(&v.nv[enter], (uint8_t)0); ch_stl<LOCAL>(&v.nv[leave], (uint8_t)1);          // lpsol.h:1504-1510
+            ch_stl<LOCAL>(&v.bv[enter], (uint8_t)1); ch_stl<LOCAL>(&v.bv[leave], (uint8_t)0);
+            ch_stl<LOCAL>(&v.eq2bv[r], enter); ch_stl<LOCAL>(&v.bv2eq[enter], r); ch_stl<LOCAL>(&v.bv2eq[leave], -1);
             if ((int)tp < v.trace_cap) { v.trace[2 * tp] = enter; v.trace[2 * tp + 1] = leave; }
             st->total_pivots = tp + 1;
             st->done = done + 1;
@@ -281,10 +320,12 @@ __device__ __forceinline__ void ch_commit_loop(const LpView<F64> & v, int batch,
             st->blk.r[t] = r; st->blk.n = t + 1;
             st->blk.la_from_state = 0;
             st->blk.la_epoch = tag;
+            // (the next batch's pick(0) looks through ceil(W / 64) partial slots for this tag: the chain's nprep <= that many
+            // carry it, the rest still hold stage 0's and are ignored)
         }
         ch_drain();                                             // the commit is out: the pick role of stage t+1 may read it
         if (lane == 0)
-            ch_store_granule((char *)v.blkP + (size_t)nprep * CH_PART_BYTES, (unsigned long long)(unsigned)INT_MAX, (unsigned long long)tag);
+            ch_store_granule<LOCAL>(ch_part_g0(v, nprep), (unsigned long long)(unsigned)INT_MAX, (unsigned long long)tag);
         tp += 1; done += 1; budget -= 1;
     }
 }
@@ -296,69 +337,102 @@ __device__ unsigned long long g_ch_ts[4][16][8];            // [worker class][st
 #define CH_TS(pt_) do { } while (0)
 #endif
 
-// npick = ceil(m / 64) <= 256 pick workers, nprep = ceil(W / 64) <= 510 prep workers; grid = max of the two, + 1.
-// force_abort: test hook (XPG_CHAIN_TEST_ABORT=k makes every k-th chain launch fail its roll call).
-__global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int t0, int B, int npick, int nprep, int force_abort)
+// A worker is ONE wave; its lane l owns RPL rows (pick role: rows base + 64 u + l, u < RPL, base = 64 RPL w) and CPL columns
+// (prep role, likewise). npick = ceil(m / (64 RPL)) <= 256 pick workers, nprep = ceil(W / (64 CPL)) <= 510 prep workers;
+// workers = max of the two, + 1 (the committer). Fewer, fatter workers make every hand-off cheaper -- each is an
+// all-to-all: every worker polls every producer's granule, and the price of a step grows with the head count
+// (tools/lab/xcd_handoff_lab.hip: 0.99 us at 64 workers, 1.85 at 129, 2.31 at 193) -- at the price of RPL / CPL times the
+// arithmetic per lane, which is the small part of a stage.
+// nparts0: how many partials the stage before t0 left (a launch of its own: one per 64 columns).
+// force_abort: test hook (XPG_CHAIN_TEST_ABORT=k makes every k-th chain launch fail its roll call, -k its placement check).
+// LOCAL: the workers are the workgroups with blockIdx % 8 == 0 of a grid of 8 x workers -- workgroups are dealt round-robin
+// over the 8 XCDs, so these all land on ONE XCD, whose L2 then is the point of coherence of every hand-off: plain stores,
+// sc1 (L1-bypassing) loads, an L2 round trip per hop instead of a fabric one. The placement is an observation, not a
+// contract (MI355X_MICROARCH.md, "Workgroup dispatch"), so the roll call CHECKS it: every worker counts itself in on the
+// counter of the XCD it reads from HW_REG_XCC_ID, and the committer says GO only if one counter holds them all; otherwise
+// ABORT + blk.ch_misplaced, and the host goes back to the spread (sc1) form of this kernel for the rest of the solve.
+template <bool LOCAL, int RPL, int CPL>
+__global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int t0, int B, int npick, int nprep, int nparts0, int force_abort)
 {
+    static_assert((RPL == 1 || RPL == 2 || RPL == 4) && (CPL == 1 || CPL == 2 || CPL == 4), "rows / columns per lane");
+    constexpr int CSHIFT = 6 + (CPL == 1 ? 0 : (CPL == 2 ? 1 : 2));         // columns per prep worker = 1 << CSHIFT
+    if (LOCAL && (blockIdx.x & 7u)) return;
     LoopState * st = v.st;
-    const int w = (int)blockIdx.x, lane = (int)threadIdx.x;
+    const int w = LOCAL ? (int)(blockIdx.x >> 3) : (int)blockIdx.x, lane = (int)threadIdx.x;
+    const unsigned nworkers = LOCAL ? gridDim.x >> 3 : gridDim.x;
     // ---- the ticket: stage 0 of THIS batch staged a pivot (fields this launch never writes)
     if (st->blk.ch_epoch != blk_epoch(batch, t0 - 1) || st->status != ST_RUNNING || st->pricing != 0) return;
     unsigned budget = st->blk.ch_budget, done = st->blk.ch_done;
     const unsigned max_iter = st->max_iter;
     // ---- roll call (see the header): count in; the committer decides GO / ABORT for everybody
-    char * const decision = (char *)v.blkP + (size_t)(nprep + 1) * CH_PART_BYTES;
+    char * const decision = ch_part_g0(v, BLK_DECISION_SLOT);
     const unsigned roll_tag = blk_epoch(batch, t0 - 1);
-    if (lane == 0) __hip_atomic_fetch_add(&st->blk.ch_arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (w == (int)gridDim.x - 1) {
+    if (lane == 0) __hip_atomic_fetch_add(&st->blk.ch_arrive[LOCAL ? ch_xcc_id() : 0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (w == (int)nworkers - 1) {
         const unsigned long long t_in = wall_clock64();
-        bool go = false;
+        bool go = false, misplaced = false;
         for (;;) {
-            if (force_abort) break;
-            if (ch_ld(&st->blk.ch_arrive) >= gridDim.x) { go = true; break; }
+            if (force_abort) { misplaced = force_abort == 2; break; }
+            // lanes 0..7 read one XCD's counter each
+            const unsigned mine = ch_ld(&st->blk.ch_arrive[lane & 7]);
+            unsigned sum = 0, top = 0;
+#pragma unroll
+            for (int x = 0; x < 8; x++) { const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)mine, x); sum += c; top = c > top ? c : top; }
+            if (top >= nworkers) { go = true; break; }
+            if (sum >= nworkers) { misplaced = true; break; }        // all here, but not on one XCD: the L2 hand-offs would not be coherent
             if (wall_clock64() - t_in > (unsigned long long)CH_ARRIVE_TICKS) break;
             __builtin_amdgcn_s_sleep(1);
         }
         if (lane == 0) {
             if (go) st->blk.ch_runs += 1u;
-            else { st->blk.closed = 1; st->blk.ch_aborts += 1u; }     // nothing of this launch has touched the state: close the batch at stage 0's pivot
+            else { st->blk.closed = 1; st->blk.ch_aborts += 1u; if (misplaced) st->blk.ch_misplaced += 1u; }     // nothing of this launch has touched the state: close the batch at stage 0's pivot
         }
         ch_drain();
-        if (lane == 0) ch_store_granule(decision, (unsigned long long)(go ? CH_GO : CH_ABORT), (unsigned long long)roll_tag);
-        if (go) ch_commit_loop(v, batch, t0, B, npick, nprep, budget, done, st->blk.ch_tp);
+        // (the decision is an sc1 store in either form: after a failed placement check its readers may sit on any XCD)
+        if (lane == 0) ch_store_granule<false>(decision, (unsigned long long)(go ? CH_GO : CH_ABORT), (unsigned long long)roll_tag);
+        if (go) ch_commit_loop<LOCAL>(v, batch, t0, B, npick, nprep, budget, done, st->blk.ch_tp);
         return;
     }
     const int m = v.m, W = v.W, rhs = v.rhs, ld = v.ld, lim = v.rhs - 1;
     const bool picker = w < npick, prepper = w < nprep;
-    const int i = w * 64 + lane, j = w * 64 + lane;         // this lane's row (pick role) and column (prep role)
-    const bool has_row = picker && i < m, has_col = prepper && j < W;
-    const int ic = has_row ? i : 0, jc = has_col ? j : 0;
+    // this lane's rows (pick role) and columns (prep role)
+    int irow[RPL], icl[RPL], jcol[CPL], jcl[CPL];
+    bool hrow[RPL], hcol[CPL];
+#pragma unroll
+    for (int u = 0; u < RPL; u++) { irow[u] = (w * RPL + u) * 64 + lane; hrow[u] = picker && irow[u] < m; icl[u] = hrow[u] ? irow[u] : 0; }
+#pragma unroll
+    for (int c = 0; c < CPL; c++) { jcol[c] = (w * CPL + c) * 64 + lane; hcol[c] = prepper && jcol[c] < W; jcl[c] = hcol[c] ? jcol[c] : 0; }
     const double * __restrict__ tab = (const double *)v.tab;
     double * K = (double *)v.blkK;
     double * E = (double *)v.blkE;
-    const char * parts = (const char *)v.blkP;
-    const int wrhs = rhs >> 6;                              // the prep worker that owns the constant column
     // ---- own data of the stages before t0 (written by previous launches): into registers once
-    double kreg[BLK_MAX], ereg[BLK_MAX];
+    double kreg[RPL][BLK_MAX], ereg[CPL][BLK_MAX];
 #pragma unroll
     for (int s = 0; s < BLK_MAX; s++) {
-        kreg[s] = (s < t0 && has_row) ? K[(size_t)ic * BLK_MAX + s] : 0.0;
-        ereg[s] = (s < t0 && has_col) ? E[(size_t)s * ld + jc] : 0.0;
+#pragma unroll
+        for (int u = 0; u < RPL; u++) kreg[u][s] = (s < t0 && hrow[u]) ? K[(size_t)icl[u] * BLK_MAX + s] : 0.0;
+#pragma unroll
+        for (int c = 0; c < CPL; c++) ereg[c][s] = (s < t0 && hcol[c]) ? E[(size_t)s * ld + jcl[c]] : 0.0;
     }
-    F64 oj = has_col ? v.obj[jc] : zero<F64>();            // this lane's objective entry
-    int bi = v.eq2bv[ic];                                   // basic variable of this lane's row (stage 0's commit is in)
-    int sstar = -1;                                         // last stage in which this lane's row was the pivot row
-    double bcur = tab[(size_t)ic * ld + rhs];               // this row's constant, replayed through the stages before t - 1
-    double klast = 0.0;                                     // k of stage t - 1 for this row
+    F64 oj[CPL];                                            // this lane's objective entries
+    int bi[RPL], sstar[RPL];                                // basic variable of this lane's rows (stage 0's commit is in); last stage in which the row was the pivot row
+    double bcur[RPL], klast[RPL];                           // the row's constant, replayed through the stages before t - 1; k of stage t - 1
+#pragma unroll
+    for (int c = 0; c < CPL; c++) oj[c] = hcol[c] ? v.obj[jcl[c]] : zero<F64>();
+#pragma unroll
+    for (int u = 0; u < RPL; u++) { bi[u] = v.eq2bv[icl[u]]; sstar[u] = -1; bcur[u] = tab[(size_t)icl[u] * ld + rhs]; klast[u] = 0.0; }
     for (int s = 0; s < t0; s++) {
         const int rs = st->blk.r[s];
-        if (rs == i) sstar = s;
-        const double ks = has_row ? K[(size_t)ic * BLK_MAX + s] : 0.0;
-        if (s + 1 < t0) {                                   // (t0 = 1: no step here; stage t0 - 1 is applied in the loop)
-            const double eb = E[(size_t)s * ld + rhs];
-            const double pb = ks * eb;
-            bcur = (rs == i) ? eb : (bcur + pb);
-        } else klast = ks;
+        const double eb = E[(size_t)s * ld + rhs];
+#pragma unroll
+        for (int u = 0; u < RPL; u++) {
+            if (rs == irow[u]) sstar[u] = s;
+            const double ks = hrow[u] ? K[(size_t)icl[u] * BLK_MAX + s] : 0.0;
+            if (s + 1 < t0) {                               // (t0 = 1: no step here; stage t0 - 1 is applied in the loop)
+                const double pb = ks * eb;
+                bcur[u] = (rs == irow[u]) ? eb : (bcur[u] + pb);
+            } else klast[u] = ks;
+        }
     }
     int r_prev = st->blk.r[t0 - 1];                         // pivot row of stage t - 1 (for the constant's step)
     // ---- the committer's decision. A worker must have it before its first WRITE: a pick worker therefore reads it only
@@ -386,55 +460,58 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
         CH_TS(0);
         // =========================== pick role =====================================================
         if (picker) {
-            // ---- poll the g0 granules of the partials of stage t-1 and the commit granule (slot nprep): four slots per
-            // lane and round; beyond 256 slots (W >= 16 320: two rounds) up to 511
+            // ---- poll the g0 granules of the partials of stage t-1 and, behind them, the commit granule (the commit of
+            // stage t0 - 1 was a launch of its own: no granule to wait for): four slots per lane and round, dense
+            const int cnt = t == t0 ? nparts0 : nprep;      // partials of the stage before
+            const int last = t == t0 ? cnt - 1 : cnt;       // the highest slot to wait for
+            const int pshift = t == t0 ? 6 : CSHIFT;        // columns per partial of that stage, as a shift
             int nf = INT_MAX;
-            for (int base = 0; base <= nprep; base += 256) {
+            for (int base = 0; base <= last; base += 256) {
                 const int k0 = base + lane, k1 = k0 + 64, k2 = k0 + 128, k3 = k0 + 192;
-                const int kc = k0 <= nprep ? k0 : base + (lane % (nprep + 1 - base));
-                const int j1 = k1 <= nprep ? k1 : kc, j2 = k2 <= nprep ? k2 : kc, j3 = k3 <= nprep ? k3 : kc;   // (no slot of its own: its first one again)
-                const void * p0 = parts + (size_t)kc * CH_PART_BYTES;
-                const void * p1 = parts + (size_t)j1 * CH_PART_BYTES;
-                const void * p2 = parts + (size_t)j2 * CH_PART_BYTES;
-                const void * p3 = parts + (size_t)j3 * CH_PART_BYTES;
-                // (the commit of stage t0 - 1 was a launch of its own: no granule to wait for)
-                const bool x0 = kc == nprep && t == t0, x1 = j1 == nprep && t == t0;
-                const bool x2 = j2 == nprep && t == t0, x3 = j3 == nprep && t == t0;
+                const int kc = k0 <= last ? k0 : base + (lane % (last + 1 - base));
+                const int j1 = k1 <= last ? k1 : kc, j2 = k2 <= last ? k2 : kc, j3 = k3 <= last ? k3 : kc;   // (no slot of its own: its first one again)
+                const void * p0 = ch_part_g0(v, kc);
+                const void * p1 = ch_part_g0(v, j1);
+                const void * p2 = ch_part_g0(v, j2);
+                const void * p3 = ch_part_g0(v, j3);
                 ch_u32x4 g0, g1, g2, g3;
                 unsigned spins = 0;
                 for (;;) {
                     ch_load4(p0, p1, p2, p3, g0, g1, g2, g3);
-                    const bool ok = (g0.z == want_part || x0) && (g1.z == want_part || x1) && (g2.z == want_part || x2) && (g3.z == want_part || x3);
+                    const bool ok = g0.z == want_part && g1.z == want_part && g2.z == want_part && g3.z == want_part;
                     if (__all(ok)) break;
                     if (++spins > CH_SPIN_LIMIT) { if (lane == 0) ch_st(&st->status, (int)ST_CHAIN_STUCK); return; }
                     __builtin_amdgcn_s_sleep(1);
                 }
-                if (k0 < nprep) nf = min(nf, (int)g0.x);
-                if (k1 < nprep) nf = min(nf, (int)g1.x);
-                if (k2 < nprep) nf = min(nf, (int)g2.x);
-                if (k3 < nprep) nf = min(nf, (int)g3.x);
+                if (k0 < cnt) nf = min(nf, (int)g0.x);
+                if (k1 < cnt) nf = min(nf, (int)g1.x);
+                if (k2 < cnt) nf = min(nf, (int)g2.x);
+                if (k3 < cnt) nf = min(nf, (int)g3.x);
             }
             CH_TS(1);                                       // partials + commit granule seen
             const int first = wave_min_int(nf);
 
             // the fast path of blk_pick_body, or the end of the batch for everyone
             const bool fast = first >= 0 && first < rhs && done < max_iter && budget != 0;
-            unsigned long long * rec = v.blkR + (size_t)w * BLK_REC_WORDS;
             if (!fast) {
                 if (!wait_decision()) return;
-                if (lane == 0) ch_store_granule3(rec, ~0u, ~0u, (unsigned)CH_CLOSE_ROW, tag);
+                if (lane == 0) ch_store_granule3<LOCAL>(ch_rec_g0(v, w), ~0u, ~0u, (unsigned)CH_CLOSE_ROW, tag);
                 return;
             }
             // ---- one round: the column gather; e_s[first] for s <= t-2 from memory (lane s); the three fresh
-            // granules of stage t-1 (lane 32: e[first], lane 33: c[first], lane 34: e[rhs]); pair word, counter
-            const double x0 = tab[(size_t)ic * ld + first];
+            // granules of stage t-1 (lane 32: e[first], lane 33: c[first], lane 34: e[rhs]); pair words, counters
+            double x0[RPL]; uint32_t pww[RPL]; int ccv[RPL];
+#pragma unroll
+            for (int u = 0; u < RPL; u++) {
+                x0[u] = tab[(size_t)icl[u] * ld + first];
+                pww[u] = ch_ld(&v.ppt[(size_t)first * v.pw + (bi[u] >> 5)]);
+                ccv[u] = ch_ld(&v.colcnt[bi[u]]);
+            }
             double ev = 0.0;
             if (lane + 1 < t) ev = ch_ld(&E[(size_t)lane * ld + first]);
-            const uint32_t pw_word = ch_ld(&v.ppt[(size_t)first * v.pw + (bi >> 5)]);
-            const int cc = ch_ld(&v.colcnt[bi]);
             {
                 const bool fresh = lane >= 32 && lane <= 34;
-                const char * gp = parts + (size_t)(lane == 34 ? wrhs : (first >> 6)) * CH_PART_BYTES + (fresh ? 16 * (lane - 31) : 0);
+                const char * gp = ch_part_pay(v, (lane == 34 ? rhs : first) >> pshift) + (fresh ? 16 * (lane - 32) : 0);
                 unsigned spins = 0;
                 for (;;) {
                     const ch_u32x4 g = ch_load1(gp);
@@ -447,43 +524,65 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
             const double ec_new = ch_readlane_f64(ev, 32), eb_new = ch_readlane_f64(ev, 34);
             const unsigned long long cnv_bits = __builtin_bit_cast(unsigned long long, ch_readlane_f64(ev, 33));
             // the constant column: ONE step, stage t-1 (the arithmetic of every other cell of the sweep)
-            {
-                const double pb = klast * eb_new;
-                bcur = (i == r_prev) ? eb_new : (bcur + pb);
+#pragma unroll
+            for (int u = 0; u < RPL; u++) {
+                const double pb = klast[u] * eb_new;
+                bcur[u] = (irow[u] == r_prev) ? eb_new : (bcur[u] + pb);
             }
             // the entering column through the stages 0 .. t-1
-            double a = x0;
+            double a[RPL];
+#pragma unroll
+            for (int u = 0; u < RPL; u++) a[u] = x0[u];
 #pragma unroll
             for (int s = 0; s < BLK_MAX; s++) {
                 if (s < t) {
                     const double ec = (s + 1 < t) ? ch_readlane_f64(ev, s) : ec_new;
-                    const double pa = kreg[s] * ec;
-                    a = (s == sstar) ? ec : (a + pa);
+#pragma unroll
+                    for (int u = 0; u < RPL; u++) {
+                        const double pa = kreg[u][s] * ec;
+                        a[u] = (s == sstar[u]) ? ec : (a[u] + pa);
+                    }
                 }
             }
-            klast = -a;                                                           // -a_i,nv (lpsol.h:1485)
-#pragma unroll
-            for (int s = 0; s < BLK_MAX; s++) if (s == t) kreg[s] = klast;
             if (!wait_decision()) return;                                         // (first stage only: nothing has been written so far)
-            if (has_row) ch_st(&K[(size_t)i * BLK_MAX + t], klast);
-            // findPivotBV's first pass (lpsol.h:553-663)
+            // -a_i,nv (lpsol.h:1485) -> K; findPivotBV's first pass (lpsol.h:553-663): this lane's best row (the lower row
+            // wins a tie: rows ascend with u)
             unsigned long long key = ~0ull;
-            if (has_row && !le(F64(a), zero<F64>()) && !((pw_word >> (bi & 31)) & 1u) && cc < lim) key = ch_ratio_key(bcur / a);
+            int brow = INT_MAX, bbi = 0, bcc = 0, bss = -1; uint32_t bpw = 0; double ba = 0.0;
+#pragma unroll
+            for (int u = 0; u < RPL; u++) {
+                klast[u] = -a[u];
+#pragma unroll
+                for (int s = 0; s < BLK_MAX; s++) if (s == t) kreg[u][s] = klast[u];
+                if (hrow[u]) ch_stl<LOCAL>(&K[(size_t)irow[u] * BLK_MAX + t], klast[u]);
+                if (hrow[u] && !le(F64(a[u]), zero<F64>()) && !((pww[u] >> (bi[u] & 31)) & 1u) && ccv[u] < lim) {
+                    const unsigned long long ku = ch_ratio_key(bcur[u] / a[u]);
+                    if (ku < key) { key = ku; brow = irow[u]; bbi = bi[u]; bcc = ccv[u]; bss = sstar[u]; bpw = pww[u]; ba = a[u]; }
+                }
+            }
             const unsigned long long kmin = ch_wave_min_u64(key);
-            const unsigned long long hit = __ballot(key == kmin);
-            const bool publisher = kmin != ~0ull ? (lane == __ffsll((long long)hit) - 1) : (lane == 0);
+            bool publisher;
+            if (RPL == 1) {                                 // (rows ascend with the lane: the first hit is the lowest row)
+                const unsigned long long hit = __ballot(key == kmin);
+                publisher = kmin != ~0ull ? (lane == __ffsll((long long)hit) - 1) : (lane == 0);
+            } else {
+                const int myrow = (kmin != ~0ull && key == kmin) ? brow : INT_MAX;
+                const int rmin = wave_min_int(myrow);
+                publisher = kmin != ~0ull ? (myrow == rmin) : (lane == 0);
+            }
             if (publisher) {
-                const unsigned long long ab = to_bits(F64(a));
-                ch_store_granule3(rec + 2, (unsigned)ab, (unsigned)(ab >> 32), (unsigned)bi, tag);
-                ch_store_granule3(rec + 4, pw_word, (unsigned)cc, (unsigned)first | ((unsigned)(sstar + 1) << 24), tag);
-                ch_store_granule3(rec + 6, (unsigned)cnv_bits, (unsigned)(cnv_bits >> 32), 0u, tag);
-                ch_store_granule3(rec + 0, (unsigned)kmin, (unsigned)(kmin >> 32), (unsigned)(kmin != ~0ull ? i : INT_MAX), tag);
+                const unsigned long long ab = to_bits(F64(ba));
+                char * pay = ch_rec_pay(v, w);
+                ch_store_granule3<LOCAL>(pay, (unsigned)ab, (unsigned)(ab >> 32), (unsigned)bbi, tag);
+                ch_store_granule3<LOCAL>(pay + 16, bpw, (unsigned)bcc, (unsigned)first | ((unsigned)(bss + 1) << 24), tag);
+                ch_store_granule3<LOCAL>(pay + 32, (unsigned)cnv_bits, (unsigned)(cnv_bits >> 32), 0u, tag);
+                ch_store_granule3<LOCAL>(ch_rec_g0(v, w), (unsigned)kmin, (unsigned)(kmin >> 32), (unsigned)(kmin != ~0ull ? brow : INT_MAX), tag);
             }
             CH_TS(3);                                       // record issued
         }
         // =========================== every worker reads the records: all leave together ======================
         ChWinner g;
-        const int widx = ch_poll_records(v.blkR, npick, tag, lane, g);
+        const int widx = ch_poll_records(v, npick, tag, lane, g);
         if (widx == -3) { if (lane == 0) ch_st(&st->status, (int)ST_CHAIN_STUCK); return; }
         if (widx < 0) return;                               // CLOSE / empty first pass: the committer records it
         CH_TS(4);                                           // records seen and combined
@@ -493,61 +592,83 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
         // ---- one round: the pivot row gather, k_q[r] (lane q), this column's basis words (the previous stage's
         // commit is behind the records just read), and the rest of the winner's record (whose wait completes the
         // loads before it as well)
-        double x0 = 0.0, kv = 0.0; int nvj = 0, rcj0 = INT_MAX;
+        double x0[CPL]; double kv = 0.0; int nvj[CPL], rcj0[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; c++) { x0[c] = 0.0; nvj[c] = 0; rcj0[c] = INT_MAX; }
         if (prepper) {
-            x0 = tab[(size_t)r * ld + jc];
-            if (has_col && j < rhs) { nvj = (int)ch_ld(&v.nv[jc]); rcj0 = ch_ld(&v.rowcnt[jc]); }
+#pragma unroll
+            for (int c = 0; c < CPL; c++) {
+                x0[c] = tab[(size_t)r * ld + jcl[c]];
+                if (hcol[c] && jcol[c] < rhs) { nvj[c] = (int)ch_ld(&v.nv[jcl[c]]); rcj0[c] = ch_ld(&v.rowcnt[jcl[c]]); }
+            }
             if (lane < t) kv = ch_ld(&K[(size_t)r * BLK_MAX + lane]);
         }
-        if (!ch_load_winner(v.blkR, widx, tag, g)) { if (lane == 0) ch_st(&st->status, (int)ST_CHAIN_STUCK); return; }
+        if (!ch_load_winner(v, widx, tag, g)) { if (lane == 0) ch_st(&st->status, (int)ST_CHAIN_STUCK); return; }
         const int enter = g.enter, leave = g.leave;
-        if (i == r) { bi = enter; sstar = t; }              // lpsol.h:1508, as every later pick of this launch sees it
+#pragma unroll
+        for (int u = 0; u < RPL; u++) if (irow[u] == r) { bi[u] = enter; sstar[u] = t; }   // lpsol.h:1508, as every later pick of this launch sees it
         if (prepper) {
             const F64 sc = div(one<F64>(), F64(g.a));       // 1/(eq.get(eqnum, nv)), lpsol.h:1471
             const int smode = scale_mode(sc);
             const F64 cnv = from_bits<F64>(g.cnv);
             const int cmode = scale_mode(cnv);
             const int qstar = g.qstar;                      // the last stage before t in which row r was the pivot row
-            double x = x0;
+            double x[CPL];
+#pragma unroll
+            for (int c = 0; c < CPL; c++) x[c] = x0[c];
 #pragma unroll
             for (int q = 0; q < BLK_MAX; q++) {             // the pivot row as the pending sweeps would leave it
                 if (q < t) {
                     const double kq = ch_readlane_f64(kv, q);
-                    const double pr = kq * ereg[q];
-                    x = (q == qstar) ? ereg[q] : (x + pr);
+#pragma unroll
+                    for (int c = 0; c < CPL; c++) {
+                        const double pr = kq * ereg[c][q];
+                        x[c] = (q == qstar) ? ereg[c][q] : (x[c] + pr);
+                    }
                 }
             }
-            const F64 e = scaled(F64(x), sc, smode);
-            CH_TS(5);                                       // row gather in, replayed, scaled
+            F64 e[CPL];
 #pragma unroll
-            for (int q = 0; q < BLK_MAX; q++) if (q == t) ereg[q] = e.v;
+            for (int c = 0; c < CPL; c++) {
+                e[c] = scaled(F64(x[c]), sc, smode);
+#pragma unroll
+                for (int q = 0; q < BLK_MAX; q++) if (q == t) ereg[c][q] = e[c].v;
+            }
+            CH_TS(5);                                       // row gather in, replayed, scaled
             int nf = INT_MAX, any = 0;
-            if (has_col) {
-                ch_st(&E[(size_t)t * ld + j], e.v);
-                F64 tt = mul(e, minus_one<F64>());          // nvexp.mul(-1), lpsol.h:1496
-                if (j >= rhs) tt = neg(tt);                 // :1497-1499
-                tt = scaled(tt, cnv, cmode);                // nvexp.mul(tgtf(nv)), :1500
-                const bool in = j < rhs;
-                const bool nv_mem = in && j != enter && j != leave && nvj != 0;
-                const bool nv_old = in && (j == enter ? true : (j == leave ? false : nv_mem));
-                const bool nv_new = in && (j == enter ? false : (j == leave ? true : nv_mem));
-                const int rcj = (in && j != enter) ? rcj0 : INT_MAX;
-                if (j < enter && in && !nv_old) oj = zero<F64>();     // lpsol.h:1055-1060
-                oj = add(tt, oj);                           // addRowToRow, :1501
-                v.obj[j] = oj;                              // (read again only by later launches)
-                if (nv_new && gt(oj, zero<F64>())) { any = 1; if (rcj < lim) nf = j; }
+#pragma unroll
+            for (int c = 0; c < CPL; c++) {
+                if (hcol[c]) {
+                    const int j = jcol[c];
+                    ch_stl<LOCAL>(&E[(size_t)t * ld + j], e[c].v);
+                    F64 tt = mul(e[c], minus_one<F64>());   // nvexp.mul(-1), lpsol.h:1496
+                    if (j >= rhs) tt = neg(tt);             // :1497-1499
+                    tt = scaled(tt, cnv, cmode);            // nvexp.mul(tgtf(nv)), :1500
+                    const bool in = j < rhs;
+                    const bool nv_mem = in && j != enter && j != leave && nvj[c] != 0;
+                    const bool nv_old = in && (j == enter ? true : (j == leave ? false : nv_mem));
+                    const bool nv_new = in && (j == enter ? false : (j == leave ? true : nv_mem));
+                    const int rcj = (in && j != enter) ? rcj0[c] : INT_MAX;
+                    if (j < enter && in && !nv_old) oj[c] = zero<F64>();  // lpsol.h:1055-1060
+                    oj[c] = add(tt, oj[c]);                 // addRowToRow, :1501
+                    v.obj[j] = oj[c];                       // (read again only by later launches)
+                    if (nv_new && gt(oj[c], zero<F64>())) { any = 1; if (rcj < lim) nf = min(nf, j); }
+                }
             }
             nf = wave_min_int(nf);
             any = __ballot(any != 0) != 0ull ? 1 : 0;
             // ---- the partial: the lane that owns the worker's candidate column publishes what the next pick needs
             // fresh of it, the lane that owns the constant column its new e, lane 0 the candidate itself
-            char * P = (char *)v.blkP + (size_t)w * CH_PART_BYTES;
-            if (has_col && j == nf) {
-                ch_store_granule(P + 16, to_bits(e), (unsigned long long)tag);
-                ch_store_granule(P + 32, to_bits(oj), (unsigned long long)tag);
+            char * pay = ch_part_pay(v, w);
+#pragma unroll
+            for (int c = 0; c < CPL; c++) {
+                if (hcol[c] && jcol[c] == nf) {
+                    ch_store_granule<LOCAL>(pay, to_bits(e[c]), (unsigned long long)tag);
+                    ch_store_granule<LOCAL>(pay + 16, to_bits(oj[c]), (unsigned long long)tag);
+                }
+                if (hcol[c] && jcol[c] == rhs) ch_store_granule<LOCAL>(pay + 32, to_bits(e[c]), (unsigned long long)tag);
             }
-            if (has_col && j == rhs) ch_store_granule(P + 48, to_bits(e), (unsigned long long)tag);
-            if (lane == 0) ch_store_granule(P, ((unsigned long long)(unsigned)any << 32) | (unsigned)nf, (unsigned long long)tag);
+            if (lane == 0) ch_store_granule<LOCAL>(ch_part_g0(v, w), ((unsigned long long)(unsigned)any << 32) | (unsigned)nf, (unsigned long long)tag);
             CH_TS(6);                                       // partial issued
         }
         done += 1; budget -= 1;

@@ -93,8 +93,9 @@ template <> inline void launch_pipe_sweep<R32>(xpg_ctx * ctx, const LpView<R32> 
     if (timed) prof_close(ctx);
 }
 // One batch of the blocked loop: B x (pick, prep) -- the generic pick once after pick(0) -- and a sweep.
-template <class S> inline void launch_blk_batch(xpg_ctx *, const LpView<S> &, int, int, bool, bool, bool) {}
-template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> & v, int batch, int B, bool ref_pricing, bool closes_often, bool chain_off)
+template <class S> inline void launch_blk_batch(xpg_ctx *, const LpView<S> &, int, int, bool, bool, bool, bool) {}
+template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> & v, int batch, int B, bool ref_pricing, bool closes_often, bool chain_off,
+                                              bool chain_spread)
 {
     const int strips = (v.W + 511) / 512;
     // workgroup sizes of pick and prep: 64 = one wave per workgroup, no LDS round in the reductions
@@ -110,15 +111,41 @@ template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> &
     // cannot seat them all, so the shape limits here are only those of the hand-off areas: 256 records, 511 partial slots
     // (W <= 32 640), and at most four workers per CU. Taller or wider tableaux, and the opt-in Dantzig pricing, take the
     // launch-per-stage path.
-    const int cpick = (v.m + 63) / 64, cprep = (v.W + 63) / 64;
+    // rows / columns per lane of a worker: ONE each wherever the hand-off areas hold that many workers (256 records,
+    // 510 partials). Fewer, fatter workers were measured and are slower although every hand-off is an all-to-all whose
+    // price grows with the head count (tools/lab/xcd_handoff_lab.hip): at 4096 x 8192 / 4096 x 12289, batches of 16,
+    // 1 x 1 91.9 / 71.1 k pivots/s, 2 x 1 89.1 / 69.6, 1 x 2 86.8 / 69.3, 2 x 2 85.2 / 61.5, 2 x 4 75.3 / 61.4 -- the
+    // arithmetic of ONE wave is what a stage is made of. XPG_CHAIN_RPL / XPG_CHAIN_CPL force a form for A/B runs.
+    static const int rpl_env = [] { const char * s = getenv("XPG_CHAIN_RPL"); return s ? atoi(s) : 0; }();
+    static const int cpl_env = [] { const char * s = getenv("XPG_CHAIN_CPL"); return s ? atoi(s) : 0; }();
+    int rpl = 1, cpl = 1;
+    if (rpl_env == 1 || rpl_env == 2) rpl = rpl_env;
+    if (cpl_env == 1 || cpl_env == 2 || cpl_env == 4) cpl = cpl_env;
+    if ((v.m + 64 * rpl - 1) / (64 * rpl) > BLK_REC_MAX) rpl = 2;
+    while (cpl < 4 && (v.W + 64 * cpl - 1) / (64 * cpl) > 510) cpl *= 2;
+    const int cpick = (v.m + 64 * rpl - 1) / (64 * rpl), cprep = (v.W + 64 * cpl - 1) / (64 * cpl);
     const bool chain = ctx->chain && !chain_off && ref_pricing && B > 1 &&
                        cpick <= BLK_REC_MAX && cprep <= 510 && (cpick > cprep ? cpick : cprep) + 1 <= 4 * (ctx->num_cus > 0 ? ctx->num_cus : 1) &&
-                       tpb_prep == 64;             // stage 0's prep leaves one look-ahead partial per 64 columns, as the chain's workers do
+                       (v.W + 63) / 64 <= 510 &&   // stage 0's prep leaves one look-ahead partial per 64 columns: they share the slots
+                       tpb_prep == 64;
     for (int t = 0; t < B; t++) {
         if (t == 1 && chain) {
             const int test_abort = ctx->chain_test_abort;
-            hipLaunchKernelGGL(k_blk_chain, dim3((cpick > cprep ? cpick : cprep) + 1), dim3(64), 0, ctx->stream, v, batch, 1, B, cpick, cprep,
-                               test_abort > 0 && batch % test_abort == test_abort - 1 ? 1 : 0);
+            const int workers = (cpick > cprep ? cpick : cprep) + 1;
+            // test hooks: k > 0 -- every k-th launch fails its roll call; k < 0 -- every |k|-th one-XCD launch "finds" its
+            // workers on several XCDs
+            const int fa = test_abort > 0 ? (batch % test_abort == test_abort - 1 ? 1 : 0)
+                                          : (test_abort < 0 && batch % -test_abort == -test_abort - 1 ? 2 : 0);
+            // every worker on one XCD, hand-offs through that XCD's L2 (lp_chain.hip.h); XPG_CHAIN_XCD=0, or a launch whose
+            // placement check failed, selects the spread form with sc1 stores
+            const bool local = ctx->chain_local && !chain_spread;
+            const int nparts0 = (int)gprep.x;
+#define XPG_CHAIN(L_, R_, C_) hipLaunchKernelGGL((k_blk_chain<L_, R_, C_>), dim3((L_ ? 8 : 1) * workers), dim3(64), 0, ctx->stream, v, batch, 1, B, cpick, cprep, nparts0, fa)
+#define XPG_CHAIN_RC(R_, C_) do { if (local) XPG_CHAIN(true, R_, C_); else XPG_CHAIN(false, R_, C_); } while (0)
+            if (rpl == 1) { if (cpl == 1) XPG_CHAIN_RC(1, 1); else if (cpl == 2) XPG_CHAIN_RC(1, 2); else XPG_CHAIN_RC(1, 4); }
+            else { if (cpl == 1) XPG_CHAIN_RC(2, 1); else if (cpl == 2) XPG_CHAIN_RC(2, 2); else XPG_CHAIN_RC(2, 4); }
+#undef XPG_CHAIN_RC
+#undef XPG_CHAIN
             break;
         }
         hipLaunchKernelGGL(k_blk_pick, dim3(npick), dim3(tp), 0, ctx->stream, v, batch, t, (int)gprep.x);
@@ -135,25 +162,27 @@ template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> &
 #define XPG_BLK_LAUNCH(ROWS_, UNR_, CAP_)                                                                                 \
     hipExtLaunchKernelGGL((k_blk_sweep<ROWS_, UNR_, CAP_>), dim3(strips, (v.m + ROWS_ - 1) / ROWS_), dim3(256), 0,        \
                           ctx->stream, e0, e1, 0, (double *)v.tab, v.m, v.W, v.ld, (const double *)v.blkE,                \
-                          (const double *)v.blkK, v.st, batch, 0)
-#define XPG_BLK_FULL(ROWS_, UNR_)                                                                                         \
-    hipExtLaunchKernelGGL((k_blk_sweep_full<ROWS_, UNR_>), dim3(blk_sweep_grid(strips, (v.m + ROWS_ - 1) / ROWS_)),      \
+                          (const double *)v.blkK, v.st, batch, 0, B)
+#define XPG_BLK_FULL(ROWS_, UNR_, NB_)                                                                                    \
+    hipExtLaunchKernelGGL((k_blk_sweep_full<ROWS_, UNR_, NB_>), dim3(blk_sweep_grid(strips, (v.m + ROWS_ - 1) / ROWS_)), \
                           dim3(256), 0, ctx->stream, e0, e1, 0, (double *)v.tab, v.m, v.W, v.ld,                          \
                           (const double *)v.blkE, (const double *)v.blkK, v.st, batch, closes_often ? 1 : 0,              \
                           serpentine ? (batch & 1) : 0)
-    if (B <= 8) XPG_BLK_LAUNCH(32, 8, 8);
-    else if (B < BLK_MAX || rows_env == 1) XPG_BLK_LAUNCH(32, 4, 16);
-    else if (rows_env == 324) XPG_BLK_FULL(32, 4);
-    else if (rows_env == 162) XPG_BLK_FULL(16, 2);
-    else if (rows_env == 82) XPG_BLK_FULL(8, 2);
-    else XPG_BLK_FULL(16, 4);                           // the default: full batches of 16
+    // the full-batch kernels: 32 pivots per pass (the default; two register sets of e_s, 2-3 waves per SIMD: 110 / 166 us
+    // per pass at 4096 x 8192 / 4096 x 12289 = 3.4 / 5.2 us per pivot against 4.9 / 7.9 with 16, tools/lab/sweep_lab2.hip) and
+    // 16 (XPG_BLOCK=16); every other length -- the tail of an iteration budget -- goes through the switch kernel
+    const bool full32 = B == 32 && rows_env != 1, full16 = B == 16 && rows_env != 1;
+    if (full32) { if (rows_env == 322) XPG_BLK_FULL(32, 2, 32); else if (rows_env == 164) XPG_BLK_FULL(16, 4, 32); else XPG_BLK_FULL(16, 2, 32); }
+    else if (full16) { if (rows_env == 324) XPG_BLK_FULL(32, 4, 16); else if (rows_env == 162) XPG_BLK_FULL(16, 2, 16); else XPG_BLK_FULL(16, 4, 16); }
+    else if (B <= 8) XPG_BLK_LAUNCH(32, 8, 8);
+    else XPG_BLK_LAUNCH(32, 4, 16);
     // An LP whose batches often close early (a rare branch of solveSlackForm met with pivots staged: 34-44 % of
     // the sweeps on whole solves of 300 x 300 and 1024 x 1500 LPs, 1 of 261 on the bench LP,
     // tools/lab/probe_partial_batches.py) gets a second launch with the stage count as a template switch for those
     // batches; the full-batch kernel above then leaves them alone.
-    if (closes_often && B == BLK_MAX && rows_env != 1)
+    if (closes_often && (full32 || full16))
         hipLaunchKernelGGL((k_blk_sweep<32, 4, 16>), dim3(strips, (v.m + 31) / 32), dim3(256), 0, ctx->stream, (double *)v.tab,
-                           v.m, v.W, v.ld, (const double *)v.blkE, (const double *)v.blkK, v.st, batch, 1);
+                           v.m, v.W, v.ld, (const double *)v.blkE, (const double *)v.blkK, v.st, batch, B, B);
 #undef XPG_BLK_LAUNCH
 #undef XPG_BLK_FULL
     if (timed) ctx->prof_n++;
@@ -194,6 +223,8 @@ template <class S> struct Lp : LpBase {
     int blk_batch = 0;      // blocked loop: id of the next batch since reset_loop
     bool closes_often = false;   // blocked loop: >= 5 % of this solve's sweeps so far were of a batch closed early
     bool chain_off = false;      // blocked loop: a chain launch of this solve failed its roll call (the device is shared): launch per stage from here on
+    bool chain_spread = false;   // blocked loop: a one-XCD chain launch found its workers on several XCDs: the spread (sc1) form from here on
+    unsigned chain_misplaced_seen = 0;
     unsigned chain_aborts_seen = 0;
     int colstride = 0;      // elements per colbuf half
     int opt_pricing = 0;    // xpg_lp_set_options: 0 the reference's rule, 1 Dantzig (non-parity)
@@ -266,8 +297,8 @@ template <class S> struct Lp : LpBase {
         if ((rc = alloc((void **)&v.pickrec, (size_t)PICK_WORDS * 8))) return rc;
         if ((rc = alloc((void **)&v.blkK, (size_t)round_up(mcap, 16) * BLK_MAX * sizeof(S)))) return rc;
         if ((rc = alloc((void **)&v.blkE, (size_t)BLK_MAX * ld * sizeof(S)))) return rc;
-        if ((rc = alloc((void **)&v.blkR, (size_t)BLK_REC_MAX * BLK_REC_WORDS * 8))) return rc;
-        if ((rc = alloc((void **)&v.blkP, (size_t)((ld + BLK_TPB_MIN - 1) / BLK_TPB_MIN + 3) * BLK_PART_INTS * 4))) return rc;
+        if ((rc = alloc((void **)&v.blkR, (size_t)BLK_REC_TOTAL_WORDS * 8))) return rc;
+        if ((rc = alloc((void **)&v.blkP, (size_t)BLK_PART_TOTAL_INTS * 4))) return rc;
         if ((rc = alloc((void **)&v.trace, (size_t)v.trace_cap * 8))) return rc;
         if ((rc = alloc((void **)&d_leq, (size_t)m * cols * sizeof(S)))) return rc;
         if ((rc = alloc((void **)&d_tgtf, (size_t)cols * sizeof(S)))) return rc;
@@ -303,6 +334,10 @@ template <class S> struct Lp : LpBase {
         XPG_HIP(ctx, hipMemcpyAsync(out, v.st, sizeof(LoopState), hipMemcpyDeviceToHost, ctx->stream));
         XPG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         closes_often = out->blk.sweeps_part >= 8 && out->blk.sweeps_part * 20u >= out->blk.sweeps_full + out->blk.sweeps_part;
+        if (out->blk.ch_misplaced != chain_misplaced_seen) {        // (an abort of its own kind: it only changes the chain's form)
+            chain_aborts_seen += out->blk.ch_misplaced - chain_misplaced_seen;
+            chain_misplaced_seen = out->blk.ch_misplaced; chain_spread = true;
+        }
         if (out->blk.ch_aborts != chain_aborts_seen) { chain_aborts_seen = out->blk.ch_aborts; chain_off = true; }
         if (out->status == XPG_ERR_CHAIN_STUCK)
             ctx->err = "blocked loop: a worker of the persistent chain launch stopped answering after the roll call (preempted queue?); rebuild the LP";
@@ -323,7 +358,7 @@ template <class S> struct Lp : LpBase {
     {
         hipLaunchKernelGGL((k_reset_loop<S>), dim3(1024), dim3(256), 0, ctx->stream, v, max_iter, opt_pricing,
                            opt_feas_tol);
-        pipe_t = 0; pipe_primed = false; blk_batch = 0; closes_often = false; chain_off = false; chain_aborts_seen = 0;
+        pipe_t = 0; pipe_primed = false; blk_batch = 0; closes_often = false; chain_off = false; chain_aborts_seen = 0; chain_spread = false; chain_misplaced_seen = 0;
     }
     void queue_pivot(int guarded, int counted)
     {
@@ -393,7 +428,7 @@ template <class S> struct Lp : LpBase {
             // the last batch of a budget that is not a multiple of B is enqueued at its own length, so its
             // sweep is the kernel specialised for that many stages (not the full-batch kernel's slow tail)
             const unsigned left = k - b * (unsigned)B;
-            launch_blk_batch(ctx, v, batch, left < (unsigned)B ? (int)left : B, opt_pricing == 0, closes_often, chain_off);
+            launch_blk_batch(ctx, v, batch, left < (unsigned)B ? (int)left : B, opt_pricing == 0, closes_often, chain_off, chain_spread);
             if ((b & 7) == 7) {                         // throttle: at most 2 x 8 batches in flight
                 hipEvent_t e = throttle[(b >> 3) & 1];
                 if ((b >> 3) >= 2) (void)hipEventSynchronize(e);

@@ -75,7 +75,7 @@ struct LoopState {
         int generic;           // the first pick of the batch hands over to the generic single-workgroup pick
         int from_generic;      // the pivot now in row/col/leave was chosen by the generic pick (column in colbuf)
         unsigned budget;       // loop iterations the host still allows (xpg_lp_iterate)
-        int r[16];             // pivot rows of the staged pivots
+        int r[32];             // pivot rows of the staged pivots (BLK_MAX)
         unsigned long long price_key;   // Dantzig look-ahead of the blocked loop's prep
         unsigned la_epoch;     // tag of the prep whose partials (blkP) hold the current look-ahead
         int want_generic;      // a fast pick found no row in its first pass: the next batch starts generic
@@ -83,7 +83,9 @@ struct LoopState {
                                // pick), not the per-workgroup partials of the last prep
         unsigned ch_epoch;     // chain kernel ticket: epoch of the stage-0 prep that staged this batch's first pivot
         unsigned ch_budget, ch_done, ch_tp;   // budget / done / total_pivots after that stage
-        unsigned ch_arrive;    // chain kernel: workers of this batch's launch that have started (zeroed by stage 0's prep)
+        unsigned ch_arrive[8]; // chain kernel: workers of this batch's launch that have started, by the XCD they run on (the spread
+                               // form counts in [0] only; zeroed by stage 0's prep)
+        unsigned ch_misplaced; // one-XCD chain launches aborted because their workers were NOT all on one XCD
         unsigned ch_aborts;    // chain launches given up before their first stage because not every worker got a CU in time
         unsigned ch_runs;      // chain launches that passed their roll call
         unsigned sweeps_full;  // sweeps that applied a full batch of BLK_MAX pivots (xpg_lp_counters)
@@ -91,10 +93,26 @@ struct LoopState {
         unsigned long long dbg[8];   // diagnostic builds (-DXPG_STAMPS): 100 MHz ticks between points of pick / prep
     } blk;
 };
-enum { BLK_MAX = 16, BLK_REC_WORDS = 16, BLK_PART_INTS = 20,
+enum { BLK_MAX = 32,           // the most pivots a batch stages (the default batch length; XPG_BLOCK selects a shorter one)
+       BLK_REC_WORDS = 16,
        BLK_PICK_WGS = 64,      // pick workgroups (= records) of the launch-per-stage path: one lane of a wave combines each
-       BLK_REC_MAX = 256,      // records allocated: the chain kernel has one per 64 rows, up to 256 workers
+       BLK_REC_MAX = 256,      // records of the chain kernel: one per pick worker
+       BLK_PART_MAX = 520,     // partial slots: one per prep worker (<= 510), the commit granule behind them; the last slot is the roll-call decision
+       BLK_DECISION_SLOT = BLK_PART_MAX - 1,
        BLK_TPB_MIN = 64 };     // smallest workgroup of pick / prep: sizes the partial array
+// Hand-off areas of the blocked loop. What MANY waves poll lies DENSE -- one 16-byte granule {data, tag} per producer,
+// back to back, so that a polling wave's load covers 64 granules in eight 128-byte lines instead of 40 (80-byte
+// partials) or 64 (128-byte records) -- and what only the consumer of ONE producer reads (the payload) lies behind it.
+//   blkR (8-byte words): [0, 64 x 16)        the launch-per-stage records (blk_pick_body -> blk_prep_body), 16 words each
+//                        + 2 w               chain record w, g0 {ratio key, row, tag}: polled by every worker
+//                        + 2 x 256 + 8 w     its payload g1 {pivot element, leaving} g2 {pair word, counter, entering | last
+//                                            stage} g3 {c_nv}: fetched of the winner only
+//   blkP (ints):         4 w                 partial w, g0 {lowest eligible column, any c_j > 0, tag, 0}
+//                        4 x 520 + 16 w      its payload g1 {e_t[that column]} g2 {its objective entry} g3 {e_t[rhs]} (the
+//                                            owner of the constant column), then the Dantzig key (2 ints)
+enum { BLK_REC_G0 = BLK_PICK_WGS * BLK_REC_WORDS, BLK_REC_PAY = BLK_REC_G0 + 2 * BLK_REC_MAX, BLK_REC_PAY_WORDS = 8,
+       BLK_REC_TOTAL_WORDS = BLK_REC_PAY + BLK_REC_PAY_WORDS * BLK_REC_MAX,
+       BLK_PART_PAY = 4 * BLK_PART_MAX, BLK_PART_PAY_INTS = 16, BLK_PART_TOTAL_INTS = BLK_PART_PAY + BLK_PART_PAY_INTS * BLK_PART_MAX };
 enum { NF_UNKNOWN = -2 };
 typedef LoopState::PipeDesc PipeDesc;
 // LpView::pickrec layout (8-byte words): PICK_MAX_WGS records of PICK_REC_WORDS, then one arrival
@@ -1271,6 +1289,8 @@ template <class S> __global__ void k_reset_loop(LpView<S> v, unsigned max_iter, 
     for (int i = gid; i < v.rhs; i += gsz) { v.rowcnt[i] = 0; v.colcnt[i] = 0; }
     const size_t words = (size_t)v.rhs * v.pw;
     for (size_t t = gid; t < words; t += gsz) v.ppt[t] = 0u;
+    if (v.blkR) for (int t = gid; t < BLK_REC_TOTAL_WORDS; t += gsz) v.blkR[t] = 0ull;        // records and partials: no tag of an earlier solve survives
+    if (v.blkP) for (int t = gid; t < BLK_PART_TOTAL_INTS; t += gsz) v.blkP[t] = 0;
     if (gid == 0) {
         LoopState * st = v.st;
         st->status = ST_RUNNING; st->done = 0; st->max_iter = max_iter;
@@ -1282,12 +1302,9 @@ template <class S> __global__ void k_reset_loop(LpView<S> v, unsigned max_iter, 
         st->blk.want_generic = 0; st->blk.la_from_state = 1; st->blk.la_epoch = 0u;
         st->blk.sweeps_full = 0u; st->blk.sweeps_part = 0u;
         st->blk.ch_epoch = 0u; st->blk.ch_budget = 0u; st->blk.ch_done = 0u; st->blk.ch_tp = 0u;
-        st->blk.ch_arrive = 0u; st->blk.ch_aborts = 0u; st->blk.ch_runs = 0u;
+        for (int x = 0; x < 8; x++) st->blk.ch_arrive[x] = 0u;
+        st->blk.ch_aborts = 0u; st->blk.ch_runs = 0u; st->blk.ch_misplaced = 0u;
         for (int k = 0; k < 8; k++) st->blk.dbg[k] = 0ull;
-        for (int k = 0; k < BLK_REC_MAX; k++)                 // record tags
-            for (int q = 1; q < 12; q += 2) v.blkR[(size_t)k * BLK_REC_WORDS + q] = 0ull;
-        for (int k = 0; k < (v.ld + BLK_TPB_MIN - 1) / BLK_TPB_MIN + 2; k++)                      // partial epochs (four granules each)
-            for (int q = 2; q < 16; q += 4) v.blkP[(size_t)k * BLK_PART_INTS + q] = 0;
         for (int k = 0; k < 2; k++) v.pickrec[PICK_CTR_OFF + 16 * k] = 0ull;   // arrival counters
         for (int k = 0; k < 2; k++) {                  // pipelined loop: iteration 0 has no pivot yet
             PipeDesc & D = st->pd[k];

@@ -99,15 +99,17 @@ int xpg_create(xpg_ctx ** out, int device)
     if (lm && lm[0] == 'p') c->loop_mode = 0;          // "pipe": always the pipelined loop
     const char * ch = getenv("XPG_CHAIN");               // "0": launch-per-stage chain, for A/B runs
     c->chain = ch ? atoi(ch) : 1;
+    const char * cx = getenv("XPG_CHAIN_XCD");
+    c->chain_local = cx ? (atoi(cx) != 0 ? 1 : 0) : 1;
     const char * cta = getenv("XPG_CHAIN_TEST_ABORT");
     c->chain_test_abort = cta ? atoi(cta) : 0;
     c->num_cus = 0;
     if (hipDeviceGetAttribute(&c->num_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) c->num_cus = 0;
     c->loop_auto = lm ? 0 : 1;                         // unset: blocked loop for large fp64 tableaux, else pipelined
     const char * bl = getenv("XPG_BLOCK");
-    c->block_len = bl ? atoi(bl) : 16;
+    c->block_len = bl ? atoi(bl) : BLK_MAX;
     if (c->block_len < 1) c->block_len = 1;
-    if (c->block_len > 16) c->block_len = 16;
+    if (c->block_len > BLK_MAX) c->block_len = BLK_MAX;
     c->prof_cap = 0; c->prof_n = 0; c->prof_stride = 1; c->prof_seen = 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return XPG_ERR_HIP; }
     if (hipMalloc((void **)&c->st, sizeof(LoopState)) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return XPG_ERR_ALLOC; }
@@ -493,54 +495,7 @@ int xpg_lp_chain_aborts(xpg_lp * lp, unsigned * aborts, int * chain_off, unsigne
     return 0;
 }
 
-#ifdef XPG_LIFE
-// diagnostic builds (-DXPG_LIFE) only: the per-LP pivot time marks of k_batch (4096 LPs x 32 marks), cleared on read
-int xpg_life_debug(xpg_ctx * ctx, unsigned long long * out)
-{
-    XPG_BIND(ctx);
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_life), sizeof(unsigned long long) * 4096 * 32) != hipSuccess) return XPG_ERR_HIP;
-    std::vector<unsigned long long> z(4096 * 32, 0ull);
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_life), z.data(), sizeof(unsigned long long) * 4096 * 32) != hipSuccess) return XPG_ERR_HIP;
-    return 0;
-}
-#endif
 #ifdef XPG_STAMPS
-// diagnostic builds only: reads and clears the tick sums of k_mip_tree (build, solve, feed)
-int xpg_mip_debug(xpg_ctx * ctx, unsigned long long * out4)
-{
-    XPG_BIND(ctx);
-    unsigned long long z[4] = {0};
-    if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_mip_ticks), sizeof(z)) != hipSuccess) return XPG_ERR_HIP;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_mip_ticks), z, sizeof(z)) != hipSuccess) return XPG_ERR_HIP;
-    return 0;
-}
-// diagnostic builds only: reads and clears sm_solve_lp's tick sums (phase one, plain build, main solve, pivots, counts)
-int xpg_lp_solve_debug(xpg_ctx * ctx, unsigned long long * out8)
-{
-    XPG_BIND(ctx);
-    unsigned long long z[8] = {0};
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_lp_ticks), sizeof(z)) != hipSuccess) return XPG_ERR_HIP;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_lp_ticks), z, sizeof(z)) != hipSuccess) return XPG_ERR_HIP;
-    return 0;
-}
-// diagnostic builds only: reads and clears sm_fast_loop's counters
-int xpg_fastloop_debug(xpg_ctx * ctx, unsigned long long * out16)
-{
-    XPG_BIND(ctx);
-    unsigned long long z[16] = {0};
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_fl), sizeof(z)) != hipSuccess) return XPG_ERR_HIP;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_fl), z, sizeof(z)) != hipSuccess) return XPG_ERR_HIP;
-    return 0;
-}
-// diagnostic builds only: reads and clears the phase tick sums of k_fme_batch
-int xpg_lineq_debug(xpg_ctx * ctx, unsigned long long * out16)
-{
-    XPG_BIND(ctx);
-    unsigned long long z[16] = {0};
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_lq_ticks), sizeof(z)) != hipSuccess) return XPG_ERR_HIP;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_lq_ticks), z, sizeof(z)) != hipSuccess) return XPG_ERR_HIP;
-    return 0;
-}
 // diagnostic builds only (not declared in the header): the phase tick sums of the blocked loop
 int xpg_lp_debug(xpg_lp * lp, unsigned long long * out8)
 {
@@ -641,6 +596,37 @@ int xpg_mip_warm_f64(xpg_ctx * ctx, int is_max, const double * tgtf, const doubl
 
 #if XPG_IN(1)
 extern "C" {
+#ifdef XPG_LIFE
+// diagnostic builds (-DXPG_LIFE) only: the per-LP pivot time marks of k_batch (4096 LPs x 32 marks), cleared on read
+int xpg_life_debug(xpg_ctx * ctx, unsigned long long * out)
+{
+    XPG_BIND(ctx);
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_life), sizeof(unsigned long long) * 4096 * 32) != hipSuccess) return XPG_ERR_HIP;
+    std::vector<unsigned long long> z(4096 * 32, 0ull);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_life), z.data(), sizeof(unsigned long long) * 4096 * 32) != hipSuccess) return XPG_ERR_HIP;
+    return 0;
+}
+#endif
+#ifdef XPG_STAMPS
+// diagnostic builds only: reads and clears sm_solve_lp's tick sums (phase one, plain build, main solve, pivots, counts)
+int xpg_lp_solve_debug(xpg_ctx * ctx, unsigned long long * out8)
+{
+    XPG_BIND(ctx);
+    unsigned long long z[8] = {0};
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_lp_ticks), sizeof(z)) != hipSuccess) return XPG_ERR_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_lp_ticks), z, sizeof(z)) != hipSuccess) return XPG_ERR_HIP;
+    return 0;
+}
+// diagnostic builds only: reads and clears sm_fast_loop's counters
+int xpg_fastloop_debug(xpg_ctx * ctx, unsigned long long * out16)
+{
+    XPG_BIND(ctx);
+    unsigned long long z[16] = {0};
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_fl), sizeof(z)) != hipSuccess) return XPG_ERR_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_fl), z, sizeof(z)) != hipSuccess) return XPG_ERR_HIP;
+    return 0;
+}
+#endif
 // ---- SIX::maxm / minm ---------------------------------------------------------------------
 int xpg_six_maxm_f64(xpg_ctx * ctx, const double * tgtf, const double * vc, int vc_rows,
                      const double * eq, int eq_rows, const double * leq, int leq_rows, int cols,
@@ -1065,6 +1051,17 @@ int xpg_lineq_fme_batch_ragged_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * ma
 #endif
 #if XPG_IN(2)
 extern "C" {
+#ifdef XPG_STAMPS
+// diagnostic builds only: reads and clears the tick sums of k_mip_tree (build, solve, feed)
+int xpg_mip_debug(xpg_ctx * ctx, unsigned long long * out4)
+{
+    XPG_BIND(ctx);
+    unsigned long long z[4] = {0};
+    if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_mip_ticks), sizeof(z)) != hipSuccess) return XPG_ERR_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_mip_ticks), z, sizeof(z)) != hipSuccess) return XPG_ERR_HIP;
+    return 0;
+}
+#endif
 // ---- MIP / has_solution -------------------------------------------------------------------------
 int xpg_mip_maxm_rat32(xpg_ctx * ctx, const xpg_rat32 * tgtf, const xpg_rat32 * vc, int vc_rows,
                        const xpg_rat32 * eq, int eq_rows, const xpg_rat32 * leq, int leq_rows, int cols,
@@ -1144,6 +1141,17 @@ int xpg_dep_is_empty_batch_ex_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mat
 #endif
 #if XPG_IN(3)
 extern "C" {
+#ifdef XPG_STAMPS
+// diagnostic builds only: reads and clears the phase tick sums of k_fme_batch
+int xpg_lineq_debug(xpg_ctx * ctx, unsigned long long * out16)
+{
+    XPG_BIND(ctx);
+    unsigned long long z[16] = {0};
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_lq_ticks), sizeof(z)) != hipSuccess) return XPG_ERR_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_lq_ticks), z, sizeof(z)) != hipSuccess) return XPG_ERR_HIP;
+    return 0;
+}
+#endif
 int xpg_lineq_move2var_batch_rat32(xpg_ctx * ctx, int nb, xpg_rat32 * mats, int rows, int cols, int rhs_idx,
                                    int first_sym, int last_sym)
 {
