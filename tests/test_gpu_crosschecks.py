@@ -28,13 +28,14 @@ CASES = [
     ("crosscheck_lineq_weird.py", ["7", "64"], ["7", "256"]),   # reduce / fme / gauss on non-canonical input
     ("crosscheck_mip_weird.py", ["5"], ["5"]),              # device tree walk + dep front end on non-canonical input
     ("crosscheck_pivot_weird.py", ["9"], ["9"]),            # K1 on non-canonical / non-finite cells
-    ("crosscheck_batch_rat.py", ["5", "96"], ["5", "512"]),     # rational LDS batches, several shapes
+    ("crosscheck_batch_rat.py", ["5", "24"], ["5", "512"]),     # rational LDS batches, several shapes
     ("crosscheck_dep.py", ["1", "192"], ["1", "1024"]),     # DepPoly::is_empty front end
     ("crosscheck_lineq.py", ["2026", "128"], ["2026", "768"]),  # reduce / fme / calcBound / gauss / hnf
     ("crosscheck_mip.py", ["3", "48"], ["3", "256"]),       # MIP batches (integer and 0-1)
 ]
 
-COUNT = re.compile(r"(?:mismatch(?:es|ing LPs)?(?: so far)?:?\s+(\d+))|(?:(\d+)\s+mismatch)", re.I)
+# "TOTAL mismatches: 0", "compared 382 mismatches 0 ...", "mismatching LPs 0"  |  "..., 0 mismatches so far", "..., 0 mismatches"
+COUNT = re.compile(r"mismatch(?:es|ing LPs):?[ \t]+(\d+)|(\d+)[ \t]+mismatches(?![ \t]*:?[ \t]*\d)")
 
 
 @pytest.mark.parametrize("script,quick,full", CASES, ids=[c[0][len("crosscheck_"):-3] for c in CASES])

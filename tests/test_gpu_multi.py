@@ -108,28 +108,33 @@ def test_entry_points_bind_their_own_device_and_restore_the_callers(ctx, port):
 
 
 def test_sweep_counters_and_tail_batches(monkeypatch):
-    """xpg_lp_counters: 100 iterations of the blocked loop are 6 full sweeps and one of 4 pivots (the
-    tail of the budget is enqueued at its own length); a budget that is a multiple of 16 has no
-    partial sweep. The tableau is the serial loop's either way."""
+    """xpg_lp_counters: 100 iterations of the blocked loop are 3 full sweeps (32 pivots each) and one of 4 pivots
+    (the tail of the budget is enqueued at its own length); a budget that is a multiple of 32 has no partial
+    sweep. The same with batches of 16 (XPG_BLOCK). The tableau is the serial loop's either way."""
     import xpoly_amd
     leq, tg = gen.hard_lp_f64(96, 120)
     out = {}
-    for mode in ("block", "serial"):
-        monkeypatch.setenv("XPG_LOOP", mode)
+    for mode in ("block", "block16", "serial"):
+        monkeypatch.setenv("XPG_LOOP", mode[:5])
+        if mode == "block16":
+            monkeypatch.setenv("XPG_BLOCK", "16")
+        else:
+            monkeypatch.delenv("XPG_BLOCK", raising=False)
         c = xpoly_amd.Context(0)
         lp = xpoly_amd.DeviceLP(c, F64, leq, tg)
         lp.begin()
         assert lp.iterate(100) == xpoly_amd.six.XPG_RUNNING
-        if mode == "block":
-            assert lp.counters() == (6, 1)
+        if mode != "serial":
+            assert lp.counters() == ((3, 1) if mode == "block" else (6, 1))
         assert lp.iterate(64) == xpoly_amd.six.XPG_RUNNING
-        if mode == "block":
-            assert lp.counters() == (10, 1)
+        if mode != "serial":
+            assert lp.counters() == ((5, 1) if mode == "block" else (10, 1))
         out[mode] = lp.read()
         assert lp.pivots_done() == 164
         lp.close(); c.close()
-    assert np.array_equal(bits(out["block"]["tab"]), bits(out["serial"]["tab"]))
-    assert np.array_equal(bits(out["block"]["tgtf"]), bits(out["serial"]["tgtf"]))
+    for mode in ("block", "block16"):
+        assert np.array_equal(bits(out[mode]["tab"]), bits(out["serial"]["tab"]))
+        assert np.array_equal(bits(out[mode]["tgtf"]), bits(out["serial"]["tgtf"]))
 
 
 def test_bench_two_ranks_real_solver_on_one_gpu():

@@ -1,5 +1,4 @@
 # A/B of the blocked loop's forms on the bench LPs (run through gpurun from the repo root)
-python -m pytest tests/test_gpu_large_golden.py tests/test_gpu_edges.py tests/test_gpu_sane_mode.py -m gpu -x -q 2>&1 | tail -8
 run() { # name, env...
   name=$1; shift
   env "$@" python bench.py --legs pivots,cfg2b --steps 10 --warmup 3 --no-cpu-baseline --no-ref-baseline > gpurun_out/b_$name.json 2> gpurun_out/b_$name.err
@@ -12,8 +11,7 @@ except Exception as e:
     print("$name FAILED", e); print(open("gpurun_out/b_$name.err").read()[-1500:])
 PY
 }
-run b32 XPG_CHAIN_RPL=1 XPG_CHAIN_CPL=1
-run b16 XPG_BLOCK=16 XPG_CHAIN_RPL=1 XPG_CHAIN_CPL=1
-run b32_322 XPG_BLK_ROWS=322 XPG_CHAIN_RPL=1 XPG_CHAIN_CPL=1
-run b32_164 XPG_BLK_ROWS=164 XPG_CHAIN_RPL=1 XPG_CHAIN_CPL=1
-run b24 XPG_BLOCK=24 XPG_CHAIN_RPL=1 XPG_CHAIN_CPL=1
+run b32 XPG_NOOP=1
+run b16 XPG_BLOCK=16
+run b32_spread XPG_CHAIN_XCD=0
+python -m pytest tests -m gpu -x -q --durations=30 2>&1 | tail -50

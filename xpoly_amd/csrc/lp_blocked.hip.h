@@ -440,6 +440,7 @@ __device__ __forceinline__ bool blk_prep_body(const LpView<F64> & v, int batch, 
         // of that launch reads what the early ones read
         if (t == 0) {
             for (int x = 0; x < 8; x++) st->blk.ch_arrive[x] = 0u;   // (the previous batch's chain launch has completed: stream order)
+            st->blk.ch_decide = 0u;
             st->blk.ch_epoch = epoch;
             st->blk.ch_budget = generic_pivot ? budget : budget - 1;
             st->blk.ch_done = generic_pivot ? done : done + 1;

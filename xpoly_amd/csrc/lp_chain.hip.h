@@ -62,6 +62,7 @@ namespace xpg {
 
 enum { ST_CHAIN_STUCK = XPG_ERR_CHAIN_STUCK, CH_SPIN_LIMIT = 1 << 21, CH_CLOSE = 0x7FFFFFFF,
        CH_ARRIVE_TICKS = 30000,    // roll call: 0.3 ms of the 100 MHz clock
+       CH_VETO_TICKS = 100000,     // a worker that has waited 1 ms for the verdict closes the roll call itself
        CH_GO = 1, CH_ABORT = 2 };
 typedef unsigned int ch_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -337,13 +338,20 @@ __device__ unsigned long long g_ch_ts[4][16][8];            // [worker class][st
 #define CH_TS(pt_) do { } while (0)
 #endif
 
-// A worker is ONE wave; its lane l owns RPL rows (pick role: rows base + 64 u + l, u < RPL, base = 64 RPL w) and CPL columns
-// (prep role, likewise). npick = ceil(m / (64 RPL)) <= 256 pick workers, nprep = ceil(W / (64 CPL)) <= 510 prep workers;
-// workers = max of the two, + 1 (the committer). Fewer, fatter workers make every hand-off cheaper -- each is an
-// all-to-all: every worker polls every producer's granule, and the price of a step grows with the head count
-// (tools/lab/xcd_handoff_lab.hip: 0.99 us at 64 workers, 1.85 at 129, 2.31 at 193) -- at the price of RPL / CPL times the
-// arithmetic per lane, which is the small part of a stage.
-// nparts0: how many partials the stage before t0 left (a launch of its own: one per 64 columns).
+// Roles are WORKERS of their own (round 4): npick = ceil(m / 64) pick workers (worker w owns rows 64 w .. 64 w + 63, lane l
+// row 64 w + l), nprep = ceil(W / 64) prep workers (columns likewise), one committer; every worker is ONE wave. A worker
+// keeps the history its replays need -- a pick worker k_s of its rows, a prep worker e_s of its columns, one double per
+// lane and stage -- in 16 KB of LDS: the replay reads it with a run-time stage number (four stages per group, the four
+// reads in flight together), the one write per stage is a plain ds_write. Register-resident histories were measured
+// first and are worse in every form the compiler offers: 32 `if (s < t)` blocks test all 32 conditions whatever t is and
+// writing slot t costs 32 compare-and-select pairs (98.4 k pivots/s at 4096 x 8192); a loop with an early exit, a search
+// over t or any other formulation is recognised as a[t] and moves the arrays to scratch memory; 16-wide vector types get
+// indexed register moves, but the compiler inserts into both halves and selects, and the half not meant is written with
+// an index beyond its vector (a memory fault at t >= 16). Fatter workers (2 rows / 2-4 columns per lane, fewer heads in
+// every all-to-all hand-off) were measured too: 1 x 1 91.9 / 71.1 k pivots/s at 4096 x 8192 / 4096 x 12289 in batches of
+// 16, 2 x 1 89.1 / 69.6, 1 x 2 86.8 / 69.3, 2 x 2 85.2 / 61.5, 2 x 4 75.3 / 61.4 -- the arithmetic of ONE wave is what a
+// stage is made of, so it is split over more waves, not fewer.
+// nparts0: how many partials the stage before t0 left (a launch of its own: one per 64 columns, like the chain's).
 // force_abort: test hook (XPG_CHAIN_TEST_ABORT=k makes every k-th chain launch fail its roll call, -k its placement check).
 // LOCAL: the workers are the workgroups with blockIdx % 8 == 0 of a grid of 8 x workers -- workgroups are dealt round-robin
 // over the 8 XCDs, so these all land on ONE XCD, whose L2 then is the point of coherence of every hand-off: plain stores,
@@ -351,15 +359,15 @@ __device__ unsigned long long g_ch_ts[4][16][8];            // [worker class][st
 // contract (MI355X_MICROARCH.md, "Workgroup dispatch"), so the roll call CHECKS it: every worker counts itself in on the
 // counter of the XCD it reads from HW_REG_XCC_ID, and the committer says GO only if one counter holds them all; otherwise
 // ABORT + blk.ch_misplaced, and the host goes back to the spread (sc1) form of this kernel for the rest of the solve.
-template <bool LOCAL, int RPL, int CPL>
+enum { CH_LDS_BYTES = BLK_MAX * 64 * 8 };
+template <bool LOCAL>
 __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int t0, int B, int npick, int nprep, int nparts0, int force_abort)
 {
-    static_assert((RPL == 1 || RPL == 2 || RPL == 4) && (CPL == 1 || CPL == 2 || CPL == 4), "rows / columns per lane");
-    constexpr int CSHIFT = 6 + (CPL == 1 ? 0 : (CPL == 2 ? 1 : 2));         // columns per prep worker = 1 << CSHIFT
+    extern __shared__ __attribute__((aligned(16))) double ch_hist[];     // [BLK_MAX][64]: this worker's history, stage-major
     if (LOCAL && (blockIdx.x & 7u)) return;
     LoopState * st = v.st;
     const int w = LOCAL ? (int)(blockIdx.x >> 3) : (int)blockIdx.x, lane = (int)threadIdx.x;
-    const unsigned nworkers = LOCAL ? gridDim.x >> 3 : gridDim.x;
+    const unsigned nworkers = LOCAL ? gridDim.x >> 3 : gridDim.x;      // npick + nprep + 1
     // ---- the ticket: stage 0 of THIS batch staged a pivot (fields this launch never writes)
     if (st->blk.ch_epoch != blk_epoch(batch, t0 - 1) || st->status != ST_RUNNING || st->pricing != 0) return;
     unsigned budget = st->blk.ch_budget, done = st->blk.ch_done;
@@ -383,6 +391,11 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
             if (wall_clock64() - t_in > (unsigned long long)CH_ARRIVE_TICKS) break;
             __builtin_amdgcn_s_sleep(1);
         }
+        // the verdict is set once: a worker that gave up waiting for this one may have closed the roll call already
+        unsigned prev = 0u;
+        if (lane == 0) prev = atomicCAS(&st->blk.ch_decide, 0u, go ? (unsigned)CH_GO : (unsigned)CH_ABORT);
+        prev = (unsigned)__builtin_amdgcn_readfirstlane((int)prev);
+        if (prev != 0u) return;                                 // (vetoed: that worker has done the bookkeeping and published ABORT)
         if (lane == 0) {
             if (go) st->blk.ch_runs += 1u;
             else { st->blk.closed = 1; st->blk.ch_aborts += 1u; if (misplaced) st->blk.ch_misplaced += 1u; }     // nothing of this launch has touched the state: close the batch at stage 0's pivot
@@ -394,77 +407,78 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
         return;
     }
     const int m = v.m, W = v.W, rhs = v.rhs, ld = v.ld, lim = v.rhs - 1;
-    const bool picker = w < npick, prepper = w < nprep;
-    // this lane's rows (pick role) and columns (prep role)
-    int irow[RPL], icl[RPL], jcol[CPL], jcl[CPL];
-    bool hrow[RPL], hcol[CPL];
-#pragma unroll
-    for (int u = 0; u < RPL; u++) { irow[u] = (w * RPL + u) * 64 + lane; hrow[u] = picker && irow[u] < m; icl[u] = hrow[u] ? irow[u] : 0; }
-#pragma unroll
-    for (int c = 0; c < CPL; c++) { jcol[c] = (w * CPL + c) * 64 + lane; hcol[c] = prepper && jcol[c] < W; jcl[c] = hcol[c] ? jcol[c] : 0; }
+    const bool picker = w < npick;
     const double * __restrict__ tab = (const double *)v.tab;
     double * K = (double *)v.blkK;
     double * E = (double *)v.blkE;
-    // ---- own data of the stages before t0 (written by previous launches): into registers once
-    double kreg[RPL][BLK_MAX], ereg[CPL][BLK_MAX];
-#pragma unroll
-    for (int s = 0; s < BLK_MAX; s++) {
-#pragma unroll
-        for (int u = 0; u < RPL; u++) kreg[u][s] = (s < t0 && hrow[u]) ? K[(size_t)icl[u] * BLK_MAX + s] : 0.0;
-#pragma unroll
-        for (int c = 0; c < CPL; c++) ereg[c][s] = (s < t0 && hcol[c]) ? E[(size_t)s * ld + jcl[c]] : 0.0;
-    }
-    F64 oj[CPL];                                            // this lane's objective entries
-    int bi[RPL], sstar[RPL];                                // basic variable of this lane's rows (stage 0's commit is in); last stage in which the row was the pivot row
-    double bcur[RPL], klast[RPL];                           // the row's constant, replayed through the stages before t - 1; k of stage t - 1
-#pragma unroll
-    for (int c = 0; c < CPL; c++) oj[c] = hcol[c] ? v.obj[jcl[c]] : zero<F64>();
-#pragma unroll
-    for (int u = 0; u < RPL; u++) { bi[u] = v.eq2bv[icl[u]]; sstar[u] = -1; bcur[u] = tab[(size_t)icl[u] * ld + rhs]; klast[u] = 0.0; }
-    for (int s = 0; s < t0; s++) {
-        const int rs = st->blk.r[s];
-        const double eb = E[(size_t)s * ld + rhs];
-#pragma unroll
-        for (int u = 0; u < RPL; u++) {
-            if (rs == irow[u]) sstar[u] = s;
-            const double ks = hrow[u] ? K[(size_t)icl[u] * BLK_MAX + s] : 0.0;
-            if (s + 1 < t0) {                               // (t0 = 1: no step here; stage t0 - 1 is applied in the loop)
-                const double pb = ks * eb;
-                bcur[u] = (rs == irow[u]) ? eb : (bcur[u] + pb);
-            } else klast[u] = ks;
-        }
-    }
-    int r_prev = st->blk.r[t0 - 1];                         // pivot row of stage t - 1 (for the constant's step)
-    // ---- the committer's decision. A worker must have it before its first WRITE: a pick worker therefore reads it only
-    // after the partial poll and the column gather of its first stage (read-only work that hides the hand-off), a worker
-    // without rows -- which would otherwise wait for records that an aborted launch never publishes -- right here.
+    double * const hist = ch_hist + lane;                   // this lane's history: hist[64 s]
+    // The committer answers within CH_ARRIVE_TICKS of its own start. A worker that has waited CH_VETO_TICKS knows that
+    // the committer itself is not running (no CU for it while these workers hold theirs): it closes the roll call with
+    // ABORT through the same compare-and-swap, does the committer's bookkeeping and tells the others.
+    // A worker must have the verdict before its first WRITE to global memory: a pick worker reads it only after the partial
+    // poll and the column gather of its first stage (read-only work that hides the hand-off), a prep worker -- which would
+    // otherwise wait for records that an aborted launch never publishes -- before its first poll.
     bool decided = false;
     auto wait_decision = [&]() -> bool {
         if (decided) return true;
         unsigned spins = 0;
+        const unsigned long long t_wait = wall_clock64();
+        bool asked = false;
         for (;;) {
             const ch_u32x4 g = ch_load1(decision);
             if (g.z == roll_tag) { if (g.x != (unsigned)CH_GO) return false; decided = true; return true; }
+            if (!asked && wall_clock64() - t_wait > (unsigned long long)CH_VETO_TICKS) {
+                asked = true;
+                unsigned prev = 0u;
+                if (lane == 0) prev = atomicCAS(&st->blk.ch_decide, 0u, (unsigned)CH_ABORT);
+                prev = (unsigned)__builtin_amdgcn_readfirstlane((int)prev);
+                if (prev == 0u) {                               // this worker closed it
+                    if (lane == 0) { st->blk.closed = 1; st->blk.ch_aborts += 1u; }
+                    ch_drain();
+                    if (lane == 0) ch_store_granule<false>(decision, (unsigned long long)CH_ABORT, (unsigned long long)roll_tag);
+                    return false;
+                }
+                if (prev == (unsigned)CH_ABORT) return false;
+                // CH_GO: the committer is about to publish it
+            }
             if (++spins > CH_SPIN_LIMIT) { if (lane == 0) ch_st(&st->status, (int)ST_CHAIN_STUCK); return false; }
             __builtin_amdgcn_s_sleep(1);
         }
     };
-    if (!picker && !wait_decision()) return;
 #ifdef XPG_STAMPS
-    const int tsw = w == 0 ? 0 : (w == npick - 1 ? 1 : (w == npick ? 2 : (w == nprep - 1 ? 3 : -1)));
+    const int tsw = w == 0 ? 0 : (w == npick - 1 ? 1 : (w == npick ? 2 : (w == npick + nprep - 1 ? 3 : -1)));
 #endif
 
+    if (picker) {
+        // =========================== a pick worker ================================================================
+        const int i = w * 64 + lane;                        // this lane's row
+        const bool has_row = i < m;
+        const int ic = has_row ? i : 0;
+        // own data of the stages before t0 (written by previous launches)
+        for (int s = 0; s < t0; s++) hist[64 * s] = has_row ? K[(size_t)ic * BLK_MAX + s] : 0.0;
+        int bi = v.eq2bv[ic];                               // basic variable of this lane's row (stage 0's commit is in)
+        int sstar = -1;                                     // last stage in which this lane's row was the pivot row
+        double bcur = tab[(size_t)ic * ld + rhs];           // this row's constant, replayed through the stages before t - 1
+        double klast = 0.0;                                 // k of stage t - 1 for this row
+        for (int s = 0; s < t0; s++) {
+            const int rs = st->blk.r[s];
+            if (rs == i) sstar = s;
+            const double ks = has_row ? K[(size_t)ic * BLK_MAX + s] : 0.0;
+            if (s + 1 < t0) {                               // (t0 = 1: no step here; stage t0 - 1 is applied in the loop)
+                const double eb = E[(size_t)s * ld + rhs];
+                const double pb = ks * eb;
+                bcur = (rs == i) ? eb : (bcur + pb);
+            } else klast = ks;
+        }
+        int r_prev = st->blk.r[t0 - 1];                     // pivot row of stage t - 1 (for the constant's step)
 #pragma unroll 1
-    for (int t = t0; t < B; t++) {
-        const unsigned want_part = blk_epoch(batch, t - 1), tag = blk_epoch(batch, t);
-        CH_TS(0);
-        // =========================== pick role =====================================================
-        if (picker) {
+        for (int t = t0; t < B; t++) {
+            const unsigned want_part = blk_epoch(batch, t - 1), tag = blk_epoch(batch, t);
+            CH_TS(0);
             // ---- poll the g0 granules of the partials of stage t-1 and, behind them, the commit granule (the commit of
             // stage t0 - 1 was a launch of its own: no granule to wait for): four slots per lane and round, dense
             const int cnt = t == t0 ? nparts0 : nprep;      // partials of the stage before
             const int last = t == t0 ? cnt - 1 : cnt;       // the highest slot to wait for
-            const int pshift = t == t0 ? 6 : CSHIFT;        // columns per partial of that stage, as a shift
             int nf = INT_MAX;
             for (int base = 0; base <= last; base += 256) {
                 const int k0 = base + lane, k1 = k0 + 64, k2 = k0 + 128, k3 = k0 + 192;
@@ -490,7 +504,6 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
             }
             CH_TS(1);                                       // partials + commit granule seen
             const int first = wave_min_int(nf);
-
             // the fast path of blk_pick_body, or the end of the batch for everyone
             const bool fast = first >= 0 && first < rhs && done < max_iter && budget != 0;
             if (!fast) {
@@ -499,19 +512,15 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
                 return;
             }
             // ---- one round: the column gather; e_s[first] for s <= t-2 from memory (lane s); the three fresh
-            // granules of stage t-1 (lane 32: e[first], lane 33: c[first], lane 34: e[rhs]); pair words, counters
-            double x0[RPL]; uint32_t pww[RPL]; int ccv[RPL];
-#pragma unroll
-            for (int u = 0; u < RPL; u++) {
-                x0[u] = tab[(size_t)icl[u] * ld + first];
-                pww[u] = ch_ld(&v.ppt[(size_t)first * v.pw + (bi[u] >> 5)]);
-                ccv[u] = ch_ld(&v.colcnt[bi[u]]);
-            }
+            // granules of stage t-1 (lane 32: e[first], lane 33: c[first], lane 34: e[rhs]); pair word, counter
+            const double x0 = tab[(size_t)ic * ld + first];
+            const uint32_t pw_word = ch_ld(&v.ppt[(size_t)first * v.pw + (bi >> 5)]);
+            const int cc = ch_ld(&v.colcnt[bi]);
             double ev = 0.0;
             if (lane + 1 < t) ev = ch_ld(&E[(size_t)lane * ld + first]);
             {
                 const bool fresh = lane >= 32 && lane <= 34;
-                const char * gp = ch_part_pay(v, (lane == 34 ? rhs : first) >> pshift) + (fresh ? 16 * (lane - 32) : 0);
+                const char * gp = ch_part_pay(v, (lane == 34 ? rhs : first) >> 6) + (fresh ? 16 * (lane - 32) : 0);
                 unsigned spins = 0;
                 for (;;) {
                     const ch_u32x4 g = ch_load1(gp);
@@ -523,155 +532,157 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
             CH_TS(2);                                       // gather round issued, fresh granules in
             const double ec_new = ch_readlane_f64(ev, 32), eb_new = ch_readlane_f64(ev, 34);
             const unsigned long long cnv_bits = __builtin_bit_cast(unsigned long long, ch_readlane_f64(ev, 33));
+            if (lane == t - 1) ev = ec_new;                 // lane s of ev now holds e_s[first] for every s < t
             // the constant column: ONE step, stage t-1 (the arithmetic of every other cell of the sweep)
-#pragma unroll
-            for (int u = 0; u < RPL; u++) {
-                const double pb = klast[u] * eb_new;
-                bcur[u] = (irow[u] == r_prev) ? eb_new : (bcur[u] + pb);
+            {
+                const double pb = klast * eb_new;
+                bcur = (i == r_prev) ? eb_new : (bcur + pb);
             }
-            // the entering column through the stages 0 .. t-1
-            double a[RPL];
-#pragma unroll
-            for (int u = 0; u < RPL; u++) a[u] = x0[u];
-#pragma unroll
-            for (int s = 0; s < BLK_MAX; s++) {
-                if (s < t) {
-                    const double ec = (s + 1 < t) ? ch_readlane_f64(ev, s) : ec_new;
-#pragma unroll
-                    for (int u = 0; u < RPL; u++) {
-                        const double pa = kreg[u][s] * ec;
-                        a[u] = (s == sstar[u]) ? ec : (a[u] + pa);
+            // the entering column through the stages 0 .. t-1: groups of four, the four history reads in flight together
+            // (slots at and beyond t hold nothing that is used)
+            double a = x0;
+            for (int s = 0; s < t; s += 4) {
+                const double h0 = hist[64 * s], h1 = hist[64 * s + 64], h2 = hist[64 * s + 128], h3 = hist[64 * s + 192];
+                {
+                    const double ec = ch_readlane_f64(ev, s);
+                    const double pa = h0 * ec;
+                    a = (s == sstar) ? ec : (a + pa);
+                }
+                if (s + 1 < t) {
+                    const double ec = ch_readlane_f64(ev, s + 1);
+                    const double pa = h1 * ec;
+                    a = (s + 1 == sstar) ? ec : (a + pa);
+                    if (s + 2 < t) {
+                        const double ec2 = ch_readlane_f64(ev, s + 2);
+                        const double pa2 = h2 * ec2;
+                        a = (s + 2 == sstar) ? ec2 : (a + pa2);
+                        if (s + 3 < t) {
+                            const double ec3 = ch_readlane_f64(ev, s + 3);
+                            const double pa3 = h3 * ec3;
+                            a = (s + 3 == sstar) ? ec3 : (a + pa3);
+                        }
                     }
                 }
             }
-            if (!wait_decision()) return;                                         // (first stage only: nothing has been written so far)
-            // -a_i,nv (lpsol.h:1485) -> K; findPivotBV's first pass (lpsol.h:553-663): this lane's best row (the lower row
-            // wins a tie: rows ascend with u)
+            klast = -a;                                                           // -a_i,nv (lpsol.h:1485)
+            hist[64 * t] = klast;
+            if (!wait_decision()) return;                                         // (first stage only: nothing global has been written so far)
+            if (has_row) ch_stl<LOCAL>(&K[(size_t)i * BLK_MAX + t], klast);
+            // findPivotBV's first pass (lpsol.h:553-663)
             unsigned long long key = ~0ull;
-            int brow = INT_MAX, bbi = 0, bcc = 0, bss = -1; uint32_t bpw = 0; double ba = 0.0;
-#pragma unroll
-            for (int u = 0; u < RPL; u++) {
-                klast[u] = -a[u];
-#pragma unroll
-                for (int s = 0; s < BLK_MAX; s++) if (s == t) kreg[u][s] = klast[u];
-                if (hrow[u]) ch_stl<LOCAL>(&K[(size_t)irow[u] * BLK_MAX + t], klast[u]);
-                if (hrow[u] && !le(F64(a[u]), zero<F64>()) && !((pww[u] >> (bi[u] & 31)) & 1u) && ccv[u] < lim) {
-                    const unsigned long long ku = ch_ratio_key(bcur[u] / a[u]);
-                    if (ku < key) { key = ku; brow = irow[u]; bbi = bi[u]; bcc = ccv[u]; bss = sstar[u]; bpw = pww[u]; ba = a[u]; }
-                }
-            }
+            if (has_row && !le(F64(a), zero<F64>()) && !((pw_word >> (bi & 31)) & 1u) && cc < lim) key = ch_ratio_key(bcur / a);
             const unsigned long long kmin = ch_wave_min_u64(key);
-            bool publisher;
-            if (RPL == 1) {                                 // (rows ascend with the lane: the first hit is the lowest row)
-                const unsigned long long hit = __ballot(key == kmin);
-                publisher = kmin != ~0ull ? (lane == __ffsll((long long)hit) - 1) : (lane == 0);
-            } else {
-                const int myrow = (kmin != ~0ull && key == kmin) ? brow : INT_MAX;
-                const int rmin = wave_min_int(myrow);
-                publisher = kmin != ~0ull ? (myrow == rmin) : (lane == 0);
-            }
+            const unsigned long long hit = __ballot(key == kmin);
+            const bool publisher = kmin != ~0ull ? (lane == __ffsll((long long)hit) - 1) : (lane == 0);
             if (publisher) {
-                const unsigned long long ab = to_bits(F64(ba));
+                const unsigned long long ab = to_bits(F64(a));
                 char * pay = ch_rec_pay(v, w);
-                ch_store_granule3<LOCAL>(pay, (unsigned)ab, (unsigned)(ab >> 32), (unsigned)bbi, tag);
-                ch_store_granule3<LOCAL>(pay + 16, bpw, (unsigned)bcc, (unsigned)first | ((unsigned)(bss + 1) << 24), tag);
+                ch_store_granule3<LOCAL>(pay, (unsigned)ab, (unsigned)(ab >> 32), (unsigned)bi, tag);
+                ch_store_granule3<LOCAL>(pay + 16, pw_word, (unsigned)cc, (unsigned)first | ((unsigned)(sstar + 1) << 24), tag);
                 ch_store_granule3<LOCAL>(pay + 32, (unsigned)cnv_bits, (unsigned)(cnv_bits >> 32), 0u, tag);
-                ch_store_granule3<LOCAL>(ch_rec_g0(v, w), (unsigned)kmin, (unsigned)(kmin >> 32), (unsigned)(kmin != ~0ull ? brow : INT_MAX), tag);
+                ch_store_granule3<LOCAL>(ch_rec_g0(v, w), (unsigned)kmin, (unsigned)(kmin >> 32), (unsigned)(kmin != ~0ull ? i : INT_MAX), tag);
             }
             CH_TS(3);                                       // record issued
+            // ---- the records of this stage: who won (this lane's row may have: its basic variable changes, lpsol.h:1508)
+            ChWinner g;
+            const int widx = ch_poll_records(v, npick, tag, lane, g);
+            if (widx == -3) { if (lane == 0) ch_st(&st->status, (int)ST_CHAIN_STUCK); return; }
+            if (widx < 0) return;                           // CLOSE / empty first pass: the committer records it
+            CH_TS(4);                                       // records seen and combined
+            r_prev = g.r;
+            if (__any(i == g.r)) {                          // (only the owner of the pivot row needs the rest of the record)
+                if (!ch_load_winner(v, widx, tag, g)) { if (lane == 0) ch_st(&st->status, (int)ST_CHAIN_STUCK); return; }
+                if (i == g.r) { bi = g.enter; sstar = t; }
+            }
+            done += 1; budget -= 1;
         }
-        // =========================== every worker reads the records: all leave together ======================
+        return;
+    }
+
+    // =========================== a prep worker ====================================================================
+    const int wp = w - npick;                               // its partial slot
+    const int j = wp * 64 + lane;                           // this lane's column
+    const bool has_col = j < W;
+    const int jc = has_col ? j : 0;
+    for (int s = 0; s < t0; s++) hist[64 * s] = has_col ? E[(size_t)s * ld + jc] : 0.0;
+    F64 oj = has_col ? v.obj[jc] : zero<F64>();            // this lane's objective entry
+    if (!wait_decision()) return;
+#pragma unroll 1
+    for (int t = t0; t < B; t++) {
+        const unsigned tag = blk_epoch(batch, t);
+        CH_TS(0);
         ChWinner g;
         const int widx = ch_poll_records(v, npick, tag, lane, g);
         if (widx == -3) { if (lane == 0) ch_st(&st->status, (int)ST_CHAIN_STUCK); return; }
         if (widx < 0) return;                               // CLOSE / empty first pass: the committer records it
         CH_TS(4);                                           // records seen and combined
         const int r = g.r;
-        r_prev = r;
-        // =========================== prep role =====================================================
         // ---- one round: the pivot row gather, k_q[r] (lane q), this column's basis words (the previous stage's
         // commit is behind the records just read), and the rest of the winner's record (whose wait completes the
         // loads before it as well)
-        double x0[CPL]; double kv = 0.0; int nvj[CPL], rcj0[CPL];
-#pragma unroll
-        for (int c = 0; c < CPL; c++) { x0[c] = 0.0; nvj[c] = 0; rcj0[c] = INT_MAX; }
-        if (prepper) {
-#pragma unroll
-            for (int c = 0; c < CPL; c++) {
-                x0[c] = tab[(size_t)r * ld + jcl[c]];
-                if (hcol[c] && jcol[c] < rhs) { nvj[c] = (int)ch_ld(&v.nv[jcl[c]]); rcj0[c] = ch_ld(&v.rowcnt[jcl[c]]); }
-            }
-            if (lane < t) kv = ch_ld(&K[(size_t)r * BLK_MAX + lane]);
-        }
+        const double x0 = tab[(size_t)r * ld + jc];
+        int nvj = 0, rcj0 = INT_MAX;
+        if (has_col && j < rhs) { nvj = (int)ch_ld(&v.nv[jc]); rcj0 = ch_ld(&v.rowcnt[jc]); }
+        double kv = 0.0;
+        if (lane < t) kv = ch_ld(&K[(size_t)r * BLK_MAX + lane]);
         if (!ch_load_winner(v, widx, tag, g)) { if (lane == 0) ch_st(&st->status, (int)ST_CHAIN_STUCK); return; }
         const int enter = g.enter, leave = g.leave;
-#pragma unroll
-        for (int u = 0; u < RPL; u++) if (irow[u] == r) { bi[u] = enter; sstar[u] = t; }   // lpsol.h:1508, as every later pick of this launch sees it
-        if (prepper) {
-            const F64 sc = div(one<F64>(), F64(g.a));       // 1/(eq.get(eqnum, nv)), lpsol.h:1471
-            const int smode = scale_mode(sc);
-            const F64 cnv = from_bits<F64>(g.cnv);
-            const int cmode = scale_mode(cnv);
-            const int qstar = g.qstar;                      // the last stage before t in which row r was the pivot row
-            double x[CPL];
-#pragma unroll
-            for (int c = 0; c < CPL; c++) x[c] = x0[c];
-#pragma unroll
-            for (int q = 0; q < BLK_MAX; q++) {             // the pivot row as the pending sweeps would leave it
-                if (q < t) {
-                    const double kq = ch_readlane_f64(kv, q);
-#pragma unroll
-                    for (int c = 0; c < CPL; c++) {
-                        const double pr = kq * ereg[c][q];
-                        x[c] = (q == qstar) ? ereg[c][q] : (x[c] + pr);
+        const F64 sc = div(one<F64>(), F64(g.a));           // 1/(eq.get(eqnum, nv)), lpsol.h:1471
+        const int smode = scale_mode(sc);
+        const F64 cnv = from_bits<F64>(g.cnv);
+        const int cmode = scale_mode(cnv);
+        const int qstar = g.qstar;                          // the last stage before t in which row r was the pivot row
+        double x = x0;
+        for (int q = 0; q < t; q += 4) {                    // the pivot row as the pending sweeps would leave it
+            const double h0 = hist[64 * q], h1 = hist[64 * q + 64], h2 = hist[64 * q + 128], h3 = hist[64 * q + 192];
+            {
+                const double pr = ch_readlane_f64(kv, q) * h0;
+                x = (q == qstar) ? h0 : (x + pr);
+            }
+            if (q + 1 < t) {
+                const double pr = ch_readlane_f64(kv, q + 1) * h1;
+                x = (q + 1 == qstar) ? h1 : (x + pr);
+                if (q + 2 < t) {
+                    const double pr2 = ch_readlane_f64(kv, q + 2) * h2;
+                    x = (q + 2 == qstar) ? h2 : (x + pr2);
+                    if (q + 3 < t) {
+                        const double pr3 = ch_readlane_f64(kv, q + 3) * h3;
+                        x = (q + 3 == qstar) ? h3 : (x + pr3);
                     }
                 }
             }
-            F64 e[CPL];
-#pragma unroll
-            for (int c = 0; c < CPL; c++) {
-                e[c] = scaled(F64(x[c]), sc, smode);
-#pragma unroll
-                for (int q = 0; q < BLK_MAX; q++) if (q == t) ereg[c][q] = e[c].v;
-            }
-            CH_TS(5);                                       // row gather in, replayed, scaled
-            int nf = INT_MAX, any = 0;
-#pragma unroll
-            for (int c = 0; c < CPL; c++) {
-                if (hcol[c]) {
-                    const int j = jcol[c];
-                    ch_stl<LOCAL>(&E[(size_t)t * ld + j], e[c].v);
-                    F64 tt = mul(e[c], minus_one<F64>());   // nvexp.mul(-1), lpsol.h:1496
-                    if (j >= rhs) tt = neg(tt);             // :1497-1499
-                    tt = scaled(tt, cnv, cmode);            // nvexp.mul(tgtf(nv)), :1500
-                    const bool in = j < rhs;
-                    const bool nv_mem = in && j != enter && j != leave && nvj[c] != 0;
-                    const bool nv_old = in && (j == enter ? true : (j == leave ? false : nv_mem));
-                    const bool nv_new = in && (j == enter ? false : (j == leave ? true : nv_mem));
-                    const int rcj = (in && j != enter) ? rcj0[c] : INT_MAX;
-                    if (j < enter && in && !nv_old) oj[c] = zero<F64>();  // lpsol.h:1055-1060
-                    oj[c] = add(tt, oj[c]);                 // addRowToRow, :1501
-                    v.obj[j] = oj[c];                       // (read again only by later launches)
-                    if (nv_new && gt(oj[c], zero<F64>())) { any = 1; if (rcj < lim) nf = min(nf, j); }
-                }
-            }
-            nf = wave_min_int(nf);
-            any = __ballot(any != 0) != 0ull ? 1 : 0;
-            // ---- the partial: the lane that owns the worker's candidate column publishes what the next pick needs
-            // fresh of it, the lane that owns the constant column its new e, lane 0 the candidate itself
-            char * pay = ch_part_pay(v, w);
-#pragma unroll
-            for (int c = 0; c < CPL; c++) {
-                if (hcol[c] && jcol[c] == nf) {
-                    ch_store_granule<LOCAL>(pay, to_bits(e[c]), (unsigned long long)tag);
-                    ch_store_granule<LOCAL>(pay + 16, to_bits(oj[c]), (unsigned long long)tag);
-                }
-                if (hcol[c] && jcol[c] == rhs) ch_store_granule<LOCAL>(pay + 32, to_bits(e[c]), (unsigned long long)tag);
-            }
-            if (lane == 0) ch_store_granule<LOCAL>(ch_part_g0(v, w), ((unsigned long long)(unsigned)any << 32) | (unsigned)nf, (unsigned long long)tag);
-            CH_TS(6);                                       // partial issued
         }
-        done += 1; budget -= 1;
+        const F64 e = scaled(F64(x), sc, smode);
+        hist[64 * t] = e.v;
+        CH_TS(5);                                           // row gather in, replayed, scaled
+        int nf = INT_MAX, any = 0;
+        if (has_col) {
+            ch_stl<LOCAL>(&E[(size_t)t * ld + j], e.v);
+            F64 tt = mul(e, minus_one<F64>());              // nvexp.mul(-1), lpsol.h:1496
+            if (j >= rhs) tt = neg(tt);                     // :1497-1499
+            tt = scaled(tt, cnv, cmode);                    // nvexp.mul(tgtf(nv)), :1500
+            const bool in = j < rhs;
+            const bool nv_mem = in && j != enter && j != leave && nvj != 0;
+            const bool nv_old = in && (j == enter ? true : (j == leave ? false : nv_mem));
+            const bool nv_new = in && (j == enter ? false : (j == leave ? true : nv_mem));
+            const int rcj = (in && j != enter) ? rcj0 : INT_MAX;
+            if (j < enter && in && !nv_old) oj = zero<F64>();     // lpsol.h:1055-1060
+            oj = add(tt, oj);                               // addRowToRow, :1501
+            v.obj[j] = oj;                                  // (read again only by later launches)
+            if (nv_new && gt(oj, zero<F64>())) { any = 1; if (rcj < lim) nf = j; }
+        }
+        nf = wave_min_int(nf);
+        any = __ballot(any != 0) != 0ull ? 1 : 0;
+        // ---- the partial: the lane that owns the worker's candidate column publishes what the next pick needs
+        // fresh of it, the lane that owns the constant column its new e, lane 0 the candidate itself
+        char * pay = ch_part_pay(v, wp);
+        if (has_col && j == nf) {
+            ch_store_granule<LOCAL>(pay, to_bits(e), (unsigned long long)tag);
+            ch_store_granule<LOCAL>(pay + 16, to_bits(oj), (unsigned long long)tag);
+        }
+        if (has_col && j == rhs) ch_store_granule<LOCAL>(pay + 32, to_bits(e), (unsigned long long)tag);
+        if (lane == 0) ch_store_granule<LOCAL>(ch_part_g0(v, wp), ((unsigned long long)(unsigned)any << 32) | (unsigned)nf, (unsigned long long)tag);
+        CH_TS(6);                                           // partial issued
     }
 }
 

@@ -111,41 +111,26 @@ template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> &
     // cannot seat them all, so the shape limits here are only those of the hand-off areas: 256 records, 511 partial slots
     // (W <= 32 640), and at most four workers per CU. Taller or wider tableaux, and the opt-in Dantzig pricing, take the
     // launch-per-stage path.
-    // rows / columns per lane of a worker: ONE each wherever the hand-off areas hold that many workers (256 records,
-    // 510 partials). Fewer, fatter workers were measured and are slower although every hand-off is an all-to-all whose
-    // price grows with the head count (tools/lab/xcd_handoff_lab.hip): at 4096 x 8192 / 4096 x 12289, batches of 16,
-    // 1 x 1 91.9 / 71.1 k pivots/s, 2 x 1 89.1 / 69.6, 1 x 2 86.8 / 69.3, 2 x 2 85.2 / 61.5, 2 x 4 75.3 / 61.4 -- the
-    // arithmetic of ONE wave is what a stage is made of. XPG_CHAIN_RPL / XPG_CHAIN_CPL force a form for A/B runs.
-    static const int rpl_env = [] { const char * s = getenv("XPG_CHAIN_RPL"); return s ? atoi(s) : 0; }();
-    static const int cpl_env = [] { const char * s = getenv("XPG_CHAIN_CPL"); return s ? atoi(s) : 0; }();
-    int rpl = 1, cpl = 1;
-    if (rpl_env == 1 || rpl_env == 2) rpl = rpl_env;
-    if (cpl_env == 1 || cpl_env == 2 || cpl_env == 4) cpl = cpl_env;
-    if ((v.m + 64 * rpl - 1) / (64 * rpl) > BLK_REC_MAX) rpl = 2;
-    while (cpl < 4 && (v.W + 64 * cpl - 1) / (64 * cpl) > 510) cpl *= 2;
-    const int cpick = (v.m + 64 * rpl - 1) / (64 * rpl), cprep = (v.W + 64 * cpl - 1) / (64 * cpl);
+    const int cpick = (v.m + 63) / 64, cprep = (v.W + 63) / 64;
+    const int workers = cpick + cprep + 1;
+    const int cus = ctx->num_cus > 0 ? ctx->num_cus : 1;
     const bool chain = ctx->chain && !chain_off && ref_pricing && B > 1 &&
-                       cpick <= BLK_REC_MAX && cprep <= 510 && (cpick > cprep ? cpick : cprep) + 1 <= 4 * (ctx->num_cus > 0 ? ctx->num_cus : 1) &&
-                       (v.W + 63) / 64 <= 510 &&   // stage 0's prep leaves one look-ahead partial per 64 columns: they share the slots
-                       tpb_prep == 64;
+                       cpick <= BLK_REC_MAX && cprep <= 510 && workers <= 8 * cus &&
+                       tpb_prep == 64;             // stage 0's prep leaves one look-ahead partial per 64 columns, as the chain's workers do
     for (int t = 0; t < B; t++) {
         if (t == 1 && chain) {
             const int test_abort = ctx->chain_test_abort;
-            const int workers = (cpick > cprep ? cpick : cprep) + 1;
             // test hooks: k > 0 -- every k-th launch fails its roll call; k < 0 -- every |k|-th one-XCD launch "finds" its
             // workers on several XCDs
             const int fa = test_abort > 0 ? (batch % test_abort == test_abort - 1 ? 1 : 0)
                                           : (test_abort < 0 && batch % -test_abort == -test_abort - 1 ? 2 : 0);
-            // every worker on one XCD, hand-offs through that XCD's L2 (lp_chain.hip.h); XPG_CHAIN_XCD=0, or a launch whose
+            // every worker on one XCD, hand-offs through that XCD's L2 (lp_chain.hip.h) -- where one XCD seats them all: a
+            // worker is one wave with 16 KB of LDS, an XCD has cus / 8 CUs of 160 KB; XPG_CHAIN_XCD=0, or a launch whose
             // placement check failed, selects the spread form with sc1 stores
-            const bool local = ctx->chain_local && !chain_spread;
+            const bool local = ctx->chain_local && !chain_spread && workers <= (cus / 8) * 9;
             const int nparts0 = (int)gprep.x;
-#define XPG_CHAIN(L_, R_, C_) hipLaunchKernelGGL((k_blk_chain<L_, R_, C_>), dim3((L_ ? 8 : 1) * workers), dim3(64), 0, ctx->stream, v, batch, 1, B, cpick, cprep, nparts0, fa)
-#define XPG_CHAIN_RC(R_, C_) do { if (local) XPG_CHAIN(true, R_, C_); else XPG_CHAIN(false, R_, C_); } while (0)
-            if (rpl == 1) { if (cpl == 1) XPG_CHAIN_RC(1, 1); else if (cpl == 2) XPG_CHAIN_RC(1, 2); else XPG_CHAIN_RC(1, 4); }
-            else { if (cpl == 1) XPG_CHAIN_RC(2, 1); else if (cpl == 2) XPG_CHAIN_RC(2, 2); else XPG_CHAIN_RC(2, 4); }
-#undef XPG_CHAIN_RC
-#undef XPG_CHAIN
+            if (local) hipLaunchKernelGGL(k_blk_chain<true>, dim3(8 * workers), dim3(64), CH_LDS_BYTES, ctx->stream, v, batch, 1, B, cpick, cprep, nparts0, fa);
+            else hipLaunchKernelGGL(k_blk_chain<false>, dim3(workers), dim3(64), CH_LDS_BYTES, ctx->stream, v, batch, 1, B, cpick, cprep, nparts0, fa);
             break;
         }
         hipLaunchKernelGGL(k_blk_pick, dim3(npick), dim3(tp), 0, ctx->stream, v, batch, t, (int)gprep.x);
@@ -162,7 +147,7 @@ template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> &
 #define XPG_BLK_LAUNCH(ROWS_, UNR_, CAP_)                                                                                 \
     hipExtLaunchKernelGGL((k_blk_sweep<ROWS_, UNR_, CAP_>), dim3(strips, (v.m + ROWS_ - 1) / ROWS_), dim3(256), 0,        \
                           ctx->stream, e0, e1, 0, (double *)v.tab, v.m, v.W, v.ld, (const double *)v.blkE,                \
-                          (const double *)v.blkK, v.st, batch, 0, B)
+                          (const double *)v.blkK, v.st, batch, 0, ctx->block_len)
 #define XPG_BLK_FULL(ROWS_, UNR_, NB_)                                                                                    \
     hipExtLaunchKernelGGL((k_blk_sweep_full<ROWS_, UNR_, NB_>), dim3(blk_sweep_grid(strips, (v.m + ROWS_ - 1) / ROWS_)), \
                           dim3(256), 0, ctx->stream, e0, e1, 0, (double *)v.tab, v.m, v.W, v.ld,                          \
@@ -182,7 +167,7 @@ template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> &
     // batches; the full-batch kernel above then leaves them alone.
     if (closes_often && (full32 || full16))
         hipLaunchKernelGGL((k_blk_sweep<32, 4, 16>), dim3(strips, (v.m + 31) / 32), dim3(256), 0, ctx->stream, (double *)v.tab,
-                           v.m, v.W, v.ld, (const double *)v.blkE, (const double *)v.blkK, v.st, batch, B, B);
+                           v.m, v.W, v.ld, (const double *)v.blkE, (const double *)v.blkK, v.st, batch, B, ctx->block_len);
 #undef XPG_BLK_LAUNCH
 #undef XPG_BLK_FULL
     if (timed) ctx->prof_n++;

@@ -86,6 +86,9 @@ struct LoopState {
         unsigned ch_arrive[8]; // chain kernel: workers of this batch's launch that have started, by the XCD they run on (the spread
                                // form counts in [0] only; zeroed by stage 0's prep)
         unsigned ch_misplaced; // one-XCD chain launches aborted because their workers were NOT all on one XCD
+        unsigned ch_decide;    // the roll call's verdict for this batch's launch: 0 open, CH_GO, CH_ABORT -- set ONCE, by compare-and-swap
+                               // (the committer when everybody has counted in or its patience ends; a worker that has waited
+                               // for the verdict far longer than that: the committer itself never got a CU); zeroed by stage 0's prep
         unsigned ch_aborts;    // chain launches given up before their first stage because not every worker got a CU in time
         unsigned ch_runs;      // chain launches that passed their roll call
         unsigned sweeps_full;  // sweeps that applied a full batch of BLK_MAX pivots (xpg_lp_counters)
@@ -1303,7 +1306,7 @@ template <class S> __global__ void k_reset_loop(LpView<S> v, unsigned max_iter, 
         st->blk.sweeps_full = 0u; st->blk.sweeps_part = 0u;
         st->blk.ch_epoch = 0u; st->blk.ch_budget = 0u; st->blk.ch_done = 0u; st->blk.ch_tp = 0u;
         for (int x = 0; x < 8; x++) st->blk.ch_arrive[x] = 0u;
-        st->blk.ch_aborts = 0u; st->blk.ch_runs = 0u; st->blk.ch_misplaced = 0u;
+        st->blk.ch_aborts = 0u; st->blk.ch_runs = 0u; st->blk.ch_misplaced = 0u; st->blk.ch_decide = 0u;
         for (int k = 0; k < 8; k++) st->blk.dbg[k] = 0ull;
         for (int k = 0; k < 2; k++) v.pickrec[PICK_CTR_OFF + 16 * k] = 0ull;   // arrival counters
         for (int k = 0; k < 2; k++) {                  // pipelined loop: iteration 0 has no pivot yet
