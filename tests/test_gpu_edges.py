@@ -304,3 +304,48 @@ def test_fp64_loop_on_tableaux_with_inf_and_nan_cells(ctx, port):
                 for k in ("tab", "tgtf", "eq2bv"):
                     assert same(got[k], want[k]), (it, K, k)
     assert len(seen) >= 3
+
+
+@pytest.mark.parametrize("chain", ["1", "0"])
+def test_blocked_loop_meets_nan_that_arises_mid_solve(port, monkeypatch, chain):
+    """FINITE input that overflows after a few pivots (gen.overflow_lp_f64: magnitudes spread over hundreds of decades):
+    inf - inf leaves NaN cells, findPivotBV meets NaN ratios, and its answer then depends on the order of its own scan
+    (`minbval > v` is false either way round, lpsol.h:599-611; flty.cpp:61-94). The blocked loop chooses rows by
+    reductions over records, which cannot say "unordered": a pick that meets a NaN candidate ends the batch and hands the
+    pivot to the generic pick, which scans in order (lp_chain.hip.h ch_poll_records, lp_blocked.hip.h blk_pick_body).
+    States at iteration limits around the first NaN and at the end must be the oracle's -- which equals the real reference
+    on these very LPs (tools/crosscheck_oracle_weird.py overflow: 21 LPs x 6 limits, 0 mismatches). With the persistent
+    chain launch and with the launch-per-stage kernels (XPG_CHAIN=0)."""
+    import xpoly_amd
+    monkeypatch.setenv("XPG_LOOP", "block")              # read when the context is created
+    monkeypatch.setenv("XPG_CHAIN", chain)
+    c = xpoly_amd.Context(0)
+    six = xpoly_amd.SIX(c, F64)
+
+    def same(a, b):
+        a, b = np.asarray(a), np.asarray(b)
+        if a.shape != b.shape:
+            return False
+        if a.dtype != np.float64:
+            return a.tobytes() == b.tobytes()
+        na, nb = np.isnan(a), np.isnan(b)                # NaN signs and payloads differ between x86 and the GPU
+        return np.array_equal(na, nb) and a[~na].tobytes() == b[~nb].tobytes()
+    cases = compared = 0
+    for trial in range(1200):
+        leq, tg = gen.overflow_lp_f64(trial)
+        assert np.isfinite(leq).all() and np.isfinite(tg).all()
+        if not np.isnan(port.two_stage(F64, leq, tg, 0xFFFFFFFF)["tab"]).any():
+            continue
+        lo = next(K for K in range(1, 1000) if np.isnan(port.two_stage(F64, leq, tg, K)["tab"]).any())
+        cases += 1
+        for K in sorted({max(1, lo - 1), lo, lo + 1, lo + 2, lo + 5, 0xFFFFFFFF}):
+            want = port.two_stage(F64, leq, tg, K)
+            six.set_param(0, K)
+            got = six.TwoStageMethod(leq, tg)
+            assert got["status"] == want["status"], (trial, K, lo, got["status"], want["status"])
+            if want["status"] != 2:
+                for k in ("tab", "tgtf", "eq2bv"):
+                    assert same(got[k], want[k]), (trial, K, lo, k)
+            compared += 1
+    c.close()
+    assert cases >= 20 and compared >= 6 * 20 - 20

@@ -157,3 +157,27 @@ def test_bench_two_ranks_real_solver_on_one_gpu():
     assert b["strong_scaling"]["lps_per_rank"] == 32768
     assert out["sharded"]["mip"]["problems_total"] == 2048 and out["sharded"]["dep_is_empty"]["problems_total"] == 8192
     assert "identical" in out["self_check"]["batched"]["dep_test_like"]
+
+
+def test_bench_rccl_at_world_size_one():
+    """RCCL itself, once, before the first 8-GPU run: bench.py --gpus 1 --force-dist spawns its rank through
+    torch.distributed.run before any GPU call and then takes the N > 1 path with the real solver --
+    init_process_group("nccl", device_id=cuda:0), record tensors resident on the device, all_reduce (timing) and
+    all_gather_into_tensor (result records) over RCCL at world size 1 -- and bench.py's self-check reads the gathered
+    records against the reference fixture. (No scaling can be measured on one GPU; this makes sure the 8-GPU driver
+    run is not also the collective path's first run.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--backend", "nccl",
+                        "--legs", "batched,sharded", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and "stub_solver" not in out
+    b = out["batched"]
+    assert b["ranks"] == 1 and "RCCL, world size 1" in b["collective"], b.get("collective")
+    assert b["families"]["dep_test_like"]["gather_ms"] > 0
+    assert "RCCL, world size 1" in out["sharded"]["mip"]["collective"]
+    assert "identical" in out["self_check"]["batched"]["dep_test_like"]

@@ -2,7 +2,8 @@
 inputs outside ordinary arithmetic: SIX with equalities whose substitution divides by zero, rational tableaux with
 n/0 cells, fp64 tableaux with inf / NaN. The reference may die on such inputs (integer division by zero is a SIGFPE
 there), so every case runs in a child process; a case the reference does not survive is skipped.
-Run by hand in the build container: python tools/crosscheck_oracle_weird.py [cases]"""
+Run by hand in the build container: python tools/crosscheck_oracle_weird.py [cases]
+                                    python tools/crosscheck_oracle_weird.py overflow [trials]   (finite LPs that overflow mid-solve)"""
 import json, os, subprocess, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -45,7 +46,33 @@ def run(which, case):
         if ln.startswith("RESULT "): return json.loads(ln[7:])
     return None                                              # died (SIGFPE / assert) or reported nothing
 
+def overflow(trials):
+    """gen.overflow_lp_f64: FINITE input whose products overflow after a few pivots (inf - inf -> NaN cells mid-solve, NaN
+    ratios in findPivotBV whose outcome only the reference's scan order decides): restatement against the real reference at
+    iteration limits around the first NaN and at the end -- the same LPs tests/test_gpu_edges.py runs through the blocked loop."""
+    from tools import gen
+    from oracle.checker import Port
+    port = Port()
+    compared = bad = cases = 0
+    for trial in range(trials):
+        leq, tg = gen.overflow_lp_f64(trial)
+        if not np.isnan(port.two_stage(0, leq, tg, 0xFFFFFFFF)["tab"]).any(): continue
+        lo = next(K for K in range(1, 1000) if np.isnan(port.two_stage(0, leq, tg, K)["tab"]).any())
+        cases += 1
+        case = dict(what="two_stage", kind=0, tg=tg.tolist(), vc=gen.vc_nonneg(leq.shape[1] - 1, True).tolist(), leq=leq.tolist(),
+                    Ks=sorted({max(1, lo - 1), lo, lo + 1, lo + 2, lo + 5, 100000}))
+        a = run("port", case); r = run("ref", case)
+        if r is None or a is None: bad += 1; print("DIED", trial, a is None, r is None); continue
+        for k in r:
+            compared += 1
+            if a.get(k) != r[k]:
+                bad += 1
+                if bad <= 5: print("MISMATCH trial", trial, "K", k, "\n oracle", str(a.get(k))[:200], "\n ref   ", str(r[k])[:200])
+    print("overflow LPs", cases, "compared", compared, "mismatches", bad)
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "overflow":
+        return overflow(int(sys.argv[2]) if len(sys.argv) > 2 else 1200)
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     rng = np.random.default_rng(20261003)
     from tools import gen

@@ -278,3 +278,19 @@ def interval_mip_f64(rng, m=25, nv=35, maxlen=6):
     leq = np.concatenate([A, b[:, None]], axis=1).astype(np.float64)
     tgtf = np.concatenate([c, [0]]).astype(np.float64)
     return leq, tgtf
+
+
+def overflow_lp_f64(trial, key=2026):
+    """A dense LP of FINITE cells whose magnitudes are spread element by element over hundreds of decades: products overflow
+    after a few pivots, inf - inf follows, and NaN cells appear MID-SOLVE (row / column scalings alone would not do it: the
+    simplex is invariant under them). Returns (leq, tgtf); tests keep the trials whose oracle run does meet a NaN."""
+    rng = np.random.default_rng([key, trial])
+    m = int(rng.integers(20, 70))
+    n = int(rng.integers(20, 90))
+    span = int(rng.choice([200, 250, 300]))
+    A = rng.uniform(0.1, 1.0, size=(m, n)) * 10.0 ** rng.integers(-span, span + 1, size=(m, n))
+    b = rng.uniform(0.5, 1.0, size=m) * 10.0 ** rng.integers(0, span + 1, size=m)
+    c = rng.uniform(0.1, 1.0, size=n) * 10.0 ** rng.integers(-span, span + 1, size=n)
+    leq = np.ascontiguousarray(np.concatenate([A, b[:, None]], axis=1))
+    tgtf = np.ascontiguousarray(np.concatenate([c, [0.0]]))
+    return leq, tgtf

@@ -152,6 +152,7 @@ __device__ __forceinline__ bool blk_pick_body(const LpView<F64> & v, int batch, 
     // replayed constant column, first pass of the ratio test
     Cand<F64> best; best.q = zero<F64>(); best.idx = INT_MAX;
     double best_a = 0.0; int best_b = 0, best_cc = 0; uint32_t best_w = 0;
+    bool unordered = false;                                     // a candidate whose ratio is NaN: see below
     for (int i = p * tpb + tid; i < m; i += tpb * N) {
         // eq2bv and the blkK row of this thread's first row were loaded with the state (they do not depend
         // on the entering column): everything that does goes out in ONE further round
@@ -179,12 +180,17 @@ __device__ __forceinline__ bool blk_pick_body(const LpView<F64> & v, int batch, 
         if (le(F64(a), zero<F64>())) continue;                            // findPivotBV, lpsol.h:553-663
         if (((w >> (bi & 31)) & 1u) || cc >= lim) continue;
         Cand<F64> c; c.q = div(F64(bc), F64(a)); c.idx = i;
+        unordered = unordered || c.q.v != c.q.v;
         const Cand<F64> nbest = better(best, c);
         if (nbest.idx != best.idx) { best_a = a; best_b = bi; best_cc = cc; best_w = w; }
         best = nbest;
     }
     XPG_STAMP(st, 2);                                   // division + candidate
     const Cand<F64> wbest = block_argmin(best, sh_c);
+    // A candidate ratio that is NaN (an overflow's inf - inf, mid-solve) has no place in any order: findPivotBV's answer
+    // then depends on the order of its scan (lpsol.h:599-611, `minbval > v` is false either way round), which no reduction
+    // reproduces. The record says so and prep hands the pivot to the generic pick, which scans in order.
+    const int any_unordered = __syncthreads_or(unordered ? 1 : 0);
     XPG_STAMP(st, 3);                                   // arg-min
     const bool publisher = wbest.idx != INT_MAX ? (best.idx == wbest.idx) : (tid == 0);
     if (publisher) {
@@ -196,7 +202,7 @@ __device__ __forceinline__ bool blk_pick_body(const LpView<F64> & v, int batch, 
         rec[4] = ((unsigned long long)(unsigned)wbest.idx << 32) | (unsigned)best_b; rec[5] = tag;
         rec[6] = ((unsigned long long)best_w << 32) | (unsigned)best_cc; rec[7] = tag;
         rec[8] = cnv_bits; rec[9] = tag;
-        rec[10] = (unsigned long long)(unsigned)first; rec[11] = tag;
+        rec[10] = (unsigned long long)(unsigned)first | (any_unordered ? 1ull << 32 : 0ull); rec[11] = tag;
     }
     return true;
 }
@@ -285,7 +291,7 @@ __device__ __forceinline__ bool blk_prep_body(const LpView<F64> & v, int batch, 
     // (one round of loads), a 64-lane butterfly picks the best row, the winner's payload comes by shuffle
     Cand<F64> g; g.q = zero<F64>(); g.idx = INT_MAX;
     double g_a = 0.0; int g_b = 0, cand_first = -1; unsigned long long g_cnv = 0;
-    bool any_rec = false;
+    bool any_rec = false, unordered_rec = false;
     {
         const int lane = threadIdx.x & 63;
         unsigned long long w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0, w5 = 0;
@@ -297,6 +303,7 @@ __device__ __forceinline__ bool blk_prep_body(const LpView<F64> & v, int batch, 
         }
         const unsigned long long vmask = __ballot(valid);
         any_rec = vmask != 0;
+        unordered_rec = __ballot(valid && ((w5 >> 32) & 1ull)) != 0ull;
         if (any_rec) {
             Cand<F64> c; c.q = from_bits<F64>(w0); c.idx = valid ? (int)(unsigned)(w2 >> 32) : INT_MAX;
             g = c;
@@ -318,7 +325,7 @@ __device__ __forceinline__ bool blk_prep_body(const LpView<F64> & v, int batch, 
     XPG_STAMP(st, 4);                                   // state + records (combined) + this thread's obj / nv / rowcnt / E column
     if (status != ST_RUNNING) return false;
     if (any_rec) {
-        if (g.idx == INT_MAX) {                                // first pass empty: second pass / disableNV are generic
+        if (g.idx == INT_MAX || unordered_rec) {               // first pass empty (second pass / disableNV), or a NaN among the candidates: generic
             if (gid == 0) {
                 st->blk.closed = 1;
                 if (t == 0) { st->blk.want_generic = 1; st->blk.batch = batch; st->blk.n = 0; }

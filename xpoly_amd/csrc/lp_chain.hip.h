@@ -219,7 +219,7 @@ __device__ __forceinline__ unsigned long long ch_wave_min_u64(unsigned long long
 
 // The winner of a stage, as every worker derives it from the records.
 struct ChWinner { int r, enter, leave, qstar, cc; uint32_t w; double a; unsigned long long cnv; };
-enum { CH_CLOSE_ROW = 0x7FFFFFFE };
+enum { CH_CLOSE_ROW = 0x7FFFFFFE, CH_UNORDERED_ROW = 0x7FFFFFFD };
 
 // addresses in the hand-off areas (layout: lp_kernels.hip.h)
 __device__ __forceinline__ char * ch_rec_g0(const LpView<F64> & v, int w) { return (char *)(v.blkR + BLK_REC_G0) + (size_t)w * 16; }
@@ -259,6 +259,10 @@ __device__ __forceinline__ int ch_poll_records(const LpView<F64> & v, int npick,
     // every pick worker takes the same fast / close decision, so record 0 tells which it was
     if (__builtin_amdgcn_readfirstlane((int)g0.z) == CH_CLOSE_ROW) return -1;
     const unsigned long long kmin = ch_wave_min_u64(key);
+    // key 0 is no ratio's key (it would be a NaN's): a pick worker met an UNORDERED candidate -- a ratio that is NaN -- and
+    // findPivotBV's answer then depends on the order of its scan (lpsol.h:599-611: `minbval > v` is false either way round),
+    // which a reduction cannot reproduce. The batch ends here like a CLOSE; the generic pick, which scans in order, takes over.
+    if (kmin == 0ull) return -1;
     if (kmin == ~0ull) return -2;
     // the lowest row among the records with the least ratio (lpsol.h:604-611)
     const int myrow = key == kmin ? row : INT_MAX;
@@ -570,11 +574,21 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
             if (has_row) ch_stl<LOCAL>(&K[(size_t)i * BLK_MAX + t], klast);
             // findPivotBV's first pass (lpsol.h:553-663)
             unsigned long long key = ~0ull;
-            if (has_row && !le(F64(a), zero<F64>()) && !((pw_word >> (bi & 31)) & 1u) && cc < lim) key = ch_ratio_key(bcur / a);
+            bool unordered = false;
+            if (has_row && !le(F64(a), zero<F64>()) && !((pw_word >> (bi & 31)) & 1u) && cc < lim) {
+                const double q = bcur / a;
+                unordered = q != q;                         // NaN (an overflow's inf - inf, mid-solve): no place in any order
+                key = ch_ratio_key(q);
+            }
+            if (__any(unordered)) {                         // see ch_poll_records: everybody leaves, the generic pick scans in order
+                if (lane == 0) ch_store_granule3<LOCAL>(ch_rec_g0(v, w), 0u, 0u, (unsigned)CH_UNORDERED_ROW, tag);
+                key = ~0ull;
+            }
+            const bool told = __any(unordered);
             const unsigned long long kmin = ch_wave_min_u64(key);
             const unsigned long long hit = __ballot(key == kmin);
             const bool publisher = kmin != ~0ull ? (lane == __ffsll((long long)hit) - 1) : (lane == 0);
-            if (publisher) {
+            if (publisher && !told) {
                 const unsigned long long ab = to_bits(F64(a));
                 char * pay = ch_rec_pay(v, w);
                 ch_store_granule3<LOCAL>(pay, (unsigned)ab, (unsigned)(ab >> 32), (unsigned)bi, tag);

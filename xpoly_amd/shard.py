@@ -61,9 +61,10 @@ def gather_records(rec, total, rank, world, dist=None):
     """All-gathers per-rank record blocks (ragged by at most one row) into the global order.
 
     rec: [n_local, width] float64 tensor of this rank (n_local = shard size). Returns a
-    [total, width] tensor on every rank. With world == 1 (or dist None) it is a no-op."""
+    [total, width] tensor on every rank. Without a process group (dist None) it is a no-op; with one the
+    collective runs whatever the world size (bench.py --force-dist: RCCL at world size 1)."""
     import torch
-    if world == 1 or dist is None:
+    if dist is None:
         return rec
     base, extra = divmod(total, world)
     cap = base + (1 if extra else 0)
