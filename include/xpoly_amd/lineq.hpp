@@ -14,6 +14,7 @@
 #define XPOLY_AMD_LINEQ_HPP
 
 #include <cstring>
+#include <utility>
 #include <vector>
 #include "../xpoly_amd.h"
 #include "six.hpp"
@@ -92,10 +93,14 @@ public:
                                              is_int_sol ? 1 : 0, is_unique_sol ? 1 : 0);
         return r == 1;
     }
-    // Lineq::calcBound, linsys.cpp:1047-1078: limits[j] receives the bounds of variable j (every other variable
-    // eliminated). `limits` is anything with push_back / append_tail of RMatT* -- here a std::vector<RMatT> out
-    // parameter keeps ownership simple.
-    bool calcBound(std::vector<RMatT> & limits)
+    // Lineq::calcBound, linsys.cpp:1047-1078: the bounds of variable j alone (every other variable eliminated, inner to
+    // outer) for every j, all chains on the device in one call.
+    //   bool calcBound(List<RMat*> & limits)   -- the reference's own signature (linsys.h:151): `limits` holds m_rhs_idx
+    //                                             matrices the caller owns, *limits.get_head_nth(j) receives variable j's
+    //                                             (linsys.cpp:1072-1074), so the call site at linsys.cpp:312 compiles unchanged
+    //   bool calcBound(std::vector<RMat> &)    -- the same with value semantics (resized to m_rhs_idx)
+private:
+    template <class Sink> bool calc_bound_into(Sink sink)
     {
         const int rows = (int)m_coeff->get_row_size(), cols = (int)m_coeff->get_col_size(), nv = m_rhs_idx;
         int cap = 4 * rows + 16;
@@ -106,15 +111,26 @@ public:
             if (xpg_lineq_calc_bound_batch_rat32(ctx(), 1, (const xpg_rat32 *)m_coeff->get_matrix(), rows, cols, nv, cap, out.data(),
                                                  orows.data(), &ok) != 0) return false;
             if (ok < 0) { cap = -ok; continue; }
-            if (ok == 0) return false;
-            limits.resize((size_t)nv);
+            if (ok == 0) return false;                       // "system inconsistency!" (linsys.cpp:1065-1068)
             for (int j = 0; j < nv; j++) {
                 std::vector<xpg_rat32> one(out.begin() + (size_t)j * cap * cols, out.begin() + (size_t)j * cap * cols + (size_t)orows[(size_t)j] * cols);
-                put(limits[(size_t)j], one, orows[(size_t)j], cols);
+                sink(j, one, orows[(size_t)j], cols);
             }
             return true;
         }
         return false;
+    }
+public:
+    bool calcBound(std::vector<RMatT> & limits)
+    {
+        limits.resize((size_t)m_rhs_idx);
+        return calc_bound_into([&](int j, const std::vector<xpg_rat32> & a, int r, int c) { put(limits[(size_t)j], a, r, c); });
+    }
+    template <class ListT, class = decltype(std::declval<ListT &>().get_head_nth(0u)), class = decltype(std::declval<ListT &>().get_elem_count())>
+    bool calcBound(ListT & limits)
+    {
+        if ((int)limits.get_elem_count() != m_rhs_idx) return false;      // the reference ASSERTs (linsys.cpp:1050-1051)
+        return calc_bound_into([&](int j, const std::vector<xpg_rat32> & a, int r, int c) { put(*limits.get_head_nth((unsigned)j), a, r, c); });
     }
 };
 

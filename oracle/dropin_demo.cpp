@@ -197,6 +197,19 @@ int main()
             mis = fa != fb || f1.get_row_size() != f2.get_row_size() ||
                   (f1.size() && memcmp(f1.get_matrix(), f2.get_matrix(), sizeof(Rational) * f1.size()) != 0);
         }
+        if (!mis && ra && sys1.get_row_size() > 1) {
+            // Lineq::calcBound with the reference's own signature, List<RMat*> (linsys.h:151; call site linsys.cpp:312)
+            RMat a1[4], a2[4];
+            List<RMat*> lim1, lim2;
+            for (int j = 0; j < nv; j++) { lim1.append_tail(&a1[j]); lim2.append_tail(&a2[j]); }
+            xcom::Lineq r3(&sys1, nv); xpoly_amd::Lineq<RMat> g3(&sys2, nv);
+            bool ca = r3.calcBound(lim1), cb = g3.calcBound(lim2);
+            mis = ca != cb;
+            for (int j = 0; !mis && ca && j < nv; j++)
+                mis = a1[j].get_row_size() != a2[j].get_row_size() || a1[j].get_col_size() != a2[j].get_col_size() ||
+                      (a1[j].size() && memcmp(a1[j].get_matrix(), a2[j].get_matrix(), sizeof(Rational) * a1[j].size()) != 0);
+            if (mis) printf("MISMATCH calcBound(List<RMat*>) on system %d (reference %d, xpoly_amd %d)\n", it, (int)ca, (int)cb);
+        }
         if (mis) printf("MISMATCH Lineq adapter on system %d\n", it);
         bad += mis; n++;
     }

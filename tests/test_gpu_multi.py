@@ -179,5 +179,5 @@ def test_bench_rccl_at_world_size_one():
     b = out["batched"]
     assert b["ranks"] == 1 and "RCCL, world size 1" in b["collective"], b.get("collective")
     assert b["families"]["dep_test_like"]["gather_ms"] > 0
-    assert "RCCL, world size 1" in out["sharded"]["mip"]["collective"]
+    assert "RCCL, world size 1" in out["sharded"]["collective"]
     assert "identical" in out["self_check"]["batched"]["dep_test_like"]

@@ -584,7 +584,7 @@ void k_blk_sweep_full(double * __restrict__ tab, int m, int W, int ld, const dou
     const int i0 = by * ROWS;
     const int iend = min(i0 + ROWS, m);
     // the first row group goes out before anything else: it comes from HBM, the state and E from the L2.
-    // ld is a multiple of 16 and the cells of a row beyond W are padding nobody reads (E is zero there), so a thread
+    // ld is a multiple of 16 and the cells of a row beyond W are padding nobody reads (undefined contents), so a thread
     // whose first column is live always owns a whole 16-byte pair: an odd W has no scalar last column.
     const bool full = i0 + ROWS <= m && j < W;
     double2 a[U], b[U];

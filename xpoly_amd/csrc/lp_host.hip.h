@@ -301,7 +301,8 @@ template <class S> struct Lp : LpBase {
         XPG_HIP(ctx, hipMemsetAsync(v.st, 0, sizeof(LoopState), s));
         XPG_HIP(ctx, hipMemsetAsync(v.pickrec, 0, (size_t)PICK_WORDS * 8, s));
         // the cells of a row beyond W are padding: the sweeps update them along with the last live column (whole
-        // 16-byte pairs) and nobody reads them; zero E there keeps them finite
+        // 16-byte pairs) and NOBODY READS THEM -- their contents are undefined (E starts as zero there, but once phase
+        // one's k_delete_col has shrunk W the column that becomes padding keeps what it held, in the tableau and in E)
         XPG_HIP(ctx, hipMemsetAsync(v.tab, 0, tab_elems * sizeof(S), s));
         XPG_HIP(ctx, hipMemsetAsync(v.blkE, 0, (size_t)BLK_MAX * ld * sizeof(S), s));
         // launch-throttle events, exercised once so their first use is not inside a solve

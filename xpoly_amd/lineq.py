@@ -119,13 +119,15 @@ class Lineq:
         rhs = None if rhs_idx is None else np.ascontiguousarray(rhs_idx, dtype=np.int32)
         uu = np.ascontiguousarray(u, dtype=np.int32)
         out_rows = np.zeros(nb, dtype=np.int32); ok = np.zeros(nb, dtype=np.int32); ooff = np.zeros(nb + 1, dtype=np.int64)
-        call = lambda outs, capc: lib().xpg_lineq_fme_batch_ragged_rat32(
-            self.ctx._h, C.c_int(nb), vp(flat), vp(rows), vp(cols), vp(off), vp(rhs), vp(uu), C.c_int(int(darkshadow)), outs,
-            C.c_longlong(capc), vp(ooff), vp(out_rows), vp(ok))
-        self.ctx.check(call(None, 0), "xpg_lineq_fme_batch_ragged_rat32")          # sizing call
-        outs = np.zeros((int(ooff[nb]), 2), dtype=np.int32)
-        self.ctx.check(call(vp(outs), int(ooff[nb])), "xpg_lineq_fme_batch_ragged_rat32")
-        return ok, [outs[int(ooff[b]): int(ooff[b + 1])].reshape(int(out_rows[b]), int(cols[b]), 2) for b in range(nb)]
+        # ONE call: the entry point computes every elimination before it looks at the output buffer, so a sizing call
+        # would do the whole batch twice. An elimination of R rows leaves at most R*R/4 + R rows (P positive x N negative
+        # combinations with P + N <= R, plus the rows without the variable): the buffer is sized for that and trimmed.
+        capc = int(sum((int(r) * int(r) // 4 + int(r)) * int(c) for r, c in zip(rows, cols)))
+        outs = np.zeros((max(capc, 1), 2), dtype=np.int32)
+        self.ctx.check(lib().xpg_lineq_fme_batch_ragged_rat32(
+            self.ctx._h, C.c_int(nb), vp(flat), vp(rows), vp(cols), vp(off), vp(rhs), vp(uu), C.c_int(int(darkshadow)), vp(outs),
+            C.c_longlong(capc), vp(ooff), vp(out_rows), vp(ok)), "xpg_lineq_fme_batch_ragged_rat32")
+        return ok, [outs[int(ooff[b]): int(ooff[b + 1])].reshape(int(out_rows[b]), int(cols[b]), 2).copy() for b in range(nb)]
 
     def calcBound(self, mats, rhs_idx, cap_rows=None):
         """Lineq::calcBound (linsys.cpp:1047-1078): chained eliminations on the device.
