@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 
 M, NVARS = 4096, 4095                      # tableau 4096 x (4095 + 4096 + 1) = 4096 x 8192
 TAB_W = NVARS + M + 1
-BLOCK = int(os.environ.get("XPG_BLOCK", "32"))   # pivots one blocked sweep applies (XPG_BLOCK default: 32)
+BLOCK = int(os.environ.get("XPG_BLOCK", "24"))   # pivots one blocked sweep applies (XPG_BLOCK default: 24)
 PIVOTS_PER_STEP = 3840                     # 240 full batches; the LP ends after 4165 (tools/lab/probe_count.py)
 ALG_BYTES_PER_LAUNCH = 2 * M * TAB_W * 8   # one sweep LAUNCH reads and writes every entry once (SURVEY 8d:
                                            # 2*m*W*8 B; the blocked loop pays it per BLOCK pivots, not per pivot)
@@ -421,7 +421,7 @@ def main():
                 bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src,
                 kernel="k_blk_sweep_full<%s,%d>: one launch applies the %d staged pivots of a batch to every cell (XCD-static "
-                       "tile map, alternate passes in opposite directions)" % ("16,2" if BLOCK == 32 else "16,4", BLOCK, BLOCK),
+                       "tile map, alternate passes in opposite directions)" % ("16,2" if BLOCK in (24, 32) else "16,4", BLOCK, BLOCK),
                 algorithmic_bytes_per_launch=ALG_BYTES_PER_LAUNCH, launches_sampled=launches,
                 avg_launch_us=round(sweep_avg_s * 1e6, 2),
                 sweeps_in_region=dict(full=sweeps_full, partial=sweeps_part),
@@ -747,7 +747,7 @@ def leg_cfg2b(ctx, xpoly_amd, gen, m=4096, n=8192):
     if launches:
         avg = sweep_ms / 1e3 / launches
         out["roofline"] = dict(
-            bound="hbm", kernel="k_blk_sweep_full<%s,%d> on the 403 MB tableau (1.57 x the 256 MiB Infinity Cache)" % ("16,2" if BLOCK == 32 else "16,4", BLOCK),
+            bound="hbm", kernel="k_blk_sweep_full<%s,%d> on the 403 MB tableau (1.57 x the 256 MiB Infinity Cache)" % ("16,2" if BLOCK in (24, 32) else "16,4", BLOCK),
             achieved=round(bytes_per_launch / avg / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
             frac=round(bytes_per_launch / avg / 1e9 / HBM_PEAK_GBS, 4), avg_launch_us=round(avg * 1e6, 2),
             launches_sampled=launches,

@@ -128,6 +128,8 @@ int  xpg_lp_counters(xpg_lp * lp, unsigned * sweeps_full, unsigned * sweeps_part
  * has switched this solve to launch-per-stage kernels because of it; runs (may be NULL) = the launches that passed.
  * Results are the same either way. */
 int  xpg_lp_chain_aborts(xpg_lp * lp, unsigned * aborts, int * chain_off, unsigned * runs);
+/* ... and how many of the launches that passed did their batch's first stage themselves (no pick / prep launches for it). */
+int  xpg_lp_chain_folds(xpg_lp * lp, unsigned * folds);
 /* Launch geometry, host-side views for tests (no device needed).  xpg_test_sweep_tile: the blocked sweep's workgroup ->
  * tile map for a tableau of `strips` 512-column strips and `rowblocks` row blocks: lid < 0 returns the grid size, else
  * 1 / 0 = workgroup lid has / has no tile, written to (*bx, *by).  xpg_test_pick_ld: the leading dimension a device

@@ -253,7 +253,7 @@ def test_wide_tableau_keeps_the_chain(port, monkeypatch):
         lp.close(); c.close()
     a, ta, na, runs, aborts = got["block"]
     b, tb, nb, _, _ = got["serial"]
-    assert runs >= 5 and aborts == 0, (runs, aborts)     # the persistent launch really ran (32 + 18, then 3 x 32 + 14 pivots)
+    assert runs >= 5 and aborts == 0, (runs, aborts)     # the persistent launch really ran (2 x 24 + 2, then 4 x 24 + 14 pivots)
     assert na == nb == K and np.array_equal(ta, tb)
     for k in ("tab", "tgtf"):
         assert np.array_equal(a[k].view(np.uint64), b[k].view(np.uint64)), k

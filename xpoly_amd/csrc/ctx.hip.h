@@ -36,6 +36,7 @@ struct xpg_ctx {
     int num_cus;            // compute units of the device
     int chain;              // blocked loop: stages 1.. of a batch in ONE persistent launch (lp_chain.hip.h); XPG_CHAIN=0 turns it off
     int chain_local = 1;        // the chain's workers all on ONE XCD, hand-offs through its L2 (XPG_CHAIN_XCD=0: spread over the chip, sc1 stores)
+    int chain_fold = 1;         // a batch's stage 0 inside the chain launch wherever the batch before admitted it (XPG_CHAIN_FOLD=0: always as launches of its own)
     int chain_test_abort = 0;   // test hook XPG_CHAIN_TEST_ABORT=k (read when the handle is created): every k-th chain launch fails its roll call
     // xpg_profile_begin/end: event pairs around each sweep launch
     std::vector<hipEvent_t> ev0, ev1;

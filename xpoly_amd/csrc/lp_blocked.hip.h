@@ -61,6 +61,9 @@ __device__ double g_dbg_rows[4][8192];                      // per row of the la
 #endif
 
 __device__ __forceinline__ unsigned blk_epoch(int batch, int t) { return (((unsigned)batch << 5) | (unsigned)t) + 1u; }
+// the ticket (and roll-call tag) of a chain launch that starts at stage 0 of `batch`: no stage's epoch (bit 31; an epoch would
+// need batch >= 2^26)
+__device__ __forceinline__ unsigned blk_ticket0(int batch) { return 0x80000000u | (unsigned)batch; }
 
 __device__ __forceinline__ unsigned long long shfl_u64(unsigned long long x, int src)
 {

@@ -290,7 +290,7 @@ __device__ __forceinline__ bool ch_load_winner(const LpView<F64> & v, int widx, 
 
 // ---- the committer: one extra worker that owns the basis arrays --------------------------------------
 template <bool LOCAL> __device__ __forceinline__ void ch_commit_loop(const LpView<F64> & v, int batch, int t0, int B, int npick, int nprep,
-                                                                     unsigned budget, unsigned done, unsigned tp)
+                                                                     unsigned budget, unsigned done, unsigned tp, bool fold_next)
 {
     LoopState * st = v.st;
     const int lane = (int)threadIdx.x;
@@ -303,6 +303,13 @@ template <bool LOCAL> __device__ __forceinline__ void ch_commit_loop(const LpVie
             // CLOSE with budget left, or an empty first ratio pass: the batch takes no more pivots (blk_pick_body /
             // blk_prep_body set `closed` in the same cases); with the budget spent it just ends
             if (lane == 0 && (widx == -2 || budget != 0)) st->blk.closed = 1;
+            // at stage 0 nothing is staged: the batch is this launch's, empty, and what the fast path could not do (second
+            // ratio pass, disableNV, findPivotNVandBVPair, optimum, limits) is the generic pick's, which the next batch
+            // with launches of its own starts with (blk_prep_body leaves the same fields when pick(0)'s first pass is empty)
+            if (lane == 0 && t == 0) {
+                st->blk.batch = batch; st->blk.n = 0; st->blk.closed = 1; st->blk.generic = 0;
+                if (widx == -2) st->blk.want_generic = 1;
+            }
             return;
         }
         if (lane == 0) {
@@ -322,9 +329,18 @@ template <bool LOCAL> __device__ __forceinline__ void ch_commit_loop(const LpVie
             st->total_pivots = tp + 1;
             st->done = done + 1;
             st->blk.budget = budget - 1;
+            if (t == 0) { st->blk.batch = batch; st->blk.closed = 0; st->blk.generic = 0; }     // (as blk_prep_body's commit of stage 0)
             st->blk.r[t] = r; st->blk.n = t + 1;
             st->blk.la_from_state = 0;
             st->blk.la_epoch = tag;
+            if (t == B - 1 && fold_next) {
+                // every stage of this batch is committed: the ticket of a chain launch that does the NEXT batch's stage 0
+                // itself (behind this batch's sweep, stream order). The roll call's counters are this launch's no longer.
+                for (int x = 0; x < 8; x++) st->blk.ch_arrive[x] = 0u;
+                st->blk.ch_decide = 0u;
+                st->blk.ch0_la_epoch = tag; st->blk.ch0_budget = budget - 1; st->blk.ch0_done = done + 1; st->blk.ch0_tp = tp + 1;
+                st->blk.ch0_ticket = blk_ticket0(batch + 1);
+            }
             // (the next batch's pick(0) looks through ceil(W / 64) partial slots for this tag: the chain's nprep <= that many
             // carry it, the rest still hold stage 0's and are ignored)
         }
@@ -336,7 +352,7 @@ template <bool LOCAL> __device__ __forceinline__ void ch_commit_loop(const LpVie
 }
 
 #ifdef XPG_STAMPS
-__device__ unsigned long long g_ch_ts[4][16][8];            // [worker class][stage][point]: raw 100 MHz stamps of the last batch
+__device__ unsigned long long g_ch_ts[4][BLK_MAX][8];            // [worker class][stage][point]: raw 100 MHz stamps of the last batch
 #define CH_TS(pt_) do { if (lane == 0 && tsw >= 0) g_ch_ts[tsw][t][pt_] = wall_clock64(); } while (0)
 #else
 #define CH_TS(pt_) do { } while (0)
@@ -365,20 +381,27 @@ __device__ unsigned long long g_ch_ts[4][16][8];            // [worker class][st
 // ABORT + blk.ch_misplaced, and the host goes back to the spread (sc1) form of this kernel for the rest of the solve.
 enum { CH_LDS_BYTES = BLK_MAX * 64 * 8 };
 template <bool LOCAL>
-__global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int t0, int B, int npick, int nprep, int nparts0, int force_abort)
+__global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int t0, int B, int npick, int nprep, int nparts0, int force_abort, int fold_next)
 {
     extern __shared__ __attribute__((aligned(16))) double ch_hist[];     // [BLK_MAX][64]: this worker's history, stage-major
     if (LOCAL && (blockIdx.x & 7u)) return;
     LoopState * st = v.st;
     const int w = LOCAL ? (int)(blockIdx.x >> 3) : (int)blockIdx.x, lane = (int)threadIdx.x;
     const unsigned nworkers = LOCAL ? gridDim.x >> 3 : gridDim.x;      // npick + nprep + 1
-    // ---- the ticket: stage 0 of THIS batch staged a pivot (fields this launch never writes)
-    if (st->blk.ch_epoch != blk_epoch(batch, t0 - 1) || st->status != ST_RUNNING || st->pricing != 0) return;
-    unsigned budget = st->blk.ch_budget, done = st->blk.ch_done;
+    // ---- the ticket (fields this launch never writes before its last stage is committed). t0 = 1: stage 0 of THIS batch --
+    // launches of their own -- staged a pivot. t0 = 0: the chain launch of the batch before committed all its stages and
+    // admitted this one (ch_commit_loop); this launch then does stage 0 itself, on the tableau that batch's sweep left: no
+    // pending update, so nothing is replayed and nothing fresh is needed but the look-ahead partials of that batch's last stage.
+    const bool fold = t0 == 0;
+    if ((fold ? st->blk.ch0_ticket != blk_ticket0(batch) : st->blk.ch_epoch != blk_epoch(batch, t0 - 1)) ||
+        st->status != ST_RUNNING || st->pricing != 0 || (fold && (st->blk.la_from_state != 0 || st->blk.want_generic != 0))) return;
+    unsigned budget = fold ? st->blk.ch0_budget : st->blk.ch_budget, done = fold ? st->blk.ch0_done : st->blk.ch_done;
+    const unsigned tp0 = fold ? st->blk.ch0_tp : st->blk.ch_tp;
+    const unsigned la_tag = st->blk.ch0_la_epoch;             // (t0 = 0: the tag of the partials stage 0 prices from)
     const unsigned max_iter = st->max_iter;
     // ---- roll call (see the header): count in; the committer decides GO / ABORT for everybody
     char * const decision = ch_part_g0(v, BLK_DECISION_SLOT);
-    const unsigned roll_tag = blk_epoch(batch, t0 - 1);
+    const unsigned roll_tag = fold ? blk_ticket0(batch) : blk_epoch(batch, t0 - 1);
     if (lane == 0) __hip_atomic_fetch_add(&st->blk.ch_arrive[LOCAL ? ch_xcc_id() : 0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (w == (int)nworkers - 1) {
         const unsigned long long t_in = wall_clock64();
@@ -401,13 +424,13 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
         prev = (unsigned)__builtin_amdgcn_readfirstlane((int)prev);
         if (prev != 0u) return;                                 // (vetoed: that worker has done the bookkeeping and published ABORT)
         if (lane == 0) {
-            if (go) st->blk.ch_runs += 1u;
+            if (go) { st->blk.ch_runs += 1u; if (fold) st->blk.ch_folds += 1u; }
             else { st->blk.closed = 1; st->blk.ch_aborts += 1u; if (misplaced) st->blk.ch_misplaced += 1u; }     // nothing of this launch has touched the state: close the batch at stage 0's pivot
         }
         ch_drain();
         // (the decision is an sc1 store in either form: after a failed placement check its readers may sit on any XCD)
         if (lane == 0) ch_store_granule<false>(decision, (unsigned long long)(go ? CH_GO : CH_ABORT), (unsigned long long)roll_tag);
-        if (go) ch_commit_loop<LOCAL>(v, batch, t0, B, npick, nprep, budget, done, st->blk.ch_tp);
+        if (go) ch_commit_loop<LOCAL>(v, batch, t0, B, npick, nprep, budget, done, tp0, fold_next != 0);
         return;
     }
     const int m = v.m, W = v.W, rhs = v.rhs, ld = v.ld, lim = v.rhs - 1;
@@ -474,10 +497,10 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
                 bcur = (rs == i) ? eb : (bcur + pb);
             } else klast = ks;
         }
-        int r_prev = st->blk.r[t0 - 1];                     // pivot row of stage t - 1 (for the constant's step)
+        int r_prev = t0 > 0 ? st->blk.r[t0 - 1] : -1;       // pivot row of stage t - 1 (for the constant's step)
 #pragma unroll 1
         for (int t = t0; t < B; t++) {
-            const unsigned want_part = blk_epoch(batch, t - 1), tag = blk_epoch(batch, t);
+            const unsigned want_part = t > 0 ? blk_epoch(batch, t - 1) : la_tag, tag = blk_epoch(batch, t);
             CH_TS(0);
             // ---- poll the g0 granules of the partials of stage t-1 and, behind them, the commit granule (the commit of
             // stage t0 - 1 was a launch of its own: no granule to wait for): four slots per lane and round, dense
@@ -522,7 +545,9 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
             const int cc = ch_ld(&v.colcnt[bi]);
             double ev = 0.0;
             if (lane + 1 < t) ev = ch_ld(&E[(size_t)lane * ld + first]);
-            {
+            if (t == 0) {                                   // nothing pending: c[first] as the last prep stored it
+                if (lane == 33) ev = v.obj[first].v;
+            } else {
                 const bool fresh = lane >= 32 && lane <= 34;
                 const char * gp = ch_part_pay(v, (lane == 34 ? rhs : first) >> 6) + (fresh ? 16 * (lane - 32) : 0);
                 unsigned spins = 0;
@@ -538,7 +563,7 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
             const unsigned long long cnv_bits = __builtin_bit_cast(unsigned long long, ch_readlane_f64(ev, 33));
             if (lane == t - 1) ev = ec_new;                 // lane s of ev now holds e_s[first] for every s < t
             // the constant column: ONE step, stage t-1 (the arithmetic of every other cell of the sweep)
-            {
+            if (t > 0) {
                 const double pb = klast * eb_new;
                 bcur = (i == r_prev) ? eb_new : (bcur + pb);
             }

@@ -93,9 +93,13 @@ template <> inline void launch_pipe_sweep<R32>(xpg_ctx * ctx, const LpView<R32> 
     if (timed) prof_close(ctx);
 }
 // One batch of the blocked loop: B x (pick, prep) -- the generic pick once after pick(0) -- and a sweep.
-template <class S> inline void launch_blk_batch(xpg_ctx *, const LpView<S> &, int, int, bool, bool, bool, bool) {}
+// fold: this batch's stage 0 is the chain launch's (t0 = 0) -- no pick / generic pick / prep launches. Speculative: the chain
+// launch of the batch before admits it by a ticket once it has committed all its stages; without the ticket this batch's
+// launches do nothing and the host, which sees the iteration budget not spent at its next status read, enqueues the rest
+// with stage-0 launches again (Lp::iterate / run_loop). next_folds: the batch after this one will be enqueued that way.
+template <class S> inline void launch_blk_batch(xpg_ctx *, const LpView<S> &, int, int, bool, bool, bool, bool, bool, bool) {}
 template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> & v, int batch, int B, bool ref_pricing, bool closes_often, bool chain_off,
-                                              bool chain_spread)
+                                              bool chain_spread, bool fold, bool next_folds)
 {
     const int strips = (v.W + 511) / 512;
     // workgroup sizes of pick and prep: 64 = one wave per workgroup, no LDS round in the reductions
@@ -114,11 +118,12 @@ template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> &
     const int cpick = (v.m + 63) / 64, cprep = (v.W + 63) / 64;
     const int workers = cpick + cprep + 1;
     const int cus = ctx->num_cus > 0 ? ctx->num_cus : 1;
-    const bool chain = ctx->chain && !chain_off && ref_pricing && B > 1 &&
+    const bool chain = ctx->chain && !chain_off && ref_pricing && (B > 1 || fold) &&
                        cpick <= BLK_REC_MAX && cprep <= 510 && workers <= 8 * cus &&
                        tpb_prep == 64;             // stage 0's prep leaves one look-ahead partial per 64 columns, as the chain's workers do
     for (int t = 0; t < B; t++) {
-        if (t == 1 && chain) {
+        if (chain && (t == 1 || fold)) {
+            const int t0 = fold ? 0 : 1;
             const int test_abort = ctx->chain_test_abort;
             // test hooks: k > 0 -- every k-th launch fails its roll call; k < 0 -- every |k|-th one-XCD launch "finds" its
             // workers on several XCDs
@@ -129,8 +134,9 @@ template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> &
             // placement check failed, selects the spread form with sc1 stores
             const bool local = ctx->chain_local && !chain_spread && workers <= (cus / 8) * 9;
             const int nparts0 = (int)gprep.x;
-            if (local) hipLaunchKernelGGL(k_blk_chain<true>, dim3(8 * workers), dim3(64), CH_LDS_BYTES, ctx->stream, v, batch, 1, B, cpick, cprep, nparts0, fa);
-            else hipLaunchKernelGGL(k_blk_chain<false>, dim3(workers), dim3(64), CH_LDS_BYTES, ctx->stream, v, batch, 1, B, cpick, cprep, nparts0, fa);
+            const int fn = next_folds ? 1 : 0;
+            if (local) hipLaunchKernelGGL(k_blk_chain<true>, dim3(8 * workers), dim3(64), CH_LDS_BYTES, ctx->stream, v, batch, t0, B, cpick, cprep, nparts0, fa, fn);
+            else hipLaunchKernelGGL(k_blk_chain<false>, dim3(workers), dim3(64), CH_LDS_BYTES, ctx->stream, v, batch, t0, B, cpick, cprep, nparts0, fa, fn);
             break;
         }
         hipLaunchKernelGGL(k_blk_pick, dim3(npick), dim3(tp), 0, ctx->stream, v, batch, t, (int)gprep.x);
@@ -156,8 +162,9 @@ template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> &
     // the full-batch kernels: 32 pivots per pass (the default; two register sets of e_s, 2-3 waves per SIMD: 110 / 166 us
     // per pass at 4096 x 8192 / 4096 x 12289 = 3.4 / 5.2 us per pivot against 4.9 / 7.9 with 16, tools/lab/sweep_lab2.hip) and
     // 16 (XPG_BLOCK=16); every other length -- the tail of an iteration budget -- goes through the switch kernel
-    const bool full32 = B == 32 && rows_env != 1, full16 = B == 16 && rows_env != 1;
+    const bool full32 = B == 32 && rows_env != 1, full16 = B == 16 && rows_env != 1, full24 = B == 24 && rows_env != 1;
     if (full32) { if (rows_env == 322) XPG_BLK_FULL(32, 2, 32); else if (rows_env == 164) XPG_BLK_FULL(16, 4, 32); else XPG_BLK_FULL(16, 2, 32); }
+    else if (full24) { if (rows_env == 164) XPG_BLK_FULL(16, 4, 24); else XPG_BLK_FULL(16, 2, 24); }
     else if (full16) { if (rows_env == 324) XPG_BLK_FULL(32, 4, 16); else if (rows_env == 162) XPG_BLK_FULL(16, 2, 16); else XPG_BLK_FULL(16, 4, 16); }
     else if (B <= 8) XPG_BLK_LAUNCH(32, 8, 8);
     else XPG_BLK_LAUNCH(32, 4, 16);
@@ -165,7 +172,7 @@ template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> &
     // the sweeps on whole solves of 300 x 300 and 1024 x 1500 LPs, 1 of 261 on the bench LP,
     // tools/lab/probe_partial_batches.py) gets a second launch with the stage count as a template switch for those
     // batches; the full-batch kernel above then leaves them alone.
-    if (closes_often && (full32 || full16))
+    if (closes_often && (full32 || full24 || full16))
         hipLaunchKernelGGL((k_blk_sweep<32, 4, 16>), dim3(strips, (v.m + 31) / 32), dim3(256), 0, ctx->stream, (double *)v.tab,
                            v.m, v.W, v.ld, (const double *)v.blkE, (const double *)v.blkK, v.st, batch, B, ctx->block_len);
 #undef XPG_BLK_LAUNCH
@@ -208,6 +215,7 @@ template <class S> struct Lp : LpBase {
     int blk_batch = 0;      // blocked loop: id of the next batch since reset_loop
     bool closes_often = false;   // blocked loop: >= 5 % of this solve's sweeps so far were of a batch closed early
     bool chain_off = false;      // blocked loop: a chain launch of this solve failed its roll call (the device is shared): launch per stage from here on
+    bool blocked_now = false;    // the last queue_iterations call went through the blocked loop
     bool chain_spread = false;   // blocked loop: a one-XCD chain launch found its workers on several XCDs: the spread (sc1) form from here on
     unsigned chain_misplaced_seen = 0;
     unsigned chain_aborts_seen = 0;
@@ -370,6 +378,7 @@ template <class S> struct Lp : LpBase {
             irregular_known = true;
         }
         if (blocked && irregular) blocked = false;          // NaN ratios need the generic pick's scan order: the pipelined loop has it
+        blocked_now = blocked;
         if (blocked) { queue_blocked(k); return; }
         // (the rational scalar: XPG_R32_LOOP=serial keeps the three-launch loop for A/B runs)
         static const bool r32_serial = [] { const char * s = getenv("XPG_R32_LOOP"); return s && !strcmp(s, "serial"); }();
@@ -414,7 +423,11 @@ template <class S> struct Lp : LpBase {
             // the last batch of a budget that is not a multiple of B is enqueued at its own length, so its
             // sweep is the kernel specialised for that many stages (not the full-batch kernel's slow tail)
             const unsigned left = k - b * (unsigned)B;
-            launch_blk_batch(ctx, v, batch, left < (unsigned)B ? (int)left : B, opt_pricing == 0, closes_often, chain_off, chain_spread);
+            // a batch behind a full-length batch of this call may have its stage 0 done by its chain launch (launch_blk_batch)
+            const bool can_fold = ctx->chain_fold && ctx->chain && !chain_off && !closes_often && opt_pricing == 0;
+            const bool fold = can_fold && b > 0;
+            const bool next_folds = can_fold && b + 1 < nb && left >= (unsigned)B;
+            launch_blk_batch(ctx, v, batch, left < (unsigned)B ? (int)left : B, opt_pricing == 0, closes_often, chain_off, chain_spread, fold, next_folds);
             if ((b & 7) == 7) {                         // throttle: at most 2 x 8 batches in flight
                 hipEvent_t e = throttle[(b >> 3) & 1];
                 if ((b >> 3) >= 2) (void)hipEventSynchronize(e);
@@ -470,6 +483,14 @@ template <class S> struct Lp : LpBase {
         LoopState hs;
         int rc = read_state(&hs);
         if (rc) return rc;
+        // blocked loop: a batch whose stage 0 was left to its chain launch does nothing when the batch before did not admit it
+        // (it closed early: a rare branch, an aborted roll call) -- and neither does any batch behind it. What is left of the
+        // budget is then enqueued again, starting with stage-0 launches, which always make progress or end the loop.
+        for (int again = 0; blocked_now && hs.status == ST_RUNNING && hs.blk.budget != 0u && hs.blk.budget <= pivots && again < 1 << 20; again++) {
+            queue_iterations(hs.blk.budget);
+            rc = read_state(&hs);
+            if (rc) return rc;
+        }
         if (hs.status == ST_RUNNING) return XPG_RUNNING;
         final_status = finish(hs.status);
         return final_status;

@@ -86,6 +86,12 @@ struct LoopState {
         unsigned ch_arrive[8]; // chain kernel: workers of this batch's launch that have started, by the XCD they run on (the spread
                                // form counts in [0] only; zeroed by stage 0's prep)
         unsigned ch_misplaced; // one-XCD chain launches aborted because their workers were NOT all on one XCD
+        // the ticket of a chain launch that does a batch's stage 0 itself (lp_chain.hip.h, t0 = 0): written by the committer of the
+        // chain before it, once that one has committed its last stage
+        unsigned ch0_ticket;   // blk_ticket0(batch) of the batch it admits
+        unsigned ch0_la_epoch; // the tag its look-ahead partials carry
+        unsigned ch0_budget, ch0_done, ch0_tp;
+        unsigned ch_folds;     // chain launches that did their batch's stage 0 themselves (xpg_lp_chain_aborts)
         unsigned ch_decide;    // the roll call's verdict for this batch's launch: 0 open, CH_GO, CH_ABORT -- set ONCE, by compare-and-swap
                                // (the committer when everybody has counted in or its patience ends; a worker that has waited
                                // for the verdict far longer than that: the committer itself never got a CU); zeroed by stage 0's prep
@@ -96,7 +102,12 @@ struct LoopState {
         unsigned long long dbg[8];   // diagnostic builds (-DXPG_STAMPS): 100 MHz ticks between points of pick / prep
     } blk;
 };
-enum { BLK_MAX = 32,           // the most pivots a batch stages (the default batch length; XPG_BLOCK selects a shorter one)
+enum { BLK_MAX = 32,           // the most pivots a batch stages (XPG_BLOCK up to this)
+       BLK_DEFAULT = 24,       // the default batch length: the pass applying 24 staged pivots holds 24 register pairs of e_s at four
+                               // waves per SIMD and stays memory-bound (83 us at 4096 x 8192 = 0.81 of the HBM peak, 134 us at
+                               // 4096 x 12289); with 32 it is bound by fp64 issue as much (110 / 172 us, three waves), with 16 the
+                               // pass is at the copy ceiling (78 / 126 us) but paid per 16 pivots: 111.3 k / 108.5 k / 97.6 k
+                               // pivots/s at 4096 x 8192 with 24 / 32 / 16, 88.2 k / 87.8 k / 74.7 k at 4096 x 12289
        BLK_REC_WORDS = 16,
        BLK_PICK_WGS = 64,      // pick workgroups (= records) of the launch-per-stage path: one lane of a wave combines each
        BLK_REC_MAX = 256,      // records of the chain kernel: one per pick worker
@@ -1307,6 +1318,7 @@ template <class S> __global__ void k_reset_loop(LpView<S> v, unsigned max_iter, 
         st->blk.ch_epoch = 0u; st->blk.ch_budget = 0u; st->blk.ch_done = 0u; st->blk.ch_tp = 0u;
         for (int x = 0; x < 8; x++) st->blk.ch_arrive[x] = 0u;
         st->blk.ch_aborts = 0u; st->blk.ch_runs = 0u; st->blk.ch_misplaced = 0u; st->blk.ch_decide = 0u;
+        st->blk.ch0_ticket = 0u; st->blk.ch0_la_epoch = 0u; st->blk.ch0_budget = 0u; st->blk.ch0_done = 0u; st->blk.ch0_tp = 0u; st->blk.ch_folds = 0u;
         for (int k = 0; k < 8; k++) st->blk.dbg[k] = 0ull;
         for (int k = 0; k < 2; k++) v.pickrec[PICK_CTR_OFF + 16 * k] = 0ull;   // arrival counters
         for (int k = 0; k < 2; k++) {                  // pipelined loop: iteration 0 has no pivot yet

@@ -101,13 +101,15 @@ int xpg_create(xpg_ctx ** out, int device)
     c->chain = ch ? atoi(ch) : 1;
     const char * cx = getenv("XPG_CHAIN_XCD");
     c->chain_local = cx ? (atoi(cx) != 0 ? 1 : 0) : 1;
+    const char * cf = getenv("XPG_CHAIN_FOLD");
+    c->chain_fold = cf ? (atoi(cf) != 0 ? 1 : 0) : 1;
     const char * cta = getenv("XPG_CHAIN_TEST_ABORT");
     c->chain_test_abort = cta ? atoi(cta) : 0;
     c->num_cus = 0;
     if (hipDeviceGetAttribute(&c->num_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) c->num_cus = 0;
     c->loop_auto = lm ? 0 : 1;                         // unset: blocked loop for large fp64 tableaux, else pipelined
     const char * bl = getenv("XPG_BLOCK");
-    c->block_len = bl ? atoi(bl) : BLK_MAX;
+    c->block_len = bl ? atoi(bl) : BLK_DEFAULT;
     if (c->block_len < 1) c->block_len = 1;
     if (c->block_len > BLK_MAX) c->block_len = BLK_MAX;
     c->prof_cap = 0; c->prof_n = 0; c->prof_stride = 1; c->prof_seen = 0;
@@ -526,11 +528,11 @@ int xpg_lp_debug_counts(xpg_lp * lp, int * rowcnt, int * colcnt, int n)
     XPG_HIP(ctx, hipMemcpy(colcnt, p->v.colcnt, (size_t)n * 4, hipMemcpyDeviceToHost));
     return 0;
 }
-int xpg_lp_debug_chain_ts(xpg_lp * lp, unsigned long long * out)   // [4][16][8]
+int xpg_lp_debug_chain_ts(xpg_lp * lp, unsigned long long * out)   // [4][BLK_MAX][8]
 {
     if (!lp || !lp->impl) return XPG_ERR_SHAPE;
     xpg_ctx * ctx = lp->impl->ctx;
-    XPG_HIP(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ch_ts), sizeof(unsigned long long) * 4 * 16 * 8));
+    XPG_HIP(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ch_ts), sizeof(unsigned long long) * 4 * BLK_MAX * 8));
     return 0;
 }
 int xpg_lp_debug_rows(xpg_lp * lp, double * out)              // [4][8192]
@@ -541,6 +543,19 @@ int xpg_lp_debug_rows(xpg_lp * lp, double * out)              // [4][8192]
     return 0;
 }
 #endif
+
+int xpg_lp_chain_folds(xpg_lp * lp, unsigned * folds)
+{
+    if (!lp || !lp->impl || !folds) return XPG_ERR_SHAPE;
+    XPG_BIND(lp->impl->ctx);
+    *folds = 0;
+    if (lp->impl->kind != 0) return 0;
+    LoopState hs;
+    const int rc = ((Lp<F64> *)lp->impl)->read_state(&hs);
+    if (rc) return rc;
+    *folds = hs.blk.ch_folds;
+    return 0;
+}
 
 int xpg_lp_trace(xpg_lp * lp, int32_t * pairs, int cap_pairs, int * n_pairs)
 {

@@ -246,6 +246,12 @@ class DeviceLP:
         self.chain_runs = runs.value
         return n.value, bool(off.value)
 
+    def chain_folds(self):
+        """chain launches of this solve that did their batch's stage 0 themselves."""
+        n = C.c_uint()
+        self.ctx.check(lib().xpg_lp_chain_folds(self._h, C.byref(n)), "xpg_lp_chain_folds")
+        return n.value
+
     def shape(self):
         r, w, rhs = C.c_int(), C.c_int(), C.c_int()
         self.ctx.check(lib().xpg_lp_shape(self._h, C.byref(r), C.byref(w), C.byref(rhs)), "xpg_lp_shape")
