@@ -577,7 +577,7 @@ __host__ __device__ __forceinline__ bool blk_sweep_tile(int lid, int strips, int
 
 template <int ROWS, int U, int NB> __global__ __launch_bounds__(256)
 void k_blk_sweep_full(double * __restrict__ tab, int m, int W, int ld, const double * __restrict__ E,
-                      const double * __restrict__ K, LoopState * __restrict__ st, int batch, int only_full, int rev)
+                      const double * __restrict__ K, LoopState * __restrict__ st, int batch, int only_full, int rev, int full_n)
 {
     static_assert(NB <= BLK_MAX, "a full batch is at most BLK_MAX pivots");
     static_assert(ROWS % (2 * U) == 0, "a row block holds whole ping-pong pairs");
@@ -602,7 +602,7 @@ void k_blk_sweep_full(double * __restrict__ tab, int m, int W, int ld, const dou
     // closed early -- the host turns that on for LPs that close batches often (Lp::queue_blocked)
     if (only_full && n != NB) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) {                        // xpg_lp_counters
-        if (n == NB) st->blk.sweeps_full += 1u; else st->blk.sweeps_part += 1u;
+        if (n == full_n) st->blk.sweeps_full += 1u; else st->blk.sweeps_part += 1u;   // (full = the configured batch length, xpg_lp_counters)
     }
 
     if (n != NB) {

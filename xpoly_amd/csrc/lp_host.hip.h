@@ -158,7 +158,7 @@ template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> &
     hipExtLaunchKernelGGL((k_blk_sweep_full<ROWS_, UNR_, NB_>), dim3(blk_sweep_grid(strips, (v.m + ROWS_ - 1) / ROWS_)), \
                           dim3(256), 0, ctx->stream, e0, e1, 0, (double *)v.tab, v.m, v.W, v.ld,                          \
                           (const double *)v.blkE, (const double *)v.blkK, v.st, batch, closes_often ? 1 : 0,              \
-                          serpentine ? (batch & 1) : 0)
+                          serpentine ? (batch & 1) : 0, ctx->block_len)
     // the full-batch kernels: 32 pivots per pass (the default; two register sets of e_s, 2-3 waves per SIMD: 110 / 166 us
     // per pass at 4096 x 8192 / 4096 x 12289 = 3.4 / 5.2 us per pivot against 4.9 / 7.9 with 16, tools/lab/sweep_lab2.hip) and
     // 16 (XPG_BLOCK=16); every other length -- the tail of an iteration budget -- goes through the switch kernel
