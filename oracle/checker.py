@@ -151,9 +151,9 @@ class _Lib:
         else:
             fn = self._f("mip_solve_stats")
             fn.restype = C.c_int
-            nodes, rows = C.c_long(0), C.c_int(0)
-            st = fn(*args, C.byref(nodes), C.byref(rows))
-            stats["nodes"], stats["max_leq_rows"] = nodes.value, rows.value
+            nodes, rows = C.c_long(0), (C.c_int * 3)(0, 0, 0)
+            st = fn(*args, C.byref(nodes), rows)
+            stats["nodes"], stats["max_leq_rows"], stats["max_depth"], stats["spec_chain"] = nodes.value, rows[0], rows[1], rows[2]
         return st, v[0], sol
 
     # ---- Rational / Float scalars ----------------------------------------

@@ -107,9 +107,11 @@ int t_mip_solve(int is_max, int is_bin, const void * tgtf, const void * vc, int 
                 const void * eq, int eq_rows, const void * leq, int leq_rows, int cols,
                 const uint8_t * rat_ind, void * out_v, void * out_sol, long * nodes, int * max_leq_rows = 0)
 {
+    // (max_leq_rows, when given, is three ints: the most inequality rows of a node LP, the deepest recursion level, the node
+    // LPs on the sequential chain when ceiling children are solved ahead)
     Problem<S> Q = load_problem<S>(tgtf, vc, vc_rows, eq, eq_rows, leq, leq_rows, cols);
     S v; std::vector<S> sol;
-    int st = mip_solve(Q, is_max != 0, is_bin != 0, rat_ind, v, sol, nodes, max_leq_rows);
+    int st = mip_solve(Q, is_max != 0, is_bin != 0, rat_ind, v, sol, nodes, max_leq_rows, max_leq_rows ? max_leq_rows + 1 : 0);
     Raw<S>::put(out_v, 0, v);
     if (st == IP_SUCC && (int)sol.size() == cols) store(sol, out_sol);
     return st;

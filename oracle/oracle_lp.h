@@ -565,7 +565,11 @@ template <class S> struct Mip {
     int rhs0;
     long nodes;
     int max_leq_rows;                 // the most inequality rows any node LP had (test statistics only)
-    Mip() : have_best(false), allow_rational(0), rhs0(0), nodes(0), max_leq_rows(0) {}
+    int depth, max_depth;             // recursion depth of the node being solved / the deepest one (statistics only)
+    long spec_chain;                  // node LPs left on the walk's sequential chain when every ceiling child's LP is solved ahead
+                                      // (the device walk's speculation, mip_kernels.hip.h): set by node() for its subtree
+    Mip() : have_best(false), allow_rational(0), rhs0(0), nodes(0), max_leq_rows(0), depth(0), max_depth(0), spec_chain(0) {}
+    struct DepthGuard { Mip & m; explicit DepthGuard(Mip & m_) : m(m_) { if (++m.depth > m.max_depth) m.max_depth = m.depth; } ~DepthGuard() { --m.depth; } };
 
     bool all_int(const std::vector<S> & s, int & col) const               // xmat.cpp:603-616, :1523-1536
     {
@@ -605,6 +609,8 @@ template <class S> struct Mip {
              S & v, std::vector<S> & sol)                                  // lpsol.h:2427-2612
     {
         nodes++;
+        spec_chain = 1;                                                    // (a node that does not branch: its own LP)
+        DepthGuard depth_guard(*this);
         if (Q.leq.r > max_leq_rows) max_leq_rows = Q.leq.r;
         int st = is_max ? six_maxm(Q, 10000u, v, sol) : six_minm(Q, 10000u, v, sol);
         if (st < 0) return st;
@@ -633,6 +639,7 @@ template <class S> struct Mip {
         }
         std::vector<S> keep_sol; S keep_v; bool kept = false;
         st = node(L, is_max, is_bin, forks, v, sol);
+        const long chain_floor = spec_chain;
         if (st < 0) return st;
         if (st == IP_SUCC) { keep_sol = sol; keep_v = v; kept = keep_sol.size() != 0; keep_best(sol, v, is_max); }
         Problem<S> H = Q;                                                  // ceiling branch
@@ -644,6 +651,7 @@ template <class S> struct Mip {
             grow_row(H.leq, Q.cols); H.leq.at(H.leq.r - 1, col) = S(-1); H.leq.at(H.leq.r - 1, rhs0) = S(-hi);
         }
         st = node(H, is_max, is_bin, forks, v, sol);
+        spec_chain = 1 + chain_floor + (spec_chain - 1);                   // this node's LP, the floor subtree, the ceiling subtree less its root's LP
         if (st < 0) return st;
         if (st == IP_SUCC) {                                               // :2563-2592
             if (kept && (is_max ? gt(keep_v, v) : lt(keep_v, v))) { v = keep_v; sol = keep_sol; }
@@ -663,7 +671,7 @@ template <class S> struct Mip {
 
 template <class S>
 int mip_solve(const Problem<S> & Q, bool is_max, bool is_bin, const uint8_t * allow_rational,
-              S & v, std::vector<S> & sol, long * nodes = 0, int * max_leq_rows = 0)
+              S & v, std::vector<S> & sol, long * nodes = 0, int * max_leq_rows = 0, int * max_depth_out = 0)
 {
     Mip<S> M;
     M.allow_rational = allow_rational;
@@ -672,7 +680,8 @@ int mip_solve(const Problem<S> & Q, bool is_max, bool is_bin, const uint8_t * al
     v = S(0);
     int st = M.node(Q, is_max, is_bin, forks, v, sol);
     if (nodes) *nodes = M.nodes;
-    if (max_leq_rows) *max_leq_rows = M.max_leq_rows;
+    if (max_leq_rows) { max_leq_rows[0] = M.max_leq_rows; }
+    if (max_depth_out) { max_depth_out[0] = M.max_depth; max_depth_out[1] = (int)M.spec_chain; }
     return st;
 }
 

@@ -31,12 +31,15 @@ template <class S> struct MipWs {
     S * vals;         // v, best_v
     int * frame;      // [depth][6]: stage, col, lo, hi, kept, -
     int * forks;      // [cols]
-    int * ctl;        // have_best, top, nodes, final_status
+    int * ctl;        // have_best, top, nodes, final_status, speculation sequence number
+    S * spec_y;       // [depth][cols] raw LP solution of frame f's CEILING child, solved ahead by a helper workgroup
+    int * spec_ctl;   // [depth][2]: (sequence number << 3) | state, the child's SIX status
 };
 __host__ __device__ inline size_t mip_ws_words(int rmax, int cols, int depth)
 {
     size_t w = (size_t)rmax * cols + 3 * (size_t)cols + (size_t)depth * cols + depth + 2;
-    w += ((size_t)depth * 6 + cols + 8 + 1) / 2;
+    w += (size_t)depth * cols;                                   // spec_y
+    w += ((size_t)depth * 6 + cols + 8 + (size_t)depth * 2 + 1) / 2;
     return (w + 1) & ~(size_t)1;
 }
 template <class S> __device__ __forceinline__ MipWs<S> mip_ws_carve(unsigned long long * base, int rmax, int cols, int depth)
@@ -50,10 +53,12 @@ template <class S> __device__ __forceinline__ MipWs<S> mip_ws_carve(unsigned lon
     w.kept_sol = p; p += (size_t)depth * cols;
     w.kept_v = p; p += depth;
     w.vals = p; p += 2;
+    w.spec_y = p; p += (size_t)depth * cols;
     int * q = (int *)p;
     w.frame = q; q += depth * 6;
     w.forks = q; q += cols;
-    w.ctl = q;
+    w.ctl = q; q += 8;
+    w.spec_ctl = q;
     return w;
 }
 
@@ -66,7 +71,24 @@ __device__ unsigned long long g_mip_ticks[4];                 // diagnostic buil
 #define MIP_T(k)
 #endif
 enum { MF_STAGE = 0, MF_COL = 1, MF_LO = 2, MF_HI = 3, MF_KEPT = 4 };
-enum { MC_HAVE_BEST = 0, MC_TOP = 1, MC_NODES = 2, MC_FINAL = 3 };
+enum { MC_HAVE_BEST = 0, MC_TOP = 1, MC_NODES = 2, MC_FINAL = 3, MC_SEQ = 4 };
+// Speculative solves of ceiling children (round 4). MIP::RecusivePart solves the floor child of a branching node, its whole
+// subtree, and then ALWAYS the ceiling child (lpsol.h:2506-2560) -- whose LP depends only on the path to it. While the walk
+// is in the floor subtree a HELPER workgroup (extra workgroups at the end of the grid, which get a CU once trees finish)
+// solves the ceiling child's LP and parks (status, raw solution) in the tree's workspace; when the walk arrives there it
+// takes the parked answer instead of building and solving the node. Everything that depends on the order of the walk --
+// is_satisfying, the best-so-far test, forks, remember -- still runs in the walk (mip_feed), so results are the walk's.
+// States of a frame's slot: requested by the walk -> claimed by a helper -> done; the walk cancels a request no helper has
+// claimed when it gets there first, and waits for one that is claimed (the helper started earlier than the walk could).
+enum { SP_NONE = 0, SP_REQ = 1, SP_CLAIMED = 2, SP_DONE = 3, SP_CANCEL = 4, SP_QCAP = 1 << 16 };
+// queue (ints): [0] tail, [1] head, [2] trees finished, [3] parked answers taken, then valid[SP_QCAP], then entries[SP_QCAP][4] {block, frame, seq, -}
+__device__ __forceinline__ int * spq_valid(int * q) { return q + 4; }
+__device__ __forceinline__ int * spq_entry(int * q, int slot) { return q + 4 + SP_QCAP + 4 * slot; }
+__host__ __device__ inline size_t spq_bytes() { return (size_t)(4 + SP_QCAP + 4 * SP_QCAP) * 4; }
+__device__ __forceinline__ int sp_load(const int * p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void sp_store(int * p, int x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool sp_cas(int * p, int expect, int want)
+{ return __hip_atomic_compare_exchange_strong(p, &expect, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __device__ __forceinline__ bool mip_int_cast_ok(F64) { return true; }
 __device__ __forceinline__ bool mip_int_cast_ok(R32 a) { return a.den != 0; }
@@ -80,7 +102,7 @@ template <class S> __device__ int mip_build_node_eq(const MipWs<S> & w, const S 
                                                      int top, int rows, int * sh_flag);
 template <class S> __device__ int mip_build_node(const MipWs<S> & w, const S * root_leq, int leq_rows, const S * root_eq, int eq_rows,
                                                   int cols, bool is_bin, int top, int * sh_flag)
-{
+{   // (a helper builds the ceiling child of frame f from a COPY of the frames with frame f's stage set to 2, top = f + 1)
     const int rhs0 = cols - 1;
     for (int t = threadIdx.x; t < leq_rows * cols; t += blockDim.x) w.L[t] = root_leq[t];
     if (threadIdx.x == 0) *sh_flag = 0;
@@ -353,7 +375,8 @@ template <class S> __device__ bool mip_feed(const MipWs<S> & w, int cols, bool i
 template <class S> __global__ __launch_bounds__(256, 2)
 void k_mip_tree(int nb, const S * tgtf_all, const S * leq_all, int leq_rows, int cols, int is_max, int is_bin, int rmax,
                 int depth, unsigned long long * ws_all, size_t ws_words, int32_t * out_status, S * out_v, S * out_sol,
-                int * out_nodes, const int * rows_of, const int * active, const uint8_t * allow, const S * eq_all, int eq_rows)
+                int * out_nodes, const int * rows_of, const int * active, const uint8_t * allow, const S * eq_all, int eq_rows,
+                int nmain, int * spq)
 {
     // eq_all / eq_rows (may be NULL / 0): eq_rows equalities per problem at the root.
     // allow (may be NULL): MIP's rational_indicator, one row of cols flags shared by the batch -- variables whose flag is
@@ -361,13 +384,72 @@ void k_mip_tree(int nb, const S * tgtf_all, const S * leq_all, int leq_rows, int
     // rows_of (may be NULL): problem b has rows_of[b] of its leq_rows-row slot live (ragged batches: the systems
     // Lineq::reduce leaves); active (may be NULL): only problems whose entry is 1 are walked, the others' outputs
     // are left alone.
+    // nmain: the first nmain workgroups walk trees (tree b by workgroup b % nmain); spq != NULL: speculation (see SP_*): then
+    // nmain == nb (one tree per walking workgroup, its workspace never reused) and the workgroups behind them are helpers.
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    __shared__ int sh_ctl[4];
+    __shared__ int sh_ctl[8];
+    __shared__ unsigned long long sh_v;                      // the node's own objective: recomputed by mip_feed
     const int n = cols - 1;
     Small<S> P;
     sm_carve(P, lds, is_max ? rmax : n, is_max ? n : rmax);
-    for (int b = blockIdx.x; b < nb; b += gridDim.x) {
-        if (active && active[b] != 1) continue;
+    if ((int)blockIdx.x >= nmain) {
+        // ================================ a helper ======================================================
+        if (!spq) return;
+        const MipWs<S> hw = mip_ws_carve<S>(ws_all + (size_t)blockIdx.x * ws_words, rmax, cols, depth);
+        for (;;) {
+            if (threadIdx.x == 0) {
+                int verdict = 0, blk = 0, f = 0, seq = 0;   // 0: leave, 1: next task, 2: solve
+                const int my = atomicAdd(&spq[1], 1);
+                unsigned spins = 0;
+                for (;;) {
+                    if (my < SP_QCAP && sp_load(&spq_valid(spq)[my]) == my + 1) { verdict = 1; break; }
+                    if (my >= SP_QCAP || (sp_load(&spq[2]) >= nmain && sp_load(&spq[0]) <= my)) break;   // nothing more will come
+                    if (++spins > (1u << 24)) break;        // (seconds: a walk that never ends its tree; leave rather than hang)
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                if (verdict == 1) {
+                    __threadfence();
+                    const int * e = spq_entry(spq, my);
+                    blk = sp_load(&e[0]); f = sp_load(&e[1]); seq = sp_load(&e[2]);
+                    const MipWs<S> tw = mip_ws_carve<S>(ws_all + (size_t)blk * ws_words, rmax, cols, depth);
+                    if (sp_cas(&tw.spec_ctl[2 * f], (seq << 3) | SP_REQ, (seq << 3) | SP_CLAIMED)) verdict = 2;   // (else: cancelled)
+                }
+                sh_ctl[4] = verdict; sh_ctl[5] = blk; sh_ctl[6] = f; sh_ctl[7] = seq;
+            }
+            __syncthreads();
+            const int verdict = sh_ctl[4], blk = sh_ctl[5], f = sh_ctl[6], seq = sh_ctl[7];
+            __syncthreads();
+            if (verdict == 0) return;
+            if (verdict == 1) continue;
+            __threadfence();                                 // acquire: the walk's frames (published before the request)
+            const MipWs<S> tw = mip_ws_carve<S>(ws_all + (size_t)blk * ws_words, rmax, cols, depth);
+            const int b = blk;                               // (one tree per walking workgroup)
+            // the frames of the path, copied; frame f in its ceiling stage
+            for (int t = threadIdx.x; t < (f + 1) * 6; t += blockDim.x) {
+                int x = tw.frame[t];
+                if (t == f * 6 + MF_STAGE) x = 2;
+                hw.frame[t] = x;
+            }
+            __syncthreads();
+            const S * tgtf = tgtf_all + (size_t)b * cols;
+            const S * root = leq_all + (size_t)b * leq_rows * cols;
+            const int my_rows = rows_of ? rows_of[b] : leq_rows;
+            int st = mip_build_node<S>(hw, root, my_rows, (const S *)0, 0, cols, is_bin != 0, f + 1, &sh_ctl[1]);
+            if (st >= 0) {
+                Source<S> src;
+                src.leq = hw.L; src.tgtf = tgtf; src.m = st; src.cols = cols; src.is_max = is_max;
+                st = sm_solve_lp<S>(P, src, 10000u, /*raw_sol=*/1, hw.y, (S *)&sh_v);
+            }
+            __syncthreads();
+            for (int j = threadIdx.x; j < cols; j += blockDim.x) tw.spec_y[(size_t)f * cols + j] = hw.y[j];
+            if (threadIdx.x == 0) tw.spec_ctl[2 * f + 1] = st;
+            __threadfence();                                 // release: the answer before the state
+            __syncthreads();
+            if (threadIdx.x == 0) sp_store(&tw.spec_ctl[2 * f], (seq << 3) | SP_DONE);
+        }
+    }
+    for (int b = blockIdx.x; b < nb; b += nmain) {
+        if (active && active[b] != 1) { if (spq && threadIdx.x == 0) atomicAdd(&spq[2], 1); continue; }
         const S * tgtf = tgtf_all + (size_t)b * cols;
         const S * root = leq_all + (size_t)b * leq_rows * cols;
         const S * root_eq = eq_rows > 0 ? eq_all + (size_t)b * eq_rows * cols : (const S *)0;
@@ -375,8 +457,9 @@ void k_mip_tree(int nb, const S * tgtf_all, const S * leq_all, int leq_rows, int
         const MipWs<S> w = mip_ws_carve<S>(ws_all + (size_t)blockIdx.x * ws_words, rmax, cols, depth);
         // MipTask::start
         for (int j = threadIdx.x; j < cols; j += blockDim.x) w.forks[j] = 0;
+        for (int j = threadIdx.x; j < 2 * depth; j += blockDim.x) w.spec_ctl[j] = 0;
         if (threadIdx.x == 0) {
-            w.ctl[MC_HAVE_BEST] = 0; w.ctl[MC_TOP] = 0; w.ctl[MC_NODES] = 0; w.ctl[MC_FINAL] = 0;
+            w.ctl[MC_HAVE_BEST] = 0; w.ctl[MC_TOP] = 0; w.ctl[MC_NODES] = 0; w.ctl[MC_FINAL] = 0; w.ctl[MC_SEQ] = 0;
             w.vals[0] = zero<S>(); w.vals[1] = zero<S>();
             int * f = w.frame;
             f[MF_STAGE] = 0; f[MF_COL] = 0; f[MF_LO] = 0; f[MF_HI] = 1; f[MF_KEPT] = 0;
@@ -388,17 +471,70 @@ void k_mip_tree(int nb, const S * tgtf_all, const S * leq_all, int leq_rows, int
             __syncthreads();
             if (threadIdx.x == 0) w.ctl[MC_NODES] += 1;
             MIP_T0
-            int st = mip_build_node<S>(w, root, my_rows, root_eq, eq_rows, cols, is_bin != 0, top, &sh_ctl[1]);
-            MIP_T(0)
-            if (st >= 0) {
-                Source<S> src;
-                src.leq = w.L; src.tgtf = tgtf; src.m = st; src.cols = cols; src.is_max = is_max;
-                __shared__ unsigned long long sh_v;              // the node's own objective: recomputed by mip_feed
-                st = sm_solve_lp<S>(P, src, 10000u, /*raw_sol=*/1, w.y, (S *)&sh_v);
+            int st = 0;
+            bool parked = false;
+            if (spq && top > 0) {
+                // is this node a ceiling child whose LP a helper was asked to solve?
+                if (threadIdx.x == 0) {
+                    int got = 0;
+                    int * sc = w.spec_ctl + 2 * (top - 1);
+                    const int mine = sp_load(&sc[0]);
+                    if (w.frame[(top - 1) * 6 + MF_STAGE] == 2 && (mine & 7) != SP_NONE) {
+                        const int seq = mine >> 3;
+                        unsigned spins = 0;
+                        for (;;) {
+                            const int cur = sp_load(&sc[0]);
+                            if (cur == ((seq << 3) | SP_DONE)) { got = 1; break; }
+                            if (cur == ((seq << 3) | SP_REQ)) { if (sp_cas(&sc[0], cur, (seq << 3) | SP_CANCEL)) break; continue; }
+                            if (cur != ((seq << 3) | SP_CLAIMED)) break;
+                            if (++spins > (1u << 26)) break;                  // (a helper that never finishes: solve it here after all)
+                            __builtin_amdgcn_s_sleep(4);
+                        }
+                        if (got) { __threadfence(); atomicAdd(&spq[3], 1); }   // acquire: the parked answer behind its state (spq[3]: answers taken)
+                        // (a slot left CLAIMED by the timeout above is never requested again: its late answer can land)
+                        if (sp_load(&sc[0]) != ((seq << 3) | SP_CLAIMED)) sp_store(&sc[0], SP_NONE);
+                    }
+                    sh_ctl[2] = got; sh_ctl[3] = got ? sc[1] : 0;
+                }
+                __syncthreads();
+                parked = sh_ctl[2] != 0;
+                if (parked) {
+                    st = sh_ctl[3];
+                    for (int j = threadIdx.x; j < cols; j += blockDim.x) w.y[j] = w.spec_y[(size_t)(top - 1) * cols + j];
+                }
+                __syncthreads();
+            }
+            if (!parked) {
+                st = mip_build_node<S>(w, root, my_rows, root_eq, eq_rows, cols, is_bin != 0, top, &sh_ctl[1]);
+                MIP_T(0)
+                if (st >= 0) {
+                    Source<S> src;
+                    src.leq = w.L; src.tgtf = tgtf; src.m = st; src.cols = cols; src.is_max = is_max;
+                    st = sm_solve_lp<S>(P, src, 10000u, /*raw_sol=*/1, w.y, (S *)&sh_v);
+                }
             }
             MIP_T(1)
             if (st == XPG_SIX_SUCC) mip_feed_products<S>(w, tgtf, cols);       // (st is the same in every thread)
-            if (threadIdx.x == 0) sh_ctl[0] = mip_feed<S>(w, cols, is_max != 0, is_bin != 0, st, allow) ? 1 : 0;
+            if (threadIdx.x == 0) {
+                const bool ended = mip_feed<S>(w, cols, is_max != 0, is_bin != 0, st, allow);
+                sh_ctl[0] = ended ? 1 : 0;
+                if (spq && !ended) {
+                    // the walk has just branched (the frame under the new top is in its floor stage): ask for its ceiling child
+                    const int nt = w.ctl[MC_TOP];
+                    if (nt > 0 && w.frame[(nt - 1) * 6 + MF_STAGE] == 1 && sp_load(&w.spec_ctl[2 * (nt - 1)]) == SP_NONE) {
+                        const int slot = atomicAdd(&spq[0], 1);
+                        if (slot < SP_QCAP) {
+                            const int seq = ++w.ctl[MC_SEQ];
+                            w.spec_ctl[2 * (nt - 1) + 1] = 0;
+                            sp_store(&w.spec_ctl[2 * (nt - 1)], (seq << 3) | SP_REQ);
+                            int * e = spq_entry(spq, slot);
+                            e[0] = (int)blockIdx.x; e[1] = nt - 1; e[2] = seq; e[3] = 0;
+                            __threadfence();                 // release: frames, slot state and entry before the ticket
+                            sp_store(&spq_valid(spq)[slot], slot + 1);
+                        }
+                    }
+                }
+            }
             __syncthreads();
             MIP_T(2)
             if (sh_ctl[0]) break;
@@ -408,6 +544,7 @@ void k_mip_tree(int nb, const S * tgtf_all, const S * leq_all, int leq_rows, int
             out_status[b] = fin;
             out_v[b] = w.vals[0];
             out_nodes[b] = w.ctl[MC_NODES];
+            if (spq) atomicAdd(&spq[2], 1);
         }
         if (w.ctl[MC_FINAL] == XPG_IP_SUCC && out_sol)
             for (int j = threadIdx.x; j < cols; j += blockDim.x) out_sol[(size_t)b * cols + j] = w.sol[j];
