@@ -106,14 +106,132 @@ inline int lineq_fme_batch(xpg_ctx * ctx, int nb, const R32 * mats, int rows, in
 }
 
 // Pinned host memory of the packed-result entry points: grows, never shrinks, freed with the handle.
-inline int hpack_reserve(xpg_ctx * ctx, size_t bytes)
+// keep: the first `keep` bytes survive a growth (the chunked pipeline below appends while earlier chunks' rows are in it).
+inline int hpack_reserve(xpg_ctx * ctx, size_t bytes, size_t keep = 0)
 {
     if (bytes <= ctx->hpack_cap) return 0;
-    if (ctx->hpack) (void)hipHostFree(ctx->hpack);
-    ctx->hpack = 0; ctx->hpack_cap = 0;
     const size_t cap = bytes + bytes / 4 + 4096;
-    if (hipHostMalloc(&ctx->hpack, cap, hipHostMallocDefault) != hipSuccess) { ctx->err = "hipHostMalloc(packed results)"; return XPG_ERR_ALLOC; }
-    ctx->hpack_cap = cap;
+    void * fresh = 0;
+    if (hipHostMalloc(&fresh, cap, hipHostMallocDefault) != hipSuccess) { ctx->err = "hipHostMalloc(packed results)"; return XPG_ERR_ALLOC; }
+    if (ctx->hpack && keep) memcpy(fresh, ctx->hpack, keep < ctx->hpack_cap ? keep : ctx->hpack_cap);
+    if (ctx->hpack) (void)hipHostFree(ctx->hpack);
+    ctx->hpack = fresh; ctx->hpack_cap = cap;
+    return 0;
+}
+
+// The packed call for LARGE batches as a pipeline of chunks on two streams (round 4): chunk k goes up, is eliminated, scanned,
+// packed and comes down on stream k & 1, so the upload of chunk k + 1 runs while chunk k's rows come down -- the link is
+// full duplex, and a single stream uses it one way at a time (2.24 M systems/s at 40 x 13 against 3.1 M if up and down
+// were serialised at the link's rate). Opt-in (XPG_FME_CHUNKS): measured no faster than the single stream, see the caller. Row offsets are global: a chunk's base is the total of the chunks before it, known
+// when their (small) offset arrays have come down; the rows land behind each other in the pinned buffer (`view`) or `out`.
+inline int lineq_fme_batch_packed_chunked(xpg_ctx * ctx, int nb, const R32 * mats, int rows, int cols, int rhs, int u, int darkshadow,
+                                          int cap, R32 * out, long long out_cap_rows, const R32 ** view, long long * row_offsets,
+                                          int32_t * out_ok, int nch)
+{
+    if (ctx->lanes.empty()) {                                      // the second stream: a lane handle on the same device
+        xpg_ctx * l = 0;
+        const int rc = xpg_create(&l, ctx->device);
+        if (rc) return rc;
+        ctx->lanes.push_back(l);
+    }
+    xpg_ctx * cs[2] = { ctx, ctx->lanes[0] };
+    // device buffers for the WHOLE batch, as the single-stream path has them (they come from and go back to the handle's cache:
+    // a buffer per chunk would thrash its 16 blocks); the packed rows of a chunk pass through one of two buffers, one per stream
+    struct Chunk { int lo, n; long long * h_off; int32_t * h_ok; int32_t * h_rows; hipEvent_t ev; };
+    std::vector<Chunk> ch((size_t)nch);
+    DevBuf di, dout, dr, dk, doff, dpk[2];
+    {
+        const size_t bi_all = (size_t)nb * rows * cols * 8, bo_all = (size_t)nb * cap * cols * 8;
+        XPG_TRY(di.alloc(ctx, bi_all)); XPG_TRY(dout.alloc(ctx, bo_all)); XPG_TRY(dr.alloc(ctx, (size_t)nb * 4)); XPG_TRY(dk.alloc(ctx, (size_t)nb * 4));
+        XPG_TRY(doff.alloc(ctx, (size_t)(nb + nch) * 8));
+    }
+    // pinned meta of all chunks: (n + 1) offsets, n ok, n rows each -- in the batch staging buffer (grow-only, pinned)
+    const size_t meta_bytes = (size_t)(nb + nch) * 8 + (size_t)nb * 8 + 64 * (size_t)nch;
+    if (meta_bytes > ctx->hstage_cap) {
+        if (ctx->hstage) (void)hipHostFree(ctx->hstage);
+        ctx->hstage = 0; ctx->hstage_cap = 0;
+        if (hipHostMalloc(&ctx->hstage, meta_bytes + 4096, hipHostMallocDefault) != hipSuccess) { ctx->err = "hipHostMalloc(fme meta)"; return XPG_ERR_ALLOC; }
+        ctx->hstage_cap = meta_bytes + 4096;
+    }
+    char * hm = (char *)ctx->hstage;
+    const size_t rowb = (size_t)cols * 8;
+    int rc = 0;
+    for (int k = 0; k < nch; k++) {
+        Chunk & c = ch[(size_t)k];
+        c.lo = (int)((long long)nb * k / nch); c.n = (int)((long long)nb * (k + 1) / nch) - c.lo;
+        c.h_off = (long long *)hm; hm += (size_t)(c.n + 1) * 8;
+        c.h_ok = (int32_t *)hm; hm += (size_t)c.n * 4; c.h_rows = (int32_t *)hm; hm += (size_t)c.n * 4;
+        hm = (char *)(((uintptr_t)hm + 15) & ~(uintptr_t)15);
+        c.ev = 0;
+    }
+    auto fail = [&](int code) {                                    // (every chunk's stream is idle before its buffers go back to the cache)
+        (void)hipStreamSynchronize(cs[0]->stream); (void)hipStreamSynchronize(cs[1]->stream);
+        for (auto & c : ch) if (c.ev) (void)hipEventDestroy(c.ev);
+        return code;
+    };
+    auto first_half = [&](int k) -> int {
+        Chunk & c = ch[(size_t)k];
+        xpg_ctx * x = cs[k & 1];
+        const size_t bi = (size_t)c.n * rows * cols * 8;
+        R32 * d_in = (R32 *)di.p + (size_t)c.lo * rows * cols; R32 * d_out = (R32 *)dout.p + (size_t)c.lo * cap * cols;
+        int32_t * d_r = (int32_t *)dr.p + c.lo; int32_t * d_k = (int32_t *)dk.p + c.lo; long long * d_off = (long long *)doff.p + c.lo + k;
+        XPG_TRY(hipEventCreateWithFlags(&c.ev, hipEventDisableTiming));
+        XPG_TRY(hipMemcpyAsync(d_in, mats + (size_t)c.lo * rows * cols, bi, hipMemcpyHostToDevice, x->stream));
+        const int r = lineq_fme_batch_dev(x, c.n, d_in, rows, cols, rhs, u, darkshadow, d_out, cap, d_r, d_k);
+        if (r) { if (x != ctx) ctx->err = x->err; return r; }
+        hipLaunchKernelGGL(k_rows_scan, dim3(1), dim3(1024), 0, x->stream, c.n, (const int *)d_r, d_off);
+        XPG_TRY(hipMemcpyAsync(c.h_off, d_off, (size_t)(c.n + 1) * 8, hipMemcpyDeviceToHost, x->stream));
+        XPG_TRY(hipMemcpyAsync(c.h_ok, d_k, (size_t)c.n * 4, hipMemcpyDeviceToHost, x->stream));
+        XPG_TRY(hipMemcpyAsync(c.h_rows, d_r, (size_t)c.n * 4, hipMemcpyDeviceToHost, x->stream));
+        XPG_TRY(hipEventRecord(c.ev, x->stream));
+        return 0;
+    };
+    for (int k = 0; k < nch && k < 2; k++) if ((rc = first_half(k))) return fail(rc);
+    long long base = 0;
+    bool fits = true;
+    for (int k = 0; k < nch; k++) {
+        Chunk & c = ch[(size_t)k];
+        xpg_ctx * x = cs[k & 1];
+        if (hipEventSynchronize(c.ev) != hipSuccess) { ctx->err = "hipEventSynchronize(fme chunk)"; return fail(XPG_ERR_HIP); }
+        for (int b = 0; b < c.n; b++)
+            if (c.h_rows[b] < 0) { ctx->err = "fme: a result needs more rows than cap_rows"; row_offsets[0] = c.h_rows[b]; return fail(XPG_ERR_UNSUPPORTED); }
+        for (int b = 0; b < c.n; b++) row_offsets[c.lo + b] = base + c.h_off[b];
+        memcpy(out_ok + c.lo, c.h_ok, (size_t)c.n * 4);
+        const long long total = c.h_off[c.n];
+        if (out && base + total > out_cap_rows) fits = false;
+        if (total > 0 && (view || (out && fits))) {
+            const size_t bp = (size_t)total * rowb, at = (size_t)base * rowb;
+            DevBuf & pk = dpk[k & 1];
+            if (bp > pk.cap) {                                     // (the chunk two back used it on this stream: idle before it goes back to the cache)
+                (void)hipStreamSynchronize(x->stream);
+                DevBuf bigger;
+                if ((rc = [&]() -> int { XPG_TRY(bigger.alloc(ctx, bp + bp / 4)); return 0; }())) return fail(rc);
+                std::swap(pk.p, bigger.p); std::swap(pk.cap, bigger.cap); std::swap(pk.owner, bigger.owner);
+            }
+            hipLaunchKernelGGL(k_pack_rows, dim3(c.n < 4096 ? c.n : 4096), dim3(256), 0, x->stream, c.n,
+                               (const R32 *)dout.p + (size_t)c.lo * cap * cols, cap, cols,
+                               (const int *)((int32_t *)dr.p + c.lo), (const long long *)((long long *)doff.p + c.lo + k), (R32 *)pk.p);
+            char * dst;
+            if (view) {
+                if (at + bp > ctx->hpack_cap) {                    // grow: nothing may be in flight into the old buffer
+                    (void)hipStreamSynchronize(cs[0]->stream); (void)hipStreamSynchronize(cs[1]->stream);
+                    if ((rc = hpack_reserve(ctx, (at + bp) * (size_t)nch / (size_t)(k + 1), at))) return fail(rc);
+                }
+                dst = (char *)ctx->hpack + at;
+            } else dst = (char *)out + at;
+            if (hipMemcpyAsync(dst, pk.p, bp, hipMemcpyDeviceToHost, x->stream) != hipSuccess) { ctx->err = "hipMemcpyAsync(fme rows)"; return fail(XPG_ERR_HIP); }
+        }
+        base += total;
+        if (k + 2 < nch && (rc = first_half(k + 2))) return fail(rc);
+    }
+    row_offsets[nb] = base;
+    if (hipStreamSynchronize(cs[0]->stream) != hipSuccess || hipStreamSynchronize(cs[1]->stream) != hipSuccess) { ctx->err = "hipStreamSynchronize(fme chunks)"; return fail(XPG_ERR_HIP); }
+    for (auto & c : ch) if (c.ev) { (void)hipEventDestroy(c.ev); c.ev = 0; }
+    if (out && !fits) return XPG_ERR_SHAPE;
+    if (view) {
+        if (out && base > 0) memcpy(out, ctx->hpack, (size_t)base * rowb);
+        *view = base > 0 ? (const R32 *)ctx->hpack : (const R32 *)0;
+    }
     return 0;
 }
 
@@ -133,6 +251,16 @@ inline int lineq_fme_batch_packed(xpg_ctx * ctx, int nb, const R32 * mats, int r
     if (cap <= 0) cap = rows * rows / 4 + rows + 1;                  // every (positive, negative) pair + the rows without u
     if (cap < rows) cap = rows;
     const size_t bi = (size_t)nb * rows * cols * 8, bo = (size_t)nb * cap * cols * 8;
+    // XPG_FME_CHUNKS=n (n > 1): large batches through the two-stream chunk pipeline above. Measured and NOT the default: with
+    // the input in the caller's pageable memory the runtime stages every upload itself and the two directions do not overlap --
+    // 16 384 systems of 40 x 13: 2.25 M systems/s on one stream, 1.78 / 1.71 / 2.20 M with 4 / 8 / 16 chunks; 60 x 20: 0.757 M
+    // against 0.621 / 0.592 / 0.811 M (tools/lab/run_fme_chunks_ab.sh).
+    static const int chunks_env = [] { const char * e = getenv("XPG_FME_CHUNKS"); return e ? atoi(e) : 0; }();
+    if ((out || view) && nb >= 2048 && bi + bo / 3 >= ((size_t)96 << 20) && chunks_env > 1) {
+        int nch = chunks_env;
+        if (nch > 16) nch = 16;
+        return lineq_fme_batch_packed_chunked(ctx, nb, mats, rows, cols, rhs, u, darkshadow, cap, out, out_cap_rows, view, row_offsets, out_ok, nch);
+    }
     const size_t meta = (size_t)(nb + 1) * 8 + (size_t)nb * 8;       // offsets, then ok and rows
     DevBuf di, dout, dr, dk, doff, dpk;
     XPG_TRY(di.alloc(ctx, bi)); XPG_TRY(dout.alloc(ctx, bo)); XPG_TRY(dr.alloc(ctx, (size_t)nb * 4)); XPG_TRY(dk.alloc(ctx, (size_t)nb * 4));
