@@ -50,8 +50,8 @@ PCIE_GBS = 63.0                            # MI355X_MICROARCH.md: host link PCIe
 BATCH_PER_GPU = 8192                       # 65 536 LPs over 8 GPUs (BASELINE.json configs[2])
 BATCH_M, BATCH_COLS = 32, 64
 PREWARM_SECONDS = 0.5
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "round3_pmc_hbm_traffic_4096x8192.json")
-PMC_SUMMARY_2B = os.path.join(ROOT, "profiles", "round3_pmc_hbm_traffic_4096x12289.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "round4_pmc_hbm_traffic_4096x8192.json")
+PMC_SUMMARY_2B = os.path.join(ROOT, "profiles", "round4_pmc_hbm_traffic_4096x12289.json")
 PMC_BATCH = os.path.join(ROOT, "profiles", "round3_pmc_batch_issue.json")
 PMC_RATIONAL = os.path.join(ROOT, "profiles", "round3_pmc_rational_issue.json")
 LEGS = ("pivots", "batched", "sharded", "cfg2b", "rational", "mip", "lineq")
@@ -433,11 +433,17 @@ def main():
                     bytes_per_pivot=round(ALG_BYTES_PER_LAUNCH / ppl), us_per_pivot=round(per_pivot_s * 1e6, 3),
                     achieved=round(ALG_BYTES_PER_LAUNCH / ppl / per_pivot_s / 1e9, 1),
                     frac=round(ALG_BYTES_PER_LAUNCH / ppl / per_pivot_s / 1e9 / HBM_PEAK_GBS, 4)),
-                caveat="fraction of the 8 TB/s HBM peak; the 268 MB tableau is exactly the size of the 256 MiB Infinity Cache "
-                       "(MALL) and FETCH_SIZE counts its hits, so part of the stream is served by the MALL -- which is how "
-                       "`achieved` can exceed the ~6.3 TB/s a pure HBM copy reaches. The same kernel on a tableau 1.57 x the "
-                       "MALL is the `cfg2b.roofline` object of this line (0.79-0.82); a plain in-place copy with the same "
-                       "tiling runs at 0.86 / 0.79 of the peak at the two sizes (profiles/round3_sweep_lab.txt)")
+                caveat="fraction of the 8 TB/s HBM peak for ONE pass that applies %d staged pivots to every cell (per pivot the "
+                       "pass moves 1/%d of these bytes). The 268 MB tableau is exactly the size of the 256 MiB Infinity Cache "
+                       "(MALL) and FETCH_SIZE counts its hits, so part of the stream is served by the MALL. The same kernel on a "
+                       "tableau 1.57 x the MALL is the `cfg2b.roofline` object of this line; a plain in-place copy with the same "
+                       "tiling runs at 0.86 / 0.79 of the peak at the two sizes (profiles/round3_sweep_lab.txt). With XPG_BLOCK=16 "
+                       "the pass is at that copy ceiling (78 us, 0.86) but is paid per 16 pivots; with 32 it is bound by fp64 issue "
+                       "as much as by memory (110 us, 0.61): DESIGN section 4.2b" % (BLOCK, BLOCK),
+                chain=dict(note="the time-dominant kernel of the loop is not the pass but k_blk_chain, the persistent launch that "
+                                "stages the batch's pivots: latency-bound (two L2 hand-offs and two gathers per stage), no byte or "
+                                "flop roofline applies; us per stage from the whole-loop time",
+                           us_per_stage=round((per_pivot_s * 1e6 * ppl - sweep_avg_s * 1e6) / ppl, 3) if ppl else None))
         if rank == 0:
             out["self_check"] = {"pivots": selfcheck_bench_lp(lp)}      # outside the timed region
         lp.close()
@@ -752,7 +758,7 @@ def leg_cfg2b(ctx, xpoly_amd, gen, m=4096, n=8192):
             frac=round(bytes_per_launch / avg / 1e9 / HBM_PEAK_GBS, 4), avg_launch_us=round(avg * 1e6, 2),
             launches_sampled=launches,
             traffic=(round(json.load(open(PMC_SUMMARY_2B))["traffic_bytes_per_launch"]) if os.path.exists(PMC_SUMMARY_2B) else None),
-            traffic_source="profiles/round3_pmc_hbm_traffic_4096x12289.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of this leg; not collected in this run)",
+            traffic_source="profiles/round4_pmc_hbm_traffic_4096x12289.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of this leg; not collected in this run)",
             note="HIP events on the sweep launches of the timed pass; a plain in-place copy of this tableau with the same "
                  "tiling runs at 0.79 of the peak (tools/lab/sweep_lab2.hip, profiles/round3_sweep_lab.txt)")
     return out
