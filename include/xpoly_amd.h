@@ -271,6 +271,16 @@ int xpg_mip_batch_rat32(xpg_ctx * ctx, int nb, int is_max, int is_bin, const xpg
 int xpg_mip_batch_f64(xpg_ctx * ctx, int nb, int is_max, int is_bin, const double * tgtf,
                       const double * leq, int leq_rows, int cols, int32_t * out_status,
                       double * out_v, double * out_sol, long long * out_nodes);
+/* The same for nb MIPs with eq_rows EQUALITIES each at the root, eq[nb][eq_rows][cols] (x >= 0; the shape
+ * PolyTran::FeaSchedule hands to MIP::maxm / minm, src/eng/poly.cpp:5118-5130); leq may be NULL with
+ * leq_rows = 0.  Every node runs SIX::convertEq2Ineq (src/com/lpsol.h:1197-1278) over the root's and the
+ * branches' equalities, as the reference's recursion does. */
+int xpg_mip_batch_eq_rat32(xpg_ctx * ctx, int nb, int is_max, int is_bin, const xpg_rat32 * tgtf,
+                           const xpg_rat32 * leq, int leq_rows, const xpg_rat32 * eq, int eq_rows, int cols,
+                           int32_t * out_status, xpg_rat32 * out_v, xpg_rat32 * out_sol, long long * out_nodes);
+int xpg_mip_batch_eq_f64(xpg_ctx * ctx, int nb, int is_max, int is_bin, const double * tgtf,
+                         const double * leq, int leq_rows, const double * eq, int eq_rows, int cols,
+                         int32_t * out_status, double * out_v, double * out_sol, long long * out_nodes);
 /* DepPoly::is_empty(keepit, vc = NULL), src/eng/poly.cpp:530-573, for nb dependence polyhedra
  * mats[nb][rows][cols] without constant symbols (constant in the last column):
  * Lineq::reduce pre-filter, then Lineq::has_solution(is_int_sol, is_unique_sol) = MIP::maxm

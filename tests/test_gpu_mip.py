@@ -331,3 +331,44 @@ def test_f64_mip_whose_nodes_pass_32_rows_in_a_block_carved_for_more(ctx, port):
         assert np.array_equal(np.atleast_1d(v[b]), np.atleast_1d(want[1])), b
         if want[0] == 0:
             assert np.array_equal(sol[b].reshape(-1), want[2].reshape(-1)), b
+
+
+@pytest.mark.parametrize("kind", [RAT, F64])
+def test_mip_batch_with_root_equalities_matches_oracle(ctx, port, kind):
+    """xpg_mip_batch_eq_*: batches of MIPs WITH equalities at the root (PolyTran::FeaSchedule's shape), every tree on the
+    device, against MIP::maxm / minm of the oracle problem by problem -- integer and 0-1 branching, several shapes."""
+    from mip_eq_cases import random_mip_eq
+    from xpoly_amd.six import mip_batch_eq
+    rng = np.random.default_rng(909 + kind)
+    compared, seen = 0, set()
+    for (m_leq, m_eq, nv) in ((3, 1, 4), (2, 2, 5), (0, 2, 3), (4, 3, 6)):
+        for is_bin in (False, True):
+            nb = 40
+            probs = []
+            for _ in range(nb):
+                p = random_mip_eq(rng, m_leq, m_eq, nv, is_bin)
+                p.pop("ind", None)
+                probs.append(p)
+            # one shape per call: the 0-1 family sometimes appends x <= 1 rows -- keep the problems of the commonest shape
+            shapes = {}
+            for p in probs:
+                shapes.setdefault(None if p["leq"] is None else p["leq"].shape[0], []).append(p)
+            probs = max(shapes.values(), key=len)
+            conv = (lambda a: a[..., 0].astype(np.float64)) if kind == F64 else (lambda a: a)
+            tg = np.stack([conv(p["tgtf"]) for p in probs]); eq = np.stack([conv(p["eq"]) for p in probs])
+            leq = None if probs[0]["leq"] is None else np.stack([conv(p["leq"]) for p in probs])
+            vc = conv(probs[0]["vc"])
+            for is_max in (True, False):
+                st, v, sol, nodes = mip_batch_eq(ctx, is_max, is_bin, tg, leq, eq, kind=kind)
+                for b, p in enumerate(probs):
+                    want = port.mip_solve(kind, is_max, is_bin, tg[b], vc, eq[b], None if leq is None else leq[b])
+                    if want[0] == -7:
+                        assert st[b] == -7, (m_leq, m_eq, nv, is_bin, is_max, b)
+                        continue
+                    assert st[b] == want[0], (m_leq, m_eq, nv, is_bin, is_max, b, st[b], want[0])
+                    assert np.array_equal(np.atleast_1d(v[b]), np.atleast_1d(want[1])), (m_leq, m_eq, nv, is_bin, is_max, b)
+                    if want[0] == 0:
+                        assert np.array_equal(sol[b].reshape(-1), np.asarray(want[2]).reshape(-1)), (m_leq, m_eq, nv, is_bin, is_max, b)
+                    compared += 1
+                    seen.add(int(want[0]))
+    assert compared > 200 and 0 in seen

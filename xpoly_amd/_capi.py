@@ -16,7 +16,7 @@ SYMBOLS = [
     "xpg_sync", "xpg_profile_begin", "xpg_profile_end", "xpg_malloc", "xpg_free", "xpg_upload", "xpg_download",
     "xpg_pivot_f64_dev", "xpg_pivot_rat32_dev", "xpg_pivot_f64", "xpg_pivot_rat32",
     "xpg_lp_create", "xpg_lp_destroy", "xpg_lp_two_stage", "xpg_lp_begin", "xpg_lp_iterate",
-    "xpg_lp_pivots_done", "xpg_lp_counters", "xpg_lp_chain_folds", "xpg_lp_set_options", "xpg_lp_shape", "xpg_lp_read", "xpg_lp_trace",
+    "xpg_lp_pivots_done", "xpg_lp_counters", "xpg_lp_chain_folds", "xpg_mip_batch_eq_rat32", "xpg_mip_batch_eq_f64", "xpg_lp_set_options", "xpg_lp_shape", "xpg_lp_read", "xpg_lp_trace",
     "xpg_six_maxm_f64", "xpg_six_minm_f64", "xpg_six_maxm_rat32", "xpg_six_minm_rat32",
     "xpg_six_batch_f64", "xpg_six_batch_rat32", "xpg_six_batch_f64_dev", "xpg_six_batch_rat32_dev",
     "xpg_mip_maxm_rat32", "xpg_mip_minm_rat32", "xpg_mip_maxm_f64", "xpg_mip_minm_f64",

@@ -513,6 +513,46 @@ int mip_batch(xpg_ctx * ctx, int kind, int nb, bool is_max, bool is_bin, const S
     return 0;
 }
 
+// nb independent MIPs of one shape WITH equalities at the root (x >= 0; the shape PolyTran::FeaSchedule passes,
+// src/eng/poly.cpp:5118-5130, batched): leq may be NULL with leq_rows = 0. The device tree walk where the node LPs fit
+// (every node runs convertEq2Ineq over the root's and the branches' equalities in its workgroup), the host controller
+// -- problems advancing in lock step -- otherwise.
+template <class S>
+int mip_batch_eq(xpg_ctx * ctx, int kind, int nb, bool is_max, bool is_bin, const S * tgtf, const S * leq, int leq_rows,
+                 const S * eqs, int eq_rows, int cols, int32_t * out_status, S * out_v, S * out_sol, long long * out_nodes)
+{
+    if (!ctx || nb < 0 || !tgtf || eq_rows <= 0 || !eqs || leq_rows < 0 || (leq_rows > 0 && !leq) || cols < 2 || !out_status || !out_v)
+        return XPG_ERR_SHAPE;
+    if (nb == 0) return 0;
+    static const bool on_device = [] { const char * e = getenv("XPG_MIP_DEVICE"); return !(e && e[0] == '0'); }();
+    if (on_device && mip_device_fits<S>(leq_rows, cols, is_bin, eq_rows)) {
+        const int rc = mip_batch_device<S>(ctx, nb, is_max, is_bin, tgtf, leq, leq_rows, cols, out_status, out_v, out_sol, out_nodes,
+                                           (const uint8_t *)0, eqs, eq_rows);
+        if (rc != XPG_ERR_UNSUPPORTED) return rc;
+    }
+    const int rhs = cols - 1;
+    std::vector<S> vc((size_t)rhs * cols, zero<S>());
+    for (int i = 0; i < rhs; i++) vc[(size_t)i * cols + i] = minus_one<S>();
+    std::vector<MipTask<S> > tasks(nb);
+    for (int b = 0; b < nb; b++)
+        tasks[b].start(make_problem<S>(tgtf + (size_t)b * cols, vc.data(), rhs, eqs + (size_t)b * eq_rows * cols, eq_rows,
+                                       leq_rows > 0 ? leq + (size_t)b * leq_rows * cols : (const S *)0, leq_rows, cols),
+                       is_max, is_bin, (const uint8_t *)0);
+    int rc = run_mip_tasks<S>(ctx, kind, tasks);
+    if (rc) return rc;
+    long long nodes = 0;
+    for (int b = 0; b < nb; b++) {
+        const MipTask<S> & T = tasks[b];
+        out_status[b] = T.final_status;
+        out_v[b] = T.v;
+        nodes += T.nodes;
+        if (T.final_status == XPG_IP_SUCC && out_sol && (int)T.sol.size() == cols)
+            for (int j = 0; j < cols; j++) out_sol[(size_t)b * cols + j] = T.sol[j];
+    }
+    if (out_nodes) *out_nodes = nodes;
+    return 0;
+}
+
 // SIX::reviseTargetFunc on the all-ones objective (lpsol.h:2053-2074, linsys.cpp:851-862).
 inline std::vector<R32> feasibility_objective(const R32 * leq, int leq_rows, const R32 * eqs, int eq_rows, int cols, int rhs)
 {

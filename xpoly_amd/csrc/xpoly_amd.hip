@@ -1134,6 +1134,22 @@ int xpg_mip_batch_f64(xpg_ctx * ctx, int nb, int is_max, int is_bin, const doubl
     return mip_batch<F64>(ctx, 0, nb, is_max != 0, is_bin != 0, (const F64 *)tgtf, (const F64 *)leq, leq_rows, cols,
                           out_status, (F64 *)out_v, (F64 *)out_sol, out_nodes);
 }
+int xpg_mip_batch_eq_rat32(xpg_ctx * ctx, int nb, int is_max, int is_bin, const xpg_rat32 * tgtf, const xpg_rat32 * leq,
+                           int leq_rows, const xpg_rat32 * eq, int eq_rows, int cols, int32_t * out_status, xpg_rat32 * out_v,
+                           xpg_rat32 * out_sol, long long * out_nodes)
+{
+    XPG_BIND(ctx);
+    return mip_batch_eq<R32>(ctx, 1, nb, is_max != 0, is_bin != 0, (const R32 *)tgtf, (const R32 *)leq, leq_rows, (const R32 *)eq, eq_rows,
+                             cols, out_status, (R32 *)out_v, (R32 *)out_sol, out_nodes);
+}
+int xpg_mip_batch_eq_f64(xpg_ctx * ctx, int nb, int is_max, int is_bin, const double * tgtf, const double * leq, int leq_rows,
+                         const double * eq, int eq_rows, int cols, int32_t * out_status, double * out_v, double * out_sol,
+                         long long * out_nodes)
+{
+    XPG_BIND(ctx);
+    return mip_batch_eq<F64>(ctx, 0, nb, is_max != 0, is_bin != 0, (const F64 *)tgtf, (const F64 *)leq, leq_rows, (const F64 *)eq, eq_rows,
+                             cols, out_status, (F64 *)out_v, (F64 *)out_sol, out_nodes);
+}
 int xpg_dep_is_empty_batch_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols,
                                  int32_t * out_empty, long long * out_nodes)
 {

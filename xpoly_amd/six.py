@@ -345,6 +345,21 @@ def mip_batch(ctx, is_max, is_bin, tgtf, leq, kind=RAT):
     return st, v, sol, nodes.value
 
 
+def mip_batch_eq(ctx, is_max, is_bin, tgtf, leq, eq, kind=RAT):
+    """nb independent MIPs with equalities at the root (x >= 0): tgtf [nb, cols(,2)], leq [nb, rows, cols(,2)] or None,
+    eq [nb, eq_rows, cols(,2)]. Returns (status[nb], v[nb(,2)], sol[nb,cols(,2)], nodes)."""
+    tgtf = as_kind(tgtf, kind, 2); eq = as_kind(eq, kind, 3)
+    leq = None if leq is None else as_kind(leq, kind, 3)
+    nb, eq_rows, cols = eq.shape[0], eq.shape[1], eq.shape[2]
+    rows = 0 if leq is None else leq.shape[1]
+    st = np.zeros(nb, dtype=np.int32); v = empty_kind((nb,), kind); sol = empty_kind((nb, cols), kind)
+    nodes = C.c_longlong()
+    fn = lib().xpg_mip_batch_eq_rat32 if kind == RAT else lib().xpg_mip_batch_eq_f64
+    ctx.check(fn(ctx._h, C.c_int(nb), C.c_int(int(is_max)), C.c_int(int(is_bin)), vp(tgtf), vp(leq), C.c_int(rows), vp(eq),
+                 C.c_int(eq_rows), C.c_int(cols), vp(st), vp(v), vp(sol), C.byref(nodes)), "xpg_mip_batch_eq")
+    return st, v, sol, nodes.value
+
+
 def dep_is_empty_batch(ctx, mats, rhs_idx=None, vc=None):
     """DepPoly::is_empty(keepit, vc) (src/eng/poly.cpp:530-573) for a stack of dependence polyhedra
     [nb, rows, cols(,2)]: the constant is column rhs_idx (default: the last), the columns behind it are constant
