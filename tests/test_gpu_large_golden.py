@@ -161,6 +161,49 @@ def test_chain_roll_call_abort_falls_back_bit_exactly(monkeypatch):
     lp.close(); c.close()
 
 
+def test_chain_placement_check_failure_switches_to_the_spread_form(monkeypatch):
+    """Round 4: the chain's workers are the workgroups with blockIdx % 8 == 0, which the dispatcher puts on ONE XCD -- an
+    observation, not a contract, so the roll call checks it (a counter per XCD id). The test hook makes every second
+    one-XCD launch "find" its workers on several XCDs: that launch aborts without touching the state, the host switches the
+    solve to the spread form of the kernel (sc1 stores, any placement) -- NOT to launch-per-stage kernels -- and the state
+    after 1024 pivots is the reference's. Most batches still have their first stage inside the chain launch."""
+    import xpoly_amd
+    monkeypatch.setenv("XPG_CHAIN_TEST_ABORT", "-2")
+    c = xpoly_amd.Context(0)
+    leq, tgtf = gen.hard_lp_f64(4096, 4095)
+    lp = xpoly_amd.DeviceLP(c, F64, leq, tgtf)
+    lp.begin()
+    rec = GOLD_BENCH["bench_lp"][0]
+    assert lp.iterate(rec["K"]) == xpoly_amd.six.XPG_RUNNING      # (iterate re-queues what an aborted batch left undone)
+    assert lp.pivots_done() == rec["K"]
+    aborts, off = lp.chain_aborts()
+    assert aborts >= 1 and not off                       # placement failures are counted as aborts, the chain stays on
+    assert lp.chain_runs >= 20 and lp.chain_folds() >= 10
+    check_bench_lp_state(lp.read(), rec)
+    lp.close(); c.close()
+
+
+def test_chain_folds_stage_zero_and_the_unfolded_loop_agree(monkeypatch):
+    """Round 4: in the steady state a batch is [chain launch incl. stage 0, sweep]; XPG_CHAIN_FOLD=0 keeps stage 0 as
+    launches of its own. Same state either way (= the reference's at K = 1024), and the folded run really folded."""
+    import xpoly_amd
+    rec = GOLD_BENCH["bench_lp"][0]
+    leq, tgtf = gen.hard_lp_f64(4096, 4095)
+    folds = {}
+    for fold in ("1", "0"):
+        monkeypatch.setenv("XPG_CHAIN_FOLD", fold)
+        c = xpoly_amd.Context(0)
+        lp = xpoly_amd.DeviceLP(c, F64, leq, tgtf)
+        lp.begin()
+        for k in (100, rec["K"] - 100):                  # two calls: each starts with stage-0 launches
+            assert lp.iterate(k) == xpoly_amd.six.XPG_RUNNING
+        assert lp.pivots_done() == rec["K"]
+        folds[fold] = lp.chain_folds()
+        check_bench_lp_state(lp.read(), rec)
+        lp.close(); c.close()
+    assert folds["0"] == 0 and folds["1"] >= rec["K"] // 24 - 4
+
+
 BUSY_SCRIPT = r"""
 import json, os, sys, zlib
 import numpy as np

@@ -125,14 +125,14 @@ template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> &
         if (chain && (t == 1 || fold)) {
             const int t0 = fold ? 0 : 1;
             const int test_abort = ctx->chain_test_abort;
-            // test hooks: k > 0 -- every k-th launch fails its roll call; k < 0 -- every |k|-th one-XCD launch "finds" its
-            // workers on several XCDs
-            const int fa = test_abort > 0 ? (batch % test_abort == test_abort - 1 ? 1 : 0)
-                                          : (test_abort < 0 && batch % -test_abort == -test_abort - 1 ? 2 : 0);
             // every worker on one XCD, hand-offs through that XCD's L2 (lp_chain.hip.h) -- where one XCD seats them all: a
             // worker is one wave with 16 KB of LDS, an XCD has cus / 8 CUs of 160 KB; XPG_CHAIN_XCD=0, or a launch whose
             // placement check failed, selects the spread form with sc1 stores
             const bool local = ctx->chain_local && !chain_spread && workers <= (cus / 8) * 9;
+            // test hooks: k > 0 -- every k-th launch fails its roll call; k < 0 -- every |k|-th ONE-XCD launch "finds" its
+            // workers on several XCDs (the spread form has no placement to check)
+            const int fa = test_abort > 0 ? (batch % test_abort == test_abort - 1 ? 1 : 0)
+                                          : (test_abort < 0 && local && batch % -test_abort == -test_abort - 1 ? 2 : 0);
             const int nparts0 = (int)gprep.x;
             const int fn = next_folds ? 1 : 0;
             if (local) hipLaunchKernelGGL(k_blk_chain<true>, dim3(8 * workers), dim3(64), CH_LDS_BYTES, ctx->stream, v, batch, t0, B, cpick, cprep, nparts0, fa, fn);
