@@ -92,6 +92,22 @@ template <> inline void launch_pipe_sweep<R32>(xpg_ctx * ctx, const LpView<R32> 
     hipLaunchKernelGGL(k_pipe_sweep_r32, dim3(v.m > N ? v.m : N, 1 + (v.W + 255) / 256), dim3(256), 0, ctx->stream, v, slot, colstride, N);
     if (timed) prof_close(ctx);
 }
+// Fused Rational loop (lp_fused_r32.hip.h): one launch per pivot; generic = the generic point before it (generic pick in
+// place if the descriptor is idle, then staging of what it chose)
+template <class S> inline void launch_fused(xpg_ctx *, const LpView<S> &, int, int, bool) {}
+template <class S> inline void launch_side_home(xpg_ctx *, const LpView<S> &) {}
+template <> inline void launch_fused<R32>(xpg_ctx * ctx, const LpView<R32> & v, int slot, int colstride, bool generic)
+{
+    const int NP = (v.W + 255) / 256;
+    if (generic)
+        for (int k = 1; k <= 2; k++) hipLaunchKernelGGL((k_pipe_prep<R32>), dim3(NP), dim3(256), 0, ctx->stream, v, slot, colstride, k);
+    const bool timed = prof_open(ctx);
+    const int N = (v.m + 255) / 256 < PICK_MAX_WGS ? (v.m + 255) / 256 : PICK_MAX_WGS;
+    hipLaunchKernelGGL(k_pipe_fused_r32, dim3(v.m > N + NP ? v.m : N + NP, 1 + NP), dim3(256), 0, ctx->stream, v, slot, colstride, N, NP);
+    if (timed) prof_close(ctx);
+}
+template <> inline void launch_side_home<R32>(xpg_ctx * ctx, const LpView<R32> & v)
+{ hipLaunchKernelGGL(k_side_home, dim3(v.m, (v.W + 255) / 256), dim3(256), 0, ctx->stream, v); }
 // One batch of the blocked loop: B x (pick, prep) -- the generic pick once after pick(0) -- and a sweep.
 // fold: this batch's stage 0 is the chain launch's (t0 = 0) -- no pick / generic pick / prep launches. Speculative: the chain
 // launch of the batch before admits it by a ticket once it has committed all its stages; without the ticket this batch's
@@ -212,6 +228,9 @@ template <class S> struct Lp : LpBase {
     unsigned pipe_t = 0;    // pipelined loop: iteration counter since reset_loop (slot = pipe_t & 1)
     bool irregular = false, irregular_known = false;   // fp64: the input held an inf / NaN (read back once per build)
     bool pipe_primed = false;
+    bool fused_unavailable = false;   // fused Rational loop: its buffers could not be allocated
+    bool fused_idles_often = false;   // ... this solve defers decisions often: a generic point before every launch
+    unsigned fused_idle_seen = 0;
     int blk_batch = 0;      // blocked loop: id of the next batch since reset_loop
     bool closes_often = false;   // blocked loop: >= 5 % of this solve's sweeps so far were of a batch closed early
     bool chain_off = false;      // blocked loop: a chain launch of this solve failed its roll call (the device is shared): launch per stage from here on
@@ -263,7 +282,7 @@ template <class S> struct Lp : LpBase {
         const int ld = pick_ld(Wmax) > pick_ld(Wmax - 1) ? pick_ld(Wmax) : pick_ld(Wmax - 1);
         ld_cap = ld;
         const int nmax = Wmax - 1;
-        v.m = m; v.ld = ld; v.W = 0; v.rhs = 0;
+        v.m = m; v.ld = ld; v.W = 0; v.rhs = 0; v.tab2 = nullptr; v.stage = nullptr;
         v.pw = (nmax + 31) / 32;
         v.trace_cap = 1 << 16;
         tab_elems = (size_t)mcap * ld;
@@ -323,10 +342,26 @@ template <class S> struct Lp : LpBase {
         return 0;
     }
 
+    // the second tableau copy and the staging buffers of the fused Rational loop, on first use; false: not to be had
+    // (the two-launch pipelined loop needs neither)
+    bool fused_buffers()
+    {
+        if (v.tab2) return true;
+        if (fused_unavailable) return false;
+        void * t2 = nullptr; void * sg = nullptr;
+        if (alloc(&t2, tab_elems * sizeof(S)) || alloc(&sg, (size_t)4 * ld_cap * sizeof(S))) { fused_unavailable = true; ctx->err.clear(); return false; }
+        (void)hipMemsetAsync(t2, 0, tab_elems * sizeof(S), ctx->stream);
+        (void)hipMemsetAsync(sg, 0, (size_t)4 * ld_cap * sizeof(S), ctx->stream);
+        v.tab2 = (S *)t2; v.stage = (S *)sg;
+        return true;
+    }
+
     int read_state(LoopState * out)
     {
         XPG_HIP(ctx, hipMemcpyAsync(out, v.st, sizeof(LoopState), hipMemcpyDeviceToHost, ctx->stream));
         XPG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (out->r32_idle - fused_idle_seen >= 8u) fused_idles_often = true;
+        fused_idle_seen = out->r32_idle;
         closes_often = out->blk.sweeps_part >= 8 && out->blk.sweeps_part * 20u >= out->blk.sweeps_full + out->blk.sweeps_part;
         if (out->blk.ch_misplaced != chain_misplaced_seen) {        // (an abort of its own kind: it only changes the chain's form)
             chain_aborts_seen += out->blk.ch_misplaced - chain_misplaced_seen;
@@ -352,7 +387,7 @@ template <class S> struct Lp : LpBase {
     {
         hipLaunchKernelGGL((k_reset_loop<S>), dim3(1024), dim3(256), 0, ctx->stream, v, max_iter, opt_pricing,
                            opt_feas_tol);
-        pipe_t = 0; pipe_primed = false; blk_batch = 0; closes_often = false; chain_off = false; chain_aborts_seen = 0; chain_spread = false; chain_misplaced_seen = 0;
+        pipe_t = 0; pipe_primed = false; fused_idles_often = false; fused_idle_seen = 0; blk_batch = 0; closes_often = false; chain_off = false; chain_aborts_seen = 0; chain_spread = false; chain_misplaced_seen = 0;
     }
     void queue_pivot(int guarded, int counted)
     {
@@ -380,21 +415,39 @@ template <class S> struct Lp : LpBase {
         if (blocked && irregular) blocked = false;          // NaN ratios need the generic pick's scan order: the pipelined loop has it
         blocked_now = blocked;
         if (blocked) { queue_blocked(k); return; }
-        // (the rational scalar: XPG_R32_LOOP=serial keeps the three-launch loop for A/B runs)
+        // (the rational scalar: XPG_R32_LOOP=serial keeps the three-launch loop, =pipe the two-launch one, for A/B runs)
         static const bool r32_serial = [] { const char * s = getenv("XPG_R32_LOOP"); return s && !strcmp(s, "serial"); }();
+        static const bool r32_pipe = [] { const char * s = getenv("XPG_R32_LOOP"); return s && !strcmp(s, "pipe"); }();
+        static const unsigned generic_every = [] { const char * s = getenv("XPG_R32_GENERIC_EVERY"); const int n = s ? atoi(s) : 0; return (unsigned)(n > 0 ? n : 8); }();
         const bool pipelined = ctx->loop_mode != 1 && (std::is_same<S, F64>::value || !r32_serial);
+        if (pipelined && !std::is_same<S, F64>::value && !r32_pipe && k > 0 && fused_buffers()) {
+            // one launch per pivot (lp_fused_r32.hip.h); the first launch of a call and every generic_every-th one are
+            // preceded by a generic point, the last is followed by the copy back onto side 0
+            for (unsigned t = 0; t < k; t++) {
+                const int slot = (int)(pipe_t++ & 1u);
+                launch_fused<S>(ctx, v, slot, colstride, fused_idles_often || t % generic_every == 0);
+                if ((t & 63) == 63) {
+                    hipEvent_t e = throttle[blk & 1];
+                    if (blk >= 2) (void)hipEventSynchronize(e);
+                    (void)hipEventRecord(e, ctx->stream);
+                    blk++;
+                }
+            }
+            launch_side_home<S>(ctx, v);
+            return;
+        }
         if (pipelined && k > 0 && !pipe_primed) {
             // the first pivot is chosen by a launch that has nothing to sweep (pd[1].row < 0): fp64 the sweep launch's
             // pick workgroup, Rational the prep launch's first workgroup
             if (std::is_same<S, F64>::value) launch_pipe_sweep(ctx, v, 1, colstride, false);
-            else hipLaunchKernelGGL((k_pipe_prep<S>), dim3(1), dim3(256), 0, ctx->stream, v, 1, colstride);
+            else hipLaunchKernelGGL((k_pipe_prep<S>), dim3(1), dim3(256), 0, ctx->stream, v, 1, colstride, 0);
             pipe_primed = true;
         }
         for (unsigned t = 0; t < k; t++) {
             if (pipelined) {
                 // two launches per pivot; the next pivot is chosen inside the sweep launch
                 const int slot = (int)(pipe_t++ & 1u);
-                hipLaunchKernelGGL((k_pipe_prep<S>), dim3((v.W + 255) / 256), dim3(256), 0, ctx->stream, v, slot, colstride);
+                hipLaunchKernelGGL((k_pipe_prep<S>), dim3((v.W + 255) / 256), dim3(256), 0, ctx->stream, v, slot, colstride, 0);
                 launch_pipe_sweep(ctx, v, slot, colstride, true);
             } else {
                 hipLaunchKernelGGL((k_pick<S>), dim3(1), dim3(1024), 0, ctx->stream, v);

@@ -58,13 +58,15 @@ struct LoopState {
         int cached_col, bcol_valid;    // what nextcol[] / bcol[] hold for the following pick
         int zero_upto;                 // basic objective entries below this index are still to be zeroed
         unsigned done_after, total_after;   // LoopState::done / total_pivots once this pivot is committed
-        int pad_;
+        int side;                      // fused Rational loop (lp_fused_r32.hip.h): the tableau copy that is current for this descriptor
+        int staged, pad_;              // ... and: its scaled pivot row / objective row are already in the staging buffers
         unsigned long long cnv_bits, piv_bits;
         unsigned long long price_key;  // Dantzig look-ahead (atomicMax of dz_key), 0: none / not used
     } pd[2];
     // opt-in NON-PARITY modes of the fp64 loop; both 0 = the reference's behaviour
     int pricing;           // 1: Dantzig's rule (largest reduced cost) instead of the first positive one
-    int pad2_;
+    int r32_side;          // fused Rational loop: the tableau copy the LAST launch left current (k_side_home reads it)
+    unsigned r32_idle;     // fused Rational loop: launches that found a deferred decision and carried it over
     double feas_tol;       // > 0: SIX::is_feasible with this relative tolerance instead of Float's 1e-17 '=='
     // Blocked fp64 loop (lp_blocked.hip.h): up to BLK_MAX pivots are chosen and staged against the
     // un-swept tableau, then ONE sweep applies them all. Fields tagged with the batch they belong to.
@@ -130,8 +132,11 @@ enum { BLK_REC_G0 = BLK_PICK_WGS * BLK_REC_WORDS, BLK_REC_PAY = BLK_REC_G0 + 2 *
 enum { NF_UNKNOWN = -2 };
 typedef LoopState::PipeDesc PipeDesc;
 // LpView::pickrec layout (8-byte words): PICK_MAX_WGS records of PICK_REC_WORDS, then one arrival
-// counter per descriptor slot, each on a 128-byte line of its own.
-enum { PICK_MAX_WGS = 16, PICK_REC_WORDS = 4, PICK_CTR_OFF = 128, PICK_WORDS = PICK_CTR_OFF + 32 };
+// counter per descriptor slot, each on a 128-byte line of its own; the fused Rational loop adds one hand-over block of
+// PICK_GO_WORDS per slot (GO_*: flag, the chosen pivot, the look-ahead accumulators, the stagers' arrival counter).
+enum { PICK_MAX_WGS = 16, PICK_REC_WORDS = 4, PICK_CTR_OFF = 128, PICK_GO_OFF = PICK_CTR_OFF + 32, PICK_GO_WORDS = 32,
+       PICK_WORDS = PICK_GO_OFF + 2 * PICK_GO_WORDS };
+enum { GO_FLAG = 0, GO_ROWLEAVE = 1, GO_PIV = 2, GO_CNV = 3, GO_NF = 16, GO_ANY = 17, GO_ARRIVED = 18 };
 
 template <class S> struct LpView {
     S * tab; int m, W, ld, rhs;
@@ -146,6 +151,8 @@ template <class S> struct LpView {
     int * blkP;                     // blocked loop: look-ahead pricing partials of the prep workgroups (BLK_PART_INTS each)
     LoopState * st;
     int * trace; int trace_cap;
+    S * tab2;                       // fused Rational loop: the other copy of the ping-pong tableau (null: not in use)
+    S * stage;                      // fused Rational loop: scaled pivot row [2][ld], then staged objective row [2][ld]
 };
 
 template <class S> __device__ __forceinline__ S from_bits(unsigned long long b)
@@ -848,9 +855,15 @@ void k_update_f64(double * __restrict__ tab, int m, int W, int ld,
 // that the sweep in flight completes.
 // What the first workgroup does when the descriptor has no pivot to stage: nothing (fp64: the sweep launch's pick
 // workgroup runs the generic pick) or that generic pick itself (Rational, lp_pipe_r32.hip.h).
-template <class S> __device__ inline void prep_idle(const LpView<S> &, int, int) {}
-template <> __device__ inline void prep_idle<R32>(const LpView<R32> & v, int slot, int colstride);
-template <class S> __global__ __launch_bounds__(256) void k_pipe_prep(LpView<S> v, int slot, int colstride)
+template <class S> __device__ inline void prep_idle(const LpView<S> &, int, int, bool) {}
+template <> __device__ inline void prep_idle<R32>(const LpView<R32> & v, int slot, int colstride, bool inplace);
+// fused != 0 (Rational, lp_fused_r32.hip.h): the generic point of the one-launch-per-pivot loop, two launches (fused = 1,
+// then 2: the second never picks, so that what the fused launch behind it finds is either idle or staged). An idle descriptor gets
+// its pivot from the generic pick IN PLACE (pd[slot] itself, -column into this slot's half of colbuf); a descriptor with a
+// pivot that nobody has staged yet is staged into the staging buffers of this slot (scaled pivot row, objective row --
+// v.obj itself is committed by the fused launch that sweeps the pivot); one that is staged is left alone. The tableau is
+// read on the side the descriptor names.
+template <class S> __global__ __launch_bounds__(256) void k_pipe_prep(LpView<S> v, int slot, int colstride, int fused)
 {
     LoopState * st = v.st;
     PipeDesc & D = st->pd[slot];
@@ -858,6 +871,7 @@ template <class S> __global__ __launch_bounds__(256) void k_pipe_prep(LpView<S> 
     const int status = st->status, pricing = st->pricing;
     const bool canon = !is_f64<S>::value && st->noncanon == 0;  // Rational: the canonical forms (scalar.hip.h)
     const int stop = D.stop, r = D.row, enter = D.col, leave = D.leave, zu = D.zero_upto;
+    const int side = D.side, staged = D.staged;
     const unsigned long long piv_bits = D.piv_bits, cnv_bits = D.cnv_bits;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
     if (status != ST_RUNNING) return;
@@ -871,10 +885,18 @@ template <class S> __global__ __launch_bounds__(256) void k_pipe_prep(LpView<S> 
         }
         return;
     }
+    const S * __restrict__ tab = (fused && side) ? v.tab2 : v.tab;
     if (r < 0) {
-        if (blockIdx.x == 0) prep_idle<S>(v, slot, colstride);
+        if (fused == 2) return;                                // the generic point's second launch only stages
+        if (blockIdx.x == 0) {
+            if (fused) { LpView<S> w = v; w.tab = (S *)tab; prep_idle<S>(w, slot, colstride, true); }
+            else prep_idle<S>(v, slot, colstride, false);
+        }
         return;
     }
+    if (fused && staged) return;
+    S * __restrict__ rowbuf = fused ? v.stage + (size_t)slot * v.ld : v.rowbuf;
+    S * __restrict__ objout = fused ? v.stage + (size_t)(2 + slot) * v.ld : v.obj;
     if (gid == 0) v.pickrec[PICK_CTR_OFF + 16 * slot] = 0ull;  // arrival counter of this iteration's pick
     const S s = div(one<S>(), from_bits<S>(piv_bits));        // 1/(eq.get(eqnum, nv)), :1471
     const int smode = scale_mode(s);
@@ -885,15 +907,15 @@ template <class S> __global__ __launch_bounds__(256) void k_pipe_prep(LpView<S> 
     int nf = INT_MAX, any = 0;
     unsigned long long key = 0;
     for (int j = gid; j < v.W; j += gsz) {
-        const S a = v.tab[(size_t)r * v.ld + j];               // all four loads in flight together
+        const S a = tab[(size_t)r * v.ld + j];                 // all four loads in flight together
         S oj = v.obj[j];
         const bool nvj = j < v.rhs && v.nv[j] != 0;            // basis BEFORE this pivot's swap
         const int rcj = v.rowcnt[j < v.rhs ? j : 0];
         S e = scaled_c(a, s, smode, canon);
-        v.rowbuf[j] = e;
+        rowbuf[j] = e;
         if (j < zu && !nvj) oj = zero<S>();                    // lpsol.h:1055-1060, deferred by the pick
         const S o = obj_update_c(e, j >= v.rhs, cnv, cmode, oj, canon);   // lpsol.h:1496-1501
-        v.obj[j] = o;
+        objout[j] = o;
         // look-ahead pricing of the next iteration, on the basis AFTER the swap
         const bool nv_next = j == enter ? false : (j == leave ? true : nvj);
         if (j < v.rhs && nv_next && gt(o, zero<S>())) {
@@ -1310,7 +1332,7 @@ template <class S> __global__ void k_reset_loop(LpView<S> v, unsigned max_iter, 
         st->status = ST_RUNNING; st->done = 0; st->max_iter = max_iter;
         st->row = -1; st->infeasible = 0;
         st->next_first = NF_UNKNOWN; st->anypos = 0; st->cached_col = -1; st->bcol_valid = 0;
-        st->pricing = pricing; st->pad2_ = 0; st->feas_tol = feas_tol;
+        st->pricing = pricing; st->r32_side = 0; st->r32_idle = 0u; st->feas_tol = feas_tol;
         st->blk.batch = -1; st->blk.n = 0; st->blk.closed = 0; st->blk.generic = 0; st->blk.from_generic = 0;
         st->blk.budget = 0xFFFFFFFFu; st->blk.price_key = 0ull;
         st->blk.want_generic = 0; st->blk.la_from_state = 1; st->blk.la_epoch = 0u;
@@ -1321,10 +1343,11 @@ template <class S> __global__ void k_reset_loop(LpView<S> v, unsigned max_iter, 
         st->blk.ch0_ticket = 0u; st->blk.ch0_la_epoch = 0u; st->blk.ch0_budget = 0u; st->blk.ch0_done = 0u; st->blk.ch0_tp = 0u; st->blk.ch_folds = 0u;
         for (int k = 0; k < 8; k++) st->blk.dbg[k] = 0ull;
         for (int k = 0; k < 2; k++) v.pickrec[PICK_CTR_OFF + 16 * k] = 0ull;   // arrival counters
+        for (int k = 0; k < 2; k++) { v.pickrec[PICK_GO_OFF + PICK_GO_WORDS * k + GO_ARRIVED] = 0ull; v.pickrec[PICK_GO_OFF + PICK_GO_WORDS * k + GO_FLAG] = 0ull; }
         for (int k = 0; k < 2; k++) {                  // pipelined loop: iteration 0 has no pivot yet
             PipeDesc & D = st->pd[k];
             D.row = -1; D.col = 0; D.leave = 0; D.next_first = NF_UNKNOWN; D.anypos = 0; D.stop = 0;
-            D.cached_col = -1; D.bcol_valid = 0; D.zero_upto = 0; D.pad_ = 0; D.cnv_bits = 0; D.piv_bits = 0;
+            D.cached_col = -1; D.bcol_valid = 0; D.zero_upto = 0; D.pad_ = 0; D.side = 0; D.staged = 0; D.cnv_bits = 0; D.piv_bits = 0;
             D.done_after = 0; D.total_after = st->total_pivots; D.price_key = 0ull;
         }
     }

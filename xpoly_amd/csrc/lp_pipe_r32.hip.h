@@ -25,7 +25,9 @@ __device__ __forceinline__ int pick_wgs_r32(int m) { const int n = (m + 255) / 2
 // the generic single-workgroup pick on a quiescent tableau. It runs in k_pipe_prep's first workgroup -- that launch
 // has nothing to stage then -- so that its registers (pick_body's relaxed pass, disableNV, findPivotNVandBVPair)
 // are not the sweep launch's.
-template <> __device__ inline void prep_idle<R32>(const LpView<R32> & v, int slot, int colstride)
+// inplace (the fused loop's generic point, lp_fused_r32.hip.h): the pivot goes into pd[slot] itself and its -column into
+// this slot's half of colbuf -- the launch that consumes it is the next one on the SAME slot.
+template <> __device__ inline void prep_idle<R32>(const LpView<R32> & v, int slot, int colstride, bool inplace)
 {
     __shared__ __attribute__((aligned(8))) unsigned char sh_c_raw[16 * sizeof(Cand<R32>)];
     __shared__ int sh_i[16];
@@ -33,22 +35,25 @@ template <> __device__ inline void prep_idle<R32>(const LpView<R32> & v, int slo
     Cand<R32> * sh_c = (Cand<R32> *)sh_c_raw;
     LoopState * st = v.st;
     PipeDesc & I = st->pd[slot];
-    PipeDesc & O = st->pd[slot ^ 1];
+    PipeDesc & O = st->pd[inplace ? slot : slot ^ 1];
     const int first = desc_first(I), anypos = I.anypos;
     const unsigned done_now = I.done_after, total_now = I.total_after, max_iter = st->max_iter;
     const int rhs = v.rhs, ld = v.ld, m = v.m;
     R32 * __restrict__ tab = v.tab;
     R32 * __restrict__ bcol = v.bcol;
-    R32 * __restrict__ cbo = v.colbuf + (size_t)(slot ^ 1) * colstride;
+    R32 * __restrict__ cbo = v.colbuf + (size_t)(inplace ? slot : slot ^ 1) * colstride;
     const int tid = threadIdx.x;
     const int izero = I.zero_upto, cached_col = I.cached_col;
     const bool b_was_cached = I.bcol_valid != 0;
+    if (inplace) __syncthreads();                  // every thread holds its copy of the descriptor before it is rewritten
     for (int j = tid; j < izero; j += 256)
         if (!v.nv[j]) v.obj[j] = zero<R32>();                              // deferred lpsol.h:1055-1060
     if (!b_was_cached)
         for (int i = tid; i < m; i += 256) bcol[i] = tab[(size_t)i * ld + rhs];
-    if (tid == 0)
+    if (tid == 0) {
         write_desc(O, -1, 0, 0, INT_MAX, 0, 0, cached_col, 0, done_now, total_now, 0ull, 0ull);
+        O.staged = 0;
+    }
     __threadfence_block();
     __syncthreads();
     if (done_now >= max_iter) {                    // while (cnt < m_max_iter), lpsol.h:1039

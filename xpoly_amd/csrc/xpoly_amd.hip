@@ -28,6 +28,7 @@
 #if XPG_IN(0)
 #include "lp_kernels.hip.h"
 #include "lp_pipe_r32.hip.h"
+#include "lp_fused_r32.hip.h"
 #include "lp_host.hip.h"
 #include "warm_mip.hip.h"
 #endif
