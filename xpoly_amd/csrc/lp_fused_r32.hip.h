@@ -9,22 +9,24 @@
 //     tab2, PipeDesc::side names the current one), so the stagers compute a'_r',j = a_r',j + k_r' * e_j themselves from
 //     the immutable input side with the sweep's own operation -- no ordering against the workgroup that sweeps that row.
 //     A column whose e_j is zero is copied instead of skipped.
-//   * A hand-over inside the launch: the pick's last adder publishes the chosen pivot as a few agent-scope stores and a
-//     flag (pickrec GO_*); ceil(W / 256) stager workgroups -- dispatched right behind the pick workgroups, spinning with
-//     s_sleep meanwhile -- take it from there. Their look-ahead goes through agent-scope atomics on accumulators that
+//   * A hand-over inside the launch: every pick workgroup publishes its best row as four self-validating 16-byte
+//     granules (write-through stores); ceil(W / 256) stager workgroups -- dispatched right behind the pick workgroups,
+//     polling with s_sleep meanwhile -- each combine the N records themselves (no counter, no last adder, no flag: one
+//     store-to-load hop) and take it from there. Their look-ahead goes through agent-scope atomics on accumulators that
 //     only atomics touch; the LAST stager to finish writes the whole next descriptor (one writer, plain stores: the
-//     launch boundary publishes it).
+//     launch boundary publishes it); stager 0 also does the pick's bookkeeping (genPair, or the deferral).
 //   * Nothing a reader of the handle sees may run ahead of the sweep: the staged scaled row and objective row live in
 //     staging buffers per slot (LpView::stage); the stagers of the launch that SWEEPS a pivot commit its objective row
 //     to v.obj first. The basis swap was already committed that way (pick workgroup 0).
 //   * The generic pick (relaxed second pass, disableNV, findPivotNVandBVPair: 131 registers and scratch) must not be
-//     compiled into this launch. The host enqueues a generic point -- k_pipe_prep<R32>(fused) twice: generic pick in
-//     place, then staging of what it chose -- before the first launch of every queue_iterations call and every
-//     XPG_R32_GENERIC_EVERY (8) launches; a deferred decision idles through the fused launches until then (workgroup
+//     compiled into this launch. The host enqueues a generic point -- k_fused_generic (generic pick in place), then
+//     k_pipe_prep<R32>(fused = 2) (staging of what it chose) -- before the first launch of every queue_iterations call and every
+//     XPG_R32_GENERIC_EVERY (16) launches; a deferred decision idles through the fused launches until then (workgroup
 //     (0,0) carries the descriptor over to the other slot and counts it: a solve that idles often gets a generic point
 //     before every launch from the host's next status read on).
-//   * After the last launch of a call k_side_home copies side 1 onto side 0 when side 1 is the current one (both copies
-//     are then current): everything outside this loop reads v.tab.
+//   * Everything outside this loop reads v.tab: the host's status read after each batch of launches (Lp::read_state)
+//     sees which side the last launch left current and enqueues k_side_home when it is side 1 (both copies are then
+//     current).
 #pragma once
 #include "lp_pipe_r32.hip.h"
 
@@ -36,23 +38,42 @@ __device__ __forceinline__ void go_store(unsigned long long * p, unsigned long l
 { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned long long go_load(const unsigned long long * p)
 { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-enum { GO_NONE = 1, GO_PIVOT = 2 };
-// the flag: kind in the high word, the ticket (total pivots of the handle once the swept pivot is committed: never
-// repeats on a handle, never 0) in the low one
-__device__ __forceinline__ void go_signal(unsigned long long * go, int kind, unsigned ticket)
-{
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    go_store(go + GO_FLAG, ((unsigned long long)(unsigned)kind << 32) | ticket);
-}
 
-// The pick workgroups (p = 0 .. N-1) of a fused launch. A: the tableau side the launch reads, B: the one it writes.
-__device__ inline void fused_pick_r32(const LpView<R32> & v, int slot, int colstride, int p, int N, int NP,
+// A pick workgroup's ratio-test record: four 16-byte granules {8 bytes of data, ticket, kind}, each stored with ONE
+// write-through store and valid by itself (ticket = the handle's pivot count once the swept pivot is committed: unique
+// per launch, never 0) -- no counter, no flag, no ordering between them: the stagers poll the granules of all N pick
+// workgroups and every stager workgroup combines them itself.
+typedef unsigned int fr_u32x4 __attribute__((ext_vector_type(4)));
+enum { FREC_CAND = 1, FREC_NONE = 2 };
+__device__ __forceinline__ char * frec(const LpView<R32> & v, int p) { return (char *)(v.pickrec + PICK_FREC_OFF + (size_t)PICK_FREC_WORDS * p); }
+__device__ __forceinline__ void fr_store(char * p, unsigned long long data, unsigned ticket, int kind)
+{
+    fr_u32x4 g; g.x = (unsigned)data; g.y = (unsigned)(data >> 32); g.z = ticket; g.w = (unsigned)kind;
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(g) : "memory");
+}
+__device__ __forceinline__ fr_u32x4 fr_load(const char * p)
+{
+    fr_u32x4 g;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g) : "v"(p) : "memory");
+    return g;
+}
+// diagnostic builds (-DXPG_STAMPS): 100 MHz wall-clock stamps of the LAST launch's chain in LoopState::blk.dbg
+// (0 pick start, 1 pick workgroup 0 through its rows, 2 its record stored, 3 stager 0 start, 4 stager 0 has every
+//  record, 5 stager 0 through its column, 6 descriptor written, 7 pick workgroup 0's record stored (2: the LAST record);
+//  tools/lab/probe_rat_chain.py)
+#ifdef XPG_STAMPS
+#define FUSED_STAMP(st_, k_) do { (st_)->blk.dbg[k_] = wall_clock64(); } while (0)
+#else
+#define FUSED_STAMP(st_, k_) do { } while (0)
+#endif
+
+// The pick workgroups (p = 0 .. N-1) of a fused launch: ONE WAVE each (the other three of the workgroup leave at once) --
+// up to 16 waves on 16 compute units, a row of the ratio test per lane at 1024 rows, the wave's best by shuffles: no LDS
+// round, no barrier, and the N <= 16 records are exactly the 64 granules one stager wave polls.
+// A: the tableau side the launch reads, B: the one it writes.
+__device__ inline void fused_pick_r32(const LpView<R32> & v, int slot, int colstride, int p, int N,
                                       const R32 * __restrict__ A, R32 * __restrict__ B)
 {
-    __shared__ __attribute__((aligned(8))) unsigned char sh_c_raw[16 * sizeof(Cand<R32>)];
-    __shared__ unsigned long long sh_cnv;
-    __shared__ int sh_rc;
-    Cand<R32> * sh_c = (Cand<R32> *)sh_c_raw;
     LoopState * st = v.st;
     PipeDesc & I = st->pd[slot];
     PipeDesc & O = st->pd[slot ^ 1];
@@ -63,16 +84,15 @@ __device__ inline void fused_pick_r32(const LpView<R32> & v, int slot, int colst
     R32 * __restrict__ nextcol = v.nextcol;
     R32 * __restrict__ bcol = v.bcol;
     R32 * __restrict__ cbo = v.colbuf + (size_t)(slot ^ 1) * colstride;
-    const R32 * __restrict__ ostage = v.stage + (size_t)(2 + slot) * ld;       // the objective row with this pivot applied
     const int tid = threadIdx.x;
+    if (tid >= 64) return;
 
     if (stop != 0) {
-        // workgroup 0 alone promotes the deferred final status (as k_pipe_prep does)
+        // wave 0 of workgroup 0 alone promotes the deferred final status (as k_pipe_prep does)
         if (p != 0) return;
         const int zu = I.zero_upto;
-        for (int j = tid; j < zu; j += 256)
+        for (int j = tid; j < zu; j += 64)
             if (!v.nv[j]) v.obj[j] = zero<R32>();              // lpsol.h:1055-1060, deferred by the pick
-        __syncthreads();
         if (tid == 0) { O = I; st->status = stop; }
         return;
     }
@@ -83,6 +103,7 @@ __device__ inline void fused_pick_r32(const LpView<R32> & v, int slot, int colst
 
     // ---- a sweep is running around us
     if (p == 0 && tid == 0) {                          // commit this iteration's pivot (lpsol.h:1504-1510)
+        FUSED_STAMP(st, 0);
         v.nv[ienter] = 0; v.nv[ileave] = 1; v.bv[ienter] = 1; v.bv[ileave] = 0;
         v.eq2bv[r] = ienter; v.bv2eq[ienter] = r; v.bv2eq[ileave] = -1;
         XPG_TRACE_PIVOT("hbm-fused", ienter, ileave, r);
@@ -90,24 +111,24 @@ __device__ inline void fused_pick_r32(const LpView<R32> & v, int slot, int colst
         if ((int)t < v.trace_cap) { v.trace[2 * t] = ienter; v.trace[2 * t + 1] = ileave; }
         st->total_pivots = total_now; st->done = done_now;
     }
-    unsigned long long * go = go_block(v, slot);
     const int xc = (first >= 0 && first < W) ? first : -1;
     const R32 * __restrict__ cb = v.colbuf + (size_t)slot * colstride;
     const R32 * __restrict__ rb = v.stage + (size_t)slot * ld;
     const R32 eb = rb[rhs];
-    const int stride = 256 * N;                        // rows are dealt to the workgroups in blocks of 256
+    const int stride = 64 * N;                         // rows are dealt to the waves in blocks of 64
     if (xc < 0 || done_now >= max_iter) {
-        // no ratio test this time: keep the columns current, workgroup 0 records the outcome
+        // no ratio test this time: keep the columns current, workgroup 0 records the outcome; the stagers are told
         if (xc >= 0) {
             const R32 e0 = rb[xc];
-            for (int i = p * 256 + tid; i < m; i += stride) {
+            for (int i = p * 64 + tid; i < m; i += stride) {
                 const R32 n0 = (i == r) ? e0 : l_fma(cn, A[(size_t)i * ld + xc], cb[i], e0);
                 B[(size_t)i * ld + xc] = n0;
                 nextcol[i] = n0;
             }
         }
-        for (int i = p * 256 + tid; i < m; i += stride)
+        for (int i = p * 64 + tid; i < m; i += stride)
             bcol[i] = (i == r) ? eb : l_fma(cn, bcol[i], cb[i], eb);
+        if (tid < 4) fr_store(frec(v, p) + 16 * tid, 0ull, total_now, FREC_NONE);
         if (p == 0 && tid == 0) {
             if (done_now >= max_iter)                  // while (cnt < m_max_iter), lpsol.h:1039
                 write_desc(O, -1, 0, 0, first, anypos, 4, xc, 0, done_now, total_now, 0ull, 0ull);
@@ -116,19 +137,16 @@ __device__ inline void fused_pick_r32(const LpView<R32> & v, int slot, int colst
             else                                       // findPivotNVandBVPair needs the whole tableau: next generic point
                 write_desc(O, -1, 0, 0, first, anypos, 0, -1, 0, done_now, total_now, 0ull, 0ull);
             O.side = side ^ 1; O.staged = 0; st->r32_side = side ^ 1;
-            go_signal(go, GO_NONE, total_now);
         }
         return;
     }
 
     // ---- fused pass over this workgroup's rows: new constant column, new entering column, -column, first ratio pass
     const R32 e0 = rb[xc];
-    unsigned long long cnv_bits = 0; int rc_enter = 0;
-    if (tid == 0) { cnv_bits = to_bits(ostage[xc]); rc_enter = v.rowcnt[xc]; }   // for the last adder's tail
     Cand<R32> best; best.q = zero<R32>(); best.idx = INT_MAX;
     R32 best_a = zero<R32>(); int best_b = 0, best_cc = 0; uint32_t best_w = 0;
     bool weird = false;                                // a quotient with den <= 0: no order to reduce by (lp_kernels.hip.h)
-    for (int i = p * 256 + tid; i < m; i += stride) {
+    for (int i = p * 64 + tid; i < m; i += stride) {
         const R32 k = cb[i], bo = bcol[i], c0 = A[(size_t)i * ld + xc];        // every load of the row in flight before the first use
         int bi = v.eq2bv[i];
         if (i == r) bi = ienter;                       // the commit above, seen without waiting for it
@@ -148,66 +166,35 @@ __device__ inline void fused_pick_r32(const LpView<R32> & v, int slot, int colst
         if (nbest.idx != best.idx) { best_a = a; best_b = bi; best_cc = cc; best_w = w; }
         best = nbest;
     }
-    const Cand<R32> wbest = block_argmin(best, sh_c);
-    const int wg_weird = __syncthreads_or(weird ? 1 : 0);
+    if (p == 0 && tid == 0) FUSED_STAMP(st, 1);
+    Cand<R32> wbest = best;
+    for (int o = 32; o > 0; o >>= 1) {
+        Cand<R32> t; t.q = shfl_xor_s(wbest.q, o); t.idx = __shfl_xor(wbest.idx, o);
+        wbest = better(wbest, t);
+    }
+    const bool wg_weird = __ballot(weird) != 0ull;
     // one lane publishes this workgroup's record: the owner of the winning row, else lane 0
     const bool publisher = wbest.idx != INT_MAX ? (best.idx == wbest.idx) : (tid == 0);
-    if (tid == 0) { sh_cnv = cnv_bits; sh_rc = rc_enter; }
-    __syncthreads();
     if (!publisher) return;
-    unsigned long long * rec = v.pickrec + (size_t)p * PICK_REC_WORDS;
-    unsigned long long * ctr = v.pickrec + PICK_CTR_OFF + 16 * slot;
-    go_store(rec + 0, to_bits(wbest.q));
-    go_store(rec + 1, to_bits(best_a));
-    go_store(rec + 2, ((unsigned long long)(unsigned)wbest.idx << 32) | (unsigned)best_b);
-    go_store(rec + 3, ((unsigned long long)best_w << 32) | (unsigned)best_cc | (wg_weird ? 0x80000000u : 0u));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned long long arrived = __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (arrived != (unsigned long long)(N - 1)) return;
-    go_store(ctr, 0ull);                               // (no prep launch zeroes it in this loop)
-    // ---- last adder: combine the records in workgroup order (ties: lowest row, lpsol.h:604-611)
-    Cand<R32> g; g.q = zero<R32>(); g.idx = INT_MAX;
-    R32 g_a = zero<R32>(); int g_b = 0, g_cc = 0; uint32_t g_w = 0;
-    bool any_weird = false;
-    for (int k = 0; k < N; k++) {
-        const unsigned long long * rk = v.pickrec + (size_t)k * PICK_REC_WORDS;
-        const unsigned long long w0 = go_load(rk + 0), w1 = go_load(rk + 1), w2 = go_load(rk + 2), w3 = go_load(rk + 3);
-        Cand<R32> c; c.q = from_bits<R32>(w0); c.idx = (int)(unsigned)(w2 >> 32);
-        any_weird |= ((unsigned)w3 & 0x80000000u) != 0u;
-        const Cand<R32> ng = better(g, c);
-        if (ng.idx != g.idx) { g_a = from_bits<R32>(w1); g_b = (int)(unsigned)w2; g_w = (uint32_t)(w3 >> 32); g_cc = (int)((unsigned)w3 & 0x7fffffffu); }
-        g = ng;
-    }
-    if (g.idx == INT_MAX || any_weird) {               // first pass empty (second pass / disableNV), or candidates that only the
-                                                       // reference's own scan order decides: the generic pick of the next generic point
-        write_desc(O, -1, 0, 0, first, anypos, 0, xc, 0, done_now, total_now, 0ull, 0ull);
-        O.side = side ^ 1; O.staged = 0; st->r32_side = side ^ 1;
-        go_signal(go, GO_NONE, total_now);
-        return;
-    }
-    const int enter = xc, leave = g_b;
-    if (!((g_w >> (leave & 31)) & 1u)) {               // genPair, lpsol.h:100-104
-        v.ppt[(size_t)enter * v.pw + (leave >> 5)] = g_w | (1u << (leave & 31));
-        v.rowcnt[enter] = sh_rc + 1; v.colcnt[leave] = g_cc + 1;
-    }
-    // the stagers take it from here; the last of them writes the descriptor
-    go_store(go + GO_ROWLEAVE, ((unsigned long long)(unsigned)g.idx << 32) | (unsigned)leave);
-    go_store(go + GO_PIV, to_bits(g_a));
-    go_store(go + GO_CNV, sh_cnv);
-    go_store(go + GO_NF, (unsigned long long)(unsigned)INT_MAX);
-    go_store(go + GO_ANY, 0ull);
-    go_signal(go, GO_PIVOT, total_now);
-    (void)NP;
+    char * rec = frec(v, p);
+    fr_store(rec, to_bits(wbest.q), total_now, FREC_CAND);
+    fr_store(rec + 16, to_bits(best_a), total_now, FREC_CAND);
+    fr_store(rec + 32, ((unsigned long long)(unsigned)wbest.idx << 32) | (unsigned)best_b, total_now, FREC_CAND);
+    fr_store(rec + 48, ((unsigned long long)best_w << 32) | (unsigned)best_cc | (wg_weird ? 0x80000000u : 0u), total_now, FREC_CAND);
+#ifdef XPG_STAMPS
+    atomicMax(&st->blk.dbg[2], (unsigned long long)wall_clock64());        // the LAST record
+    if (p == 0) FUSED_STAMP(st, 7);
+#endif
 }
 
 // The stager workgroups (q = 0 .. NP-1, one column per thread) of a fused launch.
-__device__ inline void fused_stage_r32(const LpView<R32> & v, int slot, int colstride, int q, int NP, const R32 * __restrict__ A)
+__device__ inline void fused_stage_r32(const LpView<R32> & v, int slot, int colstride, int q, int N, int NP, const R32 * __restrict__ A)
 {
-    __shared__ unsigned long long sh_flag;
+    __shared__ unsigned long long sh_res[4];           // kind | row << 32, leave, pivot bits, pair-table word << 32 | column count
     LoopState * st = v.st;
     PipeDesc & I = st->pd[slot];
     PipeDesc & O = st->pd[slot ^ 1];
-    const int r = I.row, ienter = I.col, ileave = I.leave, first = desc_first(I), stop = I.stop, side = I.side;
+    const int r = I.row, ienter = I.col, ileave = I.leave, first = desc_first(I), anypos = I.anypos, stop = I.stop, side = I.side;
     const unsigned done_now = I.done_after, total_now = I.total_after;
     const bool canon = st->noncanon == 0;
     if (r < 0 || stop != 0) return;
@@ -219,35 +206,86 @@ __device__ inline void fused_stage_r32(const LpView<R32> & v, int slot, int cols
     R32 * __restrict__ rout = v.stage + (size_t)(slot ^ 1) * ld;
     const R32 * __restrict__ oin = v.stage + (size_t)(2 + slot) * ld;
     R32 * __restrict__ oout = v.stage + (size_t)(2 + (slot ^ 1)) * ld;
+    const int enter2 = first;                          // (a launch with a ratio test has first in range; else the records say NONE)
+    const int ec = (enter2 >= 0 && enter2 < W) ? enter2 : 0;
     // this pivot's objective row becomes the handle's; what does not depend on the pick is fetched before the wait
     const R32 o_in = oin[jc];
     if (in) v.obj[j] = o_in;
     const R32 e = rin[jc];
+    const R32 cnv = oin[ec];                           // objective coefficient of the entering column (lpsol.h:1496)
     const bool nv_raw = jc < rhs && v.nv[jc] != 0;
     const int rcj = v.rowcnt[jc < rhs ? jc : 0];
     // basis after THIS pivot's swap (pick workgroup 0 commits it in this launch) = before the next one's
     const bool nvj = jc < rhs && (jc == ienter ? false : (jc == ileave ? true : nv_raw));
 
-    unsigned long long * go = go_block(v, slot);
-    if (tid == 0) {
+    if (q == 0 && tid == 0) FUSED_STAMP(st, 3);
+    if (tid < 64) {
+        // wave 0 polls the 4 N granules, one per lane, then combines the records in workgroup order (ties: lowest row,
+        // lpsol.h:604-611) -- every lane the same
+        const bool mine = tid < 4 * N;
+        const char * gp = frec(v, mine ? tid >> 2 : 0) + 16 * (tid & 3);
         const unsigned long long t0 = wall_clock64();
-        unsigned long long f;
+        fr_u32x4 g;
+        bool stuck = false;
         for (;;) {
-            f = go_load(go + GO_FLAG);
-            if ((unsigned)f == total_now) break;
-            if (wall_clock64() - t0 > 400000000ull) { f = 0ull; break; }      // 4 s: the pick never answered
-            __builtin_amdgcn_s_sleep(8);
+            g = fr_load(gp);
+            if (__all(!mine || g.z == total_now)) break;
+            if (wall_clock64() - t0 > 400000000ull) { stuck = true; break; }      // 4 s: the pick never answered
+            __builtin_amdgcn_s_sleep(4);
         }
-        sh_flag = f;
+        // every lane of a record's quad gets the record's four words, then a butterfly over the quads with the
+        // reference's tie-break (lowest row, lpsol.h:604-611; better() is symmetric: both partners keep the same one)
+        const int lo = (int)g.x, hi = (int)g.y;
+        const int base = tid & ~3;
+        int wl[4], wh[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { wl[k] = __shfl(lo, base + k); wh[k] = __shfl(hi, base + k); }
+        const bool none = stuck || __ballot(mine && (int)g.w == FREC_NONE) != 0ull;
+        const bool any_weird = __ballot(mine && (tid & 3) == 3 && (g.x & 0x80000000u) != 0u) != 0ull;
+        Cand<R32> c; R32 g_a; int g_b, g_cc; uint32_t g_w;
+        { R32 t; t.num = wl[0]; t.den = wh[0]; c.q = t; }
+        c.idx = mine ? wh[2] : INT_MAX;
+        g_a.num = wl[1]; g_a.den = wh[1];
+        g_b = wl[2]; g_w = (uint32_t)wh[3]; g_cc = wl[3] & 0x7fffffff;
+        for (int o = 4; o < 64; o <<= 1) {
+            Cand<R32> t; t.q = shfl_xor_s(c.q, o); t.idx = __shfl_xor(c.idx, o);
+            const R32 ta = shfl_xor_s(g_a, o);
+            const int tb = __shfl_xor(g_b, o), tcc = __shfl_xor(g_cc, o); const uint32_t tw = (uint32_t)__shfl_xor((int)g_w, o);
+            const Cand<R32> ng = better(c, t);
+            if (ng.idx != c.idx) { g_a = ta; g_b = tb; g_cc = tcc; g_w = tw; }
+            c = ng;
+        }
+        if (tid == 0) {
+            const int kind = stuck ? -1 : (none ? FREC_NONE : ((c.idx == INT_MAX || any_weird) ? 0 : FREC_CAND));
+            sh_res[0] = ((unsigned long long)(unsigned)c.idx << 32) | (unsigned)kind;
+            sh_res[1] = (unsigned long long)(unsigned)g_b;
+            sh_res[2] = to_bits(g_a);
+            sh_res[3] = ((unsigned long long)g_w << 32) | (unsigned)g_cc;
+        }
     }
     __syncthreads();
-    const unsigned long long flag = sh_flag;
-    if (flag == 0ull) { if (q == 0 && tid == 0) st->status = XPG_ERR_CHAIN_STUCK; return; }
-    if ((int)(flag >> 32) != GO_PIVOT) return;         // the pick wrote the descriptor itself
+    const int kind = (int)(unsigned)sh_res[0], r2 = (int)(unsigned)(sh_res[0] >> 32), leave2 = (int)(unsigned)sh_res[1];
+    const R32 piv = from_bits<R32>(sh_res[2]);
+    if (q == 0 && tid == 0) FUSED_STAMP(st, 4);
+    if (kind == -1) { if (q == 0 && tid == 0) st->status = XPG_ERR_CHAIN_STUCK; return; }
+    if (kind == FREC_NONE) return;                     // no ratio test in this launch: pick workgroup 0 wrote the descriptor
+    if (kind == 0) {                                   // first pass empty (second pass / disableNV), or candidates that only the
+                                                       // reference's own scan order decides: the generic pick of the next generic point
+        if (q == 0 && tid == 0) {
+            write_desc(O, -1, 0, 0, first, anypos, 0, enter2, 0, done_now, total_now, 0ull, 0ull);
+            O.side = side ^ 1; O.staged = 0; st->r32_side = side ^ 1;
+        }
+        return;
+    }
     __builtin_amdgcn_s_setprio(3);
-    const unsigned long long rl = go_load(go + GO_ROWLEAVE);
-    const int r2 = (int)(unsigned)(rl >> 32), leave2 = (int)(unsigned)rl, enter2 = first;
-    const R32 piv = from_bits<R32>(go_load(go + GO_PIV)), cnv = from_bits<R32>(go_load(go + GO_CNV));
+    if (q == 0 && tid == 0) {                          // genPair, lpsol.h:100-104
+        const uint32_t g_w = (uint32_t)(sh_res[3] >> 32); const int g_cc = (int)(unsigned)sh_res[3];
+        if (!((g_w >> (leave2 & 31)) & 1u)) {
+            v.ppt[(size_t)enter2 * v.pw + (leave2 >> 5)] = g_w | (1u << (leave2 & 31));
+            v.rowcnt[enter2] = v.rowcnt[enter2] + 1; v.colcnt[leave2] = g_cc + 1;
+        }
+    }
+    unsigned long long * go = go_block(v, slot);
     const R32 s = div(one<R32>(), piv);                        // 1/(eq.get(eqnum, nv)), lpsol.h:1471
     const int smode = scale_mode(s), cmode = scale_mode(cnv);
     const R32 kr = v.colbuf[(size_t)slot * colstride + r2];
@@ -266,6 +304,7 @@ __device__ inline void fused_stage_r32(const LpView<R32> & v, int slot, int cols
         if (j < rhs && nv_next && gt(o, zero<R32>())) { any = 1; if (rcj < lim) nf = j; }
     }
     for (int o = 32; o > 0; o >>= 1) { nf = min(nf, __shfl_xor(nf, o)); any |= __shfl_xor(any, o); }
+    // the look-ahead accumulators rest at (INT_MAX, 0) between launches: only atomics touch them
     if ((tid & 63) == 0) {
         if (nf != INT_MAX) __hip_atomic_fetch_min(go + GO_NF, (unsigned long long)(unsigned)nf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (any) __hip_atomic_fetch_or(go + GO_ANY, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -273,13 +312,15 @@ __device__ inline void fused_stage_r32(const LpView<R32> & v, int slot, int cols
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid != 0) return;
+    if (q == 0) FUSED_STAMP(st, 5);
     const unsigned long long arrived = __hip_atomic_fetch_add(go + GO_ARRIVED, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (arrived != (unsigned long long)(NP - 1)) return;
-    go_store(go + GO_ARRIVED, 0ull);
     const int nfirst = (int)(unsigned)go_load(go + GO_NF), anyp = (int)go_load(go + GO_ANY);
+    go_store(go + GO_ARRIVED, 0ull); go_store(go + GO_NF, (unsigned long long)(unsigned)INT_MAX); go_store(go + GO_ANY, 0ull);
     // (zero_upto = 0: the deferred zeroing of the objective row is already in the staged row)
     write_desc(O, r2, enter2, leave2, nfirst, anyp, 0, enter2, 0, done_now + 1, total_now + 1, to_bits(cnv), to_bits(piv));
     O.side = side ^ 1; O.staged = 1; st->r32_side = side ^ 1;
+    FUSED_STAMP(st, 6);
 }
 
 // Grid (max(m, N + NP), 1 + column blocks): rows are the fast index (every column block spread over the 8 XCDs);
@@ -297,9 +338,9 @@ void k_pipe_fused_r32(LpView<R32> v, int slot, int colstride, int N, int NP)
         const int x = blockIdx.x;
         if (x < N) {
             __builtin_amdgcn_s_setprio(3);
-            fused_pick_r32(v, slot, colstride, x, N, NP, A, B);
+            fused_pick_r32(v, slot, colstride, x, N, A, B);
         } else if (x < N + NP) {
-            fused_stage_r32(v, slot, colstride, x - N, NP, A);
+            fused_stage_r32(v, slot, colstride, x - N, N, NP, A);
         }
         return;
     }
@@ -318,6 +359,28 @@ void k_pipe_fused_r32(LpView<R32> v, int slot, int colstride, int N, int NP)
     if (canon && e.num == 0) { B[off] = a; return; }          // a + k * 0 = a exactly: copied, not computed
     const R32 k = v.colbuf[(size_t)slot * colstride + i];
     B[off] = l_fma(canon, a, k, e);
+}
+
+// The first launch of a generic point: one workgroup of 1024 threads (the generic pick is a latency chain of strided
+// gathers and per-row quotients: four rows per thread cost 25 us at 1024 rows with 256 threads). An idle descriptor gets
+// its pivot in place, a deferred final status is promoted; k_pipe_prep<R32>(fused = 2) behind it stages what was chosen.
+__global__ __launch_bounds__(1024) void k_fused_generic(LpView<R32> v, int slot, int colstride)
+{
+    LoopState * st = v.st;
+    PipeDesc & D = st->pd[slot];
+    const int status = st->status, stop = D.stop, r = D.row, zu = D.zero_upto, side = D.side;
+    if (status != ST_RUNNING) return;
+    if (stop != 0) {
+        for (int j = threadIdx.x; j < zu; j += blockDim.x)
+            if (!v.nv[j]) v.obj[j] = zero<R32>();              // lpsol.h:1055-1060, deferred by the pick
+        __syncthreads();
+        if (threadIdx.x == 0) st->status = stop;
+        return;
+    }
+    if (r >= 0) return;
+    LpView<R32> w = v;
+    w.tab = side ? v.tab2 : v.tab;
+    prep_idle<R32>(w, slot, colstride, true);
 }
 
 // After the last fused launch of a call: side 0 is what everything else reads.

@@ -99,10 +99,12 @@ template <class S> inline void launch_side_home(xpg_ctx *, const LpView<S> &) {}
 template <> inline void launch_fused<R32>(xpg_ctx * ctx, const LpView<R32> & v, int slot, int colstride, bool generic)
 {
     const int NP = (v.W + 255) / 256;
-    if (generic)
-        for (int k = 1; k <= 2; k++) hipLaunchKernelGGL((k_pipe_prep<R32>), dim3(NP), dim3(256), 0, ctx->stream, v, slot, colstride, k);
+    if (generic) {
+        hipLaunchKernelGGL(k_fused_generic, dim3(1), dim3(1024), 0, ctx->stream, v, slot, colstride);
+        hipLaunchKernelGGL((k_pipe_prep<R32>), dim3(NP), dim3(256), 0, ctx->stream, v, slot, colstride, 2);
+    }
     const bool timed = prof_open(ctx);
-    const int N = (v.m + 255) / 256 < PICK_MAX_WGS ? (v.m + 255) / 256 : PICK_MAX_WGS;
+    const int N = (v.m + 63) / 64 < PICK_MAX_WGS ? (v.m + 63) / 64 : PICK_MAX_WGS;     // one-wave pick workgroups
     hipLaunchKernelGGL(k_pipe_fused_r32, dim3(v.m > N + NP ? v.m : N + NP, 1 + NP), dim3(256), 0, ctx->stream, v, slot, colstride, N, NP);
     if (timed) prof_close(ctx);
 }
@@ -360,6 +362,9 @@ template <class S> struct Lp : LpBase {
     {
         XPG_HIP(ctx, hipMemcpyAsync(out, v.st, sizeof(LoopState), hipMemcpyDeviceToHost, ctx->stream));
         XPG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        // fused Rational loop: side 1 of the ping-pong tableau is the current one -- copied onto side 0, which everything
+        // outside that loop reads (stream-ordered before whatever the caller does next; both copies are then current)
+        if (v.tab2 && out->r32_side) launch_side_home<S>(ctx, v);
         if (out->r32_idle - fused_idle_seen >= 8u) fused_idles_often = true;
         fused_idle_seen = out->r32_idle;
         closes_often = out->blk.sweeps_part >= 8 && out->blk.sweeps_part * 20u >= out->blk.sweeps_full + out->blk.sweeps_part;
@@ -418,11 +423,11 @@ template <class S> struct Lp : LpBase {
         // (the rational scalar: XPG_R32_LOOP=serial keeps the three-launch loop, =pipe the two-launch one, for A/B runs)
         static const bool r32_serial = [] { const char * s = getenv("XPG_R32_LOOP"); return s && !strcmp(s, "serial"); }();
         static const bool r32_pipe = [] { const char * s = getenv("XPG_R32_LOOP"); return s && !strcmp(s, "pipe"); }();
-        static const unsigned generic_every = [] { const char * s = getenv("XPG_R32_GENERIC_EVERY"); const int n = s ? atoi(s) : 0; return (unsigned)(n > 0 ? n : 8); }();
+        static const unsigned generic_every = [] { const char * s = getenv("XPG_R32_GENERIC_EVERY"); const int n = s ? atoi(s) : 0; return (unsigned)(n > 0 ? n : 16); }();
         const bool pipelined = ctx->loop_mode != 1 && (std::is_same<S, F64>::value || !r32_serial);
         if (pipelined && !std::is_same<S, F64>::value && !r32_pipe && k > 0 && fused_buffers()) {
             // one launch per pivot (lp_fused_r32.hip.h); the first launch of a call and every generic_every-th one are
-            // preceded by a generic point, the last is followed by the copy back onto side 0
+            // preceded by a generic point
             for (unsigned t = 0; t < k; t++) {
                 const int slot = (int)(pipe_t++ & 1u);
                 launch_fused<S>(ctx, v, slot, colstride, fused_idles_often || t % generic_every == 0);
@@ -433,8 +438,7 @@ template <class S> struct Lp : LpBase {
                     blk++;
                 }
             }
-            launch_side_home<S>(ctx, v);
-            return;
+            return;                                     // (read_state, which follows every call, brings the tableau home)
         }
         if (pipelined && k > 0 && !pipe_primed) {
             // the first pivot is chosen by a launch that has nothing to sweep (pd[1].row < 0): fp64 the sweep launch's

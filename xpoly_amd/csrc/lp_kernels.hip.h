@@ -133,10 +133,11 @@ enum { NF_UNKNOWN = -2 };
 typedef LoopState::PipeDesc PipeDesc;
 // LpView::pickrec layout (8-byte words): PICK_MAX_WGS records of PICK_REC_WORDS, then one arrival
 // counter per descriptor slot, each on a 128-byte line of its own; the fused Rational loop adds one hand-over block of
-// PICK_GO_WORDS per slot (GO_*: flag, the chosen pivot, the look-ahead accumulators, the stagers' arrival counter).
+// PICK_GO_WORDS per slot (GO_*: the look-ahead accumulators, the stagers' arrival counter) and the pick workgroups'
+// records as tagged granules (PICK_FREC_*).
 enum { PICK_MAX_WGS = 16, PICK_REC_WORDS = 4, PICK_CTR_OFF = 128, PICK_GO_OFF = PICK_CTR_OFF + 32, PICK_GO_WORDS = 32,
-       PICK_WORDS = PICK_GO_OFF + 2 * PICK_GO_WORDS };
-enum { GO_FLAG = 0, GO_ROWLEAVE = 1, GO_PIV = 2, GO_CNV = 3, GO_NF = 16, GO_ANY = 17, GO_ARRIVED = 18 };
+       PICK_FREC_OFF = PICK_GO_OFF + 2 * PICK_GO_WORDS, PICK_FREC_WORDS = 8, PICK_WORDS = PICK_FREC_OFF + PICK_MAX_WGS * PICK_FREC_WORDS };
+enum { GO_NF = 16, GO_ANY = 17, GO_ARRIVED = 18 };
 
 template <class S> struct LpView {
     S * tab; int m, W, ld, rhs;
@@ -1343,7 +1344,11 @@ template <class S> __global__ void k_reset_loop(LpView<S> v, unsigned max_iter, 
         st->blk.ch0_ticket = 0u; st->blk.ch0_la_epoch = 0u; st->blk.ch0_budget = 0u; st->blk.ch0_done = 0u; st->blk.ch0_tp = 0u; st->blk.ch_folds = 0u;
         for (int k = 0; k < 8; k++) st->blk.dbg[k] = 0ull;
         for (int k = 0; k < 2; k++) v.pickrec[PICK_CTR_OFF + 16 * k] = 0ull;   // arrival counters
-        for (int k = 0; k < 2; k++) { v.pickrec[PICK_GO_OFF + PICK_GO_WORDS * k + GO_ARRIVED] = 0ull; v.pickrec[PICK_GO_OFF + PICK_GO_WORDS * k + GO_FLAG] = 0ull; }
+        for (int k = 0; k < 2; k++) {
+            unsigned long long * go = v.pickrec + PICK_GO_OFF + PICK_GO_WORDS * k;
+            go[GO_ARRIVED] = 0ull; go[GO_NF] = (unsigned long long)(unsigned)INT_MAX; go[GO_ANY] = 0ull;
+        }
+        for (int k = 0; k < PICK_MAX_WGS * PICK_FREC_WORDS; k++) v.pickrec[PICK_FREC_OFF + k] = 0ull;
         for (int k = 0; k < 2; k++) {                  // pipelined loop: iteration 0 has no pivot yet
             PipeDesc & D = st->pd[k];
             D.row = -1; D.col = 0; D.leave = 0; D.next_first = NF_UNKNOWN; D.anypos = 0; D.stop = 0;

@@ -46,10 +46,10 @@ template <> __device__ inline void prep_idle<R32>(const LpView<R32> & v, int slo
     const int izero = I.zero_upto, cached_col = I.cached_col;
     const bool b_was_cached = I.bcol_valid != 0;
     if (inplace) __syncthreads();                  // every thread holds its copy of the descriptor before it is rewritten
-    for (int j = tid; j < izero; j += 256)
+    for (int j = tid; j < izero; j += (int)blockDim.x)
         if (!v.nv[j]) v.obj[j] = zero<R32>();                              // deferred lpsol.h:1055-1060
     if (!b_was_cached)
-        for (int i = tid; i < m; i += 256) bcol[i] = tab[(size_t)i * ld + rhs];
+        for (int i = tid; i < m; i += (int)blockDim.x) bcol[i] = tab[(size_t)i * ld + rhs];
     if (tid == 0) {
         write_desc(O, -1, 0, 0, INT_MAX, 0, 0, cached_col, 0, done_now, total_now, 0ull, 0ull);
         O.staged = 0;

@@ -502,9 +502,9 @@ int xpg_lp_chain_aborts(xpg_lp * lp, unsigned * aborts, int * chain_off, unsigne
 // diagnostic builds only (not declared in the header): the phase tick sums of the blocked loop
 int xpg_lp_debug(xpg_lp * lp, unsigned long long * out8)
 {
-    if (!lp || !lp->impl || lp->impl->kind != 0) return XPG_ERR_SHAPE;
+    if (!lp || !lp->impl) return XPG_ERR_SHAPE;
     LoopState hs;
-    int rc = ((Lp<F64> *)lp->impl)->read_state(&hs);
+    int rc = lp->impl->kind == 0 ? ((Lp<F64> *)lp->impl)->read_state(&hs) : ((Lp<R32> *)lp->impl)->read_state(&hs);
     if (rc) return rc;
     for (int k = 0; k < 8; k++) out8[k] = hs.blk.dbg[k];
     return 0;
