@@ -167,11 +167,7 @@ __device__ inline void fused_pick_r32(const LpView<R32> & v, int slot, int colst
         best = nbest;
     }
     if (p == 0 && tid == 0) FUSED_STAMP(st, 1);
-    Cand<R32> wbest = best;
-    for (int o = 32; o > 0; o >>= 1) {
-        Cand<R32> t; t.q = shfl_xor_s(wbest.q, o); t.idx = __shfl_xor(wbest.idx, o);
-        wbest = better(wbest, t);
-    }
+    const Cand<R32> wbest = wave_argmin(best);                                 // four DPP steps, no LDS
     const bool wg_weird = __ballot(weird) != 0ull;
     // one lane publishes this workgroup's record: the owner of the winning row, else lane 0
     const bool publisher = wbest.idx != INT_MAX ? (best.idx == wbest.idx) : (tid == 0);
@@ -355,10 +351,17 @@ void k_pipe_fused_r32(LpView<R32> v, int slot, int colstride, int N, int NP)
     const R32 e = v.stage[(size_t)slot * v.ld + j];
     const size_t off = (size_t)i * v.ld + j;
     const R32 a = A[off];
-    if (i == r) { B[off] = e; return; }                       // the pivot row := e
-    if (canon && e.num == 0) { B[off] = a; return; }          // a + k * 0 = a exactly: copied, not computed
-    const R32 k = v.colbuf[(size_t)slot * colstride + i];
-    B[off] = l_fma(canon, a, k, e);
+    // (the written side is not read again in this launch: streamed out, so that the launch does not end on the write-back
+    // of 16 MB of dirty L2 lines -- XPG_FUSED_PLAIN_STORES builds keep the plain store for A/B runs)
+    R32 o;
+    if (i == r) o = e;                                        // the pivot row := e
+    else if (canon && e.num == 0) o = a;                      // a + k * 0 = a exactly: copied, not computed
+    else o = l_fma(canon, a, v.colbuf[(size_t)slot * colstride + i], e);
+#ifdef XPG_FUSED_PLAIN_STORES
+    B[off] = o;
+#else
+    __builtin_nontemporal_store(to_bits(o), (unsigned long long *)(B + off));
+#endif
 }
 
 // The first launch of a generic point: one workgroup of 1024 threads (the generic pick is a latency chain of strided

@@ -230,6 +230,7 @@ template <class S> struct Lp : LpBase {
     unsigned pipe_t = 0;    // pipelined loop: iteration counter since reset_loop (slot = pipe_t & 1)
     bool irregular = false, irregular_known = false;   // fp64: the input held an inf / NaN (read back once per build)
     bool pipe_primed = false;
+    LoopState * h_state = nullptr;    // pinned mirror for read_state
     bool fused_unavailable = false;   // fused Rational loop: its buffers could not be allocated
     bool fused_idles_often = false;   // ... this solve defers decisions often: a generic point before every launch
     unsigned fused_idle_seen = 0;
@@ -269,6 +270,7 @@ template <class S> struct Lp : LpBase {
     ~Lp()
     {
         for (void * p : owned) (void)hipFree(p);
+        if (h_state) (void)hipHostFree(h_state);
         for (hipEvent_t e : throttle) if (e) (void)hipEventDestroy(e);
     }
 
@@ -360,8 +362,11 @@ template <class S> struct Lp : LpBase {
 
     int read_state(LoopState * out)
     {
-        XPG_HIP(ctx, hipMemcpyAsync(out, v.st, sizeof(LoopState), hipMemcpyDeviceToHost, ctx->stream));
+        // (through a pinned mirror: a copy into pageable memory is staged by the runtime, ~10 us more per status read)
+        if (!h_state && hipHostMalloc((void **)&h_state, sizeof(LoopState)) != hipSuccess) { h_state = nullptr; (void)hipGetLastError(); }
+        XPG_HIP(ctx, hipMemcpyAsync(h_state ? h_state : out, v.st, sizeof(LoopState), hipMemcpyDeviceToHost, ctx->stream));
         XPG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (h_state) *out = *h_state;
         // fused Rational loop: side 1 of the ping-pong tableau is the current one -- copied onto side 0, which everything
         // outside that loop reads (stream-ordered before whatever the caller does next; both copies are then current)
         if (v.tab2 && out->r32_side) launch_side_home<S>(ctx, v);
