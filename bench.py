@@ -53,7 +53,7 @@ PREWARM_SECONDS = 0.5
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "round4_pmc_hbm_traffic_4096x8192.json")
 PMC_SUMMARY_2B = os.path.join(ROOT, "profiles", "round4_pmc_hbm_traffic_4096x12289.json")
 PMC_BATCH = os.path.join(ROOT, "profiles", "round3_pmc_batch_issue.json")
-PMC_RATIONAL = os.path.join(ROOT, "profiles", "round3_pmc_rational_issue.json")
+PMC_RATIONAL = os.path.join(ROOT, "profiles", "round4_pmc_rational_issue.json")
 LEGS = ("pivots", "batched", "sharded", "cfg2b", "rational", "mip", "lineq")
 LINEQ_NB = 16384                           # systems per row-elimination launch (the dependence tests' shapes)
 
@@ -796,15 +796,15 @@ def leg_rational(ctx, xpoly_amd, gen):
     alg = 2 * RAT_M * W * 8
     issue = None
     if os.path.exists(PMC_RATIONAL):                     # committed counter summary of the same leg (tools/lab/run_rat_pmc.sh)
-        k = json.load(open(PMC_RATIONAL))["kernels"].get("k_pipe_sweep_r32")
+        k = json.load(open(PMC_RATIONAL))["kernels"].get("k_pipe_fused_r32")
         if k:
-            issue = dict(kernel="k_pipe_sweep_r32", valu_wave_instructions_per_launch=round(k["SQ_INSTS_VALU"]),
+            issue = dict(kernel="k_pipe_fused_r32", valu_wave_instructions_per_launch=round(k["SQ_INSTS_VALU"]),
                          active_lanes_per_valu_instruction=k.get("active_lanes_per_valu_instruction"),
                          valu_active_us_at_2p4ghz=round(k["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / 2400.0, 2),
-                         source="profiles/round3_pmc_rational_issue.json (rocprofv3 --pmc SQ_* on bench.py --legs rational)")
+                         source="profiles/round4_pmc_rational_issue.json (rocprofv3 --pmc SQ_* on bench.py --legs rational)")
     return dict(metric="exact rational simplex pivots/sec (tableau 1024x2048, K=16)", value=round(RAT_K / best, 1),
                 unit="pivots/s", us_per_pivot=round(best / RAT_K * 1e6, 2), tableau=[RAT_M, W], dtype="int32 num/den",
-                bound="integer issue (gcd / appro per cell; pipelined loop: prep launch + sweep launch with the next pick inside), not HBM",
+                bound="integer issue (gcd / appro per cell) in the late pivots, the pick -> staging latency chain inside the launch in the early ones (fused loop: one launch per pivot sweeps, picks the next pivot and stages it); not HBM",
                 algorithmic_bytes_per_pivot=alg, achieved_gbs=round(alg * RAT_K / best / 1e9, 1),
                 hbm_frac=round(alg * RAT_K / best / 1e9 / HBM_PEAK_GBS, 4), issue_rate=issue,
                 self_check="tableau 1024x2048 (CRC-32 + sum + xor of all (num, den) cells), objective row, basis after the last run's 16 pivots = "

@@ -1,8 +1,8 @@
 # issue / stall counters of the rational loop's kernels (bench.py --legs rational: 6 solves x 16 pivots) ->
-# gpurun_out/r3rat/pmc_rational_issue.json (copied to profiles/round3_pmc_rational_issue.json)
+# gpurun_out/r4rat/pmc_rational_issue.json (copied to profiles/round4_pmc_rational_issue.json)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r3rat
+O=$R/gpurun_out/r4rat
 rm -rf $O; mkdir -p $O
 for g in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU" "SQ_INSTS_SALU SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
   n=$(echo $g | tr ' ' '_' | cut -c1-40)
@@ -15,7 +15,7 @@ acc = collections.defaultdict(lambda: [0, 0.0])
 for f in glob.glob(os.path.join(O, "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"].split("(")[0].replace("void xpg::", "").replace("xpg::", "")
-        if not any(s in k for s in ("k_pipe_sweep_r32", "k_pipe_prep", "k_update_r32", "k_pick", "k_prep")): continue
+        if not any(s in k for s in ("k_pipe_fused_r32", "k_fused_generic", "k_pipe_sweep_r32", "k_pipe_prep", "k_update_r32", "k_pick", "k_prep")): continue
         a = acc[(k, row["Counter_Name"])]; a[0] += 1; a[1] += float(row["Counter_Value"])
 per = collections.defaultdict(dict)
 for (k, c), (n, s) in acc.items(): per[k][c] = s / n; per[k]["launches"] = n
