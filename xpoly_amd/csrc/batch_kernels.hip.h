@@ -576,32 +576,48 @@ template <class S> __device__ __noinline__ FastLoopRet sm_fast_loop_32x97x256(__
 
 // SIX::solveSlackForm (lpsol.h:1008-1191) incl. is_feasible (lpsol.h:784-822,
 // vc = "-x_i <= 0" for every variable). Returns a SIX_* status; maxv on success.
-template <class S> __device__ __forceinline__ int sm_solve(Small<S> & P, unsigned max_iter, S & maxv)
+// Time slices (k_batch): with slice != SM_NO_SLICE the loop hands back SM_SUSPEND at its top once `slice` more iterations
+// are done -- everything it needs to go on is then in the LDS arrays and in (done_io, P.pivots, P.closes): the pricing
+// scan at the top of the loop (and of the pivot loop, which is told to stop there: no look-ahead after its last pivot)
+// starts from the tableau alone. resume: re-entered after such a hand-back (the pair table and counters are the LP's).
+enum { SM_SUSPEND = -100 };
+#define SM_NO_SLICE 0xFFFFFFFFu
+template <class S> __device__ __forceinline__ int sm_solve(Small<S> & P, unsigned max_iter, S & maxv, unsigned & done_io, unsigned slice, bool resume)
 {
     const int rhs = P.rhs, lim = rhs - 1;
-    for (int i = threadIdx.x; i < rhs; i += blockDim.x) { P.rowcnt[i] = 0; P.colcnt[i] = 0; }
-    for (int t = threadIdx.x; t < rhs * P.pw; t += blockDim.x) P.ppt[t] = 0u;
+    if (!resume) {
+        for (int i = threadIdx.x; i < rhs; i += blockDim.x) { P.rowcnt[i] = 0; P.colcnt[i] = 0; }
+        for (int t = threadIdx.x; t < rhs * P.pw; t += blockDim.x) P.ppt[t] = 0u;
+    }
     maxv = zero<S>();
     __syncthreads();
-    unsigned done = 0;
+    unsigned done = resume ? done_io : 0u;
     const bool fast = rhs <= 128 && P.R <= 64;
     const bool overlapped = fast && rhs <= 127 && blockDim.x >= 128;
+    const bool sliced = slice != SM_NO_SLICE && overlapped;
+    const unsigned stop_at = sliced && max_iter - done > slice ? done + slice : max_iter;
     bool preselected = false;                                   // the generic code below has staged a pivot in sh_w
     while (done < max_iter) {
+        if (sliced && !preselected && done >= stop_at) { done_io = done; return SM_SUSPEND; }
         if (overlapped) {
             int action;
             // the specialised loop re-derives every array from the tableau base as sm_carve(32, 63) lays them out: the LDS
             // must really have been carved for 32 rows (a MIP node with 32 live rows in a block carved for rmax = 60 has
             // R == 32 and ld == 97 too, and its objective row sits 60 rows behind the base, not 32)
             const bool carved_32x63 = (const unsigned char *)P.obj - (const unsigned char *)P.tab == (ptrdiff_t)32 * 97 * 8;
-            if (!is_f64<S>::value || P.R != 32 || P.ld != 97 || blockDim.x != 256 || !carved_32x63) action = sm_fast_loop<S, 0, 0, 0>(P, max_iter, done, preselected);
+            if (!is_f64<S>::value || P.R != 32 || P.ld != 97 || blockDim.x != 256 || !carved_32x63) action = sm_fast_loop<S, 0, 0, 0>(P, stop_at, done, preselected);
             else {
                 const FastLoopRet fr = sm_fast_loop_32x97x256<S>((__attribute__((address_space(3))) unsigned char *)P.tab, P.W, P.rhs, P.cn, P.pivots,
-                                                                 P.closes, max_iter, done, preselected);
+                                                                 P.closes, stop_at, done, preselected);
                 action = fr.action; P.pivots = fr.pivots; P.closes = fr.closes; done = fr.done;
             }
             preselected = false;
-            if (action == ACT_TIMEOUT) return 4;
+            if (action == ACT_TIMEOUT) {
+                if (done >= max_iter) return 4;
+                __syncthreads();
+                done_io = done;                                 // the slice is over (stop_at < max_iter)
+                return SM_SUSPEND;
+            }
             if (action == ACT_UNBOUND) return 1;                // SIX_UNBOUND, lpsol.h:1138-1142
             // rare outcomes fall through to the generic code below, which redoes the (idempotent) pricing scan
             __syncthreads();
@@ -722,6 +738,11 @@ template <class S> __device__ __forceinline__ int sm_solve(Small<S> & P, unsigne
     }
     return 4;
 }
+template <class S> __device__ __forceinline__ int sm_solve(Small<S> & P, unsigned max_iter, S & maxv)
+{
+    unsigned done = 0;
+    return sm_solve<S>(P, max_iter, maxv, done, SM_NO_SLICE, false);
+}
 
 // Source of the slack form: the primal (is_max) or the dual built the way
 // SIX::calcDualMaxm does (lpsol.h:1602-1629) straight from the caller's arrays.
@@ -770,7 +791,9 @@ template <class S> __device__ __forceinline__ void sm_build(Small<S> & P, const 
 // SIX::constructBasicFeasibleSolution (lpsol.h:839-988). Returns 1 when a
 // feasible slack form stands in P, 0 when there is none, -7 where the
 // reference's behaviour is undefined.
-template <class S> __device__ __forceinline__ int sm_phase_one(Small<S> & P, const Source<S> & src, unsigned max_iter)
+// In three parts -- the auxiliary LP with x_a pivoted in, its solve, what follows it -- so that k_batch can run the solve
+// in time slices (sm_solve_lp).
+template <class S> __device__ __forceinline__ void sm_phase_one_pre(Small<S> & P, const Source<S> & src)
 {
     const int V = src.vars(), xa = V;
     sm_build(P, src, 1);
@@ -798,8 +821,11 @@ template <class S> __device__ __forceinline__ int sm_phase_one(Small<S> & P, con
         }
     }
     sm_pivot(P, xa, P.eq2bv[best.idx]);
-    S top;
-    if (sm_solve<S>(P, max_iter, top) != 0) return 0;
+}
+template <class S> __device__ __forceinline__ int sm_phase_one_post(Small<S> & P, const Source<S> & src, int solve_status, S top)
+{
+    const int V = src.vars(), xa = V;
+    if (solve_status != 0) return 0;
     reduce(top);
     if (ne(top, zero<S>())) return 0;
     if (P.bv[xa]) {
@@ -876,6 +902,13 @@ template <class S> __device__ __forceinline__ int sm_phase_one(Small<S> & P, con
     __syncthreads();
     return 1;
 }
+template <class S> __device__ __forceinline__ int sm_phase_one(Small<S> & P, const Source<S> & src, unsigned max_iter)
+{
+    sm_phase_one_pre(P, src);
+    S top;
+    const int st = sm_solve<S>(P, max_iter, top);
+    return sm_phase_one_post(P, src, st, top);
+}
 
 template <class S> __host__ __device__ inline size_t small_lds_bytes(int R, int V)
 {
@@ -927,45 +960,61 @@ template <class S, int CR, int CLD, int CT> __device__ __forceinline__ void sm_c
 // variables + constant), stage 1 included. Returns the SIX status (or XPG_ERR_REF_UNDEFINED). On status 0 the
 // solution goes to sol[0 .. cols) (global; raw_sol: entries not reduced, the caller finishes calcFinalSolution
 // itself) and the objective to *v_out; otherwise *v_out = 0 and sol is left alone.
+// Time slices (k_batch): slice != SM_NO_SLICE lets the two solves -- stage 1's auxiliary LP and the LP's own -- hand the
+// LP back as SM_SUSPEND with (*stage_io, *done_io) saying where; a call with *stage_io != 0 goes on from there (the LDS
+// arrays and P's scalars restored by the caller).
 template <class S> __device__ __forceinline__ int sm_solve_lp(Small<S> & P, Source<S> & src, unsigned max_iter, int raw_sol,
-                                                              S * sol, S * v_out)
+                                                              S * sol, S * v_out, unsigned slice = SM_NO_SLICE, unsigned * done_io = nullptr,
+                                                              int * stage_io = nullptr)
 {
     const int m = src.m, cols = src.cols, is_max = src.is_max, n = cols - 1;
     const int R = is_max ? m : n, V = is_max ? n : m;
-    P.pivots = 0; P.closes = 0;
-    __syncthreads();
-    // stage1 trigger (lpsol.h:1794-1803)
-    if (threadIdx.x == 0) { P.sh_w[3] = 0; P.sh_w[4] = 0; P.sh_w[5] = 0; }
-    __syncthreads();
-    if (!is_f64<S>::value) {                       // one non-canonical input cell sends the LP down the generic forms
-        bool bad = false;
-        for (int t = threadIdx.x; t < m * cols; t += blockDim.x) bad |= !q_canonical(src.leq[t]);
-        for (int t = threadIdx.x; t < cols; t += blockDim.x) bad |= !q_canonical(src.tgtf[t]);
-        if (bad) P.sh_w[5] = 1;
+    const int entry = stage_io ? *stage_io : 0;        // 0: a fresh LP, 1: back in stage 1's solve, 2: back in its own
+    int status = -1, stage = entry;
+    if (entry == 0) {
+        P.pivots = 0; P.closes = 0;
         __syncthreads();
+        // stage1 trigger (lpsol.h:1794-1803)
+        if (threadIdx.x == 0) { P.sh_w[3] = 0; P.sh_w[4] = 0; P.sh_w[5] = 0; }
+        __syncthreads();
+        if (!is_f64<S>::value) {                       // one non-canonical input cell sends the LP down the generic forms
+            bool bad = false;
+            for (int t = threadIdx.x; t < m * cols; t += blockDim.x) bad |= !q_canonical(src.leq[t]);
+            for (int t = threadIdx.x; t < cols; t += blockDim.x) bad |= !q_canonical(src.tgtf[t]);
+            if (bad) P.sh_w[5] = 1;
+            __syncthreads();
+        }
+        P.cn = src.cn = !is_f64<S>::value && P.sh_w[5] == 0;
+        for (int j = threadIdx.x; j < V; j += blockDim.x) if (gt(src.c(j), zero<S>())) P.sh_w[3] = 1;
+        for (int i = threadIdx.x; i < R; i += blockDim.x) if (lt(src.b(i), zero<S>())) P.sh_w[4] = 1;
+        __syncthreads();
+        const bool phase1 = !P.sh_w[3] || P.sh_w[4];
+        __syncthreads();
+        if (phase1) { sm_phase_one_pre(P, src); stage = 1; }
+        else { sm_build(P, src, 0); stage = 2; }
     }
-    P.cn = src.cn = !is_f64<S>::value && P.sh_w[5] == 0;
-    for (int j = threadIdx.x; j < V; j += blockDim.x) if (gt(src.c(j), zero<S>())) P.sh_w[3] = 1;
-    for (int i = threadIdx.x; i < R; i += blockDim.x) if (lt(src.b(i), zero<S>())) P.sh_w[4] = 1;
-    __syncthreads();
-    const bool phase1 = !P.sh_w[3] || P.sh_w[4];
-    __syncthreads();
-    int status = -1;
 #ifdef XPG_STAMPS
     unsigned long long lp_t_ = wall_clock64();
 #endif
-    if (phase1) {
-        const int ok = sm_phase_one<S>(P, src, max_iter);
+    if (stage == 1) {
+        S top1 = zero<S>();
+        unsigned done = entry == 1 ? *done_io : 0u;
+        const int st1 = sm_solve<S>(P, max_iter, top1, done, slice, entry == 1);
+        if (st1 == SM_SUSPEND) { *done_io = done; *stage_io = 1; return SM_SUSPEND; }
+        const int ok = sm_phase_one_post<S>(P, src, st1, top1);
         if (ok == 0) status = 2;
         else if (ok < 0) status = XPG_ERR_REF_UNDEFINED;
-    } else {
-        sm_build(P, src, 0);
-    }
+        stage = 2;
 #ifdef XPG_STAMPS
-    { const unsigned long long n_ = wall_clock64(); if (threadIdx.x == 0) { atomicAdd(&g_lp_ticks[phase1 ? 0 : 1], n_ - lp_t_); atomicAdd(&g_lp_ticks[phase1 ? 4 : 5], 1ull); } lp_t_ = n_; }
+        { const unsigned long long n_ = wall_clock64(); if (threadIdx.x == 0) { atomicAdd(&g_lp_ticks[0], n_ - lp_t_); atomicAdd(&g_lp_ticks[4], 1ull); } lp_t_ = n_; }
 #endif
+    }
     S top = zero<S>();
-    if (status == -1) status = sm_solve<S>(P, max_iter, top);
+    if (status == -1) {
+        unsigned done = entry == 2 ? *done_io : 0u;
+        status = sm_solve<S>(P, max_iter, top, done, slice, entry == 2);
+        if (status == SM_SUSPEND) { *done_io = done; *stage_io = 2; return SM_SUSPEND; }
+    }
 #ifdef XPG_STAMPS
     { const unsigned long long n_ = wall_clock64(); if (threadIdx.x == 0) { atomicAdd(&g_lp_ticks[2], n_ - lp_t_); atomicAdd(&g_lp_ticks[3], (unsigned long long)P.pivots); } }
 #endif
@@ -997,28 +1046,119 @@ template <class S> __device__ __forceinline__ int sm_solve_lp(Small<S> & P, Sour
 // LDS (the 32 x 64 LPs of BASELINE configs[2]: 30 KB each): 96 registers and 336 bytes of scratch instead of 128 and 208,
 // and the fifth LP more than pays for the spills (8192 LPs: 92.9 k -> 98.3 k dependence-test, 252.9 k -> 286.4 k dense
 // LPs/s) -- the pivot is a latency chain, and what a CU lacks is LPs in flight. Four where LDS seats fewer anyway.
+// Time slices (BatchSlices::slice != SM_NO_SLICE): an LP whose own solve has run `slice` iterations gives its LDS slot
+// back -- the whole LDS block and seven words go to HBM, its index into a queue -- and CONTINUATION workgroups (the last
+// ncont of the grid: dispatched once every LP has had its first turn, resident until all LPs are done) take queued LPs
+// in turn, a slice at a time. Lengths of LPs are not known in advance and a launch ends with its longest LPs; taking
+// turns, all long LPs advance together and end together, so the launch lasts about (total pivots) / (slots x rate)
+// instead of (rounds of long LPs) x (longest LP): 8192 dense 32 x 63 LPs hold 1841 LPs of > 5000 pivots for 1280 slots --
+// two rounds of 12 ms with 40 % of the chip idle in the second. Results are the same bit for bit (sm_solve).
+// Queue: a ring of (ticket + 1) << 32 | (lp + 1) words; a pusher takes a ticket from ctl[0] and waits for its slot to be
+// empty, a popper takes one from ctl[1] and waits for that ticket's word (or for ctl[2] == nb: every LP is done).
+struct BatchSlices {
+    unsigned slice; int nmain; unsigned char * ckpt; unsigned long long stride; unsigned long long * queue; unsigned qmask; unsigned * ctl;
+};
+enum { CK_HEADER = 64 };
+template <class S> __device__ __forceinline__ void sm_checkpoint(const Small<S> & P, const unsigned char * lds, size_t lds_bytes, unsigned char * ck, unsigned done, int stage)
+{
+    const uint4 * src = (const uint4 *)lds;
+    uint4 * dst = (uint4 *)(ck + CK_HEADER);
+    for (size_t t = threadIdx.x; t < lds_bytes / 16; t += blockDim.x) dst[t] = src[t];
+    if (threadIdx.x == 0) {
+        unsigned * h = (unsigned *)ck;
+        h[0] = done; h[1] = P.pivots; h[2] = P.closes; h[3] = (unsigned)P.R; h[4] = (unsigned)P.W; h[5] = (unsigned)P.rhs; h[6] = P.cn ? 1u : 0u; h[7] = (unsigned)stage;
+    }
+    __threadfence();                                   // every wave releases its own stores (the pusher's atomic follows the barrier)
+    __syncthreads();
+}
+template <class S> __device__ __forceinline__ unsigned sm_restore(Small<S> & P, unsigned char * lds, size_t lds_bytes, const unsigned char * ck, int & stage)
+{
+    __threadfence();                                   // acquire: the checkpoint was written by another workgroup of this launch
+    const uint4 * src = (const uint4 *)(ck + CK_HEADER);
+    uint4 * dst = (uint4 *)lds;
+    for (size_t t = threadIdx.x; t < lds_bytes / 16; t += blockDim.x) dst[t] = src[t];
+    const unsigned * h = (const unsigned *)ck;
+    P.pivots = h[1]; P.closes = h[2]; P.R = (int)h[3]; P.W = (int)h[4]; P.rhs = (int)h[5]; P.cn = h[6] != 0u;
+    const unsigned done = h[0];
+    stage = (int)h[7];
+    __syncthreads();
+    return done;
+}
+__device__ __forceinline__ void slices_push(const BatchSlices & Q, int lp)
+{
+    const unsigned t = atomicAdd(&Q.ctl[0], 1u);
+    unsigned long long * e = Q.queue + (t & Q.qmask);
+    while (__hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) __builtin_amdgcn_s_sleep(8);
+    __hip_atomic_store(e, ((unsigned long long)(t + 1u) << 32) | (unsigned)(lp + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// -1: every LP of the launch is done
+__device__ __forceinline__ int slices_pop(const BatchSlices & Q, int nb)
+{
+    const unsigned t = atomicAdd(&Q.ctl[1], 1u);
+    unsigned long long * e = Q.queue + (t & Q.qmask);
+    for (;;) {
+        const unsigned long long w = __hip_atomic_load(e, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(w >> 32) == t + 1u) {
+            __hip_atomic_store(e, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return (int)(unsigned)w - 1;
+        }
+        if (__hip_atomic_load(&Q.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)nb) return -1;
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+
+// WAVES: waves per SIMD the kernel's registers allow = workgroups of 256 threads per CU. Five where five LPs fit a CU's
+// LDS (the 32 x 64 LPs of BASELINE configs[2]: 30 KB each): 96 registers and 336 bytes of scratch instead of 128 and 208,
+// and the fifth LP more than pays for the spills (8192 LPs: 92.9 k -> 98.3 k dependence-test, 252.9 k -> 286.4 k dense
+// LPs/s) -- the pivot is a latency chain, and what a CU lacks is LPs in flight. Four where LDS seats fewer anyway.
 template <class S, int WAVES> __global__ __launch_bounds__(256, WAVES) void k_batch(int nb, const S * tgtf, const S * leq, int m, int cols,
                                            int is_max, unsigned max_iter, int32_t * out_status,
-                                           S * out_v, S * out_sol, uint32_t * out_pivots, int raw_sol)
+                                           S * out_v, S * out_sol, uint32_t * out_pivots, int raw_sol, BatchSlices Q)
 {
     const bool getenv_closes = (raw_sol & 2) != 0;     // profiling: report disableNV iterations instead
     raw_sol &= 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    __shared__ int sh_next;
     const int n = cols - 1;
     Small<S> P;
-    sm_carve(P, lds, is_max ? m : n, is_max ? n : m);
-    for (int lp = blockIdx.x; lp < nb; lp += gridDim.x) {
+    const int R0 = is_max ? m : n, V0 = is_max ? n : m;
+    sm_carve(P, lds, R0, V0);
+    const bool slicing = Q.slice != SM_NO_SLICE;
+    const size_t lds_bytes = small_lds_bytes<S>(R0, V0);
+    const int nmain = slicing ? Q.nmain : (int)gridDim.x;
+    const bool cont = (int)blockIdx.x >= nmain;
+    int lp = cont ? -1 : (int)blockIdx.x;
+    for (;;) {
+        bool resume = false;
+        if (cont) {
+            __syncthreads();                           // (everybody is through with the LDS block and sh_next)
+            if (threadIdx.x == 0) sh_next = slices_pop(Q, nb);
+            __syncthreads();
+            lp = sh_next;
+            if (lp < 0) break;
+            resume = true;
+        } else if (lp >= nb) break;
         Source<S> src;
         src.leq = leq + (size_t)lp * m * cols; src.tgtf = tgtf + (size_t)lp * cols;
         src.m = m; src.cols = cols; src.is_max = is_max;
-        LIFE_MARK(lp, 0);
-        const int status = sm_solve_lp<S>(P, src, max_iter, raw_sol, out_sol + (size_t)lp * cols, out_v + lp);
-        LIFE_END(lp);
-        if (threadIdx.x == 0) {
-            out_status[lp] = status;
-            if (out_pivots) out_pivots[lp] = getenv_closes ? P.closes : P.pivots;
+        unsigned done = 0;
+        int stage = 0;
+        if (resume) { done = sm_restore(P, lds, lds_bytes, Q.ckpt + (size_t)lp * Q.stride, stage); src.cn = P.cn; }
+        else LIFE_MARK(lp, 0);
+        const int status = sm_solve_lp<S>(P, src, max_iter, raw_sol, out_sol + (size_t)lp * cols, out_v + lp, Q.slice, &done, &stage);
+        if (status == SM_SUSPEND) {
+            sm_checkpoint(P, lds, lds_bytes, Q.ckpt + (size_t)lp * Q.stride, done, stage);
+            if (threadIdx.x == 0) slices_push(Q, lp);
+        } else {
+            LIFE_END(lp);
+            if (threadIdx.x == 0) {
+                out_status[lp] = status;
+                if (out_pivots) out_pivots[lp] = getenv_closes ? P.closes : P.pivots;
+                if (slicing) { __threadfence(); atomicAdd(&Q.ctl[2], 1u); }
+            }
         }
         __syncthreads();
+        if (!cont) lp += nmain;
     }
 }
 
@@ -1095,14 +1235,41 @@ int batch_dev(xpg_ctx * ctx, int is_max, int nb, const S * tgtf, const S * leq, 
     if (const char * g = getenv("XPG_BATCH_GRID_X")) { const int v = atoi(g); if (v >= 1) grid = 256 * (per_cu > 16 ? 16 : per_cu) * v; }
     if (grid > nb) grid = nb;
     static const int waves_env = [] { const char * e = getenv("XPG_BATCH_WAVES"); return e ? atoi(e) : 0; }();   // A/B: 4 or 5
-    if ((per_cu >= 5 && waves_env != 4) || waves_env == 5) {
+    const bool five = (per_cu >= 5 && waves_env != 4) || waves_env == 5;
+    // Time slices (k_batch): where the pivot loop can hand an LP back (sm_solve's `overlapped` shapes) and the launch holds
+    // more LPs than the chip seats at once, so that LPs wait for slots at all. XPG_BATCH_SLICE=0 turns them off, =n sets
+    // the slice (iterations of the LP's own solve per turn).
+    static const unsigned slice_env = [] { const char * e = getenv("XPG_BATCH_SLICE"); return e ? (unsigned)atoi(e) : 512u; }();
+    BatchSlices Q;
+    Q.slice = SM_NO_SLICE; Q.nmain = grid; Q.ckpt = nullptr; Q.stride = 0; Q.queue = nullptr; Q.qmask = 0; Q.ctl = nullptr;
+    const int seats = ctx->num_cus * (five ? (per_cu < 5 ? per_cu : 5) : (per_cu < 4 ? per_cu : 4));
+    static const bool slice_force = [] { const char * e = getenv("XPG_BATCH_SLICE_FORCE"); return e && e[0] == '1'; }();   // tests: also when every LP has a seat
+    if (slice_env != 0u && threads >= 128 && R <= 64 && R + V <= 127 && (nb > seats + seats / 4 || slice_force) && grid == nb) {
+        const size_t stride = (CK_HEADER + lds + 255) & ~(size_t)255;
+        size_t qcap = 1; while (qcap < (size_t)2 * nb) qcap <<= 1;
+        const size_t need = stride * nb + qcap * 8 + 256;
+        if (need <= ((size_t)6 << 30)) {
+            if (need > ctx->slice_cap) {
+                if (ctx->slice_buf) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->slice_buf); ctx->slice_buf = nullptr; ctx->slice_cap = 0; }
+                if (hipMalloc(&ctx->slice_buf, need) == hipSuccess) ctx->slice_cap = need; else { ctx->slice_buf = nullptr; (void)hipGetLastError(); }
+            }
+            if (ctx->slice_buf) {
+                unsigned char * base = (unsigned char *)ctx->slice_buf;
+                Q.slice = slice_env; Q.ckpt = base; Q.stride = stride; Q.queue = (unsigned long long *)(base + stride * nb);
+                Q.qmask = (unsigned)(qcap - 1); Q.ctl = (unsigned *)(base + stride * nb + qcap * 8);
+                XPG_HIP(ctx, hipMemsetAsync(Q.queue, 0, qcap * 8 + 256, ctx->stream));
+                grid += seats;                              // the continuation workgroups, dispatched behind every LP's own
+            }
+        }
+    }
+    if (five) {
         XPG_HIP(ctx, lds_limit((const void *)k_batch<S, 5>, ctx->device, lds));
         hipLaunchKernelGGL((k_batch<S, 5>), dim3(grid), dim3(threads), lds, ctx->stream, nb, tgtf, leq, m, cols,
-                           is_max ? 1 : 0, max_iter, out_status, out_v, out_sol, out_pivots, raw_sol);
+                           is_max ? 1 : 0, max_iter, out_status, out_v, out_sol, out_pivots, raw_sol, Q);
     } else {
         XPG_HIP(ctx, lds_limit((const void *)k_batch<S, 4>, ctx->device, lds));
         hipLaunchKernelGGL((k_batch<S, 4>), dim3(grid), dim3(threads), lds, ctx->stream, nb, tgtf, leq, m, cols,
-                           is_max ? 1 : 0, max_iter, out_status, out_v, out_sol, out_pivots, raw_sol);
+                           is_max ? 1 : 0, max_iter, out_status, out_v, out_sol, out_pivots, raw_sol, Q);
     }
     XPG_HIP(ctx, hipGetLastError());
     return 0;

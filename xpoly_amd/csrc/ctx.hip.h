@@ -28,6 +28,7 @@ struct xpg_ctx {
     std::vector<xpg_ctx *> lanes;             // extra handles on the same device, one per concurrent shape class of a ragged call
     std::vector<std::pair<void *, size_t> > dev_cache;   // device blocks between host-array row-elimination calls (DevBuf)
     size_t dev_cache_bytes = 0;
+    void * slice_buf = 0; size_t slice_cap = 0;   // k_batch's time slices: checkpoints, queue and counters (grow-only)
     int update_variant;     // tuning knob for the fp64 sweep (see launch_update_f64)
     int loop_mode;          // 0: pipelined fp64 loop (2 launches per pivot), 1: serial pick/prep/update
     int zigzag;             // pipelined sweep alternates its tile order (Infinity Cache reuse)

@@ -133,6 +133,7 @@ void xpg_destroy(xpg_ctx * ctx)
     if (ctx->stage) (void)hipFree(ctx->stage);
     if (ctx->hstage) (void)hipHostFree(ctx->hstage);
     if (ctx->hpack) (void)hipHostFree(ctx->hpack);
+    if (ctx->slice_buf) (void)hipFree(ctx->slice_buf);
     for (xpg_ctx * l : ctx->lanes) xpg_destroy(l);
     ctx->lanes.clear();
     for (auto & b : ctx->dev_cache) (void)hipFree(b.first);
