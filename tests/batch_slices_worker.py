@@ -16,7 +16,7 @@ from tools import gen                                   # noqa: E402
 F64, RAT = 0, 1
 # (kind, family, LPs, is_max)
 CASES = [(F64, 0, 3072, 1), (F64, 1, 3072, 1), (F64, 1, 2048, 0), (RAT, 1, 1536, 1)]
-HEAD = 48
+HEAD = 10
 SMALL = os.environ.get("XPG_SLICE_TEST_SMALL") == "1"      # the forced tiny slices: 384 LPs per case
 
 

@@ -965,7 +965,7 @@ template <class S, int CR, int CLD, int CT> __device__ __forceinline__ void sm_c
 // arrays and P's scalars restored by the caller).
 template <class S> __device__ __forceinline__ int sm_solve_lp(Small<S> & P, Source<S> & src, unsigned max_iter, int raw_sol,
                                                               S * sol, S * v_out, unsigned slice = SM_NO_SLICE, unsigned * done_io = nullptr,
-                                                              int * stage_io = nullptr)
+                                                              int * stage_io = nullptr, unsigned slice1 = SM_NO_SLICE)
 {
     const int m = src.m, cols = src.cols, is_max = src.is_max, n = cols - 1;
     const int R = is_max ? m : n, V = is_max ? n : m;
@@ -999,7 +999,7 @@ template <class S> __device__ __forceinline__ int sm_solve_lp(Small<S> & P, Sour
     if (stage == 1) {
         S top1 = zero<S>();
         unsigned done = entry == 1 ? *done_io : 0u;
-        const int st1 = sm_solve<S>(P, max_iter, top1, done, slice, entry == 1);
+        const int st1 = sm_solve<S>(P, max_iter, top1, done, slice1, entry == 1);
         if (st1 == SM_SUSPEND) { *done_io = done; *stage_io = 1; return SM_SUSPEND; }
         const int ok = sm_phase_one_post<S>(P, src, st1, top1);
         if (ok == 0) status = 2;
@@ -1056,7 +1056,8 @@ template <class S> __device__ __forceinline__ int sm_solve_lp(Small<S> & P, Sour
 // Queue: a ring of (ticket + 1) << 32 | (lp + 1) words; a pusher takes a ticket from ctl[0] and waits for its slot to be
 // empty, a popper takes one from ctl[1] and waits for that ticket's word (or for ctl[2] == nb: every LP is done).
 struct BatchSlices {
-    unsigned slice; int nmain; unsigned char * ckpt; unsigned long long stride; unsigned long long * queue; unsigned qmask; unsigned * ctl;
+    unsigned slice; unsigned slice1;        // iterations per turn of the LP's own solve / of stage 1's (SM_NO_SLICE: not sliced)
+    int nmain; unsigned char * ckpt; unsigned long long stride; unsigned long long * queue; unsigned qmask; unsigned * ctl;
 };
 enum { CK_HEADER = 64 };
 template <class S> __device__ __forceinline__ void sm_checkpoint(const Small<S> & P, const unsigned char * lds, size_t lds_bytes, unsigned char * ck, unsigned done, int stage)
@@ -1145,7 +1146,7 @@ template <class S, int WAVES> __global__ __launch_bounds__(256, WAVES) void k_ba
         int stage = 0;
         if (resume) { done = sm_restore(P, lds, lds_bytes, Q.ckpt + (size_t)lp * Q.stride, stage); src.cn = P.cn; }
         else LIFE_MARK(lp, 0);
-        const int status = sm_solve_lp<S>(P, src, max_iter, raw_sol, out_sol + (size_t)lp * cols, out_v + lp, Q.slice, &done, &stage);
+        const int status = sm_solve_lp<S>(P, src, max_iter, raw_sol, out_sol + (size_t)lp * cols, out_v + lp, Q.slice, &done, &stage, Q.slice1);
         if (status == SM_SUSPEND) {
             sm_checkpoint(P, lds, lds_bytes, Q.ckpt + (size_t)lp * Q.stride, done, stage);
             if (threadIdx.x == 0) slices_push(Q, lp);
@@ -1238,10 +1239,11 @@ int batch_dev(xpg_ctx * ctx, int is_max, int nb, const S * tgtf, const S * leq, 
     const bool five = (per_cu >= 5 && waves_env != 4) || waves_env == 5;
     // Time slices (k_batch): where the pivot loop can hand an LP back (sm_solve's `overlapped` shapes) and the launch holds
     // more LPs than the chip seats at once, so that LPs wait for slots at all. XPG_BATCH_SLICE=0 turns them off, =n sets
-    // the slice (iterations of the LP's own solve per turn).
+    // the slice (iterations of the LP's own solve per turn; 8192 dense LPs: 416.6 k LPs/s at 256, 418.4 k at 384-512, 414.6 k
+    // at 768, 408.5 k at 1024, 313.5 k unsliced).
     static const unsigned slice_env = [] { const char * e = getenv("XPG_BATCH_SLICE"); return e ? (unsigned)atoi(e) : 512u; }();
     BatchSlices Q;
-    Q.slice = SM_NO_SLICE; Q.nmain = grid; Q.ckpt = nullptr; Q.stride = 0; Q.queue = nullptr; Q.qmask = 0; Q.ctl = nullptr;
+    Q.slice = SM_NO_SLICE; Q.slice1 = SM_NO_SLICE; Q.nmain = grid; Q.ckpt = nullptr; Q.stride = 0; Q.queue = nullptr; Q.qmask = 0; Q.ctl = nullptr;
     const int seats = ctx->num_cus * (five ? (per_cu < 5 ? per_cu : 5) : (per_cu < 4 ? per_cu : 4));
     static const bool slice_force = [] { const char * e = getenv("XPG_BATCH_SLICE_FORCE"); return e && e[0] == '1'; }();   // tests: also when every LP has a seat
     if (slice_env != 0u && threads >= 128 && R <= 64 && R + V <= 127 && (nb > seats + seats / 4 || slice_force) && grid == nb) {
@@ -1255,7 +1257,10 @@ int batch_dev(xpg_ctx * ctx, int is_max, int nb, const S * tgtf, const S * leq, 
             }
             if (ctx->slice_buf) {
                 unsigned char * base = (unsigned char *)ctx->slice_buf;
-                Q.slice = slice_env; Q.ckpt = base; Q.stride = stride; Q.queue = (unsigned long long *)(base + stride * nb);
+                // stage 1's solve in longer turns (8192 dependence-test LPs: 112 k LPs/s at 512, 124.7 k at 1024, 124.2 k at 2048, 122 k
+                // at 4096, 121 k unsliced; XPG_BATCH_SLICE_STAGE1=n, 0: not sliced; a forced test slice applies to both)
+                static const unsigned slice1_env = [] { const char * e = getenv("XPG_BATCH_SLICE_STAGE1"); return e ? (unsigned)atoi(e) : 1536u; }();
+                Q.slice = slice_env; Q.slice1 = slice1_env == 0u ? SM_NO_SLICE : (slice_force ? slice_env : slice1_env); Q.ckpt = base; Q.stride = stride; Q.queue = (unsigned long long *)(base + stride * nb);
                 Q.qmask = (unsigned)(qcap - 1); Q.ctl = (unsigned *)(base + stride * nb + qcap * 8);
                 XPG_HIP(ctx, hipMemsetAsync(Q.queue, 0, qcap * 8 + 256, ctx->stream));
                 grid += seats;                              // the continuation workgroups, dispatched behind every LP's own
