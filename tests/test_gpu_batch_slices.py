@@ -45,13 +45,13 @@ def test_time_slices_do_not_change_results(port):
             assert a == b, (env, a["kind"], a["fam"], a["nb"], a["is_max"], a["hist"], b["hist"])
     # anchor: the first LPs of every case against the oracle
     from tools import gen
-    for rec, (kind, fam, nb, is_max, leq, tg) in zip(off, W.problems()):
+    for rec, (kind, fam, nb, is_max, limit, leq, tg) in zip(off, W.problems()):
         vc = gen.vc_nonneg(63, kind_float=(kind == 0))
         if kind != 0:
             vc = gen.to_rat(vc)
         for b in range(W.HEAD):
-            st, v, _ = port.six_solve(kind, is_max, tg[b], vc, None, leq[b])
+            st, v, _ = port.six_solve(kind, is_max, tg[b], vc, None, leq[b], max_iter=limit)
             assert rec["head_status"][b] == st, (kind, fam, is_max, b)
             if st == 0:
                 assert np.asarray(rec["head_v"][b]).tolist() == np.asarray(v).tolist(), (kind, fam, is_max, b)
-    assert any(r["hist"][0] > 0 for r in off) and any(r["hist"][2] > 0 for r in off)
+    assert any(r["hist"][0] > 0 for r in off) and any(r["hist"][2] > 0 for r in off) and any(r["hist"][4] > 0 for r in off)
