@@ -1060,6 +1060,11 @@ struct BatchSlices {
     int nmain; unsigned char * ckpt; unsigned long long stride; unsigned long long * queue; unsigned qmask; unsigned * ctl;
 };
 enum { CK_HEADER = 64 };
+// A continuation workgroup that has waited this long for an LP (100 MHz ticks: 20 s -- a launch of 65 536 LPs lasts 0.6 s)
+// leaves instead of spinning on: not a state the protocol can reach (every LP is in exactly one place: a seat, the queue, or
+// done), but a launch that never ends takes the device with it. An LP left behind keeps the status the host wrote
+// before the launch, XPG_ERR_CHAIN_STUCK.
+#define SLICE_WATCHDOG_TICKS 2000000000ull
 template <class S> __device__ __forceinline__ void sm_checkpoint(const Small<S> & P, const unsigned char * lds, size_t lds_bytes, unsigned char * ck, unsigned done, int stage)
 {
     const uint4 * src = (const uint4 *)lds;
@@ -1089,7 +1094,11 @@ __device__ __forceinline__ void slices_push(const BatchSlices & Q, int lp)
 {
     const unsigned t = atomicAdd(&Q.ctl[0], 1u);
     unsigned long long * e = Q.queue + (t & Q.qmask);
-    while (__hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) __builtin_amdgcn_s_sleep(8);
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) {
+        if (wall_clock64() - t0 > SLICE_WATCHDOG_TICKS) return;        // (never seen: the LP keeps the sentinel status the host wrote)
+        __builtin_amdgcn_s_sleep(8);
+    }
     __hip_atomic_store(e, ((unsigned long long)(t + 1u) << 32) | (unsigned)(lp + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 // -1: every LP of the launch is done
@@ -1097,7 +1106,9 @@ __device__ __forceinline__ int slices_pop(const BatchSlices & Q, int nb)
 {
     const unsigned t = atomicAdd(&Q.ctl[1], 1u);
     unsigned long long * e = Q.queue + (t & Q.qmask);
+    const unsigned long long t0 = wall_clock64();
     for (;;) {
+        if (wall_clock64() - t0 > SLICE_WATCHDOG_TICKS) return -1;
         const unsigned long long w = __hip_atomic_load(e, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
         if ((unsigned)(w >> 32) == t + 1u) {
             __hip_atomic_store(e, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1263,6 +1274,7 @@ int batch_dev(xpg_ctx * ctx, int is_max, int nb, const S * tgtf, const S * leq, 
                 Q.slice = slice_env; Q.slice1 = slice1_env == 0u ? SM_NO_SLICE : (slice_force ? slice_env : slice1_env); Q.ckpt = base; Q.stride = stride; Q.queue = (unsigned long long *)(base + stride * nb);
                 Q.qmask = (unsigned)(qcap - 1); Q.ctl = (unsigned *)(base + stride * nb + qcap * 8);
                 XPG_HIP(ctx, hipMemsetAsync(Q.queue, 0, qcap * 8 + 256, ctx->stream));
+                XPG_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)out_status, (int)XPG_ERR_CHAIN_STUCK, (size_t)nb, ctx->stream));   // (SLICE_WATCHDOG_TICKS)
                 grid += seats;                              // the continuation workgroups, dispatched behind every LP's own
             }
         }
