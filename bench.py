@@ -533,7 +533,7 @@ def main():
                        n_gpus=world, ranks=world, total_lps=total, lps_per_rank=[shard_range(total, r, world)[1] -
                                                                                  shard_range(total, r, world)[0]
                                                                                  for r in range(world)],
-                       shape="leq 32x64 (63 vars + rhs), SIX::maxm, x>=0, whole solve per LP in LDS",
+                       shape="leq 32x64 (63 vars + rhs), SIX::maxm, x>=0, whole solve per LP in LDS; LPs that have run their time slice (512 iterations) hand their LDS seat back and continuation workgroups inside the launch take queued LPs in turn (results do not depend on it)",
                        scaling="weak (8192 LPs per GPU: 65 536 at N = 8)",
                        collective=("one all_gather_into_tensor of (status,v,sol) records over %s, world size %d"
                                    % ("RCCL" if a.backend == "nccl" else a.backend, world)) if dist else "none (1 GPU)",
@@ -541,7 +541,7 @@ def main():
         if os.path.exists(PMC_BATCH):                   # measured with rocprofv3 --pmc, not in this run
             pb = json.load(open(PMC_BATCH))
             batched["issue_rate"] = dict(
-                bound="latency of the two-barrier pivot at 5 LPs per CU (LDS: 30 KB per LP; the pivot loop is a function of its own on 88 registers, the kernel is held to 96 to seat the fifth LP); VALU 35-46 % busy (HBM sees 16 KiB in / 0.5 KiB out per LP)",
+                bound="latency of the two-barrier pivot at 5 LPs per CU (LDS: 30 KB per LP; the pivot loop is a function of its own on 88 registers, the kernel is held to 96 to seat the fifth LP); the counters below are round 3's, before the time slices kept every seat busy to the end of a launch: VALU 35-46 % busy (HBM sees 16 KiB in / 0.5 KiB out per LP)",
                 dep_test_like=dict(valu_busy_percent=pb.get("dep_test_like_busy_percent", {}).get("VALUBusy"),
                                    salu_busy_percent=pb.get("dep_test_like_busy_percent", {}).get("SALUBusy"),
                                    wave_instructions_per_pivot=pb.get("dep_test_like_per_pivot")),
