@@ -355,6 +355,12 @@ template <class S, int CR, int CLD, int CT> __device__ __forceinline__ int sm_fa
     const int st = tid - 64, nsw = (CT ? CT : (int)blockDim.x) - 64;       // sweeper index / count
     const int nswaves = nsw >> 6, swave = st >> 6;
     const int rhs = P.rhs, lim = rhs - 1, R = CR ? CR : P.R, W = P.W, ld = CLD ? CLD : P.ld;
+    if (CR == 32 && CLD == 97) {
+        // the specialised instance: 32 rows and 63 variables, with (W = 97) or without (96) stage 1's column -- lane-constant
+        // column tests fold (a wave-0 lane's first column always exists and is never the constant one)
+        __builtin_assume(W == 96 || W == 97);
+        __builtin_assume(rhs == W - 1);
+    }
     if (!preselected) {                                         // the first pivot: nothing to overlap with
         if (w0) sm_select_wave0(P);
         __syncthreads();
@@ -605,7 +611,7 @@ template <class S> __device__ __forceinline__ int sm_solve(Small<S> & P, unsigne
             // must really have been carved for 32 rows (a MIP node with 32 live rows in a block carved for rmax = 60 has
             // R == 32 and ld == 97 too, and its objective row sits 60 rows behind the base, not 32)
             const bool carved_32x63 = (const unsigned char *)P.obj - (const unsigned char *)P.tab == (ptrdiff_t)32 * 97 * 8;
-            if (!is_f64<S>::value || P.R != 32 || P.ld != 97 || blockDim.x != 256 || !carved_32x63) action = sm_fast_loop<S, 0, 0, 0>(P, stop_at, done, preselected);
+            if (!is_f64<S>::value || P.R != 32 || P.ld != 97 || blockDim.x != 256 || !carved_32x63 || (P.W != 96 && P.W != 97) || P.rhs != P.W - 1) action = sm_fast_loop<S, 0, 0, 0>(P, stop_at, done, preselected);
             else {
                 const FastLoopRet fr = sm_fast_loop_32x97x256<S>((__attribute__((address_space(3))) unsigned char *)P.tab, P.W, P.rhs, P.cn, P.pivots,
                                                                  P.closes, stop_at, done, preselected);
