@@ -19,8 +19,8 @@
 //     staging buffers per slot (LpView::stage); the stagers of the launch that SWEEPS a pivot commit its objective row
 //     to v.obj first. The basis swap was already committed that way (pick workgroup 0).
 //   * The generic pick (relaxed second pass, disableNV, findPivotNVandBVPair: 131 registers and scratch) must not be
-//     compiled into this launch. The host enqueues a generic point -- k_fused_generic (generic pick in place), then
-//     k_pipe_prep<R32>(fused = 2) (staging of what it chose) -- before the first launch of every queue_iterations call and every
+//     compiled into this launch. The host enqueues a generic point -- k_fused_generic: generic pick in place and the
+//     staging of what it chose -- before the first launch of every queue_iterations call and every
 //     XPG_R32_GENERIC_EVERY (16) launches; a deferred decision idles through the fused launches until then (workgroup
 //     (0,0) carries the descriptor over to the other slot and counts it: a solve that idles often gets a generic point
 //     before every launch from the host's next status read on).
@@ -364,26 +364,69 @@ void k_pipe_fused_r32(LpView<R32> v, int slot, int colstride, int N, int NP)
 #endif
 }
 
-// The first launch of a generic point: one workgroup of 1024 threads (the generic pick is a latency chain of strided
-// gathers and per-row quotients: four rows per thread cost 25 us at 1024 rows with 256 threads). An idle descriptor gets
-// its pivot in place, a deferred final status is promoted; k_pipe_prep<R32>(fused = 2) behind it stages what was chosen.
+// The generic point: one workgroup of 1024 threads (the generic pick is a latency chain of strided gathers and per-row
+// quotients: four rows per thread cost 25 us at 1024 rows with 256 threads). An idle descriptor gets its pivot IN PLACE
+// and, in the same launch, its staging (scaled pivot row, objective row, look-ahead: what k_pipe_prep<R32> does, two
+// columns per thread at W = 2049 -- a launch of its own cost 8.6 us for 3 us of work); a deferred final status is promoted.
 __global__ __launch_bounds__(1024) void k_fused_generic(LpView<R32> v, int slot, int colstride)
 {
+    __shared__ int sh_d[4];
+    __shared__ unsigned long long sh_b[2];
+    __shared__ int sh_red[32];
     LoopState * st = v.st;
     PipeDesc & D = st->pd[slot];
-    const int status = st->status, stop = D.stop, r = D.row, zu = D.zero_upto, side = D.side;
+    const int status = st->status, stop = D.stop, r0 = D.row, zu0 = D.zero_upto, side = D.side;
+    const bool canon = st->noncanon == 0;
     if (status != ST_RUNNING) return;
     if (stop != 0) {
-        for (int j = threadIdx.x; j < zu; j += blockDim.x)
+        for (int j = threadIdx.x; j < zu0; j += blockDim.x)
             if (!v.nv[j]) v.obj[j] = zero<R32>();              // lpsol.h:1055-1060, deferred by the pick
         __syncthreads();
         if (threadIdx.x == 0) st->status = stop;
         return;
     }
-    if (r >= 0) return;
+    if (r0 >= 0) return;
     LpView<R32> w = v;
     w.tab = side ? v.tab2 : v.tab;
     prep_idle<R32>(w, slot, colstride, true);
+    __syncthreads();
+    if (threadIdx.x == 0) {                                    // what the pick left in the descriptor, through the thread that wrote it
+        sh_d[0] = D.row; sh_d[1] = D.col; sh_d[2] = D.leave; sh_d[3] = D.stop ? -1 : D.zero_upto;
+        sh_b[0] = D.piv_bits; sh_b[1] = D.cnv_bits;
+    }
+    __syncthreads();
+    const int r = sh_d[0], enter = sh_d[1], leave = sh_d[2], zu = sh_d[3];
+    if (r < 0 || zu < 0) return;                               // nothing chosen (deferred again, or a final status)
+    // ---- staging, with k_pipe_prep's arithmetic, into this slot's staging buffers (v.obj is committed by the launch that sweeps)
+    const R32 * __restrict__ tab = w.tab;
+    R32 * __restrict__ rowbuf = v.stage + (size_t)slot * v.ld;
+    R32 * __restrict__ objout = v.stage + (size_t)(2 + slot) * v.ld;
+    const R32 s = div(one<R32>(), from_bits<R32>(sh_b[0]));    // 1/(eq.get(eqnum, nv)), lpsol.h:1471
+    const int smode = scale_mode(s);
+    const R32 cnv = from_bits<R32>(sh_b[1]);
+    const int cmode = scale_mode(cnv), lim = v.rhs - 1;
+    int nf = INT_MAX, any = 0;
+    for (int j = threadIdx.x; j < v.W; j += blockDim.x) {
+        const R32 a = tab[(size_t)r * v.ld + j];
+        R32 oj = v.obj[j];
+        const bool nvj = j < v.rhs && v.nv[j] != 0;            // basis BEFORE this pivot's swap
+        const int rcj = v.rowcnt[j < v.rhs ? j : 0];
+        const R32 e = scaled_c(a, s, smode, canon);
+        rowbuf[j] = e;
+        if (j < zu && !nvj) oj = zero<R32>();                  // lpsol.h:1055-1060, deferred by the pick
+        const R32 o = obj_update_c(e, j >= v.rhs, cnv, cmode, oj, canon);      // lpsol.h:1496-1501
+        objout[j] = o;
+        const bool nv_next = j == enter ? false : (j == leave ? true : nvj);
+        if (j < v.rhs && nv_next && gt(o, zero<R32>())) { any = 1; if (rcj < lim) nf = min(nf, j); }
+    }
+    for (int o = 32; o > 0; o >>= 1) { nf = min(nf, __shfl_xor(nf, o)); any |= __shfl_xor(any, o); }
+    if ((threadIdx.x & 63) == 0) { sh_red[threadIdx.x >> 6] = nf; sh_red[16 + (threadIdx.x >> 6)] = any; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = (int)(blockDim.x >> 6);
+        for (int k = 1; k < nw; k++) { nf = min(nf, sh_red[k]); any |= sh_red[16 + k]; }
+        D.next_first = nf; D.anypos = any; D.staged = 1;
+    }
 }
 
 // After the last fused launch of a call: side 0 is what everything else reads.

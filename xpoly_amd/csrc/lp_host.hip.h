@@ -99,10 +99,7 @@ template <class S> inline void launch_side_home(xpg_ctx *, const LpView<S> &) {}
 template <> inline void launch_fused<R32>(xpg_ctx * ctx, const LpView<R32> & v, int slot, int colstride, bool generic)
 {
     const int NP = (v.W + 255) / 256;
-    if (generic) {
-        hipLaunchKernelGGL(k_fused_generic, dim3(1), dim3(1024), 0, ctx->stream, v, slot, colstride);
-        hipLaunchKernelGGL((k_pipe_prep<R32>), dim3(NP), dim3(256), 0, ctx->stream, v, slot, colstride, 2);
-    }
+    if (generic) hipLaunchKernelGGL(k_fused_generic, dim3(1), dim3(1024), 0, ctx->stream, v, slot, colstride);
     const bool timed = prof_open(ctx);
     const int N = (v.m + 63) / 64 < PICK_MAX_WGS ? (v.m + 63) / 64 : PICK_MAX_WGS;     // one-wave pick workgroups
     hipLaunchKernelGGL(k_pipe_fused_r32, dim3(v.m > N + NP ? v.m : N + NP, 1 + NP), dim3(256), 0, ctx->stream, v, slot, colstride, N, NP);
@@ -449,14 +446,14 @@ template <class S> struct Lp : LpBase {
             // the first pivot is chosen by a launch that has nothing to sweep (pd[1].row < 0): fp64 the sweep launch's
             // pick workgroup, Rational the prep launch's first workgroup
             if (std::is_same<S, F64>::value) launch_pipe_sweep(ctx, v, 1, colstride, false);
-            else hipLaunchKernelGGL((k_pipe_prep<S>), dim3(1), dim3(256), 0, ctx->stream, v, 1, colstride, 0);
+            else hipLaunchKernelGGL((k_pipe_prep<S>), dim3(1), dim3(256), 0, ctx->stream, v, 1, colstride);
             pipe_primed = true;
         }
         for (unsigned t = 0; t < k; t++) {
             if (pipelined) {
                 // two launches per pivot; the next pivot is chosen inside the sweep launch
                 const int slot = (int)(pipe_t++ & 1u);
-                hipLaunchKernelGGL((k_pipe_prep<S>), dim3((v.W + 255) / 256), dim3(256), 0, ctx->stream, v, slot, colstride, 0);
+                hipLaunchKernelGGL((k_pipe_prep<S>), dim3((v.W + 255) / 256), dim3(256), 0, ctx->stream, v, slot, colstride);
                 launch_pipe_sweep(ctx, v, slot, colstride, true);
             } else {
                 hipLaunchKernelGGL((k_pick<S>), dim3(1), dim3(1024), 0, ctx->stream, v);

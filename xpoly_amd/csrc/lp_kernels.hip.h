@@ -858,13 +858,7 @@ void k_update_f64(double * __restrict__ tab, int m, int W, int ld,
 // workgroup runs the generic pick) or that generic pick itself (Rational, lp_pipe_r32.hip.h).
 template <class S> __device__ inline void prep_idle(const LpView<S> &, int, int, bool) {}
 template <> __device__ inline void prep_idle<R32>(const LpView<R32> & v, int slot, int colstride, bool inplace);
-// fused != 0 (Rational, lp_fused_r32.hip.h): the generic point of the one-launch-per-pivot loop, two launches (fused = 1,
-// then 2: the second never picks, so that what the fused launch behind it finds is either idle or staged). An idle descriptor gets
-// its pivot from the generic pick IN PLACE (pd[slot] itself, -column into this slot's half of colbuf); a descriptor with a
-// pivot that nobody has staged yet is staged into the staging buffers of this slot (scaled pivot row, objective row --
-// v.obj itself is committed by the fused launch that sweeps the pivot); one that is staged is left alone. The tableau is
-// read on the side the descriptor names.
-template <class S> __global__ __launch_bounds__(256) void k_pipe_prep(LpView<S> v, int slot, int colstride, int fused)
+template <class S> __global__ __launch_bounds__(256) void k_pipe_prep(LpView<S> v, int slot, int colstride)
 {
     LoopState * st = v.st;
     PipeDesc & D = st->pd[slot];
@@ -872,7 +866,6 @@ template <class S> __global__ __launch_bounds__(256) void k_pipe_prep(LpView<S> 
     const int status = st->status, pricing = st->pricing;
     const bool canon = !is_f64<S>::value && st->noncanon == 0;  // Rational: the canonical forms (scalar.hip.h)
     const int stop = D.stop, r = D.row, enter = D.col, leave = D.leave, zu = D.zero_upto;
-    const int side = D.side, staged = D.staged;
     const unsigned long long piv_bits = D.piv_bits, cnv_bits = D.cnv_bits;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
     if (status != ST_RUNNING) return;
@@ -886,18 +879,13 @@ template <class S> __global__ __launch_bounds__(256) void k_pipe_prep(LpView<S> 
         }
         return;
     }
-    const S * __restrict__ tab = (fused && side) ? v.tab2 : v.tab;
+    const S * __restrict__ tab = v.tab;
     if (r < 0) {
-        if (fused == 2) return;                                // the generic point's second launch only stages
-        if (blockIdx.x == 0) {
-            if (fused) { LpView<S> w = v; w.tab = (S *)tab; prep_idle<S>(w, slot, colstride, true); }
-            else prep_idle<S>(v, slot, colstride, false);
-        }
+        if (blockIdx.x == 0) prep_idle<S>(v, slot, colstride, false);
         return;
     }
-    if (fused && staged) return;
-    S * __restrict__ rowbuf = fused ? v.stage + (size_t)slot * v.ld : v.rowbuf;
-    S * __restrict__ objout = fused ? v.stage + (size_t)(2 + slot) * v.ld : v.obj;
+    S * __restrict__ rowbuf = v.rowbuf;
+    S * __restrict__ objout = v.obj;
     if (gid == 0) v.pickrec[PICK_CTR_OFF + 16 * slot] = 0ull;  // arrival counter of this iteration's pick
     const S s = div(one<S>(), from_bits<S>(piv_bits));        // 1/(eq.get(eqnum, nv)), :1471
     const int smode = scale_mode(s);
