@@ -52,7 +52,7 @@ BATCH_M, BATCH_COLS = 32, 64
 PREWARM_SECONDS = 0.5
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "round4_pmc_hbm_traffic_4096x8192.json")
 PMC_SUMMARY_2B = os.path.join(ROOT, "profiles", "round4_pmc_hbm_traffic_4096x12289.json")
-PMC_BATCH = os.path.join(ROOT, "profiles", "round3_pmc_batch_issue.json")
+PMC_BATCH = os.path.join(ROOT, "profiles", "round4_pmc_batch_issue.json")
 PMC_RATIONAL = os.path.join(ROOT, "profiles", "round4_pmc_rational_issue.json")
 LEGS = ("pivots", "batched", "sharded", "cfg2b", "rational", "mip", "lineq")
 LINEQ_NB = 16384                           # systems per row-elimination launch (the dependence tests' shapes)
@@ -541,14 +541,14 @@ def main():
         if os.path.exists(PMC_BATCH):                   # measured with rocprofv3 --pmc, not in this run
             pb = json.load(open(PMC_BATCH))
             batched["issue_rate"] = dict(
-                bound="latency of the two-barrier pivot at 5 LPs per CU (LDS: 30 KB per LP; the pivot loop is a function of its own on 88 registers, the kernel is held to 96 to seat the fifth LP); the counters below are round 3's, before the time slices kept every seat busy to the end of a launch: VALU 35-46 % busy (HBM sees 16 KiB in / 0.5 KiB out per LP)",
+                bound="latency of the two-barrier pivot at 5 LPs per CU (LDS: 30 KB per LP; the pivot loop is a function of its own on 88 registers, the kernel is held to 96 to seat the fifth LP); with the time slices every seat stays busy to the end of a launch: VALU 48-52 % and SALU 23-25 % busy over the whole launch (HBM sees 16 KiB in / 0.5 KiB out per LP)",
                 dep_test_like=dict(valu_busy_percent=pb.get("dep_test_like_busy_percent", {}).get("VALUBusy"),
                                    salu_busy_percent=pb.get("dep_test_like_busy_percent", {}).get("SALUBusy"),
                                    wave_instructions_per_pivot=pb.get("dep_test_like_per_pivot")),
                 dense_positive=dict(valu_busy_percent=pb.get("dense_busy_percent", {}).get("VALUBusy"),
                                     salu_busy_percent=pb.get("dense_busy_percent", {}).get("SALUBusy"),
                                     wave_instructions_per_pivot=pb.get("dense_per_pivot")),
-                source="profiles/round3_pmc_batch_issue.json (rocprofv3 --pmc VALUBusy / SALUBusy / SQ_INSTS_* on "
+                source="profiles/round4_pmc_batch_issue.json (rocprofv3 --pmc VALUBusy / SALUBusy / SQ_INSTS_* on "
                        "tools/lab/probe_batch.py; not collected in this run)")
         if not stub:
             # STRONG scaling beside the weak figures above: the 65 536 LPs of BASELINE configs[2] in all, split over the
