@@ -30,9 +30,31 @@ def problems():
         yield fam, m, nv, gen.random_problem(rng, RAT, fam, m, nv, plain=True)
 
 
+def small_problems():
+    """The small random LPs of test_gpu_parity.py::test_two_stage_matches_oracle (whole solves: every deferred decision --
+    relaxed ratio pass, disableNV, findPivotNVandBVPair -- and stage 1), which the size rule sends to the two-launch loop."""
+    for fam in (0, 1, 2):
+        rng = np.random.default_rng(100 + 10 * RAT + fam)
+        for it in range(12):
+            m, nv = int(rng.integers(1, 14)), int(rng.integers(1, 14))
+            yield fam, it, gen.random_problem(rng, RAT, fam, m, nv, plain=True)
+
+
+SMALL_KS = (0, 1, 2, 5, 1000)
+
 if __name__ == "__main__":
     ctx = xpoly_amd.Context()
     six = xpoly_amd.SIX(ctx, RAT)
+    if os.environ.get("XPG_FUSED_SMALL") == "1":
+        for fam, it, prob in small_problems():
+            for K in SMALL_KS:
+                six.set_param(0, K)
+                got = six.TwoStageMethod(prob["leq"], prob["tgtf"])
+                rec = dict(fam=fam, it=it, K=K, status=int(got["status"]))
+                if got["status"] != 2:
+                    rec.update(tab=crc(got["tab"]), tgtf=crc(got["tgtf"]), eq2bv=crc(np.asarray(got["eq2bv"], dtype=np.int32)))
+                print(json.dumps(rec), flush=True)
+        sys.exit(0)
     for fam, m, nv, prob in problems():
         for K in KS:
             six.set_param(0, K)

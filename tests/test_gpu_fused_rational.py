@@ -40,7 +40,7 @@ def test_fused_loop_matches_oracle_and_the_other_loops(port):
     def crc(a):
         return "%08x" % (zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF)
 
-    fused = run_worker()
+    fused = run_worker(XPG_R32_LOOP="fused")             # (forced: the size rule sends LPs this small to the two-launch loop)
     assert len(fused) == len(W.CASES) * len(W.KS)
     it = iter(fused)
     for fam, m, nv, prob in W.problems():
@@ -53,7 +53,7 @@ def test_fused_loop_matches_oracle_and_the_other_loops(port):
                 assert rec["tgtf"] == crc(want["tgtf"]), (fam, m, nv, K)
                 assert rec["eq2bv"] == crc(np.asarray(want["eq2bv"], dtype=np.int32)), (fam, m, nv, K)
     # the same pivots from the two-launch loop and with a generic point before every / every third launch
-    for env in (dict(XPG_R32_LOOP="pipe"), dict(XPG_R32_GENERIC_EVERY="1"), dict(XPG_R32_GENERIC_EVERY="3")):
+    for env in (dict(XPG_R32_LOOP="pipe"), dict(XPG_R32_LOOP="fused", XPG_R32_GENERIC_EVERY="1"), dict(XPG_R32_LOOP="fused", XPG_R32_GENERIC_EVERY="3"), {}):
         other = run_worker(**env)
         assert len(other) == len(fused)
         for a, b in zip(fused, other):
@@ -62,16 +62,41 @@ def test_fused_loop_matches_oracle_and_the_other_loops(port):
     assert any("tab" in r for r in fused)
 
 
+def test_fused_loop_small_whole_solves_match_oracle(port):
+    """Whole solves of the small random LPs of test_gpu_parity.py (stage 1, every deferred decision) forced through the
+    fused loop."""
+    import zlib
+    sys.path.insert(0, HERE)
+    import fused_rational_worker as W
+
+    def crc(a):
+        return "%08x" % (zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF)
+
+    got = run_worker(XPG_R32_LOOP="fused", XPG_FUSED_SMALL="1")
+    it = iter(got)
+    n = 0
+    for fam, k, prob in W.small_problems():
+        for K in W.SMALL_KS:
+            rec = next(it)
+            want = port.two_stage(RAT, prob["leq"], prob["tgtf"], K)
+            assert rec["status"] == want["status"], (fam, k, K, rec["status"], want["status"])
+            if want["status"] != 2:
+                assert rec["tab"] == crc(want["tab"]) and rec["tgtf"] == crc(want["tgtf"]), (fam, k, K)
+                assert rec["eq2bv"] == crc(np.asarray(want["eq2bv"], dtype=np.int32)), (fam, k, K)
+            n += 1
+    assert n == len(got) == 3 * 12 * len(W.SMALL_KS)
+
+
 def test_rational_iterate_in_chunks_equals_one_shot(ctx):
     """Chunks of 1, 2, 3, ... launches (every call starts with a generic point and ends on either side of the ping-pong
     tableau) leave the state one call of the same length leaves."""
     import xpoly_amd
-    leq, tg = gen.int_lp_rat(192, 300)
+    leq, tg = gen.int_lp_rat(512, 700)                   # 512 x 1213: a size the fused loop takes by default
     a = xpoly_amd.DeviceLP(ctx, RAT, leq, tg); a.begin()
     for k in (1, 2, 3, 1, 5, 4, 1):
         assert a.iterate(k) == xpoly_amd.six.XPG_RUNNING
         mid = a.read()                                   # a read between the calls must not disturb the loop
-        assert mid["tab"].shape[0] == 192
+        assert mid["tab"].shape[0] == 512
     b = xpoly_amd.DeviceLP(ctx, RAT, leq, tg); b.begin()
     assert b.iterate(17) == xpoly_amd.six.XPG_RUNNING
     ra, rb = a.read(), b.read()

@@ -427,7 +427,15 @@ template <class S> struct Lp : LpBase {
         static const bool r32_pipe = [] { const char * s = getenv("XPG_R32_LOOP"); return s && !strcmp(s, "pipe"); }();
         static const unsigned generic_every = [] { const char * s = getenv("XPG_R32_GENERIC_EVERY"); const int n = s ? atoi(s) : 0; return (unsigned)(n > 0 ? n : 16); }();
         const bool pipelined = ctx->loop_mode != 1 && (std::is_same<S, F64>::value || !r32_serial);
-        if (pipelined && !std::is_same<S, F64>::value && !r32_pipe && k > 0 && fused_buffers()) {
+        // The fused loop where it pays: its sweep copies the columns the in-place sweep skips (ping-pong tableau) and its
+        // launch lasts as long as the pick -> staging chain inside it. Measured against the two-launch loop
+        // (tools/lab/probe_rat_sizes.py, us per pivot fused / two-launch): 256 x 512 21.4 / 19.9, 384 x 785 21.0 / 21.0,
+        // 512 x 1213 17.0 / 18.0, 768 x 1769 16.7 / 20.9, 1024 x 2048 19.7 / 24.7, 1280 x 2281 27.0 / 30.3, 1536 x 2637
+        // 32.0 / 31.8, 2048 x 3549 51.5 / 46.4. XPG_R32_LOOP=fused / pipe force one or the other.
+        static const bool r32_fused = [] { const char * s = getenv("XPG_R32_LOOP"); return s && !strcmp(s, "fused"); }();
+        const size_t cells = (size_t)v.m * (size_t)v.W;
+        const bool fused_pays = r32_fused || (cells >= 350000u && cells <= 5000000u);
+        if (pipelined && !std::is_same<S, F64>::value && !r32_pipe && fused_pays && k > 0 && fused_buffers()) {
             // one launch per pivot (lp_fused_r32.hip.h); the first launch of a call and every generic_every-th one are
             // preceded by a generic point
             for (unsigned t = 0; t < k; t++) {
