@@ -104,6 +104,10 @@ __device__ inline void fused_pick_r32(const LpView<R32> & v, int slot, int colst
     // ---- a sweep is running around us
     if (p == 0 && tid == 0) {                          // commit this iteration's pivot (lpsol.h:1504-1510)
         FUSED_STAMP(st, 0);
+        // (a pivot nobody has staged is not a state the host's launch sequence can produce -- a generic point stages what
+        // it picks, a fused launch what its pick chooses; if it ever is seen, the solve ends with an error instead of a
+        // tableau swept with whatever the staging buffers held)
+        if (!I.staged) st->status = XPG_ERR_CHAIN_STUCK;
         v.nv[ienter] = 0; v.nv[ileave] = 1; v.bv[ienter] = 1; v.bv[ileave] = 0;
         v.eq2bv[r] = ienter; v.bv2eq[ienter] = r; v.bv2eq[ileave] = -1;
         XPG_TRACE_PIVOT("hbm-fused", ienter, ileave, r);
