@@ -1,5 +1,5 @@
 // Fused loop for the rational scalar (config 4): ONE launch per pivot. k_pipe_fused_r32 sweeps pivot t, chooses pivot
-// t + 1 (the pick workgroups of lp_pipe_r32.hip.h) and STAGES it -- scaled pivot row, objective row, look-ahead pricing
+// t + 1 (one-wave pick workgroups, fused_pick_r32 below) and STAGES it -- scaled pivot row, objective row, look-ahead pricing
 // of t + 2 -- inside the same launch, which is what k_pipe_prep did in a launch of its own (6-7 us per pivot beside a
 // 17.6 us sweep at 1024 x 2048: launch latency and a drained chip, the staging itself is 2048 cells).
 //
@@ -27,6 +27,8 @@
 //   * Everything outside this loop reads v.tab: the host's status read after each batch of launches (Lp::read_state)
 //     sees which side the last launch left current and enqueues k_side_home when it is side 1 (both copies are then
 //     current).
+// Lp::queue_iterations takes this loop for tableaux of 350 k - 5 M cells (below, both loops are a chain of latencies; above,
+// the copies of the columns an in-place sweep skips are HBM traffic the two-launch loop of lp_pipe_r32.hip.h does not have).
 #pragma once
 #include "lp_pipe_r32.hip.h"
 
