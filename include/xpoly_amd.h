@@ -57,8 +57,13 @@ extern "C" {
 #define XPG_ERR_UNSUPPORTED  (-4)
 #define XPG_ERR_NO_DEVICE    (-5)
 #define XPG_ERR_REF_UNDEFINED (-7) /* the reference's behaviour is undefined on this input */
-#define XPG_ERR_CHAIN_STUCK  (-8)  /* a persistent launch of the blocked fp64 loop lost a worker AFTER its roll call (a
-                                      preempted queue); the handle's LP must be rebuilt (xpg_lp_begin / _two_stage) */
+#define XPG_ERR_CHAIN_STUCK  (-8)  /* a launch whose workgroups wait for each other stopped making progress (a preempted
+                                      or hung queue): the persistent chain launch of the blocked fp64 loop AFTER its roll
+                                      call, the fused Rational loop's pick -> staging hand-over (also: a pivot nobody
+                                      staged), or a time-sliced batch launch whose queue did not move for 20 s.  A
+                                      device LP must be rebuilt (xpg_lp_begin / _two_stage); a batch call returns it as
+                                      the CALL's result and none of its outputs is valid (the _dev forms, which only
+                                      enqueue, leave it as the status of every LP the launch did not finish) */
 
 typedef struct xpg_ctx xpg_ctx;   /* one device + one HIP stream + scratch; re-entrant per handle */
 typedef struct xpg_lp  xpg_lp;    /* one device-resident slack-form LP (tableau, objective, basis) */
@@ -120,7 +125,8 @@ int  xpg_lp_iterate(xpg_lp * lp, unsigned pivots);
 #define XPG_RUNNING (-1000)
 int  xpg_lp_pivots_done(xpg_lp * lp, unsigned * out);
 /* Blocked loop bookkeeping since xpg_lp_begin / xpg_lp_two_stage: sweeps that applied a full batch of
- * 16 staged pivots, and sweeps that applied fewer (the tail of an iterate budget, or a batch closed
+ * staged pivots (24 by default, XPG_BLOCK <= 32: the batch's stages, the first included, are chosen and
+ * staged by one persistent chain launch; lp_chain.hip.h), and sweeps that applied fewer (the tail of an iterate budget, or a batch closed
  * early by a rare branch of SIX::solveSlackForm, src/com/lpsol.h:1138-1151).  Either may be NULL. */
 int  xpg_lp_counters(xpg_lp * lp, unsigned * sweeps_full, unsigned * sweeps_partial);
 /* Blocked fp64 loop, diagnostics: persistent chain launches of the current solve that were given up at their roll call

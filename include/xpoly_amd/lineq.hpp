@@ -1,6 +1,7 @@
 // C++ adapter: a class with the names and signatures of xpoly's Lineq (src/com/linsys.h:61-186) for the
 // members that sit on the hot path -- reduce, fme, has_solution, calcBound, move2var, removeIdenRow -- on top of
-// the C ABI in ../xpoly_amd.h, so that call sites such as
+// the C ABI in ../xpoly_amd.h, plus the small host-side members the engine's own Lineq objects call next to them
+// (appendEquation, formatBound, initVarConstraint, is_consistent), so that call sites such as
 //
 //     Lineq lin(NULL);                                      // src/eng/poly.cpp:537
 //     if (!lin.reduce(*coeff, coeff->get_col_size() - 1, true)) return true;
@@ -13,7 +14,9 @@
 #ifndef XPOLY_AMD_LINEQ_HPP
 #define XPOLY_AMD_LINEQ_HPP
 
+#include <cstddef>
 #include <cstring>
+#include <type_traits>
 #include <utility>
 #include <vector>
 #include "../xpoly_amd.h"
@@ -34,8 +37,87 @@ template <class RMatT> class Lineq {
 public:
     explicit Lineq(RMatT * m, int rhs_idx = -1, xpg_ctx * c = 0) : m_ctx(c), m_coeff(m), m_rhs_idx(rhs_idx)
     { if (m && rhs_idx == -1) m_rhs_idx = (int)m->get_col_size() - 1; }
+    void init(RMatT * m, int rhs_idx = -1) { set_param(m, rhs_idx); }   // linsys.cpp:92-108
+    void destroy() { m_coeff = 0; m_rhs_idx = -1; }
     void set_param(RMatT * m, int rhs_idx = -1)             // linsys.cpp:117-131
     { m_coeff = m; m_rhs_idx = (m && rhs_idx == -1) ? (int)m->get_col_size() - 1 : rhs_idx; }
+
+    // ---- host-side members (no arithmetic worth a launch; they only reshape the caller's matrices with the
+    //      Matrix type's own operations, exactly the ones the reference uses, so the cells are the reference's)
+    // Lineq::appendEquation, linsys.cpp:922-935 (caller PolyTran::scan's bound computation, src/eng/poly.cpp:4804):
+    // every equation a = b joins the system as a <= b and -a <= -b.
+    void appendEquation(RMatT const & eq)
+    {
+        if (eq.size() == 0 || eq.get_row_size() == 0) return;
+        RMatT both = eq;
+        m_coeff->grow_row(both, 0, both.get_row_size() - 1);
+        both.mul(-1);
+        m_coeff->grow_row(both, 0, both.get_row_size() - 1);
+    }
+    // Lineq::initVarConstraint, linsys.cpp:803-819 (caller src/eng/poly.cpp:1603): -x_i <= 0 for every variable
+    // whose sign entry is >= 0 (all of them without a sign vector), nothing for the others.
+    template <class SignVec> void initVarConstraint(SignVec const * sign, RMatT & vc, unsigned rhs_idx)
+    {
+        typedef typename std::decay<decltype(std::declval<RMatT const &>().get(0u, 0u))>::type R;
+        vc.reinit(rhs_idx, rhs_idx + 1);
+        vc.set_col(rhs_idx, R(0));
+        for (unsigned i = 0; i < rhs_idx; i++)
+            if (!sign || sign->get(i) >= 0) vc.set(i, i, -1);
+    }
+    void initVarConstraint(std::nullptr_t, RMatT & vc, unsigned rhs_idx) { initVarConstraint((all_nonnegative const *)0, vc, rhs_idx); }
+private:
+    struct all_nonnegative { int get(unsigned) const { return 0; } };
+public:
+    // Lineq::is_consistent, linsys.cpp:779-800: eliminate the variables one after the other (each step an fme on the
+    // device); the system is contradictory as soon as one elimination says so. The caller's matrix is left alone.
+    bool is_consistent()
+    {
+        RMatT * const keep = m_coeff;
+        const int keep_rhs = m_rhs_idx;
+        RMatT work = *keep;
+        set_param(&work, keep_rhs);
+        bool consistent = true;
+        for (unsigned v = 0; consistent && v < (unsigned)keep_rhs; v++) {
+            RMatT next;
+            if (!fme(v, next)) consistent = false; else work = next;
+        }
+        set_param(keep, keep_rhs);
+        return consistent;
+    }
+    // Lineq::formatBound, linsys.cpp:948-1030 (caller src/eng/ldtran.cpp:1534): the rows that mention variable u, its
+    // coefficient brought to +-1, the other variables moved to the right-hand side (negated, appended behind the
+    // constant / symbol columns), every row then over one common denominator from column 1 on.
+    void formatBound(unsigned u, RMatT & bound_of_u)
+    {
+        typedef typename std::decay<decltype(std::declval<RMatT const &>().get(0u, 0u))>::type R;
+        bound_of_u.reinit(0, 0);
+        for (unsigned i = 0; i < m_coeff->get_row_size(); i++)
+            if (m_coeff->get(i, u) != 0) {
+                RMatT row;
+                m_coeff->innerRow(row, i, i);
+                bound_of_u.grow_row(row);
+            }
+        const unsigned rows = bound_of_u.get_row_size();
+        if (rows == 0) return;                               // nothing constrains u
+        const unsigned nvar = (unsigned)m_rhs_idx;
+        const unsigned moved_at = bound_of_u.get_col_size();
+        if (nvar != 1) bound_of_u.grow_col(nvar - 1);
+        for (unsigned i = 0; i < rows; i++) {
+            for (unsigned j = moved_at; j < bound_of_u.get_col_size(); j++) bound_of_u.setr(i, j, 0, 1);
+            R c = bound_of_u.get(i, u);
+            if (c < 0) c = -c;
+            if (c != 1) bound_of_u.mulOfRow(i, 1 / c);
+            if (nvar == 1) continue;
+            unsigned k = moved_at;
+            for (unsigned j = 0; j < nvar; j++)
+                if (j != u) bound_of_u.set(i, k++, -bound_of_u.get(i, j));
+        }
+        if (nvar != 1) {
+            if (u + 1 != nvar) bound_of_u.del_col(u + 1, nvar - 1);
+            if (u > 0) bound_of_u.del_col(0, u - 1);
+        }
+        for (unsigned i = 0; i < rows; i++) bound_of_u.comden(i, 1);
+    }
 
     // Lineq::reduce, linsys.cpp:359-626: in place; false = the system is inconsistent.
     bool reduce(RMatT & m, unsigned rhs_idx, bool is_intersect)

@@ -16,7 +16,9 @@
 #ifndef XPOLY_AMD_SIX_HPP
 #define XPOLY_AMD_SIX_HPP
 
+#include <cstddef>
 #include <cstring>
+#include <mutex>
 #include <vector>
 #include "../xpoly_amd.h"
 
@@ -28,11 +30,29 @@ template <class T> struct scalar_kind { static const int value = -1; };
 
 namespace detail {
 
+// The context every default-constructed solver of this process shares (device 0). Created once, by whichever
+// host thread constructs its first solver; later calls only read the pointer. The C ABI allows one thread
+// per handle at a time: callers that solve from several threads give each solver its own context
+// (`SIX(ctx)`, `MIP(ctx)`, `Lineq(m, rhs, ctx)`).
 inline xpg_ctx * shared_context()
 {
     static xpg_ctx * ctx = 0;
-    if (!ctx && xpg_create(&ctx, 0) != 0) ctx = 0;
+    static std::once_flag once;
+    std::call_once(once, [] { if (xpg_create(&ctx, 0) != 0) ctx = 0; });
     return ctx;
+}
+
+// SIX::reviseTargetFunc / MIP::reviseTargetFunc, lpsol.h:2053-2074: a variable whose column is all zero in
+// both systems gets objective coefficient 0 (it would make the problem unbounded for no reason). Host side in the
+// reference too -- O(rows x cols) reads of the caller's matrices, no arithmetic -- so it stays on the host here.
+template <class Mat> inline void revise_target(Mat & tgtf, Mat const & eq, Mat const & leq, int rhs_idx)
+{
+    for (int j = 0; j < rhs_idx; j++) {
+        bool nonzero = false;
+        if (leq.get_col_size() > 0 && !leq.is_colequ((unsigned)j, 0)) nonzero = true;
+        if (eq.get_col_size() > 0 && !eq.is_colequ((unsigned)j, 0)) nonzero = true;
+        if (!nonzero) tgtf.set(0, (unsigned)j, 0);
+    }
 }
 
 template <class Mat> inline const void * data_of(Mat const & m)
@@ -51,6 +71,8 @@ public:
     void destroy() {}
     // SIX::set_param, lpsol.h:380-385
     void set_param(unsigned indent, unsigned max_iter = 0xFFFFFFFFu) { m_indent = indent; m_max_iter = max_iter; }
+    // SIX::reviseTargetFunc, lpsol.h:329-333 / :2053-2074 (call sites linsys.cpp:885, lpsol.h MIP)
+    void reviseTargetFunc(Mat & tgtf, Mat const & eq, Mat const & leq, int rhs_idx) { detail::revise_target(tgtf, eq, leq, rhs_idx); }
 
     // SIX::maxm, lpsol.h:1993-2033 -- same argument order and meaning.
     unsigned maxm(T & maxv, Mat & res, Mat const & tgtf, Mat & vc, Mat const & eq, Mat const & leq, int rhs_idx = -1)
@@ -159,6 +181,11 @@ public:
     void init() {}
     void destroy() {}
 
+    // MIP::maxm / minm, lpsol.h:2121-2140: `bool is_bin = false, BMat * rational_indicator = NULL, INT rhs_idx = -1`.
+    // The indicator's type is the caller's (anything with get(0, j) -> bool), so it is a template parameter; the
+    // reference's own call sites pass a literal NULL (linsys.cpp:864-866, :873-875), from which no pointer type can be
+    // deduced -- those bind to the std::nullptr_t overloads (NULL and nullptr both convert), which also carry the
+    // reference's defaults (poly.cpp:5131-5134 passes six arguments).
     template <class BoolMat>
     unsigned maxm(T & maxv, Mat & res, Mat const & tgtf, Mat & vc, Mat const & eq, Mat const & leq,
                   bool is_bin, BoolMat * rational_indicator, int rhs_idx = -1)
@@ -167,12 +194,17 @@ public:
     unsigned minm(T & minv, Mat & res, Mat const & tgtf, Mat & vc, Mat const & eq, Mat const & leq,
                   bool is_bin, BoolMat * rational_indicator, int rhs_idx = -1)
     { return solve(false, minv, res, tgtf, vc, eq, leq, is_bin, rational_indicator, rhs_idx); }
-    unsigned maxm(T & maxv, Mat & res, Mat const & tgtf, Mat & vc, Mat const & eq, Mat const & leq, bool is_bin = false)
-    { return solve(true, maxv, res, tgtf, vc, eq, leq, is_bin, (Mat *)0, -1); }
-    unsigned minm(T & minv, Mat & res, Mat const & tgtf, Mat & vc, Mat const & eq, Mat const & leq, bool is_bin = false)
-    { return solve(false, minv, res, tgtf, vc, eq, leq, is_bin, (Mat *)0, -1); }
+    unsigned maxm(T & maxv, Mat & res, Mat const & tgtf, Mat & vc, Mat const & eq, Mat const & leq, bool is_bin = false,
+                  std::nullptr_t = nullptr, int rhs_idx = -1)
+    { return solve(true, maxv, res, tgtf, vc, eq, leq, is_bin, (no_indicator *)0, rhs_idx); }
+    unsigned minm(T & minv, Mat & res, Mat const & tgtf, Mat & vc, Mat const & eq, Mat const & leq, bool is_bin = false,
+                  std::nullptr_t = nullptr, int rhs_idx = -1)
+    { return solve(false, minv, res, tgtf, vc, eq, leq, is_bin, (no_indicator *)0, rhs_idx); }
+    // MIP::reviseTargetFunc, lpsol.h:2141-2145 (it forwards to SIX's; call sites linsys.cpp:861, poly.cpp:5127)
+    void reviseTargetFunc(Mat & tgtf, Mat const & eq, Mat const & leq, int rhs_idx) { detail::revise_target(tgtf, eq, leq, rhs_idx); }
 
 private:
+    struct no_indicator { bool get(int, int) const { return false; } };
     template <class BoolMat>
     unsigned solve(bool is_max, T & v, Mat & res, Mat const & tgtf, Mat & vc, Mat const & eq, Mat const & leq,
                    bool is_bin, BoolMat * ind, int rhs_idx)

@@ -36,6 +36,23 @@ template <> struct scalar_kind<xcom::Rational> { static const int value = 1; };
 
 using namespace xcom;
 
+// Lineq::has_solution's body (src/com/linsys.cpp:842-906) exactly as the reference has it, compiled with the
+// substitution INTEGRATION.md section 2 prescribes and nothing else. The text is cut out of the reference by
+// oracle/Makefile while this file is being compiled and is not kept (HAS_SOLUTION_BODY names the temporary).
+namespace subst {
+using xpoly_amd::SIX;
+using xpoly_amd::MIP;
+static bool has_solution(RMat const& leq, RMat const& eq, RMat & vc, UINT rhs_idx, bool is_int_sol, bool is_unique_sol)
+#include HAS_SOLUTION_BODY
+}
+
+static int same_cells(RMat const & a, RMat const & b)
+{
+    if (a.get_row_size() != b.get_row_size()) return 0;
+    if (a.size() == 0 || b.size() == 0) return a.size() == b.size();
+    return a.get_col_size() == b.get_col_size() && memcmp(a.get_matrix(), b.get_matrix(), sizeof(Rational) * a.size()) == 0;
+}
+
 static unsigned long long rng_state = 88172645463325252ULL;
 static unsigned long long xs()
 {
@@ -115,7 +132,7 @@ int main()
         xcom::MIP<RMat, Rational> ref;
         xpoly_amd::MIP<RMat, Rational> gpu;
         UINT a = ref.maxm(v_ref, s_ref, tgtf, vc, eq, leq, is_bin, NULL);
-        UINT b = gpu.maxm(v_gpu, s_gpu, tgtf, vc, eq, leq, is_bin, (BMat *)NULL);
+        UINT b = gpu.maxm(v_gpu, s_gpu, tgtf, vc, eq, leq, is_bin, NULL);   // the reference's spelling (linsys.cpp:864-866)
         if (b == (UINT)XPG_ERR_REF_UNDEFINED) {
             // convertEq2Ineq reads the equality row at the inequality's row index (lpsol.h:1232);
             // with more inequality rows than columns that is a read past the buffer in the
@@ -189,6 +206,15 @@ int main()
             RMat vc2 = vc;
             bool ha = ref.has_solution(sys1, eq, vc, nv, true, true), hb = gpu.has_solution(sys2, eq, vc2, nv, true, true);
             mis = ha != hb;
+            // ... and the reference's own has_solution BODY running on xpoly_amd::SIX / MIP (reviseTargetFunc, the literal
+            // NULL indicator, rhs_idx), integer and rational question, unique or not
+            for (int q = 0; !mis && q < 4; q++) {
+                RMat vc3 = vc, vc4 = vc;
+                bool hr = ref.has_solution(sys1, eq, vc3, nv, (q & 1) != 0, (q & 2) != 0);
+                bool hs = subst::has_solution(sys2, eq, vc4, nv, (q & 1) != 0, (q & 2) != 0);
+                if (hr != hs) { mis = 1; printf("  substituted has_solution body: reference %d, on xpoly_amd %d (int %d, unique %d)\n", (int)hr, (int)hs, q & 1, (q >> 1) & 1); }
+            }
+            n += 4;
         }
         if (!mis && ra && sys1.get_row_size() > 1) {
             RMat f1, f2;
@@ -215,6 +241,56 @@ int main()
             if (mis) printf("MISMATCH calcBound(List<RMat*>) on system %d (reference %d, xpoly_amd %d)\n", it, (int)ca, (int)cb);
         }
         if (mis) printf("MISMATCH Lineq adapter on system %d\n", it);
+        bad += mis; n++;
+    }
+    // ---- the host-side members next to them: reviseTargetFunc (lpsol.h:2053-2074, :2412-2420), appendEquation
+    // (linsys.cpp:922), formatBound (:948), initVarConstraint (:803), is_consistent (:779)
+    for (int it = 0; it < 40; it++) {
+        int rows = irand(2, 7), nv = irand(1, 4), nsym = it % 3 == 0 ? 1 : 0, cols = nv + 1 + nsym;
+        RMat sys1(rows, cols), sys2, e(irand(1, 2), cols), t1(1, cols), t2, t3, none;
+        for (int i = 0; i < rows; i++) for (int j = 0; j < cols; j++) sys1.setr(i, j, j < nv ? (irand(0, 2) ? irand(-3, 3) : 0) : irand(-4, 9), irand(1, 3));
+        if (it % 4 == 0) for (int i = 0; i < rows; i++) sys1.setr(i, irand(0, nv - 1) , 0, 1);      // an all-zero column now and then
+        for (UINT i = 0; i < e.get_row_size(); i++) for (int j = 0; j < cols; j++) e.setr(i, j, it % 4 == 0 && j < nv ? 0 : irand(-2, 2), 1);
+        for (int j = 0; j < nv; j++) t1.setr(0, j, 1, 1);
+        sys2 = sys1; t2 = t1; t3 = t1;
+        int mis = 0;
+        {   xcom::SIX<RMat, Rational> rs; xpoly_amd::SIX<RMat, Rational> gs; xpoly_amd::MIP<RMat, Rational> gm;
+            RMat ta = t1, tb = t1;
+            rs.reviseTargetFunc(t1, e, sys1, nv); gs.reviseTargetFunc(t2, e, sys2, nv); gm.reviseTargetFunc(t3, e, sys2, nv);
+            rs.reviseTargetFunc(ta, none, sys1, nv); gs.reviseTargetFunc(tb, none, sys2, nv);
+            mis = !same_cells(t1, t2) || !same_cells(t1, t3) || !same_cells(ta, tb);
+            if (mis) printf("MISMATCH reviseTargetFunc on system %d\n", it);
+        }
+        if (!mis) {
+            RMat a1 = sys1, a2 = sys2;
+            xcom::Lineq r(&a1, nv); xpoly_amd::Lineq<RMat> g(&a2, nv);
+            r.appendEquation(e); g.appendEquation(e);
+            mis = !same_cells(a1, a2);
+            if (mis) printf("MISMATCH appendEquation on system %d\n", it);
+        }
+        for (int u = 0; !mis && u < nv; u++) {
+            RMat f1, f2;
+            xcom::Lineq r(&sys1, nv); xpoly_amd::Lineq<RMat> g(&sys2, nv);
+            r.formatBound(u, f1); g.formatBound(u, f2);
+            mis = !same_cells(f1, f2);
+            if (mis) printf("MISMATCH formatBound(%d) on system %d\n", u, it);
+        }
+        if (!mis) {
+            RMat v1, v2, v3, v4;
+            Vector<INT> sign;
+            for (int j = 0; j < nv; j++) sign.set(j, irand(-1, 1));
+            xcom::Lineq r(NULL); xpoly_amd::Lineq<RMat> g(NULL);
+            r.initVarConstraint(&sign, v1, nv); g.initVarConstraint(&sign, v2, nv);
+            r.initVarConstraint(NULL, v3, nv); g.initVarConstraint(NULL, v4, nv);
+            mis = !same_cells(v1, v2) || !same_cells(v3, v4);
+            if (mis) printf("MISMATCH initVarConstraint on system %d\n", it);
+        }
+        if (!mis && nsym == 0) {
+            xcom::Lineq r(&sys1, nv); xpoly_amd::Lineq<RMat> g(&sys2, nv);
+            bool c1 = r.is_consistent(), c2 = g.is_consistent();
+            mis = c1 != c2 || !same_cells(sys1, sys2);
+            if (mis) printf("MISMATCH is_consistent on system %d: reference %d, xpoly_amd %d\n", it, (int)c1, (int)c2);
+        }
         bad += mis; n++;
     }
     printf("dropin_demo: %d solves through xcom::SIX / MIP and xpoly_amd::SIX / MIP on the reference's own matrix types, "

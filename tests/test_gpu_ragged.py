@@ -113,6 +113,15 @@ def test_lineq_reduce_and_fme_ragged_match_oracle(ctx, port):
             wok, wres = port.fme(mats[k], mats[k].shape[1] - 1, us[k], dark)
             assert ok[k] == wok, (k, dark)
             assert (res[k].shape[0] == 0 and wres.shape[0] == 0) or (res[k].shape == wres.shape and np.array_equal(res[k], wres)), (k, dark)
+    # the same through the sizing call (what batches whose worst case exceeds 256 MB take): XPG_ERR_SHAPE with the offsets
+    # filled, then a buffer of exactly that size
+    ok1, res1 = lq.fme_ragged(mats, us, None, False)
+    lq.RAGGED_FME_ONE_CALL_BYTES = 0
+    try:
+        ok2, res2 = lq.fme_ragged(mats, us, None, False)
+    finally:
+        del lq.RAGGED_FME_ONE_CALL_BYTES
+    assert np.array_equal(ok1, ok2) and all(a.shape == b.shape and np.array_equal(a, b) for a, b in zip(res1, res2))
 
 
 def test_ragged_and_packed_error_paths(ctx):

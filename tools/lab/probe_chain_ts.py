@@ -12,8 +12,10 @@ ctx = xpoly_amd.Context(0)
 leq, tg = gen.hard_lp_f64(4096, 4095)
 lp = xpoly_amd.DeviceLP(ctx, xpoly_amd.F64, leq, tg)
 lp.begin(); lp.iterate(1600)
-ts = np.zeros((4, 16, 8), dtype=np.uint64)
-lib().xpg_lp_debug_chain_ts(lp._h, ts.ctypes.data_as(C.c_void_p))
+cap = C.c_int(0)
+lib().xpg_lp_debug_chain_ts(lp._h, None, C.byref(cap), 0)          # the library's stage capacity (BLK_MAX)
+ts = np.zeros((4, cap.value, 8), dtype=np.uint64)
+assert lib().xpg_lp_debug_chain_ts(lp._h, ts.ctypes.data_as(C.c_void_p), None, cap.value) == 0
 t = ts.astype(np.int64)
 base = t[0, 1, 0]
 names = ["top", "partials seen", "gather+fresh in", "record issued", "records seen", "row replayed", "partial issued"]

@@ -45,7 +45,9 @@ def stale():
 
 
 def build(force=False, extra=(), out=None, obj=None):
-    """out / obj: another library path and object directory (diagnostic builds: -DXPG_STAMPS, -DXPG_LIFE)."""
+    """force: recompile every part from its source whatever the time stamps say (what __graft_entry__.build() asks for:
+    the driver's build step proves the source, it does not re-link yesterday's objects).
+    out / obj: another library path and object directory (diagnostic builds: -DXPG_STAMPS, -DXPG_LIFE)."""
     if out is None and not force and not stale():
         return OUT
     OUT_ = out or OUT
@@ -63,7 +65,7 @@ def build(force=False, extra=(), out=None, obj=None):
     same_flags = os.path.exists(key_file) and open(key_file).read() == flags_key
 
     def part_stale(p):
-        if not same_flags or not os.path.exists(objs[p]):
+        if force or not same_flags or not os.path.exists(objs[p]):
             return True
         t = os.path.getmtime(objs[p])
         d = os.path.join(HERE, "csrc")
@@ -82,4 +84,6 @@ def build(force=False, extra=(), out=None, obj=None):
 
 
 if __name__ == "__main__":
-    print(build(force=True))
+    import sys
+    # `python -m xpoly_amd.build` recompiles the parts whose sources changed; `--force` all four
+    print(build(force="--force" in sys.argv[1:]))

@@ -1066,10 +1066,14 @@ struct BatchSlices {
     int nmain; unsigned char * ckpt; unsigned long long stride; unsigned long long * queue; unsigned qmask; unsigned * ctl;
 };
 enum { CK_HEADER = 64 };
-// A continuation workgroup that has waited this long for an LP (100 MHz ticks: 20 s -- a launch of 65 536 LPs lasts 0.6 s)
-// leaves instead of spinning on: not a state the protocol can reach (every LP is in exactly one place: a seat, the queue, or
-// done), but a launch that never ends takes the device with it. An LP left behind keeps the status the host wrote
-// before the launch, XPG_ERR_CHAIN_STUCK.
+// A watchdog for a state the protocol cannot reach (every LP is in exactly one place: a seat, the queue, or done) --
+// but a launch that never ends takes the device with it. It measures LACK OF PROGRESS, not time: a waiting popper or
+// pusher restarts its clock whenever the launch as a whole has moved (ctl[0], pushes, or ctl[2], LPs done), so a long
+// tail of slow LPs -- Rational LPs of 64 rows under a large max_iter, a shared or preempted device -- never trips it.
+// After 20 s without any movement (100 MHz ticks) the waiter raises ctl[3], the launch-wide ABORT word: every popper and
+// pusher sees it in its own loop and leaves at once (nobody burns a second 20 s), LPs left behind keep the sentinel
+// status XPG_ERR_CHAIN_STUCK the host wrote before the launch, and the host-array callers turn a sentinel they find
+// into a call-level error (batch_stuck_check).
 #define SLICE_WATCHDOG_TICKS 2000000000ull
 template <class S> __device__ __forceinline__ void sm_checkpoint(const Small<S> & P, const unsigned char * lds, size_t lds_bytes, unsigned char * ck, unsigned done, int stage)
 {
@@ -1096,31 +1100,51 @@ template <class S> __device__ __forceinline__ unsigned sm_restore(Small<S> & P, 
     __syncthreads();
     return done;
 }
+__device__ __forceinline__ unsigned slices_progress(const BatchSlices & Q)
+{
+    return __hip_atomic_load(&Q.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
+           __hip_atomic_load(&Q.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool slices_aborted(const BatchSlices & Q)
+{ return __hip_atomic_load(&Q.ctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u; }
+// true: waited SLICE_WATCHDOG_TICKS without the launch moving (the caller raises ABORT); t0 / seen are the waiter's clock
+__device__ __forceinline__ bool slices_starved(const BatchSlices & Q, unsigned long long & t0, unsigned & seen)
+{
+    const unsigned long long now = wall_clock64();
+    if (now - t0 <= SLICE_WATCHDOG_TICKS) return false;
+    const unsigned p = slices_progress(Q);
+    if (p != seen) { seen = p; t0 = now; return false; }
+    __hip_atomic_store(&Q.ctl[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
 __device__ __forceinline__ void slices_push(const BatchSlices & Q, int lp)
 {
     const unsigned t = atomicAdd(&Q.ctl[0], 1u);
     unsigned long long * e = Q.queue + (t & Q.qmask);
-    const unsigned long long t0 = wall_clock64();
+    unsigned long long t0 = wall_clock64();
+    unsigned seen = slices_progress(Q);
     while (__hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) {
-        if (wall_clock64() - t0 > SLICE_WATCHDOG_TICKS) return;        // (never seen: the LP keeps the sentinel status the host wrote)
+        // (never seen: the ring holds 2 x nb slots; the LP keeps the sentinel status the host wrote)
+        if (slices_aborted(Q) || slices_starved(Q, t0, seen)) return;
         __builtin_amdgcn_s_sleep(8);
     }
     __hip_atomic_store(e, ((unsigned long long)(t + 1u) << 32) | (unsigned)(lp + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-// -1: every LP of the launch is done
+// -1: every LP of the launch is done (or the launch was aborted)
 __device__ __forceinline__ int slices_pop(const BatchSlices & Q, int nb)
 {
     const unsigned t = atomicAdd(&Q.ctl[1], 1u);
     unsigned long long * e = Q.queue + (t & Q.qmask);
-    const unsigned long long t0 = wall_clock64();
+    unsigned long long t0 = wall_clock64();
+    unsigned seen = slices_progress(Q);
     for (;;) {
-        if (wall_clock64() - t0 > SLICE_WATCHDOG_TICKS) return -1;
         const unsigned long long w = __hip_atomic_load(e, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
         if ((unsigned)(w >> 32) == t + 1u) {
             __hip_atomic_store(e, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return (int)(unsigned)w - 1;
         }
         if (__hip_atomic_load(&Q.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)nb) return -1;
+        if (slices_aborted(Q) || slices_starved(Q, t0, seen)) return -1;
         __builtin_amdgcn_s_sleep(32);
     }
 }
@@ -1298,6 +1322,18 @@ int batch_dev(xpg_ctx * ctx, int is_max, int nb, const S * tgtf, const S * leq, 
     return 0;
 }
 
+// A sentinel left in the statuses a sliced launch brought back = the launch aborted (SLICE_WATCHDOG_TICKS): a call-level
+// error, not a per-LP status the callers of a batch (has_solution, the MIP controller) would mistake for an answer.
+inline int batch_stuck_check(xpg_ctx * ctx, const int32_t * st, int nb)
+{
+    for (int b = 0; b < nb; b++)
+        if (st[b] == (int32_t)XPG_ERR_CHAIN_STUCK) {
+            ctx->err = "batched LPs: the time-sliced launch made no progress for 20 s and was aborted (preempted or hung device); no result of this call is valid";
+            return XPG_ERR_CHAIN_STUCK;
+        }
+    return 0;
+}
+
 // Host-array form: staged through a grow-only scratch area the context owns (one hipMalloc per growth instead of
 // five hipMalloc / hipFree pairs per call: the MIP controller makes a call per lock-step round).
 template <class S>
@@ -1332,6 +1368,7 @@ int batch_host(xpg_ctx * ctx, int is_max, int nb, const S * tgtf, const S * leq,
     if (e == hipSuccess && rc == 0) e = hipMemcpyAsync(out_sol, d_sol, bt, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return XPG_ERR_HIP; }
+    if (rc == 0) rc = batch_stuck_check(ctx, out_status, nb);
     return rc;
 }
 
@@ -1388,6 +1425,7 @@ int batch_stage_run(xpg_ctx * ctx, BatchStage<S> & bs, int is_max, unsigned max_
     if (e == hipSuccess && rc == 0) e = hipMemcpyAsync(bs.h_sol, bs.d_sol, bs.out_bytes, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return XPG_ERR_HIP; }
+    if (rc == 0) rc = batch_stuck_check(ctx, bs.h_st, bs.nb);
     return rc;
 }
 

@@ -51,7 +51,10 @@ __device__ __forceinline__ char * frec(const LpView<R32> & v, int p) { return (c
 __device__ __forceinline__ void fr_store(char * p, unsigned long long data, unsigned ticket, int kind)
 {
     fr_u32x4 g; g.x = (unsigned)data; g.y = (unsigned)(data >> 32); g.z = ticket; g.w = (unsigned)kind;
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(g) : "memory");
+    // (s_nop: the hardware reads the data registers of a > 8-byte VMEM store after issue, and the compiler's hazard
+    // recogniser does not look into asm -- without it the next granule's moves can land in this one: ch_store_u32x4,
+    // lp_chain.hip.h, found that the hard way)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 3" :: "v"(p), "v"(g) : "memory");
 }
 __device__ __forceinline__ fr_u32x4 fr_load(const char * p)
 {
@@ -103,13 +106,14 @@ __device__ inline void fused_pick_r32(const LpView<R32> & v, int slot, int colst
         return;
     }
 
+    // (a pivot nobody has staged is not a state the host's launch sequence can produce -- a generic point stages what
+    // it picks, a fused launch what its pick chooses; if it ever is seen, the solve ends with an error and NOTHING of this
+    // launch is written: the sweep workgroups and the stagers test the same flag, so the handle's tableau, basis and
+    // descriptors stay those of the last good pivot)
+    if (!I.staged) { if (p == 0 && tid == 0) st->status = XPG_ERR_CHAIN_STUCK; return; }
     // ---- a sweep is running around us
     if (p == 0 && tid == 0) {                          // commit this iteration's pivot (lpsol.h:1504-1510)
         FUSED_STAMP(st, 0);
-        // (a pivot nobody has staged is not a state the host's launch sequence can produce -- a generic point stages what
-        // it picks, a fused launch what its pick chooses; if it ever is seen, the solve ends with an error instead of a
-        // tableau swept with whatever the staging buffers held)
-        if (!I.staged) st->status = XPG_ERR_CHAIN_STUCK;
         v.nv[ienter] = 0; v.nv[ileave] = 1; v.bv[ienter] = 1; v.bv[ileave] = 0;
         v.eq2bv[r] = ienter; v.bv2eq[ienter] = r; v.bv2eq[ileave] = -1;
         XPG_TRACE_PIVOT("hbm-fused", ienter, ileave, r);
@@ -199,7 +203,7 @@ __device__ inline void fused_stage_r32(const LpView<R32> & v, int slot, int cols
     const int r = I.row, ienter = I.col, ileave = I.leave, first = desc_first(I), anypos = I.anypos, stop = I.stop, side = I.side;
     const unsigned done_now = I.done_after, total_now = I.total_after;
     const bool canon = st->noncanon == 0;
-    if (r < 0 || stop != 0) return;
+    if (r < 0 || stop != 0 || !I.staged) return;       // (unstaged: pick workgroup 0 reports it, nobody writes)
     const int W = v.W, rhs = v.rhs, ld = v.ld, lim = v.rhs - 1;
     const int tid = threadIdx.x, j = q * 256 + tid;
     const bool in = j < W;
@@ -332,7 +336,7 @@ void k_pipe_fused_r32(LpView<R32> v, int slot, int colstride, int N, int NP)
 {
     LoopState * st = v.st;
     const PipeDesc & D = st->pd[slot];
-    const int status = st->status, r = D.row, first = desc_first(D), noncanon = st->noncanon, side = D.side, stop = D.stop;
+    const int status = st->status, r = D.row, first = desc_first(D), noncanon = st->noncanon, side = D.side, stop = D.stop, staged = D.staged;
     if (status != ST_RUNNING) return;
     const R32 * __restrict__ A = side ? v.tab2 : v.tab;
     R32 * __restrict__ B = side ? v.tab : v.tab2;
@@ -346,7 +350,7 @@ void k_pipe_fused_r32(LpView<R32> v, int slot, int colstride, int N, int NP)
         }
         return;
     }
-    if (r < 0 || stop != 0) return;
+    if (r < 0 || stop != 0 || !staged) return;               // (unstaged: see fused_pick_r32 -- nothing is written)
     const int i = blockIdx.x;
     if (i >= v.m) return;
     const int j = ((int)blockIdx.y - 1) * 256 + threadIdx.x;

@@ -376,7 +376,9 @@ template <class S> struct Lp : LpBase {
         }
         if (out->blk.ch_aborts != chain_aborts_seen) { chain_aborts_seen = out->blk.ch_aborts; chain_off = true; }
         if (out->status == XPG_ERR_CHAIN_STUCK)
-            ctx->err = "blocked loop: a worker of the persistent chain launch stopped answering after the roll call (preempted queue?); rebuild the LP";
+            ctx->err = std::is_same<S, R32>::value
+                ? "fused Rational loop: a launch met a pivot nobody had staged (nothing of that launch was written), or its stagers never saw the pick's records; rebuild the LP"
+                : "blocked loop: a worker of the persistent chain launch stopped answering after the roll call (preempted queue?); rebuild the LP";
         return 0;
     }
 

@@ -510,13 +510,17 @@ int xpg_lp_debug(xpg_lp * lp, unsigned long long * out8)
     for (int k = 0; k < 8; k++) out8[k] = hs.blk.dbg[k];
     return 0;
 }
-// the staged rows / columns of the last batch: E[16][ld], K[m][16]; *ld receives the leading dimension
-int xpg_lp_debug_staged(xpg_lp * lp, double * E, double * K, int * ld)
+// the staged rows / columns of the last batch: E[BLK_MAX][ld], K[m][BLK_MAX]; *ld receives the leading dimension and
+// *blk_max the stage capacity (BLK_MAX). The caller says how many stages its arrays were sized for (`cap`, from a first
+// call with E = K = NULL); a capacity that is not the library's is refused instead of overrunning the caller's heap.
+int xpg_lp_debug_staged(xpg_lp * lp, double * E, double * K, int * ld, int * blk_max, int cap)
 {
     if (!lp || !lp->impl || lp->impl->kind != 0) return XPG_ERR_SHAPE;
     Lp<F64> * p = (Lp<F64> *)lp->impl;
     xpg_ctx * ctx = p->ctx;
     if (ld) *ld = p->v.ld;
+    if (blk_max) *blk_max = BLK_MAX;
+    if ((E || K) && cap != BLK_MAX) return XPG_ERR_SHAPE;
     if (E) XPG_HIP(ctx, hipMemcpy(E, p->v.blkE, (size_t)BLK_MAX * p->v.ld * 8, hipMemcpyDeviceToHost));
     if (K) XPG_HIP(ctx, hipMemcpy(K, p->v.blkK, (size_t)p->v.m * BLK_MAX * 8, hipMemcpyDeviceToHost));
     return 0;
@@ -530,10 +534,13 @@ int xpg_lp_debug_counts(xpg_lp * lp, int * rowcnt, int * colcnt, int n)
     XPG_HIP(ctx, hipMemcpy(colcnt, p->v.colcnt, (size_t)n * 4, hipMemcpyDeviceToHost));
     return 0;
 }
-int xpg_lp_debug_chain_ts(xpg_lp * lp, unsigned long long * out)   // [4][BLK_MAX][8]
+int xpg_lp_debug_chain_ts(xpg_lp * lp, unsigned long long * out, int * blk_max, int cap)   // [4][BLK_MAX][8]; cap as above
 {
     if (!lp || !lp->impl) return XPG_ERR_SHAPE;
     xpg_ctx * ctx = lp->impl->ctx;
+    if (blk_max) *blk_max = BLK_MAX;
+    if (!out) return 0;
+    if (cap != BLK_MAX) return XPG_ERR_SHAPE;
     XPG_HIP(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ch_ts), sizeof(unsigned long long) * 4 * BLK_MAX * 8));
     return 0;
 }

@@ -110,6 +110,8 @@ class Lineq:
         return ok, [flat[2 * int(off[b]): 2 * int(off[b]) + 2 * int(out_rows[b]) * int(cols[b])].reshape(int(out_rows[b]), int(cols[b]), 2).copy()
                     for b in range(nb)]
 
+    RAGGED_FME_ONE_CALL_BYTES = 256 << 20
+
     def fme_ragged(self, mats_list, u, rhs_idx=None, darkshadow=False):
         """Lineq::fme on systems of different shapes, eliminating variable u[b] of system b: (ok[nb], [result b])."""
         from .six import _ragged_pack
@@ -119,14 +121,30 @@ class Lineq:
         rhs = None if rhs_idx is None else np.ascontiguousarray(rhs_idx, dtype=np.int32)
         uu = np.ascontiguousarray(u, dtype=np.int32)
         out_rows = np.zeros(nb, dtype=np.int32); ok = np.zeros(nb, dtype=np.int32); ooff = np.zeros(nb + 1, dtype=np.int64)
-        # ONE call: the entry point computes every elimination before it looks at the output buffer, so a sizing call
-        # would do the whole batch twice. An elimination of R rows leaves at most R*R/4 + R rows (P positive x N negative
-        # combinations with P + N <= R, plus the rows without the variable): the buffer is sized for that and trimmed.
+        # ONE call where the worst case is small: the entry point computes every elimination before it looks at the output
+        # buffer, so a sizing call does the whole batch twice. An elimination of R rows leaves at most R*R/4 + R rows (P
+        # positive x N negative combinations with P + N <= R, plus the rows without the variable): the buffer is sized for
+        # that and trimmed. Above 256 MB of worst case (large batches: several GB of zero pages that raise MemoryError where
+        # the real result fits easily) the sizing call is the cheaper evil: the first call returns XPG_ERR_SHAPE with the
+        # offsets filled (include/xpoly_amd.h), the second gets a buffer of exactly that size.
         capc = int(sum((int(r) * int(r) // 4 + int(r)) * int(c) for r, c in zip(rows, cols)))
-        outs = np.zeros((max(capc, 1), 2), dtype=np.int32)
-        self.ctx.check(lib().xpg_lineq_fme_batch_ragged_rat32(
-            self.ctx._h, C.c_int(nb), vp(flat), vp(rows), vp(cols), vp(off), vp(rhs), vp(uu), C.c_int(int(darkshadow)), vp(outs),
-            C.c_longlong(capc), vp(ooff), vp(out_rows), vp(ok)), "xpg_lineq_fme_batch_ragged_rat32")
+
+        def call(buf, cap_cells):
+            return lib().xpg_lineq_fme_batch_ragged_rat32(
+                self.ctx._h, C.c_int(nb), vp(flat), vp(rows), vp(cols), vp(off), vp(rhs), vp(uu), C.c_int(int(darkshadow)), vp(buf),
+                C.c_longlong(cap_cells), vp(ooff), vp(out_rows), vp(ok))
+
+        if capc * 8 <= self.RAGGED_FME_ONE_CALL_BYTES:
+            outs = np.zeros((max(capc, 1), 2), dtype=np.int32)
+            self.ctx.check(call(outs, capc), "xpg_lineq_fme_batch_ragged_rat32")
+        else:
+            rc = call(None, 0)
+            if rc != -3:                                    # XPG_ERR_SHAPE: "too small", offsets filled
+                self.ctx.check(rc, "xpg_lineq_fme_batch_ragged_rat32 (sizing)")
+            need = int(ooff[nb])
+            outs = np.zeros((max(need, 1), 2), dtype=np.int32)
+            if need:
+                self.ctx.check(call(outs, need), "xpg_lineq_fme_batch_ragged_rat32")
         return ok, [outs[int(ooff[b]): int(ooff[b + 1])].reshape(int(out_rows[b]), int(cols[b]), 2).copy() for b in range(nb)]
 
     def calcBound(self, mats, rhs_idx, cap_rows=None):
