@@ -153,6 +153,7 @@ public:
     bool fme(unsigned u, RMatT & res, bool darkshadow = false)
     {
         // the packed form: only the live rows travel, and they are read straight out of the handle's pinned buffer
+        if (m_coeff->size() == 0) { res.clean(); return true; }       // an empty system stays empty (linsys.cpp:661-664)
         const int rows = (int)m_coeff->get_row_size(), cols = (int)m_coeff->get_col_size();
         const xpg_rat32 * view = 0;
         long long off[2] = {0, 0};

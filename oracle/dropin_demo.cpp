@@ -10,6 +10,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdint.h>
+#include <signal.h>
+#include <unistd.h>
 
 #include "ltype.h"
 #include "comf.h"
@@ -46,6 +48,12 @@ static bool has_solution(RMat const& leq, RMat const& eq, RMat & vc, UINT rhs_id
 #include HAS_SOLUTION_BODY
 }
 
+// where the demo is, for the handler below: the reference divides integers by zero on some inputs (rational.cpp's
+// reduce / operator/ have no guard), which must be reported as the reference's crash, not as a silent exit
+static const char * g_where = "start";
+static int g_case = -1;
+static void on_fpe(int) { fprintf(stderr, "SIGFPE (integer division by zero) in: %s, case %d\n", g_where, g_case); _exit(3); }
+
 static int same_cells(RMat const & a, RMat const & b)
 {
     if (a.get_row_size() != b.get_row_size()) return 0;
@@ -79,6 +87,7 @@ template <class Mat, class T> static int compare_one(Mat & tgtf, Mat & vc, Mat &
 
 int main()
 {
+    signal(SIGFPE, on_fpe);
     int bad = 0, n = 0, undefined = 0;
     {   // src/example/example.cpp:54-93
         FloatMat leq(2, 3), tgtf(1, 3), vc(2, 3), eq;
@@ -198,18 +207,21 @@ int main()
         sys2 = sys1;
         xcom::Lineq ref(NULL);
         xpoly_amd::Lineq<RMat> gpu(NULL);
+        g_where = "Lineq::reduce"; g_case = it;
         bool ra = ref.reduce(sys1, nv, true), rb = gpu.reduce(sys2, nv, true);
         int mis = ra != rb || sys1.get_row_size() != sys2.get_row_size() ||
                   (sys1.size() && memcmp(sys1.get_matrix(), sys2.get_matrix(), sizeof(Rational) * sys1.size()) != 0);
         if (!mis && ra && sys1.get_row_size() > 0 && sys1.get_row_size() <= sys1.get_col_size()) {
             // (more rows than columns: convertEq2Ineq is out of bounds in the reference, lpsol.h:1232)
             RMat vc2 = vc;
+            g_where = "Lineq::has_solution(int, unique)";
             bool ha = ref.has_solution(sys1, eq, vc, nv, true, true), hb = gpu.has_solution(sys2, eq, vc2, nv, true, true);
             mis = ha != hb;
             // ... and the reference's own has_solution BODY running on xpoly_amd::SIX / MIP (reviseTargetFunc, the literal
             // NULL indicator, rhs_idx), integer and rational question, unique or not
             for (int q = 0; !mis && q < 4; q++) {
                 RMat vc3 = vc, vc4 = vc;
+                g_where = (q & 1) ? "has_solution body, integer" : "has_solution body, rational";
                 bool hr = ref.has_solution(sys1, eq, vc3, nv, (q & 1) != 0, (q & 2) != 0);
                 bool hs = subst::has_solution(sys2, eq, vc4, nv, (q & 1) != 0, (q & 2) != 0);
                 if (hr != hs) { mis = 1; printf("  substituted has_solution body: reference %d, on xpoly_amd %d (int %d, unique %d)\n", (int)hr, (int)hs, q & 1, (q >> 1) & 1); }
@@ -218,6 +230,7 @@ int main()
         }
         if (!mis && ra && sys1.get_row_size() > 1) {
             RMat f1, f2;
+            g_where = "Lineq::fme";
             xcom::Lineq r2(&sys1, nv); xpoly_amd::Lineq<RMat> g2(&sys2, nv);
             bool fa = r2.fme(0, f1, false), fb = g2.fme(0, f2, false);
             mis = fa != fb || f1.get_row_size() != f2.get_row_size() ||
@@ -226,6 +239,7 @@ int main()
         if (!mis && ra && sys1.get_row_size() > 1) {
             // Lineq::calcBound with the reference's own signature, List<RMat*> (linsys.h:151; call site linsys.cpp:312)
             RMat a1[4], a2[4];
+            g_where = "Lineq::calcBound";
             List<RMat*> lim1, lim2;
             for (int j = 0; j < nv; j++) { lim1.append_tail(&a1[j]); lim2.append_tail(&a2[j]); }
             xcom::Lineq r3(&sys1, nv); xpoly_amd::Lineq<RMat> g3(&sys2, nv);
@@ -248,12 +262,13 @@ int main()
     for (int it = 0; it < 40; it++) {
         int rows = irand(2, 7), nv = irand(1, 4), nsym = it % 3 == 0 ? 1 : 0, cols = nv + 1 + nsym;
         RMat sys1(rows, cols), sys2, e(irand(1, 2), cols), t1(1, cols), t2, t3, none;
-        for (int i = 0; i < rows; i++) for (int j = 0; j < cols; j++) sys1.setr(i, j, j < nv ? (irand(0, 2) ? irand(-3, 3) : 0) : irand(-4, 9), irand(1, 3));
+        for (int i = 0; i < rows; i++) for (int j = 0; j < cols; j++) { const int x = j < nv ? (irand(0, 2) ? irand(-3, 3) : 0) : irand(-4, 9); sys1.set(i, j, x == 0 ? Rational(0) : Rational(x, irand(1, 3))); }   // (canonical cells: 0/3 is not == 0 to the reference, and 1 / it divides by zero)
         if (it % 4 == 0) for (int i = 0; i < rows; i++) sys1.setr(i, irand(0, nv - 1) , 0, 1);      // an all-zero column now and then
         for (UINT i = 0; i < e.get_row_size(); i++) for (int j = 0; j < cols; j++) e.setr(i, j, it % 4 == 0 && j < nv ? 0 : irand(-2, 2), 1);
         for (int j = 0; j < nv; j++) t1.setr(0, j, 1, 1);
         sys2 = sys1; t2 = t1; t3 = t1;
         int mis = 0;
+        g_where = "reviseTargetFunc"; g_case = it;
         {   xcom::SIX<RMat, Rational> rs; xpoly_amd::SIX<RMat, Rational> gs; xpoly_amd::MIP<RMat, Rational> gm;
             RMat ta = t1, tb = t1;
             rs.reviseTargetFunc(t1, e, sys1, nv); gs.reviseTargetFunc(t2, e, sys2, nv); gm.reviseTargetFunc(t3, e, sys2, nv);
@@ -263,6 +278,7 @@ int main()
         }
         if (!mis) {
             RMat a1 = sys1, a2 = sys2;
+            g_where = "appendEquation";
             xcom::Lineq r(&a1, nv); xpoly_amd::Lineq<RMat> g(&a2, nv);
             r.appendEquation(e); g.appendEquation(e);
             mis = !same_cells(a1, a2);
@@ -270,6 +286,7 @@ int main()
         }
         for (int u = 0; !mis && u < nv; u++) {
             RMat f1, f2;
+            g_where = "formatBound";
             xcom::Lineq r(&sys1, nv); xpoly_amd::Lineq<RMat> g(&sys2, nv);
             r.formatBound(u, f1); g.formatBound(u, f2);
             mis = !same_cells(f1, f2);
@@ -277,6 +294,7 @@ int main()
         }
         if (!mis) {
             RMat v1, v2, v3, v4;
+            g_where = "initVarConstraint";
             Vector<INT> sign;
             for (int j = 0; j < nv; j++) sign.set(j, irand(-1, 1));
             xcom::Lineq r(NULL); xpoly_amd::Lineq<RMat> g(NULL);
@@ -287,6 +305,7 @@ int main()
         }
         if (!mis && nsym == 0) {
             xcom::Lineq r(&sys1, nv); xpoly_amd::Lineq<RMat> g(&sys2, nv);
+            g_where = "is_consistent";
             bool c1 = r.is_consistent(), c2 = g.is_consistent();
             mis = c1 != c2 || !same_cells(sys1, sys2);
             if (mis) printf("MISMATCH is_consistent on system %d: reference %d, xpoly_amd %d\n", it, (int)c1, (int)c2);
