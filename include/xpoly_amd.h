@@ -110,7 +110,8 @@ int xpg_pivot_rat32(xpg_ctx * ctx, xpg_rat32 * tab, int m, int W, xpg_rat32 * ob
  * `leq` is m x cols (A | b), x >= 0 for every variable, `tgtf` has cols entries.
  * vc_diag/vc_rhs hold vc(i,i) and vc(i,rhs) (the only cells SIX::is_feasible
  * reads, lpsol.h:798-802); NULL means -1 / 0.  kind: 0 = f64, 1 = rat32.
- * src_on_device != 0 when leq/tgtf are device pointers. */
+ * src_on_device: 0 leq / tgtf are host arrays, 1 both are device pointers, 2 leq is a device
+ * pointer and tgtf a host array (what SIX::minm's device-built dual hands over). */
 int  xpg_lp_create(xpg_ctx * ctx, int kind, const void * leq, int m, int cols,
                    const void * tgtf, const void * vc_diag, const void * vc_rhs,
                    int src_on_device, xpg_lp ** out);

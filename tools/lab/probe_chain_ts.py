@@ -17,11 +17,22 @@ lib().xpg_lp_debug_chain_ts(lp._h, None, C.byref(cap), 0)          # the library
 ts = np.zeros((4, cap.value, 8), dtype=np.uint64)
 assert lib().xpg_lp_debug_chain_ts(lp._h, ts.ctypes.data_as(C.c_void_p), None, cap.value) == 0
 t = ts.astype(np.int64)
+B = cap.value
+nb = int(__import__("os").environ.get("XPG_BLOCK", "24"))
 base = t[0, 1, 0]
-names = ["top", "partials seen", "gather+fresh in", "record issued", "records seen", "row replayed", "partial issued"]
-for wc, nm in enumerate(["worker 0", "last picker", "first prep-only", "last prepper"]):
+pick_names = [(0, "top"), (1, "partials seen"), (2, "gather in"), (5, "replayed"), (6, "ratio+key"), (7, "wave min"), (3, "record out"), (4, "records seen")]
+prep_names = [(0, "top"), (4, "records seen"), (1, "row+payload in"), (2, "replayed"), (5, "scaled"), (3, "obj+pricing"), (6, "partial out")]
+for wc, nm in enumerate(["pick worker 0", "last pick worker", "first prep worker", "last prep worker"]):
+    names = pick_names if wc < 2 else prep_names
     print(nm)
-    for st in (1, 2, 8, 9, 14, 15):
-        row = [(t[wc, st, p] - base) * 0.01 if t[wc, st, p] else float("nan") for p in range(7)]
-        print("  stage %2d: " % st + "  ".join("%s %7.2f" % (names[p][:14], row[p]) for p in range(7)))
-print("stage-to-stage (worker 0 top):", np.diff(t[0, 1:16, 0]) * 0.01)
+    for st in (1, 2, 8, 9, 14, 15, nb - 2, nb - 1):
+        row = [((t[wc, st, p] - base) * 0.01 if t[wc, st, p] else float("nan")) for p, _ in names]
+        print("  stage %2d: " % st + "  ".join("%s %7.2f" % (n[:14], x) for (_, n), x in zip(names, row)))
+    # mean segment lengths over the stages 2 .. nb-1 (us)
+    seg = []
+    for a, b in zip(names[:-1], names[1:]):
+        d = (t[wc, 2:nb, b[0]] - t[wc, 2:nb, a[0]]) * 0.01
+        seg.append("%s->%s %.2f" % (a[1], b[1], d.mean()))
+    print("  mean segments (stages 2..%d): " % (nb - 1) + " | ".join(seg))
+print("stage-to-stage (pick worker 0 top):", np.diff(t[0, 1:nb, 0]) * 0.01)
+print("mean stage: %.3f us" % (np.diff(t[0, 1:nb, 0]).mean() * 0.01))

@@ -217,6 +217,44 @@ __device__ __forceinline__ unsigned long long ch_wave_min_u64(unsigned long long
     return ab < cd ? ab : cd;
 }
 
+// A replay: a := start, then a := a + h_s * c_s for the stages s = 0 .. t-1 IN ORDER, each product rounded, each sum
+// rounded -- the sweep's own two roundings per pending update. h_s is this lane's history, c_s the other operand,
+// wave-uniform, held by lane s of `cv`. Round 5 (tools/lab/probe_chain_ts.py: the replays were 47 ns per step and stage,
+// a fifth of the chain launch -- a rolled loop with the stage number in an SGPR, an LDS round trip per group of four
+// and a select between "replace" and "add" inside the dependent chain):
+//   * the history is read from LDS into REGISTERS at the top of the stage (ChHist: all BLK_MAX slots, static indices
+//     only), long before the gather it is combined with has arrived -- no LDS wait inside the replay;
+//   * the products do not depend on each other, only the sums do: the loop is unrolled (the lane numbers of the
+//     broadcasts become immediates) and the ONLY dependent chain is t additions;
+//   * a stage that must not count adds -0.0 instead of its product, which leaves every double as it is (x + -0.0 = x for
+//     x = +-0, denormals, infinities; NaNs stay NaNs). Beyond t that costs nothing: the history slots at and beyond t
+//     hold +0.0 (zeroed at the start of the launch, slot s is written in stage s) and the lanes at and beyond t of `cv`
+//     hold -1.0, so the product IS -0.0. At or before `star` -- the last stage in which this element's row was the pivot
+//     row and the element was REPLACED; `start` is then that stage's value -- it is a select on the product, off the chain.
+// STAR: false no element of this wave was replaced, true `star` counts (per lane or wave-uniform alike).
+struct ChHist { double h[BLK_MAX]; };
+__device__ __forceinline__ void ch_hist_load(ChHist & H, const double * hist)
+{
+#pragma unroll
+    for (int s = 0; s < BLK_MAX; s++) H.h[s] = hist[64 * s];
+}
+template <bool STAR> __device__ __forceinline__ double ch_replay(double start, const ChHist & H, double cv, int t, int star)
+{
+    double a = start;
+#pragma unroll
+    for (int s = 0; s < BLK_MAX; s += 4) {
+        if (s >= t) break;
+        double p0 = H.h[s] * ch_readlane_f64(cv, s), p1 = H.h[s + 1] * ch_readlane_f64(cv, s + 1);
+        double p2 = H.h[s + 2] * ch_readlane_f64(cv, s + 2), p3 = H.h[s + 3] * ch_readlane_f64(cv, s + 3);
+        if (STAR) {
+            const double ident = -0.0;
+            p0 = s > star ? p0 : ident; p1 = s + 1 > star ? p1 : ident; p2 = s + 2 > star ? p2 : ident; p3 = s + 3 > star ? p3 : ident;
+        }
+        a = a + p0; a = a + p1; a = a + p2; a = a + p3;
+    }
+    return a;
+}
+
 // The winner of a stage, as every worker derives it from the records.
 struct ChWinner { int r, enter, leave, qstar, cc; uint32_t w; double a; unsigned long long cnv; };
 enum { CH_CLOSE_ROW = 0x7FFFFFFE, CH_UNORDERED_ROW = 0x7FFFFFFD };
@@ -481,8 +519,8 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
         const int i = w * 64 + lane;                        // this lane's row
         const bool has_row = i < m;
         const int ic = has_row ? i : 0;
-        // own data of the stages before t0 (written by previous launches)
-        for (int s = 0; s < t0; s++) hist[64 * s] = has_row ? K[(size_t)ic * BLK_MAX + s] : 0.0;
+        // own data of the stages before t0 (written by previous launches); every later slot +0.0 (ch_replay counts on it)
+        for (int s = 0; s < BLK_MAX; s++) hist[64 * s] = (s < t0 && has_row) ? K[(size_t)ic * BLK_MAX + s] : 0.0;
         int bi = v.eq2bv[ic];                               // basic variable of this lane's row (stage 0's commit is in)
         int sstar = -1;                                     // last stage in which this lane's row was the pivot row
         double bcur = tab[(size_t)ic * ld + rhs];           // this row's constant, replayed through the stages before t - 1
@@ -502,6 +540,8 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
         for (int t = t0; t < B; t++) {
             const unsigned want_part = t > 0 ? blk_epoch(batch, t - 1) : la_tag, tag = blk_epoch(batch, t);
             CH_TS(0);
+            ChHist H;
+            ch_hist_load(H, hist);                          // (in flight while the partials are polled)
             // ---- poll the g0 granules of the partials of stage t-1 and, behind them, the commit granule (the commit of
             // stage t0 - 1 was a launch of its own: no granule to wait for): four slots per lane and round, dense
             const int cnt = t == t0 ? nparts0 : nprep;      // partials of the stage before
@@ -562,37 +602,21 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
             const double ec_new = ch_readlane_f64(ev, 32), eb_new = ch_readlane_f64(ev, 34);
             const unsigned long long cnv_bits = __builtin_bit_cast(unsigned long long, ch_readlane_f64(ev, 33));
             if (lane == t - 1) ev = ec_new;                 // lane s of ev now holds e_s[first] for every s < t
+            if (lane >= t) ev = -1.0;                       // ... and the others what makes their product -0.0 (ch_replay)
             // the constant column: ONE step, stage t-1 (the arithmetic of every other cell of the sweep)
             if (t > 0) {
                 const double pb = klast * eb_new;
                 bcur = (i == r_prev) ? eb_new : (bcur + pb);
             }
-            // the entering column through the stages 0 .. t-1: groups of four, the four history reads in flight together
-            // (slots at and beyond t hold nothing that is used)
-            double a = x0;
-            for (int s = 0; s < t; s += 4) {
-                const double h0 = hist[64 * s], h1 = hist[64 * s + 64], h2 = hist[64 * s + 128], h3 = hist[64 * s + 192];
-                {
-                    const double ec = ch_readlane_f64(ev, s);
-                    const double pa = h0 * ec;
-                    a = (s == sstar) ? ec : (a + pa);
-                }
-                if (s + 1 < t) {
-                    const double ec = ch_readlane_f64(ev, s + 1);
-                    const double pa = h1 * ec;
-                    a = (s + 1 == sstar) ? ec : (a + pa);
-                    if (s + 2 < t) {
-                        const double ec2 = ch_readlane_f64(ev, s + 2);
-                        const double pa2 = h2 * ec2;
-                        a = (s + 2 == sstar) ? ec2 : (a + pa2);
-                        if (s + 3 < t) {
-                            const double ec3 = ch_readlane_f64(ev, s + 3);
-                            const double pa3 = h3 * ec3;
-                            a = (s + 3 == sstar) ? ec3 : (a + pa3);
-                        }
-                    }
-                }
-            }
+            // the entering column through the stages 0 .. t-1 (ch_replay). A row that was a pivot row of this batch (at most
+            // t of the m) starts from e_sstar[first] -- what the sweep of that stage would have put there -- and counts the
+            // stages after it; a wave without such a row takes the form without the per-lane test
+            double a;
+            if (__any(sstar >= 0)) {
+                const double es = __shfl(ev, sstar >= 0 ? sstar : 0);
+                a = ch_replay<true>(sstar >= 0 ? es : x0, H, ev, t, sstar);
+            } else a = ch_replay<false>(x0, H, ev, t, -1);
+            CH_TS(5);                                       // (pick) column replayed
             klast = -a;                                                           // -a_i,nv (lpsol.h:1485)
             hist[64 * t] = klast;
             if (!wait_decision()) return;                                         // (first stage only: nothing global has been written so far)
@@ -610,16 +634,20 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
                 key = ~0ull;
             }
             const bool told = __any(unordered);
+            CH_TS(6);                                       // (pick) ratio and key done
             const unsigned long long kmin = ch_wave_min_u64(key);
             const unsigned long long hit = __ballot(key == kmin);
             const bool publisher = kmin != ~0ull ? (lane == __ffsll((long long)hit) - 1) : (lane == 0);
+            CH_TS(7);                                       // (pick) wave minimum done
             if (publisher && !told) {
+                // g0 first: it is what every worker of the launch waits for; the payload is read of the winner only, one round
+                // later, and carries its own tags
+                ch_store_granule3<LOCAL>(ch_rec_g0(v, w), (unsigned)kmin, (unsigned)(kmin >> 32), (unsigned)(kmin != ~0ull ? i : INT_MAX), tag);
                 const unsigned long long ab = to_bits(F64(a));
                 char * pay = ch_rec_pay(v, w);
                 ch_store_granule3<LOCAL>(pay, (unsigned)ab, (unsigned)(ab >> 32), (unsigned)bi, tag);
                 ch_store_granule3<LOCAL>(pay + 16, pw_word, (unsigned)cc, (unsigned)first | ((unsigned)(sstar + 1) << 24), tag);
                 ch_store_granule3<LOCAL>(pay + 32, (unsigned)cnv_bits, (unsigned)(cnv_bits >> 32), 0u, tag);
-                ch_store_granule3<LOCAL>(ch_rec_g0(v, w), (unsigned)kmin, (unsigned)(kmin >> 32), (unsigned)(kmin != ~0ull ? i : INT_MAX), tag);
             }
             CH_TS(3);                                       // record issued
             // ---- the records of this stage: who won (this lane's row may have: its basic variable changes, lpsol.h:1508)
@@ -643,13 +671,15 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
     const int j = wp * 64 + lane;                           // this lane's column
     const bool has_col = j < W;
     const int jc = has_col ? j : 0;
-    for (int s = 0; s < t0; s++) hist[64 * s] = has_col ? E[(size_t)s * ld + jc] : 0.0;
+    for (int s = 0; s < BLK_MAX; s++) hist[64 * s] = (s < t0 && has_col) ? E[(size_t)s * ld + jc] : 0.0;   // (later slots +0.0: ch_replay)
     F64 oj = has_col ? v.obj[jc] : zero<F64>();            // this lane's objective entry
     if (!wait_decision()) return;
 #pragma unroll 1
     for (int t = t0; t < B; t++) {
         const unsigned tag = blk_epoch(batch, t);
         CH_TS(0);
+        ChHist H;
+        ch_hist_load(H, hist);                              // (in flight while the records are polled)
         ChWinner g;
         const int widx = ch_poll_records(v, npick, tag, lane, g);
         if (widx == -3) { if (lane == 0) ch_st(&st->status, (int)ST_CHAIN_STUCK); return; }
@@ -662,35 +692,20 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
         const double x0 = tab[(size_t)r * ld + jc];
         int nvj = 0, rcj0 = INT_MAX;
         if (has_col && j < rhs) { nvj = (int)ch_ld(&v.nv[jc]); rcj0 = ch_ld(&v.rowcnt[jc]); }
-        double kv = 0.0;
+        double kv = -1.0;                                   // (lanes at and beyond t: what makes their product -0.0, ch_replay)
         if (lane < t) kv = ch_ld(&K[(size_t)r * BLK_MAX + lane]);
         if (!ch_load_winner(v, widx, tag, g)) { if (lane == 0) ch_st(&st->status, (int)ST_CHAIN_STUCK); return; }
+        CH_TS(1);                                           // (prep) row gather round and the winner's payload in
         const int enter = g.enter, leave = g.leave;
         const F64 sc = div(one<F64>(), F64(g.a));           // 1/(eq.get(eqnum, nv)), lpsol.h:1471
         const int smode = scale_mode(sc);
         const F64 cnv = from_bits<F64>(g.cnv);
         const int cmode = scale_mode(cnv);
-        const int qstar = g.qstar;                          // the last stage before t in which row r was the pivot row
-        double x = x0;
-        for (int q = 0; q < t; q += 4) {                    // the pivot row as the pending sweeps would leave it
-            const double h0 = hist[64 * q], h1 = hist[64 * q + 64], h2 = hist[64 * q + 128], h3 = hist[64 * q + 192];
-            {
-                const double pr = ch_readlane_f64(kv, q) * h0;
-                x = (q == qstar) ? h0 : (x + pr);
-            }
-            if (q + 1 < t) {
-                const double pr = ch_readlane_f64(kv, q + 1) * h1;
-                x = (q + 1 == qstar) ? h1 : (x + pr);
-                if (q + 2 < t) {
-                    const double pr2 = ch_readlane_f64(kv, q + 2) * h2;
-                    x = (q + 2 == qstar) ? h2 : (x + pr2);
-                    if (q + 3 < t) {
-                        const double pr3 = ch_readlane_f64(kv, q + 3) * h3;
-                        x = (q + 3 == qstar) ? h3 : (x + pr3);
-                    }
-                }
-            }
-        }
+        const int qstar = __builtin_amdgcn_readfirstlane(g.qstar);     // the last stage before t in which row r was the pivot row (every lane read the same record)
+        // the pivot row as the pending sweeps would leave it (ch_replay): from e_qstar if row r was a pivot row of this
+        // batch before (wave-uniform), else from the tableau
+        const double x = qstar >= 0 ? ch_replay<true>(hist[64 * qstar], H, kv, t, qstar) : ch_replay<false>(x0, H, kv, t, -1);
+        CH_TS(2);                                           // (prep) row replayed
         const F64 e = scaled(F64(x), sc, smode);
         hist[64 * t] = e.v;
         CH_TS(5);                                           // row gather in, replayed, scaled
@@ -710,6 +725,7 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
             v.obj[j] = oj;                                  // (read again only by later launches)
             if (nv_new && gt(oj, zero<F64>())) { any = 1; if (rcj < lim) nf = j; }
         }
+        CH_TS(3);                                           // (prep) objective entry and pricing done
         nf = wave_min_int(nf);
         any = __ballot(any != 0) != 0ull ? 1 : 0;
         // ---- the partial: the lane that owns the worker's candidate column publishes what the next pick needs

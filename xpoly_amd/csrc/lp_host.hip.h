@@ -317,9 +317,10 @@ template <class S> struct Lp : LpBase {
         if ((rc = alloc((void **)&d_tgtf, (size_t)cols * sizeof(S)))) return rc;
         if ((rc = alloc((void **)&d_maxv, sizeof(S)))) return rc;
         hipStream_t s = ctx->stream;
+        // on_dev: 0 both host arrays, 1 both device arrays, 2 the system a device array and the objective a host one
         const hipMemcpyKind kd = on_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
         XPG_HIP(ctx, hipMemcpyAsync(d_leq, leq, (size_t)m * cols * sizeof(S), kd, s));
-        XPG_HIP(ctx, hipMemcpyAsync(d_tgtf, tgtf, (size_t)cols * sizeof(S), kd, s));
+        XPG_HIP(ctx, hipMemcpyAsync(d_tgtf, tgtf, (size_t)cols * sizeof(S), on_dev == 1 ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
         // vc(i,i) / vc(i,rhs): default -1 / 0; slack and xa entries are -1 / 0 (lpsol.h:1428, :867-868)
         std::vector<S> hd(ld, minus_one<S>()), hr(ld, zero<S>());
         if (vcd) for (int i = 0; i < n0; i++) hd[i] = ((const S *)vcd)[i];
