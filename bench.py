@@ -54,7 +54,7 @@ PMC_SUMMARY = os.path.join(ROOT, "profiles", "round4_pmc_hbm_traffic_4096x8192.j
 PMC_SUMMARY_2B = os.path.join(ROOT, "profiles", "round4_pmc_hbm_traffic_4096x12289.json")
 PMC_BATCH = os.path.join(ROOT, "profiles", "round4_pmc_batch_issue.json")
 PMC_RATIONAL = os.path.join(ROOT, "profiles", "round4_pmc_rational_issue.json")
-LEGS = ("pivots", "batched", "sharded", "cfg2b", "rational", "mip", "lineq")
+LEGS = ("pivots", "batched", "sharded", "cfg2b", "six_e2e", "rational", "mip", "lineq")
 LINEQ_NB = 16384                           # systems per row-elimination launch (the dependence tests' shapes)
 
 
@@ -591,6 +591,8 @@ def main():
     if world == 1 and not stub:
         if "cfg2b" in legs:
             out["cfg2b"] = leg_cfg2b(ctx, xpoly_amd, gen)
+        if "six_e2e" in legs:
+            out["six_e2e"] = leg_six_e2e(ctx, xpoly_amd, gen, with_reference=not a.no_cpu_baseline and not a.no_ref_baseline)
         if "rational" in legs:
             out["rational"] = leg_rational(ctx, xpoly_amd, gen)
         if "mip" in legs:
@@ -761,6 +763,61 @@ def leg_cfg2b(ctx, xpoly_amd, gen, m=4096, n=8192):
             traffic_source="profiles/round4_pmc_hbm_traffic_4096x12289.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of this leg; not collected in this run)",
             note="HIP events on the sweep launches of the timed pass; a plain in-place copy of this tableau with the same "
                  "tiling runs at 0.79 of the peak (tools/lab/sweep_lab2.hip, profiles/round3_sweep_lab.txt)")
+    return out
+
+
+def leg_six_e2e(ctx, xpoly_amd, gen, m=4096, n=8192, max_iter=1280, with_reference=True):
+    """What a caller of SIX::maxm / minm waits at BASELINE configs[1]: ONE xpg_six_maxm_f64 / xpg_six_minm_f64 call with host
+    arrays in (leq 4096 x 8193, vc 8192 x 8193, tgtf) and status / v / sol out, max_iter = 1280 -- split into host reshaping,
+    handle + upload, the device's stage 1 + pivot loop, read-back and release (xpg_six_last_profile) -- beside the raw
+    host-to-device copy of the same leq array (pageable, as the caller's is) and the real reference's time for the same call
+    up to its first pivot (SIX::normalize + slack + stage 1, lpsol.h:1290-1433: the 15-29 s of SURVEY section 7)."""
+    import torch
+    from xpoly_amd.six import six_last_profile
+    out = dict(workload="gen.dense_lp_f64(%d, %d) (SURVEY 8d cfg 2b: A, c ~ U(0.1,1), b = n U(0.5,1)), vc = -I, max_iter = %d" % (m, n, max_iter))
+    leq, tgtf = gen.dense_lp_f64(m, n)
+    vc = np.zeros((n, n + 1)); vc[np.arange(n), np.arange(n)] = -1.0
+    six = xpoly_amd.SIX(ctx, xpoly_amd.F64)
+    six.set_param(0, max_iter)
+    sl, st_ = gen.dense_lp_f64(64, 96)                       # warm the context and both routes' kernels
+    svc = np.zeros((96, 97)); svc[np.arange(96), np.arange(96)] = -1.0
+    six.maxm(st_, svc, None, sl); six.minm(st_, svc, None, sl)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    raws = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        d = torch.from_numpy(leq).to(dev)
+        torch.cuda.synchronize()
+        raws.append((time.perf_counter() - t0) * 1e3)
+        del d
+    raw_ms = min(raws[1:])
+    out["raw_h2d_of_leq_ms"] = round(raw_ms, 2)
+    out["leq_bytes"] = int(leq.nbytes)
+    out["raw_h2d_gbs"] = round(leq.nbytes / raw_ms / 1e6, 1)
+    for name, fn in (("maxm", six.maxm), ("minm", six.minm)):
+        best = None
+        for rep in range(2):
+            t0 = time.perf_counter()
+            st, v, sol = fn(tgtf, vc, None, leq)
+            dt = (time.perf_counter() - t0) * 1e3
+            pf = six_last_profile()
+            if best is None or dt < best["call_ms"]:
+                best = dict(call_ms=round(dt, 2), status=int(st), v=float(v), profile=pf)
+        over = best["call_ms"] - best["profile"]["device_solve_ms"]
+        best["overhead_over_device_solve_ms"] = round(over, 2)
+        best["overhead_over_raw_h2d"] = round(over / raw_ms, 3)
+        out[name] = best
+    if with_reference:
+        from oracle.checker import F64, Ref
+        if Ref.available():
+            t0 = time.perf_counter()
+            Ref().two_stage(F64, leq, tgtf, 1)
+            out["reference_setup_s"] = round(time.perf_counter() - t0, 2)
+            out["reference_setup_note"] = ("xcom::SIX<FloatMat,Float>::TwoStageMethod(max_iter = 1) on the same LP on one host core: slack form, "
+                                           "stage 1 and ONE pivot (oracle/_ref, the real reference); baseline only")
+    out["note"] = ("overhead = the call's wall time minus the device's stage 1 + pivot loop; the target is <= 1.3 x the raw pageable "
+                   "host-to-device copy of leq (the bytes that must cross the link once)")
     return out
 
 

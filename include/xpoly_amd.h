@@ -192,6 +192,13 @@ int xpg_six_minm_rat32(xpg_ctx * ctx, const xpg_rat32 * tgtf, const xpg_rat32 * 
                        const xpg_rat32 * leq, int leq_rows, int cols, unsigned max_iter,
                        xpg_rat32 * out_v, xpg_rat32 * out_sol);
 
+/* Where the calling thread's last xpg_six_{maxm,minm}_* call spent its time, host clock, milliseconds:
+ * out_ms[0..7] = total, host reshaping (SIX::normalize, lpsol.h:1290-1394: nothing but the vc diagonal when there are
+ * no equalities and no free variables), handle creation incl. the upload of the system, the dual built on the device
+ * (minm: upload + transpose; lpsol.h:1602-1629), stage 1 + pivot loop on the device, read-back, release, and the route
+ * taken (1 = the LDS-resident batch kernel, 2 = the HBM-resident loop).  Evidence for bench.py; no reference counterpart. */
+int xpg_six_last_profile(double * out_ms, int n);
+
 /* ---- batches of independent small LPs (the dependence-test workload) ------------------
  * nb problems of identical shape: leq[nb][m][cols], tgtf[nb][cols], x >= 0, no
  * equalities -- what Lineq::has_solution hands to SIX (src/com/linsys.cpp:852-904).

@@ -139,6 +139,72 @@ def test_six_maxm_minm_match_oracle(ctx, port, kind):
     assert {0, 1, 2} <= seen
 
 
+@pytest.mark.parametrize("kind", [F64, RAT])
+def test_six_large_route_without_host_copies_matches_oracle(ctx, port, kind, monkeypatch):
+    """SIX::maxm / minm through the HBM-resident route (XPG_FORCE_DEVICE_LP=1: what problems beyond a CU's LDS take). Round
+    5: with no equalities and no free variables the caller's system goes up as it lies (no host copy), and minm's dual
+    (lpsol.h:1602-1629) is built by a transpose kernel on the device; with either, the host reshaping is still there.
+    Status, optimum and solution against the oracle, bit for bit, on plain problems of both routes' shapes and on the
+    random families with equalities / free variables."""
+    import xpoly_amd
+    from xpoly_amd.six import six_last_profile
+    monkeypatch.setenv("XPG_FORCE_DEVICE_LP", "1")
+    six = xpoly_amd.SIX(ctx, kind)
+    shapes = ((40, 70), (90, 33), (65, 65)) if kind == F64 else ((12, 20), (21, 9))
+    for (m, n) in shapes:
+        if kind == F64:
+            leq, tg = gen.dense_lp_f64(m, n, seed=gen.XS_SEED + m)
+        else:
+            leq, tg = gen.int_lp_rat(m, n)
+        vc = gen.vc_nonneg(n, kind == F64) if kind == F64 else gen.to_rat(gen.vc_nonneg(n, False))
+        for is_max in (True, False):
+            want = port.six_solve(kind, is_max, tg, vc, None, leq)
+            got = (six.maxm if is_max else six.minm)(tg, vc, None, leq)
+            assert six_last_profile()["route"] == "HBM-resident loop"
+            assert got[0] == want[0], (m, n, is_max, got[0], want[0])
+            assert same(got[1], want[1]), (m, n, is_max, got[1], want[1])
+            if want[0] == 0:
+                assert same(got[2], want[2]), (m, n, is_max)
+    rng = np.random.default_rng(99 + kind)
+    seen = set()
+    for it in range(24):
+        prob = gen.random_problem(rng, kind, int(rng.integers(0, 4)), int(rng.integers(1, 9)), int(rng.integers(1, 9)))
+        for is_max in (True, False):
+            want = port.six_solve(kind, is_max, prob["tgtf"], prob["vc"], prob.get("eq"), prob.get("leq"))
+            if want[0] == -7:
+                continue
+            got = (six.maxm if is_max else six.minm)(prob["tgtf"], prob["vc"], prob.get("eq"), prob.get("leq"))
+            assert got[0] == want[0] and same(got[1], want[1]), (it, is_max, got[0], want[0])
+            if want[0] == 0:
+                assert same(got[2], want[2])
+            seen.add(want[0])
+    assert {0, 1} <= seen
+
+
+def test_six_maxm_minm_at_config_2_match_oracle(ctx, port):
+    """BASELINE configs[1] through the boundary a caller uses: ONE xpg_six_maxm_f64 / xpg_six_minm_f64 call on the 4096 x 8192
+    LP of SURVEY 8d with host arrays in -- leq 4096 x 8193, vc 8192 x 8193 (537 MB, of which the solver reads the diagonal and
+    one column) -- under iteration limits the oracle can follow in seconds: the whole path at full size (no host copy of the
+    system, the dual built on the device, stage 1, the blocked loop, read-back) must end where SIX::maxm / minm end:
+    status and the optimum lpsol.h:2024 leaves. (What the loop computes at this size is pinned cell by cell against the real
+    reference in tests/test_gpu_large_golden.py.)"""
+    import xpoly_amd
+    from xpoly_amd.six import six_last_profile
+    m, n = 4096, 8192
+    leq, tg = gen.dense_lp_f64(m, n)
+    vc = gen.vc_nonneg(n, True)
+    six = xpoly_amd.SIX(ctx, F64)
+    for is_max, k in ((True, 24), (False, 6)):
+        six.set_param(0, k)
+        want = port.six_solve(F64, is_max, tg, vc, None, leq, max_iter=k)
+        got = (six.maxm if is_max else six.minm)(tg, vc, None, leq)
+        pf = six_last_profile()
+        assert pf["route"] == "HBM-resident loop" and pf["host_reshape_ms"] < 50.0, pf      # (three 268 MB host copies took ~400 ms)
+        assert got[0] == want[0] and same(got[1], want[1]), (is_max, got[0], want[0], got[1], want[1])
+        if want[0] == 0:
+            assert same(got[2], want[2])
+
+
 def test_example_lps(ctx):
     """The reference's bundled example (src/example/example.cpp:54-93, :106-174)."""
     import xpoly_amd

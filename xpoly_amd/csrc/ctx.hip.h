@@ -99,7 +99,9 @@ inline int pick_ld(int W)
     static const int align = [] { const char * s = getenv("XPG_LD_ALIGN"); const int a = s ? atoi(s) : 64; return a >= 16 && a % 16 == 0 ? a : 64; }();
     int ld = W % 16 == 0 ? W : round_up(W, align);
     if (ld % 4112 == 0 || (ld + 16) % 4096 == 0) ld += 16;
-    return ld;
+    // A/B aid: XPG_LD_PAD=n (a multiple of 16 elements) widens every row by n
+    static const int pad = [] { const char * s = getenv("XPG_LD_PAD"); const int a = s ? atoi(s) : 0; return a > 0 && a % 16 == 0 ? a : 0; }();
+    return ld + pad;
 }
 
 // Device scratch of one host-array call. The blocks come from, and go back to, a small cache the handle owns

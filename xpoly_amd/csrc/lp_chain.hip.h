@@ -417,8 +417,22 @@ __device__ unsigned long long g_ch_ts[4][BLK_MAX][8];            // [worker clas
 // contract (MI355X_MICROARCH.md, "Workgroup dispatch"), so the roll call CHECKS it: every worker counts itself in on the
 // counter of the XCD it reads from HW_REG_XCC_ID, and the committer says GO only if one counter holds them all; otherwise
 // ABORT + blk.ch_misplaced, and the host goes back to the spread (sc1) form of this kernel for the rest of the solve.
-enum { CH_LDS_BYTES = BLK_MAX * 64 * 8 };
-template <bool LOCAL>
+// LINE (round 5): the pick workers keep the 128-byte line of their row that holds the entering column -- 16 consecutive
+// columns -- in LDS. The first positive reduced cost moves up the columns a step at a time, so the next entering column
+// is in the line already held 15 times out of 16 (tools/lab/probe_entering_cache.py); but with a row stride that is a
+// multiple of 4 KiB (4096 x 8192: 64 KiB) the 64 lines of a worker's column gather share one or two sets of the compute
+// unit's L1, which keeps four of them, and every stage paid the L2 for the rest again: 0.45 us of the gather round
+// (tools/lab/gather_lab.hip: the same gather 0.16 us from the L1 at a stride of 64 KiB + 128 B). A stage whose column is in
+// the line held now reads nothing of the tableau. The host asks for it where the stride is such a one and the XCD still
+// seats every worker with the larger LDS block (ch_lds_bytes); other strides leave the lines to the L1.
+enum { CH_LINE_BYTES = 16 * 64 * 8 };
+inline int ch_hist_slots(int B, bool line) { return line ? (B + 3) / 4 * 4 : BLK_MAX; }
+inline size_t ch_lds_bytes(int B, bool line)
+{
+    const size_t plain = (size_t)BLK_MAX * 64 * 8, with_line = (size_t)ch_hist_slots(B, true) * 64 * 8 + CH_LINE_BYTES;
+    return line ? (with_line > plain ? with_line : plain) : plain;
+}
+template <bool LOCAL, bool LINE>
 __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int t0, int B, int npick, int nprep, int nparts0, int force_abort, int fold_next)
 {
     extern __shared__ __attribute__((aligned(16))) double ch_hist[];     // [BLK_MAX][64]: this worker's history, stage-major
@@ -477,6 +491,7 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
     double * K = (double *)v.blkK;
     double * E = (double *)v.blkE;
     double * const hist = ch_hist + lane;                   // this lane's history: hist[64 s]
+    const int hslots = LINE ? (B + 3) / 4 * 4 : BLK_MAX;    // history slots in use (LINE: the lines follow them)
     // The committer answers within CH_ARRIVE_TICKS of its own start. A worker that has waited CH_VETO_TICKS knows that
     // the committer itself is not running (no CU for it while these workers hold theirs): it closes the roll call with
     // ABORT through the same compare-and-swap, does the committer's bookkeeping and tells the others.
@@ -520,7 +535,10 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
         const bool has_row = i < m;
         const int ic = has_row ? i : 0;
         // own data of the stages before t0 (written by previous launches); every later slot +0.0 (ch_replay counts on it)
-        for (int s = 0; s < BLK_MAX; s++) hist[64 * s] = (s < t0 && has_row) ? K[(size_t)ic * BLK_MAX + s] : 0.0;
+        for (int s = 0; s < hslots; s++) hist[64 * s] = 0.0;
+        for (int s = 0; s < t0; s++) hist[64 * s] = has_row ? K[(size_t)ic * BLK_MAX + s] : 0.0;
+        double * const lcache = ch_hist + (size_t)hslots * 64 + lane;       // LINE: column q of the line held at lcache[64 q]
+        int line_group = -1;
         int bi = v.eq2bv[ic];                               // basic variable of this lane's row (stage 0's commit is in)
         int sstar = -1;                                     // last stage in which this lane's row was the pivot row
         double bcur = tab[(size_t)ic * ld + rhs];           // this row's constant, replayed through the stages before t - 1
@@ -580,13 +598,27 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
             }
             // ---- one round: the column gather; e_s[first] for s <= t-2 from memory (lane s); the three fresh
             // granules of stage t-1 (lane 32: e[first], lane 33: c[first], lane 34: e[rhs]); pair word, counter
-            const double x0 = tab[(size_t)ic * ld + first];
+            // (every load of the round is UNCONDITIONAL, on a clamped address, and selected afterwards: a load under a
+            // divergent `if` makes the compiler wait for it where the branch joins -- before the loads behind it are issued;
+            // round 4's stage paid two dependent round trips here and in the prep role's round, found in the ISA)
+            double x0_mem = 0.0;
+            double2 lnew[8];
+            const bool line_miss = LINE && (first >> 4) != line_group;       // (wave-uniform)
+            if (!LINE) x0_mem = tab[(size_t)ic * ld + first];
+            else if (line_miss) {
+                const double2 * lp2 = (const double2 *)&tab[(size_t)ic * ld + (size_t)(first >> 4) * 16];     // ld is a multiple of 16
+#pragma unroll
+                for (int q = 0; q < 8; q++) lnew[q] = lp2[q];
+            }
             const uint32_t pw_word = ch_ld(&v.ppt[(size_t)first * v.pw + (bi >> 5)]);
             const int cc = ch_ld(&v.colcnt[bi]);
+            // (a column-major copy of E for this load -- two lines instead of one per stage at the tableau's row stride -- was
+            // built and measured in round 5: the preps' extra scattered store per stage costs more than the gather gains, -0.5 %)
+            const double ev_mem = ch_ld(&E[(size_t)(lane + 1 < t ? lane : 0) * ld + first]);
+            const double c0_mem = v.obj[first].v;
             double ev = 0.0;
-            if (lane + 1 < t) ev = ch_ld(&E[(size_t)lane * ld + first]);
             if (t == 0) {                                   // nothing pending: c[first] as the last prep stored it
-                if (lane == 33) ev = v.obj[first].v;
+                if (lane == 33) ev = c0_mem;
             } else {
                 const bool fresh = lane >= 32 && lane <= 34;
                 const char * gp = ch_part_pay(v, (lane == 34 ? rhs : first) >> 6) + (fresh ? 16 * (lane - 32) : 0);
@@ -599,6 +631,13 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
                 }
             }
             CH_TS(2);                                       // gather round issued, fresh granules in
+            if (lane + 1 < t) ev = ev_mem;                  // (t <= 32: the lanes of the fresh granules are beyond t - 2)
+            if (LINE && line_miss) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) { lcache[64 * (2 * q)] = lnew[q].x; lcache[64 * (2 * q + 1)] = lnew[q].y; }
+                line_group = first >> 4;
+            }
+            const double x0 = LINE ? lcache[64 * (first & 15)] : x0_mem;
             const double ec_new = ch_readlane_f64(ev, 32), eb_new = ch_readlane_f64(ev, 34);
             const unsigned long long cnv_bits = __builtin_bit_cast(unsigned long long, ch_readlane_f64(ev, 33));
             if (lane == t - 1) ev = ec_new;                 // lane s of ev now holds e_s[first] for every s < t
@@ -671,7 +710,8 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
     const int j = wp * 64 + lane;                           // this lane's column
     const bool has_col = j < W;
     const int jc = has_col ? j : 0;
-    for (int s = 0; s < BLK_MAX; s++) hist[64 * s] = (s < t0 && has_col) ? E[(size_t)s * ld + jc] : 0.0;   // (later slots +0.0: ch_replay)
+    for (int s = 0; s < hslots; s++) hist[64 * s] = 0.0;   // (slots at and beyond the current stage +0.0: ch_replay)
+    for (int s = 0; s < t0; s++) hist[64 * s] = has_col ? E[(size_t)s * ld + jc] : 0.0;
     F64 oj = has_col ? v.obj[jc] : zero<F64>();            // this lane's objective entry
     if (!wait_decision()) return;
 #pragma unroll 1
@@ -689,12 +729,14 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
         // ---- one round: the pivot row gather, k_q[r] (lane q), this column's basis words (the previous stage's
         // commit is behind the records just read), and the rest of the winner's record (whose wait completes the
         // loads before it as well)
+        // (unconditional loads on clamped addresses, selected behind the round: see the pick role's round)
         const double x0 = tab[(size_t)r * ld + jc];
-        int nvj = 0, rcj0 = INT_MAX;
-        if (has_col && j < rhs) { nvj = (int)ch_ld(&v.nv[jc]); rcj0 = ch_ld(&v.rowcnt[jc]); }
-        double kv = -1.0;                                   // (lanes at and beyond t: what makes their product -0.0, ch_replay)
-        if (lane < t) kv = ch_ld(&K[(size_t)r * BLK_MAX + lane]);
+        const bool in_vars = has_col && j < rhs;
+        const int nv_mem = (int)ch_ld(&v.nv[in_vars ? jc : 0]), rc_mem = ch_ld(&v.rowcnt[in_vars ? jc : 0]);
+        const double kv_mem = ch_ld(&K[(size_t)r * BLK_MAX + (lane < t ? lane : 0)]);
         if (!ch_load_winner(v, widx, tag, g)) { if (lane == 0) ch_st(&st->status, (int)ST_CHAIN_STUCK); return; }
+        const int nvj = in_vars ? nv_mem : 0, rcj0 = in_vars ? rc_mem : INT_MAX;
+        const double kv = lane < t ? kv_mem : -1.0;         // (lanes at and beyond t: what makes their product -0.0, ch_replay)
         CH_TS(1);                                           // (prep) row gather round and the winner's payload in
         const int enter = g.enter, leave = g.leave;
         const F64 sc = div(one<F64>(), F64(g.a));           // 1/(eq.get(eqnum, nv)), lpsol.h:1471

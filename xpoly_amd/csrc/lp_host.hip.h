@@ -150,8 +150,17 @@ template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> &
                                           : (test_abort < 0 && local && batch % -test_abort == -test_abort - 1 ? 2 : 0);
             const int nparts0 = (int)gprep.x;
             const int fn = next_folds ? 1 : 0;
-            if (local) hipLaunchKernelGGL(k_blk_chain<true>, dim3(8 * workers), dim3(64), CH_LDS_BYTES, ctx->stream, v, batch, t0, B, cpick, cprep, nparts0, fa, fn);
-            else hipLaunchKernelGGL(k_blk_chain<false>, dim3(workers), dim3(64), CH_LDS_BYTES, ctx->stream, v, batch, t0, B, cpick, cprep, nparts0, fa, fn);
+            // the entering column's line in the pick workers' LDS (lp_chain.hip.h, LINE): where the row stride is a multiple of
+            // 4 KiB -- the L1 then keeps next to nothing of a column -- and one XCD still seats every worker with the larger
+            // LDS block; XPG_CHAIN_LINE=0|1 forces it off / on for A/B runs
+            static const int line_env = [] { const char * s = getenv("XPG_CHAIN_LINE"); return s ? atoi(s) : -1; }();
+            const bool line_fits = (size_t)workers * ch_lds_bytes(B, true) <= (size_t)(cus / 8) * 160 * 1024 &&
+                                   (size_t)workers <= (size_t)(cus / 8) * ((size_t)160 * 1024 / ch_lds_bytes(B, true));
+            const bool line = local && line_fits && (line_env == 1 || (line_env != 0 && v.ld % 512 == 0));
+            const size_t lds = ch_lds_bytes(B, line);
+            if (local && line) hipLaunchKernelGGL((k_blk_chain<true, true>), dim3(8 * workers), dim3(64), lds, ctx->stream, v, batch, t0, B, cpick, cprep, nparts0, fa, fn);
+            else if (local) hipLaunchKernelGGL((k_blk_chain<true, false>), dim3(8 * workers), dim3(64), lds, ctx->stream, v, batch, t0, B, cpick, cprep, nparts0, fa, fn);
+            else hipLaunchKernelGGL((k_blk_chain<false, false>), dim3(workers), dim3(64), lds, ctx->stream, v, batch, t0, B, cpick, cprep, nparts0, fa, fn);
             break;
         }
         hipLaunchKernelGGL(k_blk_pick, dim3(npick), dim3(tp), 0, ctx->stream, v, batch, t, (int)gprep.x);
@@ -252,8 +261,27 @@ template <class S> struct Lp : LpBase {
         return 0;
     }
 
+    // create() plans its ~30 device arrays and gets them as ONE allocation (alloc_commit): a handle made and released per
+    // SIX::maxm call paid ~1 ms of hipMalloc and ~1 ms of hipFree calls around a 15 ms solve (bench.py six_e2e)
+    struct AllocReq { void ** p; size_t bytes; };
+    std::vector<AllocReq> plan;
+    bool planning = false;
+    int alloc_commit()
+    {
+        planning = false;
+        size_t total = 0;
+        for (const AllocReq & r : plan) total += (r.bytes + 255) & ~(size_t)255;
+        void * base = nullptr;
+        const int rc = alloc(&base, total);
+        if (rc) { plan.clear(); return rc; }
+        size_t off = 0;
+        for (const AllocReq & r : plan) { *r.p = (char *)base + off; off += (r.bytes + 255) & ~(size_t)255; }
+        plan.clear();
+        return 0;
+    }
     int alloc(void ** p, size_t bytes)
     {
+        if (planning) { plan.push_back(AllocReq{p, bytes ? bytes : 8}); return 0; }
         hipError_t e = hipMalloc(p, bytes ? bytes : 8);
         if (e != hipSuccess && !ctx->dev_cache.empty()) {       // the blocks parked by host-array row-elimination calls make room
             for (auto & b : ctx->dev_cache) (void)hipFree(b.first);
@@ -289,6 +317,7 @@ template <class S> struct Lp : LpBase {
         tab_elems = (size_t)mcap * ld;
         row_cap = mcap;
         int rc;
+        planning = true;
         if ((rc = alloc((void **)&v.tab, tab_elems * sizeof(S)))) return rc;
         if ((rc = alloc((void **)&v.obj, (size_t)ld * sizeof(S)))) return rc;
         if ((rc = alloc((void **)&v.rowbuf, (size_t)ld * sizeof(S)))) return rc;
@@ -316,6 +345,7 @@ template <class S> struct Lp : LpBase {
         if ((rc = alloc((void **)&d_leq, (size_t)m * cols * sizeof(S)))) return rc;
         if ((rc = alloc((void **)&d_tgtf, (size_t)cols * sizeof(S)))) return rc;
         if ((rc = alloc((void **)&d_maxv, sizeof(S)))) return rc;
+        if ((rc = alloc_commit())) return rc;
         hipStream_t s = ctx->stream;
         // on_dev: 0 both host arrays, 1 both device arrays, 2 the system a device array and the objective a host one
         const hipMemcpyKind kd = on_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;

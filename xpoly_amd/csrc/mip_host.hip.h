@@ -284,7 +284,7 @@ template <class S> int run_mip_tasks(xpg_ctx * ctx, int kind, std::vector<MipTas
             MipTask<S> & T = tasks[t];
             if (T.done) continue;
             any = true;
-            if (T.F.fits_lds(T.is_max)) { Key k = { T.is_max ? 1 : 0, T.F.N.r, T.F.n + 1 }; groups[k].push_back((int)t); }
+            if (T.F.fits_lds(T.is_max)) { Key k = { T.is_max ? 1 : 0, T.F.rows, T.F.n + 1 }; groups[k].push_back((int)t); }
             else large.push_back((int)t);
         }
         t_prep += now() - t0;
@@ -308,7 +308,7 @@ template <class S> int run_mip_tasks(xpg_ctx * ctx, int kind, std::vector<MipTas
                 S * tg = bs.h_tgtf + b * k.cols;
                 S * lq = bs.h_leq + b * (size_t)k.rows * k.cols;
                 for (int j = 0; j < k.cols; j++) tg[j] = F.obj[j];
-                for (size_t e = 0; e < F.N.a.size(); e++) lq[e] = F.N.a[e];
+                for (size_t e = 0; e < (size_t)F.rows * (size_t)(F.n + 1); e++) lq[e] = F.Np[e];      // (its own cells, or a view of the node's inequalities: six_host.hip.h)
             });
             const double t1 = now();
             rc = batch_stage_run<S>(ctx, bs, k.is_max, 10000u, /*raw_sol=*/1);

@@ -217,10 +217,12 @@ int solve_large(xpg_ctx * ctx, int kind, bool is_max, const NormalForm<S> & F, u
         for (int j = 0; j < mm; j++) pobj[j] = F.Np[(size_t)j * (n + 1) + n];
         scale_run(pobj.data(), mm + 1, 1, minus_one<S>());
         const size_t cells = (size_t)mm * (n + 1), pcells = (size_t)n * (mm + 1);
+        // (one allocation: the system as uploaded, its dual, the objective)
+        auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        char * dbase = nullptr;
         S * dN = nullptr; S * dP = nullptr; S * dobj = nullptr;
-        hipError_t e = hipMalloc((void **)&dN, cells * sizeof(S));
-        if (e == hipSuccess) e = hipMalloc((void **)&dP, pcells * sizeof(S));
-        if (e == hipSuccess) e = hipMalloc((void **)&dobj, (size_t)(n + 1) * sizeof(S));
+        hipError_t e = hipMalloc((void **)&dbase, up(cells * sizeof(S)) + up(pcells * sizeof(S)) + up((size_t)(n + 1) * sizeof(S)));
+        if (e == hipSuccess) { dP = (S *)dbase; dN = (S *)(dbase + up(pcells * sizeof(S))); dobj = (S *)(dbase + up(pcells * sizeof(S)) + up(cells * sizeof(S))); }
         if (e == hipSuccess) e = hipMemcpyAsync(dN, F.Np, cells * sizeof(S), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(dobj, F.obj.data(), (size_t)(n + 1) * sizeof(S), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) {
@@ -230,16 +232,13 @@ int solve_large(xpg_ctx * ctx, int kind, bool is_max, const NormalForm<S> & F, u
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         pf.dual_ms = six_now_ms() - t0;
         if (e == hipSuccess) {
-            (void)hipFree(dN); dN = nullptr;                     // (room for the tableau the handle allocates next)
             std::vector<S> pd(mm, minus_one<S>()), pr(mm, zero<S>());
             t0 = six_now_ms();
             // (src_on_device = 2: the system is a device array, the objective a host one)
             rc = xpg_lp_create(ctx, kind, dP, n, mm + 1, pobj.data(), pd.data(), pr.data(), 2, &lp);
             pf.create_ms = six_now_ms() - t0;
         } else { ctx->err = std::string("dual on the device: ") + hipGetErrorString(e); rc = e == hipErrorOutOfMemory ? XPG_ERR_ALLOC : XPG_ERR_HIP; (void)hipGetLastError(); }
-        if (dN) (void)hipFree(dN);
-        if (dP) (void)hipFree(dP);
-        if (dobj) (void)hipFree(dobj);
+        if (dbase) (void)hipFree(dbase);
         if (rc) return rc;
     }
     t0 = six_now_ms();

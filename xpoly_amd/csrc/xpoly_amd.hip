@@ -652,6 +652,15 @@ int xpg_fastloop_debug(xpg_ctx * ctx, unsigned long long * out16)
 }
 #endif
 // ---- SIX::maxm / minm ---------------------------------------------------------------------
+// where the calling thread's last xpg_six_* call spent its time (six_host.hip.h SixProfile)
+int xpg_six_last_profile(double * out_ms, int n)
+{
+    if (!out_ms || n < 0) return XPG_ERR_SHAPE;
+    const SixProfile & p = six_profile();
+    const double f[9] = { p.total_ms, p.reshape_ms, p.create_ms, p.dual_ms, p.solve_ms, p.read_ms, p.destroy_ms, (double)p.route, 0.0 };
+    for (int k = 0; k < n && k < 9; k++) out_ms[k] = f[k];
+    return 0;
+}
 int xpg_six_maxm_f64(xpg_ctx * ctx, const double * tgtf, const double * vc, int vc_rows,
                      const double * eq, int eq_rows, const double * leq, int leq_rows, int cols,
                      unsigned max_iter, double * out_v, double * out_sol)

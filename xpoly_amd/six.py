@@ -320,6 +320,16 @@ class MIP:
         return self._solve(False, tgtf, vc, eq, leq, is_bin, rational_indicator)
 
 
+def six_last_profile():
+    """Where the calling thread's last SIX.maxm / minm call spent its time (xpg_six_last_profile), milliseconds."""
+    out = (C.c_double * 9)()
+    lib().xpg_six_last_profile(out, C.c_int(9))
+    names = ("total_ms", "host_reshape_ms", "create_and_upload_ms", "dual_on_device_ms", "device_solve_ms", "read_back_ms", "release_ms")
+    d = {k: round(out[i], 3) for i, k in enumerate(names)}
+    d["route"] = {1: "LDS batch kernel", 2: "HBM-resident loop"}.get(int(out[7]), "none")
+    return d
+
+
 def mip_warm(ctx, is_max, tgtf, leq, is_bin=False):
     """OPT-IN, NON-PARITY (xpg_mip_warm_f64): fp64 branch and bound warm-started from the parent's tableau by the dual
     simplex. Returns (status, v, sol, dict(nodes, dual_pivots, root_pivots, max_depth))."""
