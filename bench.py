@@ -295,6 +295,12 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline and not stub:
         cpu = cpu_baselines(legs, a.no_ref_baseline)     # forks: before torch / HIP are initialised in this process
 
+    # the rank's host thread (and the pinned staging it allocates from here on) onto the NUMA node of its GPU -- from sysfs,
+    # before anything in this process has touched a GPU (and after the CPU baseline has used every core)
+    placement = None
+    if not stub:
+        from xpoly_amd.shard import pin_to_gpu_numa
+        placement = pin_to_gpu_numa(local)
     import torch
     from xpoly_amd.shard import gather_records, pack_records, pack_records_i32, pack_records_rat, shard_range, unpack_records_rat
     dist = None
@@ -521,12 +527,53 @@ def main():
                     assert torch.equal(full[:, 2], gi)
             piv = sum_over_ranks(float(d_piv.sum().item()))
             hist = torch.bincount(d_st.clamp(min=0), minlength=5).tolist()
+            # ---- what a HOST caller sees: the shard's arrays start in (pageable) host memory. Once as upload-then-solve, once
+            # with the upload in two chunks (a quarter, then the rest) on a side stream, the second under the first chunk's solve
+            e2e = None
+            if not stub:
+                import threading
+
+                def upload(lo, hi, side):
+                    with torch.cuda.stream(side):
+                        dl = torch.from_numpy(b_leq[lo:hi]).to(dev)
+                        dtg = torch.from_numpy(b_tg[lo:hi]).to(dev)
+                    side.synchronize()
+                    return dl, dtg
+
+                def e2e_pass(chunks):
+                    side = torch.cuda.Stream()
+                    torch.cuda.synchronize(); ctx.sync()
+                    t0 = time.perf_counter()
+                    cur = upload(chunks[0][0], chunks[0][1], side)
+                    for k, (lo, hi) in enumerate(chunks):
+                        box, th = [], None
+                        if k + 1 < len(chunks):
+                            th = threading.Thread(target=lambda c=chunks[k + 1]: box.append(upload(c[0], c[1], side)))
+                            th.start()
+                        ctx.six_batch_dev(xpoly_amd.F64, True, hi - lo, cur[1].data_ptr(), cur[0].data_ptr(), BATCH_M, BATCH_COLS,
+                                          d_st[lo:hi].data_ptr(), d_v[lo:hi].data_ptr(), d_sol[lo:hi].data_ptr(), d_piv[lo:hi].data_ptr())
+                        ctx.sync()
+                        if th is not None:
+                            th.join()
+                            cur = box[0]
+                    return time.perf_counter() - t0
+
+                want_st, want_v = d_st.clone(), d_v.clone()
+                q = max(1, nloc // 4)
+                plans = {"upload_then_solve": [(0, nloc)], "two_chunks_overlapped": [(0, q), (q, nloc)] if nloc > q else [(0, nloc)]}
+                e2e = {}
+                for pname, chunks in plans.items():
+                    best = min(e2e_pass(chunks) for _ in range(2))
+                    assert torch.equal(d_st, want_st) and torch.equal(d_v.view(torch.int64), want_v.view(torch.int64)), "chunked solve differs"
+                    e2e[pname + "_lps_per_s"] = round(total / max_over_ranks(best), 1)
+                e2e["note"] = ("host arrays in (pageable), results in HBM: the figure a caller of the host-array entry points gets "
+                               "before the read-back; better of two passes; the device-resident lps_per_s beside it excludes the upload")
             if rank == 0 and not stub and nloc >= 256:
                 checks.setdefault("batched", {})[name] = selfcheck_batched(fam, d_st, d_v, d_sol, full)
             fams[name] = dict(lps_per_s=round(total * reps / bdt, 1), pivots_per_s=round(piv * reps / bdt, 1),
                               status_hist_rank0=hist, ms_per_pass=round(bdt / reps * 1e3, 3),
                               solve_ms=round(solve_ms, 3), gather_ms=round(gather_ms, 3),
-                              shard_h2d_ms_untimed=h2d_ms.get(name))
+                              shard_h2d_ms_untimed=h2d_ms.get(name), end_to_end=e2e)
         batched = dict(metric="batched LPs/sec", value=fams["dep_test_like"]["lps_per_s"], unit="LPs/s",
                        headline_family="dep_test_like (entries in {-3..3} at density 0.25: the shape "
                                        "DepPoly::is_empty produces; the workload the kernel exists for)",
@@ -600,6 +647,10 @@ def main():
         if "lineq" in legs:
             out["lineq"] = leg_lineq(ctx, xpoly_amd, gen)
 
+    if world == 1 and dist is None and not stub and "batched" in legs and "batched" in out:
+        out["batched"]["rccl_world1_fixed_cost"] = rccl_world1_fixed_cost(torch, dev)
+    if rank == 0 and placement is not None:
+        out["host_placement"] = dict(placement, note="rank 0: NUMA node of its GPU from sysfs, affinity set before the first GPU call (xpoly_amd/shard.py pin_to_gpu_numa)")
     if rank == 0:
         if checks or "self_check" in out or any("self_check" in out.get(leg, {}) for leg in ("mip", "cfg2b", "rational")):
             out.setdefault("self_check", {}).update(checks)
@@ -616,6 +667,42 @@ def main():
         ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def rccl_world1_fixed_cost(torch, dev):
+    """The collective's fixed cost on this box, on file in every N = 1 line: RCCL at world size 1 (no launcher: a TCP store on
+    127.0.0.1), one all_gather_into_tensor of each record shape the sharded legs gather -- 8192 LP records of 528 B, 1024 exact
+    MIP records, 4096 dependence verdicts -- mean of 10 after 3 warm-ups. An 8-GPU run adds the ring over xGMI to this; nothing
+    here claims that figure. Never fatal: an RCCL that cannot initialise is reported as such."""
+    try:
+        import torch.distributed as dist
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        t_init = time.perf_counter()
+        dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+        res = {}
+        shapes = (("lp_records_8192x66_f64", (8192, 66), torch.float64), ("mip_records_1024x53_i32", (1024, 53), torch.int32),
+                  ("dep_verdicts_4096x2_i32", (4096, 2), torch.int32))
+        for name, shape, dtype in shapes:
+            src = torch.zeros(shape, dtype=dtype, device=dev)
+            dst = torch.empty_like(src)
+            for _ in range(3):
+                dist.all_gather_into_tensor(dst, src)
+            torch.cuda.synchronize()
+            if "init_ms" not in res:
+                res["init_ms"] = round((time.perf_counter() - t_init) * 1e3, 1)      # communicator set-up incl. the first collective
+            t0 = time.perf_counter()
+            for _ in range(10):
+                dist.all_gather_into_tensor(dst, src)
+            torch.cuda.synchronize()
+            res[name + "_gather_ms"] = round((time.perf_counter() - t0) / 10 * 1e3, 4)
+        dist.destroy_process_group()
+        res["note"] = "RCCL all_gather_into_tensor at world size 1 on this GPU; the sharded legs' one collective, fixed cost only"
+        return res
+    except Exception as e:                                  # noqa: BLE001 -- evidence only, never the reason a bench line is lost
+        return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -62,6 +62,35 @@ def test_mip_and_dep_batch_multi_equal_single(ctx):
     assert np.array_equal(g_empty, w_empty) and g_nodes == w_nodes
 
 
+def test_eight_shards_of_a_whole_node_batch_equal_the_single_call(ctx):
+    """The node-level shapes without an 8-GPU node: `ndev = 8` (device 0 eight times -- eight contexts, eight host threads,
+    eight concurrent launches on one GPU) on batches that do not divide by 8: 65 537 LPs (configs[2]'s batch + 1: shards of
+    8193 and 8192), 1 025 0-1 knapsack trees, 4 097 dependence polyhedra -- every status, optimum, solution, verdict and node
+    count identical to the single-device call, in the caller's order."""
+    from xpoly_amd.six import dep_is_empty_batch, dep_is_empty_batch_multi, mip_batch, mip_batch_multi, six_batch_multi
+    eight = [0] * 8
+    nb = 65537
+    leq, tg = gen.small_lp_batch_f64(nb, 12, 17, 1, seed=gen.XS_SEED + 4242)
+    want = ctx.six_batch(F64, True, tg, leq)
+    got = six_batch_multi(eight, F64, True, tg, leq)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(bits(got[1]), bits(want[1]))
+    ok = want[0] == 0
+    assert ok.sum() > 100, np.bincount(want[0].clip(0), minlength=5)
+    assert np.array_equal(bits(got[2])[ok], bits(want[2])[ok])
+    del leq, tg, want, got
+    leq, tg = gen.knapsack_batch_rat(1025, 16, seed=gen.XS_SEED + 5)
+    want = mip_batch(ctx, True, True, tg, leq)
+    got = mip_batch_multi(eight, True, True, tg, leq)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[3] == want[3]
+    assert np.array_equal(got[2][want[0] == 0], want[2][want[0] == 0])
+    rng = np.random.default_rng(88)
+    mats = np.stack([gen.random_system(rng, 10, 4) for _ in range(4097)])
+    mats[..., 1] = 1
+    w_empty, w_nodes = dep_is_empty_batch(ctx, mats)
+    g_empty, g_nodes = dep_is_empty_batch_multi(eight, mats)
+    assert np.array_equal(g_empty, w_empty) and g_nodes == w_nodes
+
+
 def test_multi_reports_a_missing_device():
     from xpoly_amd import XpgError
     from xpoly_amd._capi import lib

@@ -158,3 +158,29 @@ def test_bench_without_gpus_fails_loudly():
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert "XPG_ERR_NO_DEVICE" in r.stderr or "No HIP GPUs" in r.stderr or "no GPU" in r.stderr.lower(), r.stderr[-3000:]
+
+
+def test_numa_placement_reads_sysfs_only(tmp_path):
+    """A rank binds itself to the NUMA node of its GPU before its first GPU call (bench.py, xpoly_amd/shard.py): the node
+    comes from sysfs -- AMD display / accelerator functions in bus order -- and an unknown topology changes nothing."""
+    import os
+    from xpoly_amd.shard import _parse_cpulist, gpu_numa_nodes, pin_to_gpu_numa
+    assert _parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    devs = tmp_path / "bus" / "pci" / "devices"
+    for bdf, vendor, cls, node in (("0000:05:00.0", "0x1002", "0x120000", "0"), ("0000:25:00.0", "0x1002", "0x120000", "1"),
+                                   ("0000:01:00.0", "0x8086", "0x020000", "0"), ("0000:45:00.0", "0x1002", "0x030000", "-1")):
+        d = devs / bdf
+        d.mkdir(parents=True)
+        (d / "vendor").write_text(vendor + "\n"); (d / "class").write_text(cls + "\n"); (d / "numa_node").write_text(node + "\n")
+    me = sorted(os.sched_getaffinity(0))
+    for n, cl in ((0, "%d" % me[0]), (1, "%d" % me[-1])):
+        nd = tmp_path / "devices" / "system" / "node" / ("node%d" % n)
+        nd.mkdir(parents=True)
+        (nd / "cpulist").write_text(cl + "\n")
+    assert gpu_numa_nodes(str(tmp_path)) == [("0000:05:00.0", 0), ("0000:25:00.0", 1), ("0000:45:00.0", -1)]
+    r = pin_to_gpu_numa(1, sysfs=str(tmp_path), apply=False)
+    assert r == {"gpu": "0000:25:00.0", "node": 1, "cpus": 1, "pinned": False}
+    assert pin_to_gpu_numa(2, sysfs=str(tmp_path), apply=False)["node"] == -1          # no node reported: left alone
+    assert pin_to_gpu_numa(7, sysfs=str(tmp_path), apply=False)["gpu"] is None           # no such GPU
+    assert pin_to_gpu_numa(0, sysfs=str(tmp_path / "nothing"), apply=False)["gpu"] is None
+    assert sorted(os.sched_getaffinity(0)) == me

@@ -77,3 +77,79 @@ def gather_records(rec, total, rank, world, dist=None):
         lo, hi = shard_range(total, r, world)
         parts.append(out[r * cap: r * cap + (hi - lo)])
     return torch.cat(parts, dim=0)
+
+
+# ---- host placement of a rank: the NUMA node of its GPU -------------------------------------------------------------
+def _parse_cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11]"""
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_nodes(sysfs="/sys"):
+    """NUMA node of every AMD GPU function on the PCI bus, in bus order (the order HIP enumerates them in when
+    HIP_VISIBLE_DEVICES does not say otherwise): [(bdf, node), ...], node -1 where the platform reports none.
+    Reads sysfs only -- nothing here touches the GPU."""
+    import os
+    root = os.path.join(sysfs, "bus", "pci", "devices")
+    out = []
+    try:
+        names = sorted(os.listdir(root))
+    except OSError:
+        return out
+    for bdf in names:
+        d = os.path.join(root, bdf)
+        try:
+            vendor = open(os.path.join(d, "vendor")).read().strip().lower()
+            cls = open(os.path.join(d, "class")).read().strip().lower()
+        except OSError:
+            continue
+        # AMD, display controller (0x03....) or processing accelerator (0x12....: how Instinct parts present themselves)
+        if vendor != "0x1002" or not (cls.startswith("0x03") or cls.startswith("0x12")):
+            continue
+        try:
+            node = int(open(os.path.join(d, "numa_node")).read().strip())
+        except (OSError, ValueError):
+            node = -1
+        out.append((bdf, node))
+    return out
+
+
+def pin_to_gpu_numa(local_rank, sysfs="/sys", apply=True):
+    """Binds the calling process (a rank, BEFORE its first GPU call: the pinned staging it allocates afterwards then lies on
+    that node) to the CPUs of the NUMA node of GPU `local_rank`. Best effort: returns a record of what it found and did --
+    {"gpu": bdf, "node": n, "cpus": k, "pinned": bool} -- and never raises; an unknown topology leaves the affinity alone."""
+    import os
+    rec = {"gpu": None, "node": -1, "cpus": 0, "pinned": False}
+    gpus = gpu_numa_nodes(sysfs)
+    vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+    idx = local_rank
+    if vis:
+        try:
+            idx = [int(x) for x in vis.split(",")][local_rank]
+        except (ValueError, IndexError):
+            return rec
+    if idx < 0 or idx >= len(gpus):
+        return rec
+    rec["gpu"], rec["node"] = gpus[idx]
+    if rec["node"] < 0:
+        return rec
+    try:
+        cpus = _parse_cpulist(open(os.path.join(sysfs, "devices", "system", "node", "node%d" % rec["node"], "cpulist")).read())
+    except OSError:
+        return rec
+    allowed = set(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else set(cpus)
+    cpus = [c for c in cpus if c in allowed]
+    rec["cpus"] = len(cpus)
+    if cpus and apply and hasattr(os, "sched_setaffinity"):
+        try:
+            os.sched_setaffinity(0, cpus)
+            rec["pinned"] = True
+        except OSError:
+            pass
+    return rec
