@@ -191,6 +191,7 @@ template <class S> __device__ __forceinline__ void sm_select_wave0(Small<S> & P)
         S * park = (S *)P.sh_c;
         park[0] = piv;
         park[1] = pf.q;
+        park[2] = q_div(P.cn, one<S>(), piv);              // 1/(eq.get(eqnum, nv)), lpsol.h:1471: once, here (see sm_fast_loop_body)
     }
 }
 
@@ -317,6 +318,7 @@ template <class S> __device__ __forceinline__ void sm_findpair_wave0(Small<S> & 
                     S * pk = (S *)P.sh_c;
                     pk[0] = piv;
                     pk[1] = P.obj[cand];
+                    pk[2] = q_div(P.cn, one<S>(), piv);
                 }
                 return;
             }
@@ -389,8 +391,10 @@ template <class S, int CR, int CLD, int CT> __device__ __forceinline__ int sm_fa
         if (action != ACT_PIVOT) return action;
         const int enter = P.sh_w[1], leave = P.sh_w[2], r = P.sh_w[3];
         const S * park = (const S *)P.sh_c;
-        const S piv = park[0], cnv = park[1];
-        const S s = q_div(P.cn, one<S>(), piv);
+        const S cnv = park[1];
+        // 1/(eq.get(eqnum, nv)), lpsol.h:1471: computed ONCE by the wave that chose the pivot and parked beside it (round 5:
+        // every wave of the workgroup used to divide for itself -- 3 x ~25 VALU wave-instructions of the ~530 per pivot)
+        const S s = park[2];
         const int smode = scale_mode(s), cmode = scale_mode(cnv);
         const bool last = done + 1 >= max_iter;                 // while (cnt < m_max_iter), lpsol.h:1039: no pricing after the last pivot
         // ---- stage A
@@ -485,6 +489,7 @@ template <class S, int CR, int CLD, int CT> __device__ __forceinline__ int sm_fa
                         S * pk = (S *)P.sh_c;
                         pk[0] = npiv;
                         pk[1] = pf.q;
+                        pk[2] = q_div(P.cn, one<S>(), npiv);
                     }
                 }
             }
