@@ -1001,7 +1001,33 @@ def leg_mip(ctx, xpoly_amd, gen):
     t0 = time.perf_counter()
     _, _, _, nodes8 = mip_batch(ctx, True, True, tgtf8, leq8)
     dt8 = time.perf_counter() - t0
+    # the opt-in NON-parity mode beside it: the same 1024 / 8192 knapsacks as fp64 programs through the
+    # warm-started branch and bound, batch form -- one tree per workgroup, dual simplex from the parent's tableau in LDS
+    from xpoly_amd.six import mip_warm_batch
+    wl, wt = leq[..., 0].astype(np.float64), tgtf[..., 0].astype(np.float64)
+    mip_warm_batch(ctx, True, wt, wl, is_bin=True)
+    t0 = time.perf_counter()
+    wst, wv, _, wstats = mip_warm_batch(ctx, True, wt, wl, is_bin=True)
+    wdt = time.perf_counter() - t0
+    solved = st == 0                                     # where the parity walk finds the optimum too the values must agree
+    pv = v[solved][:, 0] / np.maximum(v[solved][:, 1], 1)
+    never_below = bool(np.all(wv[solved] >= pv - 1e-6)) if solved.any() else None     # an optimum is never below a feasible point's value
+    equal_share = round(float(np.mean(np.abs(wv[solved] - pv) <= 1e-6)), 3) if solved.any() else None
+    wl8, wt8 = leq8[..., 0].astype(np.float64), tgtf8[..., 0].astype(np.float64)
+    mip_warm_batch(ctx, True, wt8, wl8, is_bin=True)
+    t0 = time.perf_counter()
+    _, _, _, wstats8 = mip_warm_batch(ctx, True, wt8, wl8, is_bin=True)
+    wdt8 = time.perf_counter() - t0
+    warm = dict(mode="OPT-IN, NON-PARITY: xpg_mip_warm_batch_f64 (best incumbent, bounding by the relaxation, dual simplex warm-started from the "
+                     "parent's tableau; checked against scipy / HiGHS in tests/test_gpu_warm_mip.py, not against the reference's walk)",
+                problems=MIP_NB, wall_ms=round(wdt * 1e3, 2), mips_per_s=round(MIP_NB / wdt, 1), nodes=int(wstats["nodes"]),
+                nodes_per_s=round(wstats["nodes"] / wdt, 1), dual_pivots_per_node=round(wstats["dual_pivots"] / max(1, wstats["nodes"] - MIP_NB), 2),
+                root_pivots_per_problem=round(wstats["root_pivots"] / MIP_NB, 1), max_depth=int(wstats["max_depth"]),
+                status_hist=np.bincount(np.clip(wst, 0, 4), minlength=5).tolist(),
+                optimum_never_below_the_parity_walks_value=never_below, share_of_parity_answers_that_are_optimal=equal_share,
+                larger_batch=dict(problems=big, mips_per_s=round(big / wdt8, 1), nodes_per_s=round(wstats8["nodes"] / wdt8, 1), wall_ms=round(wdt8 * 1e3, 2)))
     return dict(metric="0-1 MIP branch and bound, one tree per workgroup on the device", value=round(nodes / dt, 1), unit="nodes/s",
+                warm_started_batch=warm,
                 mips_per_s=round(MIP_NB / dt, 1), problems=MIP_NB, vars=MIP_NV, rows=2 + MIP_NV, nodes=int(nodes),
                 nodes_per_problem=round(nodes / MIP_NB, 2), wall_ms=round(dt * 1e3, 2),
                 status_hist=np.bincount(np.clip(st, 0, 4), minlength=5).tolist(), dtype="int32 num/den",

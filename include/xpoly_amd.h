@@ -267,6 +267,15 @@ int xpg_mip_minm_f64(xpg_ctx * ctx, const double * tgtf, const double * vc, int 
  * MIP::RecusivePart.  out_stats (may be NULL): nodes, dual pivots over all nodes, primal pivots of the root, depth. */
 int xpg_mip_warm_f64(xpg_ctx * ctx, int is_max, const double * tgtf, const double * leq, int leq_rows,
                      int cols, int is_bin, double * out_v, double * out_sol, long long * out_stats);
+/* The same method for a BATCH: nb programs of one shape (tgtf [nb][cols], leq [nb][leq_rows][cols]), each tree walked by ONE
+ * WORKGROUP inside one launch with its current tableau in LDS (warm_mip_batch.hip.h) -- the root's two-phase solve, the
+ * depth-first stack, snapshots in HBM, bounding -- as the parity walk does it for MIP::RecusivePart (xpg_mip_batch_*).
+ * is_bin: the program is 0-1 (its x_j <= 1 rows are rows of leq): a path then appends at most one bound row per variable,
+ * which sizes the LDS block; 0: what 64 KB allow (a tree that needs more ends XPG_ERR_UNSUPPORTED in out_status).
+ * out_status[b] = XPG_IP_* (or XPG_ERR_UNSUPPORTED), out_v[b], out_sol[b][cols]; out_stats (may be NULL): nodes, dual
+ * pivots and root pivots summed over the batch, the deepest path. */
+int xpg_mip_warm_batch_f64(xpg_ctx * ctx, int nb, int is_max, const double * tgtf, const double * leq, int leq_rows, int cols,
+                           int is_bin, int32_t * out_status, double * out_v, double * out_sol, long long * out_stats);
 /* Lineq::has_solution(leq, eq, vc, rhs_idx, is_int_sol, is_unique_sol),
  * src/com/linsys.cpp:830-906.  Returns 1 / 0, or XPG_ERR_*. */
 int xpg_has_solution_rat32(xpg_ctx * ctx, const xpg_rat32 * leq, int leq_rows, const xpg_rat32 * eq,

@@ -31,6 +31,7 @@
 #include "lp_fused_r32.hip.h"
 #include "lp_host.hip.h"
 #include "warm_mip.hip.h"
+#include "warm_mip_batch.hip.h"
 #endif
 #if XPG_IN(1) || XPG_IN(2)
 #include "six_host.hip.h"
@@ -613,6 +614,13 @@ int xpg_mip_warm_f64(xpg_ctx * ctx, int is_max, const double * tgtf, const doubl
     if (st == XPG_IP_SUCC) *out_v = is_max ? v : -v;
     else *out_v = 0.0;
     return st;
+}
+
+int xpg_mip_warm_batch_f64(xpg_ctx * ctx, int nb, int is_max, const double * tgtf, const double * leq, int leq_rows, int cols, int is_bin,
+                           int32_t * out_status, double * out_v, double * out_sol, long long * out_stats)
+{
+    XPG_BIND(ctx);
+    return warm_mip_batch(ctx, nb, is_max, tgtf, leq, leq_rows, cols, is_bin, out_status, out_v, out_sol, out_stats);
 }
 
 } // extern "C"

@@ -342,6 +342,18 @@ def mip_warm(ctx, is_max, tgtf, leq, is_bin=False):
     return st, v.value, sol, dict(nodes=stats[0], dual_pivots=stats[1], root_pivots=stats[2], max_depth=stats[3])
 
 
+def mip_warm_batch(ctx, is_max, tgtf, leq, is_bin=False):
+    """OPT-IN, NON-PARITY (xpg_mip_warm_batch_f64): nb fp64 integer programs of one shape, each tree walked by one workgroup
+    with the dual simplex warm-started from the parent's tableau. tgtf [nb, cols], leq [nb, rows, cols].
+    Returns (status[nb], v[nb], sol[nb, cols], dict(nodes, dual_pivots, root_pivots, max_depth))."""
+    tgtf = as_kind(tgtf, F64, 2); leq = as_kind(leq, F64, 3)
+    nb, rows, cols = leq.shape
+    st = np.zeros(nb, dtype=np.int32); v = np.zeros(nb); sol = np.zeros((nb, cols)); stats = (C.c_longlong * 4)()
+    ctx.check(lib().xpg_mip_warm_batch_f64(ctx._h, C.c_int(nb), C.c_int(int(is_max)), vp(tgtf), vp(leq), C.c_int(rows), C.c_int(cols),
+                                           C.c_int(int(is_bin)), vp(st), vp(v), vp(sol), stats), "xpg_mip_warm_batch_f64")
+    return st, v, sol, dict(nodes=stats[0], dual_pivots=stats[1], root_pivots=stats[2], max_depth=stats[3])
+
+
 def mip_batch(ctx, is_max, is_bin, tgtf, leq, kind=RAT):
     """nb independent MIPs (x >= 0, inequalities only), each tree walked on the device by one workgroup.
     tgtf [nb, cols(,2)], leq [nb, rows, cols(,2)]. Returns (status[nb], v[nb(,2)], sol[nb,cols(,2)], nodes)."""
