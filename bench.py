@@ -1010,8 +1010,13 @@ def leg_mip(ctx, xpoly_amd, gen):
     wst, wv, _, wstats = mip_warm_batch(ctx, True, wt, wl, is_bin=True)
     wdt = time.perf_counter() - t0
     solved = st == 0                                     # where the parity walk finds the optimum too the values must agree
+    # (the two legs answer different questions: on 0-1 programs the reference's walk substitutes the branch equalities with
+    # lpsol.h:1232's row index and returns points that violate the capacity rows on most of these knapsacks -- "optima" ABOVE
+    # the optimum, reproduced bit for bit by the parity leg; how many of them the true optimum happens to equal is on file)
     pv = v[solved][:, 0] / np.maximum(v[solved][:, 1], 1)
-    never_below = bool(np.all(wv[solved] >= pv - 1e-6)) if solved.any() else None     # an optimum is never below a feasible point's value
+    A_, b_ = wl[solved][:, :, :MIP_NV], wl[solved][:, :, MIP_NV]
+    px = sol[solved][:, :MIP_NV, 0] / np.maximum(sol[solved][:, :MIP_NV, 1], 1)
+    parity_feasible = round(float(np.mean((np.einsum("bij,bj->bi", A_, px) <= b_ + 1e-9).all(axis=1))), 3) if solved.any() else None
     equal_share = round(float(np.mean(np.abs(wv[solved] - pv) <= 1e-6)), 3) if solved.any() else None
     wl8, wt8 = leq8[..., 0].astype(np.float64), tgtf8[..., 0].astype(np.float64)
     mip_warm_batch(ctx, True, wt8, wl8, is_bin=True)
@@ -1024,7 +1029,7 @@ def leg_mip(ctx, xpoly_amd, gen):
                 nodes_per_s=round(wstats["nodes"] / wdt, 1), dual_pivots_per_node=round(wstats["dual_pivots"] / max(1, wstats["nodes"] - MIP_NB), 2),
                 root_pivots_per_problem=round(wstats["root_pivots"] / MIP_NB, 1), max_depth=int(wstats["max_depth"]),
                 status_hist=np.bincount(np.clip(wst, 0, 4), minlength=5).tolist(),
-                optimum_never_below_the_parity_walks_value=never_below, share_of_parity_answers_that_are_optimal=equal_share,
+                share_of_the_parity_walks_points_that_satisfy_their_rows=parity_feasible, share_of_parity_answers_equal_to_the_optimum=equal_share,
                 larger_batch=dict(problems=big, mips_per_s=round(big / wdt8, 1), nodes_per_s=round(wstats8["nodes"] / wdt8, 1), wall_ms=round(wdt8 * 1e3, 2)))
     return dict(metric="0-1 MIP branch and bound, one tree per workgroup on the device", value=round(nodes / dt, 1), unit="nodes/s",
                 warm_started_batch=warm,
