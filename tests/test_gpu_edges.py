@@ -220,6 +220,46 @@ def test_blocked_loop_small_and_rare_branches(ctx, port, B, monkeypatch):
     c.close()
 
 
+@pytest.mark.parametrize("shape", [(511, 512), (1023, 1024), (640, 383), (300, 723)])
+def test_chain_with_and_without_the_column_line_equals_the_pipelined_loop(shape, monkeypatch):
+    """Round 5's chain -- replays from registers with -0.0 for the steps that do not count, one-round gathers, and where the row
+    stride is a multiple of 4 KiB (the first three shapes: W = 1024 / 2048 / 1024) the entering column's line in the pick
+    workers' LDS -- against the pipelined loop, which shares none of that code: whole solves of LPs that run thousands of
+    pivots (rows that pivot several times inside one batch, columns that come back), state compared bit for bit at three
+    iteration limits; with XPG_CHAIN_LINE forced off and on."""
+    import xpoly_amd
+    m, n = shape
+    leq, tg = gen.hard_lp_f64(m, n)
+    monkeypatch.setenv("XPG_LOOP", "pipe")
+    cp = xpoly_amd.Context(0)
+    want = {}
+    for K in (77, 1200, 3000):
+        lp = xpoly_amd.DeviceLP(cp, F64, leq, tg)
+        st = lp.two_stage(K)
+        want[K] = (st, lp.read())
+        lp.close()
+    cp.close()
+    monkeypatch.setenv("XPG_LOOP", "block")
+    for line in ("0", "1"):
+        monkeypatch.setenv("XPG_CHAIN_LINE", line)
+        cb = xpoly_amd.Context(0)
+        for K in (77, 1200, 3000):
+            lp = xpoly_amd.DeviceLP(cb, F64, leq, tg)
+            st = lp.two_stage(K)
+            got = lp.read()
+            lp.chain_aborts()
+            runs = lp.chain_runs
+            lp.close()
+            assert st == want[K][0], (shape, line, K, st, want[K][0])
+            for k in ("tab", "tgtf", "nvset", "bvset", "bv2eq", "eq2bv"):
+                a, b = np.asarray(got[k]), np.asarray(want[K][1][k])
+                assert a.shape == b.shape and (np.array_equal(a.view(np.uint64), b.view(np.uint64))
+                                               if a.dtype == np.float64 else np.array_equal(a, b)), (shape, line, K, k)
+            if K > 100:
+                assert runs > 0, (shape, line, K, runs)         # the chain launches really ran (not the launch-per-stage fallback)
+        cb.close()
+
+
 def test_batch_sizes_ragged_and_single(ctx, port):
     """nb = 1, nb not a multiple of anything, 1 x 1 LPs."""
     rng = np.random.default_rng(4)
