@@ -50,9 +50,9 @@ PCIE_GBS = 63.0                            # MI355X_MICROARCH.md: host link PCIe
 BATCH_PER_GPU = 8192                       # 65 536 LPs over 8 GPUs (BASELINE.json configs[2])
 BATCH_M, BATCH_COLS = 32, 64
 PREWARM_SECONDS = 0.5
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "round4_pmc_hbm_traffic_4096x8192.json")
-PMC_SUMMARY_2B = os.path.join(ROOT, "profiles", "round4_pmc_hbm_traffic_4096x12289.json")
-PMC_BATCH = os.path.join(ROOT, "profiles", "round4_pmc_batch_issue.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "round5_pmc_hbm_traffic_4096x8192.json")
+PMC_SUMMARY_2B = os.path.join(ROOT, "profiles", "round5_pmc_hbm_traffic_4096x12289.json")
+PMC_BATCH = os.path.join(ROOT, "profiles", "round5_pmc_batch_issue.json")
 PMC_RATIONAL = os.path.join(ROOT, "profiles", "round4_pmc_rational_issue.json")
 LEGS = ("pivots", "batched", "sharded", "cfg2b", "six_e2e", "rational", "mip", "lineq")
 LINEQ_NB = 16384                           # systems per row-elimination launch (the dependence tests' shapes)
@@ -595,7 +595,7 @@ def main():
                 dense_positive=dict(valu_busy_percent=pb.get("dense_busy_percent", {}).get("VALUBusy"),
                                     salu_busy_percent=pb.get("dense_busy_percent", {}).get("SALUBusy"),
                                     wave_instructions_per_pivot=pb.get("dense_per_pivot")),
-                source="profiles/round4_pmc_batch_issue.json (rocprofv3 --pmc VALUBusy / SALUBusy / SQ_INSTS_* on "
+                source="profiles/round5_pmc_batch_issue.json (rocprofv3 --pmc VALUBusy / SALUBusy / SQ_INSTS_* on "
                        "tools/lab/probe_batch.py; not collected in this run)")
         if not stub:
             # STRONG scaling beside the weak figures above: the 65 536 LPs of BASELINE configs[2] in all, split over the
@@ -847,7 +847,7 @@ def leg_cfg2b(ctx, xpoly_amd, gen, m=4096, n=8192):
             frac=round(bytes_per_launch / avg / 1e9 / HBM_PEAK_GBS, 4), avg_launch_us=round(avg * 1e6, 2),
             launches_sampled=launches,
             traffic=(round(json.load(open(PMC_SUMMARY_2B))["traffic_bytes_per_launch"]) if os.path.exists(PMC_SUMMARY_2B) else None),
-            traffic_source="profiles/round4_pmc_hbm_traffic_4096x12289.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of this leg; not collected in this run)",
+            traffic_source="profiles/round5_pmc_hbm_traffic_4096x12289.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of this leg; not collected in this run)",
             note="HIP events on the sweep launches of the timed pass; a plain in-place copy of this tableau with the same "
                  "tiling runs at 0.79 of the peak (tools/lab/sweep_lab2.hip, profiles/round3_sweep_lab.txt)")
     return out
