@@ -410,6 +410,15 @@ int xpg_trim(xpg_ctx * ctx);
 int xpg_lineq_calc_bound_batch_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols,
                                      int rhs_idx, int cap_rows, xpg_rat32 * bounds, int32_t * out_rows,
                                      int32_t * out_ok);
+/* The same with a PACKED result (round 5): the nb * rhs_idx bound systems back to back instead of worst-case slots --
+ * row_offsets[b * rhs_idx + j] is the first row of variable j's bounds of system b, row_offsets[nb * rhs_idx] the total; the
+ * slots stay in HBM and are compacted there, only live rows cross the link.  outs (may be NULL) has room for outs_cap_rows
+ * rows (too small: XPG_ERR_SHAPE with row_offsets filled); out_view (may be NULL) receives a pointer into the handle's
+ * pinned buffer, valid until the handle's next call; cap_rows <= 0: 4 * rows + 16.  out_ok[b] = 1, 0 (inconsistent: its
+ * chains count as empty) or -rows_needed (then nothing is packed and every offset is 0: call again with that cap_rows). */
+int xpg_lineq_calc_bound_batch_packed_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols, int rhs_idx,
+                                            int cap_rows, xpg_rat32 * outs, long long outs_cap_rows, const xpg_rat32 ** out_view,
+                                            long long * row_offsets, int32_t * out_ok);
 /* The same three on DEVICE arrays (xpg_malloc / any HIP allocation of the handle's device), enqueue only: the
  * results are there after xpg_sync.  For chains of eliminations that stay in HBM, and for measuring the kernels
  * without PCIe.  d_outs is not cleared: rows of a slot past d_out_rows[b] keep what they held. */

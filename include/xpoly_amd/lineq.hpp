@@ -185,19 +185,22 @@ public:
 private:
     template <class Sink> bool calc_bound_into(Sink sink)
     {
+        // the packed form: only the live rows of the nv bound systems travel, read straight out of the handle's pinned buffer
         const int rows = (int)m_coeff->get_row_size(), cols = (int)m_coeff->get_col_size(), nv = m_rhs_idx;
         int cap = 4 * rows + 16;
         for (int attempt = 0; attempt < 2; attempt++) {
-            std::vector<xpg_rat32> out((size_t)nv * cap * cols);
-            std::vector<int32_t> orows((size_t)nv);
+            std::vector<long long> off((size_t)nv + 1, 0);
+            const xpg_rat32 * view = 0;
             int32_t ok = 0;
-            if (xpg_lineq_calc_bound_batch_rat32(ctx(), 1, (const xpg_rat32 *)m_coeff->get_matrix(), rows, cols, nv, cap, out.data(),
-                                                 orows.data(), &ok) != 0) return false;
+            if (xpg_lineq_calc_bound_batch_packed_rat32(ctx(), 1, (const xpg_rat32 *)m_coeff->get_matrix(), rows, cols, nv, cap, (xpg_rat32 *)0, 0,
+                                                        &view, off.data(), &ok) != 0) return false;
             if (ok < 0) { cap = -ok; continue; }
             if (ok == 0) return false;                       // "system inconsistency!" (linsys.cpp:1065-1068)
             for (int j = 0; j < nv; j++) {
-                std::vector<xpg_rat32> one(out.begin() + (size_t)j * cap * cols, out.begin() + (size_t)j * cap * cols + (size_t)orows[(size_t)j] * cols);
-                sink(j, one, orows[(size_t)j], cols);
+                const int r = (int)(off[(size_t)j + 1] - off[(size_t)j]);
+                std::vector<xpg_rat32> one;
+                if (r) one.assign(view + (size_t)off[(size_t)j] * cols, view + (size_t)off[(size_t)j + 1] * cols);
+                sink(j, one, r, cols);
             }
             return true;
         }

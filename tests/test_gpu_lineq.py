@@ -118,6 +118,27 @@ def test_calc_bound_chain_matches_oracle(lq, port):
                 for j in range(nv):
                     assert rows_equal(bounds[b][j], wb[j]), (rows, nv, b, j)
     assert seen == {0, 1}
+    # the packed entry point (only live rows cross the link): the same bounds, consistent and inconsistent systems in one batch,
+    # and a cap too small reported as -rows needed with nothing packed
+    for (rows, nv) in ((5, 3), (6, 4)):
+        mats = np.stack([gen.random_system(rng, rows, nv) for _ in range(48)])
+        ok, bounds = lq.calcBound(mats, nv, cap_rows=256)
+        okp, bp = lq.calcBound_packed(mats, nv, cap_rows=256)
+        assert np.array_equal(ok, okp) and {0, 1} <= set(ok.tolist())
+        for b in range(48):
+            for j in range(nv):
+                if ok[b] == 1:
+                    assert bp[b][j].shape == bounds[b][j].shape and np.array_equal(bp[b][j], bounds[b][j]), (rows, nv, b, j)
+                else:
+                    assert bp[b][j].shape[0] == 0
+        okd, bd = lq.calcBound_packed(mats, nv)                         # the default capacity (4 rows + 16)
+        assert np.array_equal(okd, ok) and all(np.array_equal(bd[b][j], bp[b][j]) for b in range(48) for j in range(nv))
+    big = np.stack([gen.random_system(rng, 9, 4) for _ in range(8)])
+    ok_small, b_small = lq.calcBound_packed(big, 4, cap_rows=9)
+    if (ok_small < 0).any():
+        assert all(x.shape[0] == 0 for row in b_small for x in row)
+        ok_fit, _ = lq.calcBound_packed(big, 4, cap_rows=int(-ok_small.min()))
+        assert (ok_fit >= 0).all() or (ok_fit < 0).any()            # (a later step may need more still: the caller iterates)
 
 
 def int_cases(rng, nb, rows, cols):

@@ -347,13 +347,20 @@ inline int lineq_fme_batch_packed(xpg_ctx * ctx, int nb, const R32 * mats, int r
 // other variables are eliminated innermost-first by chained k_fme_batch launches that stay on
 // the device (ragged row counts travel in an int array). bounds is [nb][rhs][cap][cols],
 // out_rows [nb][rhs]; out_ok[b] = 1, 0 (inconsistent) or -needed_rows (cap too small).
+// Packed form (round 5; row_offsets != NULL): the nb * rhs results back to back -- row_offsets[b * rhs + j] is where the bounds
+// of variable j of system b start (in rows), row_offsets[nb * rhs] the total -- instead of nb * rhs worst-case slots of `cap` rows:
+// the slots stay in HBM, k_rows_scan / k_pack_rows compact them there (as for the packed fme), only live rows cross the link.
+// `bounds` (may be NULL) has room for bounds_cap_rows rows; `view` (may be NULL) receives a pointer into the handle's pinned buffer.
 inline int lineq_calc_bound_batch(xpg_ctx * ctx, int nb, const R32 * mats, int rows, int cols, int rhs, int cap,
-                                  R32 * bounds, int32_t * out_rows, int32_t * out_ok)
+                                  R32 * bounds, int32_t * out_rows, int32_t * out_ok,
+                                  long long * row_offsets = nullptr, long long bounds_cap_rows = 0, const R32 ** view = nullptr)
 {
-    if (!ctx || nb < 0 || !mats || !bounds || rows <= 0 || cols <= 1 || rhs < 1 || rhs >= cols || cap < rows ||
-        !out_rows || !out_ok)
+    const bool packed = row_offsets != nullptr;
+    if (view) *view = 0;
+    if (!ctx || nb < 0 || !mats || (!bounds && !packed) || rows <= 0 || cols <= 1 || rhs < 1 || rhs >= cols || cap < rows ||
+        (!out_rows && !packed) || !out_ok)
         return XPG_ERR_SHAPE;
-    if (nb == 0) return 0;
+    if (nb == 0) { if (packed) row_offsets[0] = 0; return 0; }
     const FmeLds fl = fme_lds(cap, cap, cols);
     if (fl.lds > 160 * 1024 || cap > 32767) return XPG_ERR_UNSUPPORTED;
     const size_t slot = (size_t)cap * cols * 8, bsz = (size_t)nb * slot;
@@ -388,6 +395,52 @@ inline int lineq_calc_bound_batch(xpg_ctx * ctx, int nb, const R32 * mats, int r
                                  hipMemcpyDeviceToDevice, ctx->stream));
         XPG_TRY(hipMemcpy2DAsync((char *)drows.p + (size_t)j * 4, (size_t)rhs * 4, cur_rows, 4, 4, nb,
                                  hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if (packed) {
+        const int nres = nb * rhs;
+        DevBuf doff, dpk;
+        XPG_TRY(doff.alloc(ctx, (size_t)(nres + 1) * 8));
+        XPG_TRY(hipMemcpyAsync(out_ok, chain.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+        XPG_TRY(hipStreamSynchronize(ctx->stream));
+        bool short_cap = false, some_bad = false;
+        for (int b = 0; b < nb; b++) { short_cap |= out_ok[b] < 0; some_bad |= out_ok[b] == 0; }
+        if (short_cap) {                                           // a step needs more rows than cap (out_ok[b] = -rows needed): nothing to pack
+            for (int k = 0; k <= nres; k++) row_offsets[k] = 0;
+            return 0;
+        }
+        if (some_bad) {
+            // an inconsistent system's chains hold whatever its last good step left: they count as empty
+            std::vector<int32_t> hrows((size_t)nres);
+            XPG_TRY(hipMemcpyAsync(hrows.data(), drows.p, (size_t)nres * 4, hipMemcpyDeviceToHost, ctx->stream));
+            XPG_TRY(hipStreamSynchronize(ctx->stream));
+            for (int b = 0; b < nb; b++)
+                if (out_ok[b] == 0) for (int j = 0; j < rhs; j++) hrows[(size_t)b * rhs + j] = 0;
+            XPG_TRY(hipMemcpyAsync(drows.p, hrows.data(), (size_t)nres * 4, hipMemcpyHostToDevice, ctx->stream));
+            XPG_TRY(hipStreamSynchronize(ctx->stream));            // (hrows is about to go out of scope)
+        }
+        hipLaunchKernelGGL(k_rows_scan, dim3(1), dim3(1024), 0, ctx->stream, nres, (const int *)drows.p, (long long *)doff.p);
+        XPG_TRY(hipMemcpyAsync(row_offsets, doff.p, (size_t)(nres + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        XPG_TRY(hipStreamSynchronize(ctx->stream));
+        const long long total = row_offsets[nres];
+        if (bounds && bounds_cap_rows < total) return XPG_ERR_SHAPE;
+        if (total == 0 || (!bounds && !view)) return 0;
+        const size_t bp = (size_t)total * cols * 8;
+        XPG_TRY(dpk.alloc(ctx, bp));
+        hipLaunchKernelGGL(k_pack_rows, dim3(nres < 4096 ? nres : 4096), dim3(256), 0, ctx->stream, nres, (const R32 *)dres.p, cap, cols,
+                           (const int *)drows.p, (const long long *)doff.p, (R32 *)dpk.p);
+        XPG_TRY(hipGetLastError());
+        if (view) {
+            const int rc = hpack_reserve(ctx, bp);
+            if (rc) return rc;
+            XPG_TRY(hipMemcpyAsync(ctx->hpack, dpk.p, bp, hipMemcpyDeviceToHost, ctx->stream));
+            XPG_TRY(hipStreamSynchronize(ctx->stream));
+            if (bounds) memcpy(bounds, ctx->hpack, bp);
+            *view = (const R32 *)ctx->hpack;
+        } else {
+            XPG_TRY(hipMemcpyAsync(bounds, dpk.p, bp, hipMemcpyDeviceToHost, ctx->stream));
+            XPG_TRY(hipStreamSynchronize(ctx->stream));
+        }
+        return 0;
     }
     XPG_TRY(hipMemcpyAsync(bounds, dres.p, bsz * rhs, hipMemcpyDeviceToHost, ctx->stream));
     XPG_TRY(hipMemcpyAsync(out_rows, drows.p, (size_t)nb * rhs * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -1245,6 +1245,16 @@ int xpg_lineq_calc_bound_batch_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * ma
                                      int cap_rows, xpg_rat32 * bounds, int32_t * out_rows, int32_t * out_ok)
 {
     XPG_BIND(ctx); return lineq_calc_bound_batch(ctx, nb, (const R32 *)mats, rows, cols, rhs_idx, cap_rows, (R32 *)bounds, out_rows, out_ok); }
+int xpg_lineq_calc_bound_batch_packed_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols, int rhs_idx,
+                                            int cap_rows, xpg_rat32 * outs, long long outs_cap_rows, const xpg_rat32 ** out_view,
+                                            long long * row_offsets, int32_t * out_ok)
+{
+    XPG_BIND(ctx);
+    if (!row_offsets) return XPG_ERR_SHAPE;
+    if (cap_rows <= 0) cap_rows = 4 * rows + 16;
+    return lineq_calc_bound_batch(ctx, nb, (const R32 *)mats, rows, cols, rhs_idx, cap_rows, (R32 *)outs, (int32_t *)0, out_ok,
+                                  row_offsets, outs_cap_rows, (const R32 **)out_view);
+}
 int xpg_lineq_reduce_batch_rat32_dev(xpg_ctx * ctx, int nb, xpg_rat32 * d_mats, int rows, int cols, int rhs_idx,
                                      int is_intersect, int32_t * d_out_rows, int32_t * d_out_ok)
 {

@@ -160,6 +160,23 @@ class Lineq:
                        "xpg_lineq_calc_bound_batch_rat32")
         return ok, [[out[b, j, : max(out_rows[b, j], 0)].copy() for j in range(rhs_idx)] for b in range(nb)]
 
+    def calcBound_packed(self, mats, rhs_idx, cap_rows=None):
+        """The same through the packed entry point (xpg_lineq_calc_bound_batch_packed_rat32): only live rows cross the link.
+        Returns (ok[nb], bounds[b][j]) like calcBound; ok[b] < 0 (a step needed -ok[b] rows) leaves every bound empty."""
+        a = _stack(mats)
+        nb, rows, cols = a.shape[:3]
+        off = np.zeros(nb * rhs_idx + 1, dtype=np.int64); ok = np.zeros(nb, dtype=np.int32)
+        view = C.c_void_p()
+        self.ctx.check(lib().xpg_lineq_calc_bound_batch_packed_rat32(self.ctx._h, C.c_int(nb), vp(a), C.c_int(rows), C.c_int(cols),
+                                                                     C.c_int(rhs_idx), C.c_int(cap_rows or 0), None, C.c_longlong(0),
+                                                                     C.byref(view), vp(off), vp(ok)),
+                       "xpg_lineq_calc_bound_batch_packed_rat32")
+        total = int(off[-1])
+        packed = np.zeros((total, cols, 2), dtype=np.int32)
+        if total:                                           # out of the handle's pinned buffer, before the next call reuses it
+            C.memmove(packed.ctypes.data, view.value, packed.nbytes)
+        return ok, [[packed[int(off[b * rhs_idx + j]): int(off[b * rhs_idx + j + 1])].copy() for j in range(rhs_idx)] for b in range(nb)]
+
     def rank(self, mats):
         a = _stack(mats)
         nb, rows, cols = a.shape[:3]
