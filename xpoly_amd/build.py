@@ -24,7 +24,7 @@ PARTS = 4
 # its object
 COMMON = ["xpoly_amd.hip", "scalar.hip.h", "ctx.hip.h", "rat_ops.hip.h", "../../include/xpoly_amd.h"]
 DEPS = {
-    0: ["lp_kernels.hip.h", "lp_pipe_r32.hip.h", "lp_fused_r32.hip.h", "lp_host.hip.h", "lp_blocked.hip.h", "lp_chain.hip.h", "warm_mip.hip.h"],
+    0: ["lp_kernels.hip.h", "lp_pipe_r32.hip.h", "lp_fused_r32.hip.h", "lp_host.hip.h", "lp_blocked.hip.h", "lp_chain.hip.h", "warm_mip.hip.h", "warm_mip_batch.hip.h"],
     1: ["lp_kernels.hip.h", "six_host.hip.h", "batch_kernels.hip.h"],
     2: ["lp_kernels.hip.h", "six_host.hip.h", "batch_kernels.hip.h", "lineq_shared.hip.h", "mip_host.hip.h", "mip_kernels.hip.h"],
     3: ["lineq_shared.hip.h", "lineq_host.hip.h", "lineq_kernels.hip.h"],

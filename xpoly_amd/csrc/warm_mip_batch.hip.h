@@ -56,12 +56,12 @@ __device__ __forceinline__ void wb_argmin(double & val, int & idx, double * red_
 
 struct WbLds {
     double * T; double * obj; double * prow; double * pcol; double * c0; double * red_v;
-    int * bv_row; int * eq2bv; int * red_i; int * ctl;
+    int * bv_row; int * eq2bv; int * red_i;
 };
 inline size_t wb_lds_bytes(const WbShape & S)
 {
     size_t b = ((size_t)S.mcap * S.wcap + 2 * (size_t)S.wcap + S.mcap + S.n0 + 8) * 8;
-    b += ((size_t)S.wcap + S.mcap + 8 + 16) * 4;
+    b += ((size_t)S.wcap + S.mcap + 8) * 4;
     return (b + 15) & ~(size_t)15;
 }
 __device__ __forceinline__ void wb_carve(WbLds & L, unsigned char * lds, const WbShape & S)
@@ -76,8 +76,7 @@ __device__ __forceinline__ void wb_carve(WbLds & L, unsigned char * lds, const W
     int * q = (int *)d;
     L.bv_row = q; q += S.wcap;
     L.eq2bv = q; q += S.mcap;
-    L.red_i = q; q += 8;
-    L.ctl = q;
+    L.red_i = q;
 }
 
 // One pivot on (r, e): row r scaled, every other row and the z-row eliminated, the basis swapped. m live rows; columns of
@@ -221,8 +220,8 @@ __global__ __launch_bounds__(WB_THREADS) void k_warm_mip_batch(int nb, const dou
                 else if (st2 == 4) status = XPG_ERR_UNSUPPORTED;
             }
         }
-        // ---- the walk. ctl: [0] what to do next (0 consider the state in LDS, 1 pop), [1] depth of the state in LDS,
-        // [2] stack height, [3] row count of the state in LDS
+        // ---- the walk: either a freshly solved state is in LDS (have_state: consider it -- prune, new incumbent, or push), or the
+        // node on top of the stack is taken up again (its next child). Every decision below is computed by every thread alike
         int depth = 0, height = 0;
         bool have_state = status == -1;
         while (status == -1) {
