@@ -566,8 +566,21 @@ def main():
                     best = min(e2e_pass(chunks) for _ in range(2))
                     assert torch.equal(d_st, want_st) and torch.equal(d_v.view(torch.int64), want_v.view(torch.int64)), "chunked solve differs"
                     e2e[pname + "_lps_per_s"] = round(total / max_over_ranks(best), 1)
-                e2e["note"] = ("host arrays in (pageable), results in HBM: the figure a caller of the host-array entry points gets "
-                               "before the read-back; better of two passes; the device-resident lps_per_s beside it excludes the upload")
+                # ... and the host-array entry point itself (xpg_six_batch_f64: host arrays in AND out, one upload, one launch)
+                best = None
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    hst, hv, hsol = ctx.six_batch(xpoly_amd.F64, True, b_tg, b_leq)
+                    dt_h = time.perf_counter() - t0
+                    best = dt_h if best is None else min(best, dt_h)
+                assert np.array_equal(hst, want_st.cpu().numpy()) and np.array_equal(hv.view(np.int64), want_v.cpu().numpy().view(np.int64)), "host-array call differs"
+                e2e["host_array_call_lps_per_s"] = round(total / max_over_ranks(best), 1)
+                e2e["note"] = ("host arrays in (pageable): upload_then_solve / two_chunks_overlapped leave the results in HBM (torch uploads + the "
+                               "device-array entry point; two LAUNCHES are slower than one: each has a tail of its own); host_array_call is "
+                               "xpg_six_batch_f64 -- results back on the host too. An upload UNDER one launch (chunks on a second stream, "
+                               "workgroups waiting on a gate word) was built in round 5 and deadlocks on a full chip: the runtime's copies "
+                               "of pageable memory are shader copies that find no registers while every seat spins (DESIGN section 5); "
+                               "best of the passes; the device-resident lps_per_s beside them excludes the upload")
             if rank == 0 and not stub and nloc >= 256:
                 checks.setdefault("batched", {})[name] = selfcheck_batched(fam, d_st, d_v, d_sol, full)
             fams[name] = dict(lps_per_s=round(total * reps / bdt, 1), pivots_per_s=round(piv * reps / bdt, 1),
