@@ -91,12 +91,19 @@ __device__ __forceinline__ void wb_pivot(const WbLds & L, const WbShape & S, int
     }
     for (int i = threadIdx.x; i <= m; i += blockDim.x) L.pcol[i] = i < m ? L.T[(size_t)i * S.wcap + e] : L.obj[e];
     __syncthreads();
-    const int cols = live + 1;
-    for (int t = threadIdx.x; t < (m + 1) * cols; t += blockDim.x) {
-        const int i = t / cols, jj = t - i * cols, c = jj < live ? jj : cst;
-        double * cell = i < m ? &L.T[(size_t)i * S.wcap + c] : &L.obj[c];
-        if (i == r) *cell = c == e ? 1.0 : L.prow[c];
-        else *cell = c == e ? 0.0 : *cell - L.pcol[i] * L.prow[c];
+    // a wave per row (rows w, w + waves, ...; the z-row is row m), a lane per column: no index arithmetic, the row's factor is
+    // wave-uniform -- and a row whose entry in the pivot column is zero is left alone (most rows of a 0-1 program: its x_j <= 1
+    // rows touch one structural column each)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    for (int i = wv; i <= m; i += nwv) {
+        const double f = L.pcol[i];
+        if (i != r && f == 0.0) continue;
+        double * row = i < m ? &L.T[(size_t)i * S.wcap] : L.obj;
+        for (int jj = lane; jj <= live; jj += 64) {
+            const int c = jj < live ? jj : cst;
+            if (i == r) row[c] = c == e ? 1.0 : L.prow[c];
+            else row[c] = c == e ? 0.0 : row[c] - f * L.prow[c];
+        }
     }
     if (threadIdx.x == 0) { const int lv = L.eq2bv[r]; L.bv_row[lv] = -1; L.bv_row[e] = r; L.eq2bv[r] = e; }
     __syncthreads();
