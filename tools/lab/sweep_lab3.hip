@@ -1,0 +1,177 @@
+// Lab bench, round 5: can a pass apply 32 staged pivots at (nearly) the price of 24? Variants of the blocked sweep's body at
+// 4096 x 8192 (268 MB), natural tile order with alternating direction, HIP events, outside the library:
+//   pair   -- the product's shape: a thread owns a column PAIR (16-byte accesses), NB register pairs of e_s
+//   single -- a thread owns ONE column (8-byte accesses, a wave still covers 512 contiguous bytes): half the e registers
+//   twoph  -- pairs, but the 2 * NH stages in two phases over the same in-register rows: e_s reloaded (from the L2) in between
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -o tools/_build/sweep_lab3 tools/lab/sweep_lab3.hip
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void tile_of(int rev, int & bx, int & by)
+{
+    const int gx = (int)gridDim.x, gy = (int)gridDim.y;
+    int lid = (int)blockIdx.y * gx + (int)blockIdx.x;
+    if (rev) lid = gx * gy - 1 - lid;
+    by = lid / gx; bx = lid % gx;
+}
+
+template <int ROWS, int U, int NB, int WAVES> __global__ __launch_bounds__(256, WAVES)
+void k_pair(double * __restrict__ tab, int m, int W, int ld, const double * __restrict__ E, const double * __restrict__ K, int rev)
+{
+    int bx, by; tile_of(rev, bx, by);
+    const int j = bx * 512 + threadIdx.x * 2, i0 = by * ROWS;
+    if (j >= W) return;
+    v2d e[NB];
+#pragma unroll
+    for (int s = 0; s < NB; s++) e[s] = *reinterpret_cast<const v2d *>(E + (size_t)s * ld + j);
+    double * base = tab + (size_t)i0 * ld + j;
+    v2d a[U], b[U];
+    auto load = [&](v2d (&d)[U], const double * p) {
+#pragma unroll
+        for (int u = 0; u < U; u++) d[u] = *reinterpret_cast<const v2d *>(p + (size_t)u * ld);
+    };
+    auto apply = [&](v2d (&d)[U], double * p, int row0) {
+#pragma unroll
+        for (int s = 0; s < NB; s++)
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const double k = K[(size_t)(row0 + u) * 32 + s];
+                const double p0 = k * e[s].x, p1 = k * e[s].y;
+                d[u].x = d[u].x + p0; d[u].y = d[u].y + p1;
+            }
+#pragma unroll
+        for (int u = 0; u < U; u++) *reinterpret_cast<v2d *>(p + (size_t)u * ld) = d[u];
+    };
+    load(a, base);
+#pragma unroll 1
+    for (int i = i0; i < i0 + ROWS; i += 2 * U) {
+        load(b, base + (size_t)U * ld);
+        apply(a, base, i);
+        if (i + 2 * U < i0 + ROWS) load(a, base + (size_t)2 * U * ld);
+        apply(b, base + (size_t)U * ld, i + U);
+        base += (size_t)2 * U * ld;
+    }
+}
+
+template <int ROWS, int U, int NB, int WAVES> __global__ __launch_bounds__(256, WAVES)
+void k_single(double * __restrict__ tab, int m, int W, int ld, const double * __restrict__ E, const double * __restrict__ K, int rev)
+{
+    int bx, by; tile_of(rev, bx, by);
+    const int j = bx * 256 + threadIdx.x, i0 = by * ROWS;
+    if (j >= W) return;
+    double e[NB];
+#pragma unroll
+    for (int s = 0; s < NB; s++) e[s] = E[(size_t)s * ld + j];
+    double * base = tab + (size_t)i0 * ld + j;
+    double a[U], b[U];
+    auto load = [&](double (&d)[U], const double * p) {
+#pragma unroll
+        for (int u = 0; u < U; u++) d[u] = p[(size_t)u * ld];
+    };
+    auto apply = [&](double (&d)[U], double * p, int row0) {
+#pragma unroll
+        for (int s = 0; s < NB; s++)
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const double k = K[(size_t)(row0 + u) * 32 + s];
+                const double p0 = k * e[s];
+                d[u] = d[u] + p0;
+            }
+#pragma unroll
+        for (int u = 0; u < U; u++) p[(size_t)u * ld] = d[u];
+    };
+    load(a, base);
+#pragma unroll 1
+    for (int i = i0; i < i0 + ROWS; i += 2 * U) {
+        load(b, base + (size_t)U * ld);
+        apply(a, base, i);
+        if (i + 2 * U < i0 + ROWS) load(a, base + (size_t)2 * U * ld);
+        apply(b, base + (size_t)U * ld, i + U);
+        base += (size_t)2 * U * ld;
+    }
+}
+
+// 2 * NH stages in two phases: all ROWS rows of the tile in registers, e_s for one half at a time
+template <int ROWS, int NH, int WAVES> __global__ __launch_bounds__(256, WAVES)
+void k_twoph(double * __restrict__ tab, int m, int W, int ld, const double * __restrict__ E, const double * __restrict__ K, int rev)
+{
+    int bx, by; tile_of(rev, bx, by);
+    const int j = bx * 512 + threadIdx.x * 2, i0 = by * ROWS;
+    if (j >= W) return;
+    double * base = tab + (size_t)i0 * ld + j;
+    v2d a[ROWS];
+#pragma unroll
+    for (int u = 0; u < ROWS; u++) a[u] = *reinterpret_cast<const v2d *>(base + (size_t)u * ld);
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {
+        v2d e[NH];
+#pragma unroll
+        for (int s = 0; s < NH; s++) e[s] = *reinterpret_cast<const v2d *>(E + (size_t)(h * NH + s) * ld + j);
+#pragma unroll
+        for (int u = 0; u < ROWS; u++)
+#pragma unroll
+            for (int s = 0; s < NH; s++) {
+                const double k = K[(size_t)(i0 + u) * 32 + h * NH + s];
+                const double p0 = k * e[s].x, p1 = k * e[s].y;
+                a[u].x = a[u].x + p0; a[u].y = a[u].y + p1;
+            }
+    }
+#pragma unroll
+    for (int u = 0; u < ROWS; u++) *reinterpret_cast<v2d *>(base + (size_t)u * ld) = a[u];
+}
+
+typedef void (*kern_t)(double *, int, int, int, const double *, const double *, int);
+int main()
+{
+    const int m = 4096, W = 8192, ld = 8192;
+    double *tab, *E, *K;
+    CK(hipMalloc(&tab, (size_t)m * ld * 8)); CK(hipMalloc(&E, (size_t)32 * ld * 8)); CK(hipMalloc(&K, (size_t)m * 32 * 8));
+    {
+        std::vector<double> h((size_t)m * ld);
+        unsigned long long x = 88172645463325252ull;
+        auto rnd = [&] { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (double)(x >> 11) / 9007199254740992.0 - 0.5; };
+        for (auto & v : h) v = rnd();
+        CK(hipMemcpy(tab, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+        for (size_t i = 0; i < (size_t)32 * ld; i++) h[i] = rnd();
+        CK(hipMemcpy(E, h.data(), (size_t)32 * ld * 8, hipMemcpyHostToDevice));
+        for (size_t i = 0; i < (size_t)m * 32; i++) h[i] = rnd() * 1e-3;
+        CK(hipMemcpy(K, h.data(), (size_t)m * 32 * 8, hipMemcpyHostToDevice));
+    }
+    struct V { const char * name; kern_t f; int rows, cols, nb; } vs[] = {
+        {"pair   NB=24 <16,2> (the product's)", k_pair<16, 2, 24, 1>, 16, 512, 24},
+        {"pair   NB=32 <16,2>", k_pair<16, 2, 32, 1>, 16, 512, 32},
+        {"pair   NB=32 <16,2> 3 waves", k_pair<16, 2, 32, 3>, 16, 512, 32},
+        {"pair   NB=32 <16,1>", k_pair<16, 1, 32, 1>, 16, 512, 32},
+        {"pair   NB=28 <16,2>", k_pair<16, 2, 28, 1>, 16, 512, 28},
+        {"single NB=32 <16,2>", k_single<16, 2, 32, 1>, 16, 256, 32},
+        {"single NB=32 <16,4>", k_single<16, 4, 32, 1>, 16, 256, 32},
+        {"single NB=32 <32,4>", k_single<32, 4, 32, 1>, 32, 256, 32},
+        {"single NB=32 <16,4> 6 waves", k_single<16, 4, 32, 6>, 16, 256, 32},
+        {"single NB=24 <16,4>", k_single<16, 4, 24, 1>, 16, 256, 24},
+        {"twoph  2 x 16, 8 rows", k_twoph<8, 16, 1>, 8, 512, 32},
+        {"twoph  2 x 16, 16 rows", k_twoph<16, 16, 1>, 16, 512, 32},
+        {"twoph  2 x 16, 4 rows", k_twoph<4, 16, 1>, 4, 512, 32},
+    };
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const double bytes = 2.0 * m * W * 8;
+    for (auto & v : vs) {
+        dim3 g((W + v.cols - 1) / v.cols, m / v.rows);
+        int flip = 0;
+        for (int w = 0; w < 6; w++) hipLaunchKernelGGL(v.f, g, dim3(256), 0, 0, tab, m, W, ld, E, K, (flip ^= 1));
+        CK(hipDeviceSynchronize());
+        const int reps = 30;
+        CK(hipEventRecord(e0, 0));
+        for (int w = 0; w < reps; w++) hipLaunchKernelGGL(v.f, g, dim3(256), 0, 0, tab, m, W, ld, E, K, (flip ^= 1));
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1000.0 / reps;
+        hipFuncAttributes fa; CK(hipFuncGetAttributes(&fa, (const void *)v.f));
+        printf("  %-38s %8.2f us/launch  frac %.3f   per pivot %5.2f us   %3d VGPRs %4zu B scratch\n", v.name, us, bytes / us / 1e6 / 8.0, us / v.nb, fa.numRegs, (size_t)fa.localSizeBytes);
+    }
+    return 0;
+}
