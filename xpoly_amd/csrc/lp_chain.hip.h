@@ -348,6 +348,10 @@ template <bool LOCAL> __device__ __forceinline__ void ch_commit_loop(const LpVie
                 st->blk.batch = batch; st->blk.n = 0; st->blk.closed = 1; st->blk.generic = 0;
                 if (widx == -2) st->blk.want_generic = 1;
             }
+            // the pick workers do not read the records: the commit granule tells them that the batch ended here
+            ch_drain();
+            if (lane == 0)
+                ch_store_granule<LOCAL>(ch_part_g0(v, nprep), ((unsigned long long)(unsigned)CH_CLOSE_ROW << 32) | (unsigned)INT_MAX, (unsigned long long)tag);
             return;
         }
         if (lane == 0) {
@@ -382,9 +386,11 @@ template <bool LOCAL> __device__ __forceinline__ void ch_commit_loop(const LpVie
             // (the next batch's pick(0) looks through ceil(W / 64) partial slots for this tag: the chain's nprep <= that many
             // carry it, the rest still hold stage 0's and are ignored)
         }
-        ch_drain();                                             // the commit is out: the pick role of stage t+1 may read it
+        // the commit is out: the pick role of stage t+1 may read it. The granule is {INT_MAX -- no column, where a partial
+        // holds its first candidate --, the pivot row, tag}: the row is all a pick worker needs of the records of stage t
+        ch_drain();
         if (lane == 0)
-            ch_store_granule<LOCAL>(ch_part_g0(v, nprep), (unsigned long long)(unsigned)INT_MAX, (unsigned long long)tag);
+            ch_store_granule<LOCAL>(ch_part_g0(v, nprep), ((unsigned long long)(unsigned)g.r << 32) | (unsigned)INT_MAX, (unsigned long long)tag);
         tp += 1; done += 1; budget -= 1;
     }
 }
@@ -554,38 +560,50 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
             } else klast = ks;
         }
         int r_prev = t0 > 0 ? st->blk.r[t0 - 1] : -1;       // pivot row of stage t - 1 (for the constant's step)
+        int first_prev = -1;                                // the entering column of stage t - 1
 #pragma unroll 1
         for (int t = t0; t < B; t++) {
             const unsigned want_part = t > 0 ? blk_epoch(batch, t - 1) : la_tag, tag = blk_epoch(batch, t);
             CH_TS(0);
             ChHist H;
             ch_hist_load(H, hist);                          // (in flight while the partials are polled)
-            // ---- poll the g0 granules of the partials of stage t-1 and, behind them, the commit granule (the commit of
-            // stage t0 - 1 was a launch of its own: no granule to wait for): four slots per lane and round, dense
+            // ---- poll the commit granule of stage t-1 (index 0; the commit of stage t0 - 1 was a launch of its own: no
+            // granule to wait for) and the g0 granules of its partials (index k: slot k - 1): four per lane and round, dense.
+            // A lane without an index of its own reads another's again -- every granule that passes is one of this stage's,
+            // and a minimum does not mind seeing one twice
             const int cnt = t == t0 ? nparts0 : nprep;      // partials of the stage before
-            const int last = t == t0 ? cnt - 1 : cnt;       // the highest slot to wait for
+            const int lo = t == t0 ? 1 : 0;
             int nf = INT_MAX;
-            for (int base = 0; base <= last; base += 256) {
-                const int k0 = base + lane, k1 = k0 + 64, k2 = k0 + 128, k3 = k0 + 192;
-                const int kc = k0 <= last ? k0 : base + (lane % (last + 1 - base));
-                const int j1 = k1 <= last ? k1 : kc, j2 = k2 <= last ? k2 : kc, j3 = k3 <= last ? k3 : kc;   // (no slot of its own: its first one again)
-                const void * p0 = ch_part_g0(v, kc);
-                const void * p1 = ch_part_g0(v, j1);
-                const void * p2 = ch_part_g0(v, j2);
-                const void * p3 = ch_part_g0(v, j3);
+            for (int base = 0; base <= cnt; base += 256) {
+                const int span = cnt + 1 - base;
+                auto slot = [&](int k) -> const void * {
+                    int kk = k <= cnt ? k : base + (lane % span);
+                    kk = kk < lo ? lo : kk;
+                    return ch_part_g0(v, kk == 0 ? nprep : kk - 1);
+                };
+                const void * p0 = slot(base + lane);
+                const void * p1 = slot(base + lane + 64);
+                const void * p2 = slot(base + lane + 128);
+                const void * p3 = slot(base + lane + 192);
                 ch_u32x4 g0, g1, g2, g3;
                 unsigned spins = 0;
                 for (;;) {
                     ch_load4(p0, p1, p2, p3, g0, g1, g2, g3);
                     const bool ok = g0.z == want_part && g1.z == want_part && g2.z == want_part && g3.z == want_part;
                     if (__all(ok)) break;
+                    // the batch ended at stage t-1 (a NaN ratio, an empty first pass: see ch_commit_loop) -- no partials will come
+                    if (base == 0 && lo == 0 && (unsigned)__builtin_amdgcn_readfirstlane((int)g0.z) == want_part
+                        && __builtin_amdgcn_readfirstlane((int)g0.y) == CH_CLOSE_ROW) return;
                     if (++spins > CH_SPIN_LIMIT) { if (lane == 0) ch_st(&st->status, (int)ST_CHAIN_STUCK); return; }
                     __builtin_amdgcn_s_sleep(1);
                 }
-                if (k0 < cnt) nf = min(nf, (int)g0.x);
-                if (k1 < cnt) nf = min(nf, (int)g1.x);
-                if (k2 < cnt) nf = min(nf, (int)g2.x);
-                if (k3 < cnt) nf = min(nf, (int)g3.x);
+                nf = min(min(nf, (int)g0.x), min(min((int)g1.x, (int)g2.x), (int)g3.x));
+                if (base == 0 && lo == 0) {
+                    // the pivot row of stage t-1: its basic variable is the column every pick worker took then (lpsol.h:1508)
+                    r_prev = __builtin_amdgcn_readfirstlane((int)g0.y);
+                    if (r_prev == CH_CLOSE_ROW) return;
+                    if (i == r_prev) { bi = first_prev; sstar = t - 1; }
+                }
             }
             CH_TS(1);                                       // partials + commit granule seen
             const int first = wave_min_int(nf);
@@ -689,17 +707,9 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
                 ch_store_granule3<LOCAL>(pay + 32, (unsigned)cnv_bits, (unsigned)(cnv_bits >> 32), 0u, tag);
             }
             CH_TS(3);                                       // record issued
-            // ---- the records of this stage: who won (this lane's row may have: its basic variable changes, lpsol.h:1508)
-            ChWinner g;
-            const int widx = ch_poll_records(v, npick, tag, lane, g);
-            if (widx == -3) { if (lane == 0) ch_st(&st->status, (int)ST_CHAIN_STUCK); return; }
-            if (widx < 0) return;                           // CLOSE / empty first pass: the committer records it
-            CH_TS(4);                                       // records seen and combined
-            r_prev = g.r;
-            if (__any(i == g.r)) {                          // (only the owner of the pivot row needs the rest of the record)
-                if (!ch_load_winner(v, widx, tag, g)) { if (lane == 0) ch_st(&st->status, (int)ST_CHAIN_STUCK); return; }
-                if (i == g.r) { bi = g.enter; sstar = t; }
-            }
+            // (who won is the committer's and the prep workers' to find out: this role meets the pivot row in the commit
+            // granule, at the top of the next stage, and none of its own work before that depends on it)
+            first_prev = first;
             done += 1; budget -= 1;
         }
         return;
