@@ -217,6 +217,25 @@ __device__ __forceinline__ unsigned long long ch_wave_min_u64(unsigned long long
     return ab < cd ? ab : cd;
 }
 
+// Waiting without asking. A role that has handed its result over knows that the answer takes the other role's whole turn:
+// a gather round trip, a replay, a wave reduction and a store's way to the L2 -- 1.7 us and more at every shape measured
+// (tools/lab/probe_chain_ts.py). It sleeps through the first part of that (s_sleep N = 64 N clocks: 32 is ~0.9 us) before
+// its first poll instead of loading the same L2 lines every 30 ns next to the loads of the workers that are busy: +1.0 %
+// pivots/s at 4096 x 8192 and 4096 x 4096, +0.6 % at 4096 x 12289; 32 / 48 / 64 within noise of each other, the shortest
+// kept. With fewer workers there is less to keep out of the way of: nothing at 2048 x 4096 (97 workers), -0.3 % at
+// 1024 x 1536 and 512 x 1024 (tools/lab/probe_nap_sizes.py) -- launches of up to CH_NAP_FROM workers poll at once.
+// Between polls: s_sleep 1 (0 the same, 2 -0.2 %, 4 -1 %).
+enum { CH_NAP_FROM = 96 };
+#ifndef CH_POLL_NAP
+#define CH_POLL_NAP 1
+#endif
+#ifndef CH_NAP_PICK
+#define CH_NAP_PICK 32
+#endif
+#ifndef CH_NAP_PREP
+#define CH_NAP_PREP 32
+#endif
+
 // A replay: a := start, then a := a + h_s * c_s for the stages s = 0 .. t-1 IN ORDER, each product rounded, each sum
 // rounded -- the sweep's own two roundings per pending update. h_s is this lane's history, c_s the other operand,
 // wave-uniform, held by lane s of `cv`. Round 5 (tools/lab/probe_chain_ts.py: the replays were 47 ns per step and stage,
@@ -285,7 +304,7 @@ __device__ __forceinline__ int ch_poll_records(const LpView<F64> & v, int npick,
         else { ch_load4(p0, p1, p2, p3, g0, g1, g2, g3); ok = g0.w == tag && g1.w == tag && g2.w == tag && g3.w == tag; }
         if (__all(ok)) break;
         if (++spins > CH_SPIN_LIMIT) return -3;
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(CH_POLL_NAP);
     }
     unsigned long long key = ~0ull; int row = INT_MAX, rec = 0;
     if (k0 < npick) { key = ch_lo64(g0); row = (int)g0.z; rec = k0; }
@@ -318,7 +337,7 @@ __device__ __forceinline__ bool ch_load_winner(const LpView<F64> & v, int widx, 
         ch_load3(p, p + 16, p + 32, g1, g2, g3);
         if (__all(g1.w == tag && g2.w == tag && g3.w == tag)) break;     // (every lane loads the same granules)
         if (++spins > CH_SPIN_LIMIT) return false;
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(CH_POLL_NAP);
     }
     W.a = __builtin_bit_cast(double, ch_lo64(g1)); W.leave = (int)g1.z;
     W.w = g2.x; W.cc = (int)g2.y; W.enter = (int)(g2.z & 0xFFFFFFu); W.qstar = (int)(g2.z >> 24) - 1;
@@ -474,7 +493,7 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
             if (top >= nworkers) { go = true; break; }
             if (sum >= nworkers) { misplaced = true; break; }        // all here, but not on one XCD: the L2 hand-offs would not be coherent
             if (wall_clock64() - t_in > (unsigned long long)CH_ARRIVE_TICKS) break;
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(CH_POLL_NAP);
         }
         // the verdict is set once: a worker that gave up waiting for this one may have closed the roll call already
         unsigned prev = 0u;
@@ -528,13 +547,14 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
                 // CH_GO: the committer is about to publish it
             }
             if (++spins > CH_SPIN_LIMIT) { if (lane == 0) ch_st(&st->status, (int)ST_CHAIN_STUCK); return false; }
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(CH_POLL_NAP);
         }
     };
 #ifdef XPG_STAMPS
     const int tsw = w == 0 ? 0 : (w == npick - 1 ? 1 : (w == npick ? 2 : (w == npick + nprep - 1 ? 3 : -1)));
 #endif
 
+    const bool crowded = npick + nprep > CH_NAP_FROM;       // (see CH_NAP_PICK)
     if (picker) {
         // =========================== a pick worker ================================================================
         const int i = w * 64 + lane;                        // this lane's row
@@ -567,6 +587,7 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
             CH_TS(0);
             ChHist H;
             ch_hist_load(H, hist);                          // (in flight while the partials are polled)
+            if (CH_NAP_PICK && crowded && t > t0) __builtin_amdgcn_s_sleep(CH_NAP_PICK);
             // ---- poll the commit granule of stage t-1 (index 0; the commit of stage t0 - 1 was a launch of its own: no
             // granule to wait for) and the g0 granules of its partials (index k: slot k - 1): four per lane and round, dense.
             // A lane without an index of its own reads another's again -- every granule that passes is one of this stage's,
@@ -595,7 +616,7 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
                     if (base == 0 && lo == 0 && (unsigned)__builtin_amdgcn_readfirstlane((int)g0.z) == want_part
                         && __builtin_amdgcn_readfirstlane((int)g0.y) == CH_CLOSE_ROW) return;
                     if (++spins > CH_SPIN_LIMIT) { if (lane == 0) ch_st(&st->status, (int)ST_CHAIN_STUCK); return; }
-                    __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_s_sleep(CH_POLL_NAP);
                 }
                 nf = min(min(nf, (int)g0.x), min(min((int)g1.x, (int)g2.x), (int)g3.x));
                 if (base == 0 && lo == 0) {
@@ -645,7 +666,7 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
                     const ch_u32x4 g = ch_load1(gp);
                     if (__all(g.z == want_part || !fresh)) { if (fresh) ev = __builtin_bit_cast(double, ch_lo64(g)); break; }
                     if (++spins > CH_SPIN_LIMIT) { if (lane == 0) ch_st(&st->status, (int)ST_CHAIN_STUCK); return; }
-                    __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_s_sleep(CH_POLL_NAP);
                 }
             }
             CH_TS(2);                                       // gather round issued, fresh granules in
@@ -730,6 +751,7 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
         CH_TS(0);
         ChHist H;
         ch_hist_load(H, hist);                              // (in flight while the records are polled)
+        if (CH_NAP_PREP && crowded && t > t0) __builtin_amdgcn_s_sleep(CH_NAP_PREP);
         ChWinner g;
         const int widx = ch_poll_records(v, npick, tag, lane, g);
         if (widx == -3) { if (lane == 0) ch_st(&st->status, (int)ST_CHAIN_STUCK); return; }
