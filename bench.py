@@ -10,7 +10,7 @@ JSON line; launched under torch.distributed.run by somebody else it just is a ra
 
 Leg 1 (the headline, `value`): a STEP is one run of the device-resident SIX::solveSlackForm loop
 (src/com/lpsol.h:1039-1188: pricing, ratio test, pivot-pair upkeep, row / column staging, rank-1
-tableau update) over PIVOTS_PER_STEP = 3840 pivots = 240 full batches of 16 on a dense LP with
+tableau update) over PIVOTS_PER_STEP = 3840 pivots = 120 full batches of 32 on a dense LP with
 m = 4096, n = 4095, whose slack tableau is exactly 4096 x 8192 fp64 (268 MB, resident in HBM before
 the timed region): xpg_lp_begin rebuilds the slack form on the device from the resident input
 (one kernel, inside the step) and xpg_lp_iterate(3840) runs the loop; the LP's bug-compatible end
@@ -41,8 +41,8 @@ sys.path.insert(0, ROOT)
 
 M, NVARS = 4096, 4095                      # tableau 4096 x (4095 + 4096 + 1) = 4096 x 8192
 TAB_W = NVARS + M + 1
-BLOCK = int(os.environ.get("XPG_BLOCK", "24"))   # pivots one blocked sweep applies (XPG_BLOCK default: 24)
-PIVOTS_PER_STEP = 3840                     # 240 full batches; the LP ends after 4165 (tools/lab/probe_count.py)
+BLOCK = int(os.environ.get("XPG_BLOCK", "32"))   # pivots one blocked sweep applies (XPG_BLOCK default: 32)
+PIVOTS_PER_STEP = 3840                     # 120 full batches of 32; the LP ends after 4165 (tools/lab/probe_count.py)
 ALG_BYTES_PER_LAUNCH = 2 * M * TAB_W * 8   # one sweep LAUNCH reads and writes every entry once (SURVEY 8d:
                                            # 2*m*W*8 B; the blocked loop pays it per BLOCK pivots, not per pivot)
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s
@@ -443,9 +443,12 @@ def main():
                        "pass moves 1/%d of these bytes). The 268 MB tableau is exactly the size of the 256 MiB Infinity Cache "
                        "(MALL) and FETCH_SIZE counts its hits, so part of the stream is served by the MALL. The same kernel on a "
                        "tableau 1.57 x the MALL is the `cfg2b.roofline` object of this line; a plain in-place copy with the same "
-                       "tiling runs at 0.86 / 0.79 of the peak at the two sizes (profiles/round3_sweep_lab.txt). With XPG_BLOCK=16 "
-                       "the pass is at that copy ceiling (78 us, 0.86) but is paid per 16 pivots; with 32 it is bound by fp64 issue "
-                       "as much as by memory (110 us, 0.61): DESIGN section 4.2b" % (BLOCK, BLOCK),
+                       "tiling runs at 0.86 / 0.79 of the peak at the two sizes (profiles/round3_sweep_lab.txt). At 32 stages the pass is "
+                       "bound by fp64 issue next to memory: 2 x 33.5 M x 32 non-fused operations in 93.5 us are 0.62 of the 37.2 T "
+                       "lane-operations/s the device issues of v_mul_f64 / v_add_f64 (tools/lab/valu_f64_lab.hip). With XPG_BLOCK=24 "
+                       "the pass is at 0.81 of the HBM peak (81 us) and with 16 at the copy ceiling (78 us, 0.86), but those bytes "
+                       "are paid per 24 / 16 pivots: 128.7 k / 107.2 k pivots/s against 134.4 k with 32 "
+                       "(profiles/round5_block_length_ab.txt, DESIGN section 4.2c)" % (BLOCK, BLOCK),
                 chain=dict(note="the time-dominant kernel of the loop is not the pass but k_blk_chain, the persistent launch that "
                                 "stages the batch's pivots: latency-bound (two L2 hand-offs and two gathers per stage), no byte or "
                                 "flop roofline applies; us per stage from the whole-loop time",

@@ -126,7 +126,7 @@ int  xpg_lp_iterate(xpg_lp * lp, unsigned pivots);
 #define XPG_RUNNING (-1000)
 int  xpg_lp_pivots_done(xpg_lp * lp, unsigned * out);
 /* Blocked loop bookkeeping since xpg_lp_begin / xpg_lp_two_stage: sweeps that applied a full batch of
- * staged pivots (24 by default, XPG_BLOCK <= 32: the batch's stages, the first included, are chosen and
+ * staged pivots (32 by default, XPG_BLOCK = 1 .. 32: the batch's stages, the first included, are chosen and
  * staged by one persistent chain launch; lp_chain.hip.h), and sweeps that applied fewer (the tail of an iterate budget, or a batch closed
  * early by a rare branch of SIX::solveSlackForm, src/com/lpsol.h:1138-1151).  Either may be NULL. */
 int  xpg_lp_counters(xpg_lp * lp, unsigned * sweeps_full, unsigned * sweeps_partial);

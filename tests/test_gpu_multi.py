@@ -137,8 +137,8 @@ def test_entry_points_bind_their_own_device_and_restore_the_callers(ctx, port):
 
 
 def test_sweep_counters_and_tail_batches(monkeypatch):
-    """xpg_lp_counters: 100 iterations of the blocked loop are 4 full sweeps (24 pivots each, the default) and one of 4
-    pivots (the tail of the budget is enqueued at its own length); 64 more are two full ones and a tail of 16. The
+    """xpg_lp_counters: 100 iterations of the blocked loop are 3 full sweeps (32 pivots each, the default) and one of 4
+    pivots (the tail of the budget is enqueued at its own length); 64 more are two full ones and no tail. The
     same with batches of 16 (XPG_BLOCK), where 64 is a whole number of batches. The tableau is the serial loop's
     either way."""
     import xpoly_amd
@@ -155,10 +155,10 @@ def test_sweep_counters_and_tail_batches(monkeypatch):
         lp.begin()
         assert lp.iterate(100) == xpoly_amd.six.XPG_RUNNING
         if mode != "serial":
-            assert lp.counters() == ((4, 1) if mode == "block" else (6, 1))
+            assert lp.counters() == ((3, 1) if mode == "block" else (6, 1))
         assert lp.iterate(64) == xpoly_amd.six.XPG_RUNNING
         if mode != "serial":
-            assert lp.counters() == ((6, 2) if mode == "block" else (10, 1))
+            assert lp.counters() == ((5, 1) if mode == "block" else (10, 1))
         out[mode] = lp.read()
         assert lp.pivots_done() == 164
         lp.close(); c.close()

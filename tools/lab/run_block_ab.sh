@@ -1,7 +1,7 @@
 # A/B inside one run: pivots staged per pass (XPG_BLOCK) on the two large-tableau legs
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-for rep in 1 2; do for b in 24 32 16; do
+for rep in 1 2; do for b in ${BLOCKS:-24 32 16}; do
   XPG_BLOCK=$b python bench.py --legs pivots,cfg2b --no-cpu-baseline --steps 10 --warmup 3 2>/dev/null | python -c "
 import json,sys
 d=json.loads([l for l in sys.stdin.read().split('\n') if l.startswith('{')][-1])

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 typedef double v2d __attribute__((ext_vector_type(2)));
@@ -124,9 +125,166 @@ void k_twoph(double * __restrict__ tab, int m, int W, int ld, const double * __r
     for (int u = 0; u < ROWS; u++) *reinterpret_cast<v2d *>(base + (size_t)u * ld) = a[u];
 }
 
-typedef void (*kern_t)(double *, int, int, int, const double *, const double *, int);
-int main()
+// KMODE 0: the row's k_s through the scalar cache (the product's); 1: no load at all (a ceiling: k from a kernel argument's
+// bits and the stage number); 2: the tile's ROWS x NB block of K staged in LDS once, read back as broadcasts
+template <int ROWS, int U, int NB, int KMODE> __global__ __launch_bounds__(256)
+void k_pairk(double * __restrict__ tab, int m, int W, int ld, const double * __restrict__ E, const double * __restrict__ K, int rev)
 {
+    __shared__ double ks[KMODE == 2 ? ROWS * NB : 1];
+    int bx, by; tile_of(rev, bx, by);
+    const int j = bx * 512 + threadIdx.x * 2, i0 = by * ROWS;
+    if (KMODE == 2) {
+        for (int q = threadIdx.x; q < ROWS * NB; q += 256) ks[q] = K[(size_t)(i0 + q / NB) * 32 + q % NB];
+        __syncthreads();
+    }
+    if (j >= W) return;
+    v2d e[NB];
+#pragma unroll
+    for (int s = 0; s < NB; s++) e[s] = *reinterpret_cast<const v2d *>(E + (size_t)s * ld + j);
+    double * base = tab + (size_t)i0 * ld + j;
+    v2d a[U], b[U];
+    double kc[U][8];                                        // KMODE 1: sixteen k loaded ONCE (distinct per row, so that no product is shared)
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int q = 0; q < 8; q++) kc[u][q] = K[(size_t)(rev * 64 + u) * 32 + q];
+    auto load = [&](v2d (&d)[U], const double * p) {
+#pragma unroll
+        for (int u = 0; u < U; u++) d[u] = *reinterpret_cast<const v2d *>(p + (size_t)u * ld);
+    };
+    auto apply = [&](v2d (&d)[U], double * p, int row0) {
+#pragma unroll
+        for (int s = 0; s < NB; s++)
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                double k;
+                if (KMODE == 0) k = K[(size_t)(row0 + u) * 32 + s];
+                else if (KMODE == 1) k = __builtin_bit_cast(double, __builtin_bit_cast(unsigned long long, kc[u][s & 7]) ^ ((unsigned long long)(row0 & 4) << 61));   // (one scalar xor per k: differs from row pair to row pair)
+                else k = ks[(row0 - i0 + u) * NB + s];
+                const double p0 = k * e[s].x, p1 = k * e[s].y;
+                d[u].x = d[u].x + p0; d[u].y = d[u].y + p1;
+            }
+#pragma unroll
+        for (int u = 0; u < U; u++) *reinterpret_cast<v2d *>(p + (size_t)u * ld) = d[u];
+    };
+    load(a, base);
+#pragma unroll 1
+    for (int i = i0; i < i0 + ROWS; i += 2 * U) {
+        load(b, base + (size_t)U * ld);
+        apply(a, base, i);
+        if (i + 2 * U < i0 + ROWS) load(a, base + (size_t)2 * U * ld);
+        apply(b, base + (size_t)U * ld, i + U);
+        base += (size_t)2 * U * ld;
+    }
+}
+
+// a ring of D row groups in flight: the rows of group g + D - 1 are requested before the arithmetic of group g (the
+// product's pass is D = 2); the row loop fully unrolled so that the ring's indices are static
+template <int ROWS, int U, int NB, int D> __global__ __launch_bounds__(256)
+void k_ring(double * __restrict__ tab, int m, int W, int ld, const double * __restrict__ E, const double * __restrict__ K, int rev)
+{
+    constexpr int NG = ROWS / U;
+    int bx, by; tile_of(rev, bx, by);
+    const int j = bx * 512 + threadIdx.x * 2, i0 = by * ROWS;
+    if (j >= W) return;
+    double * base = tab + (size_t)i0 * ld + j;
+    v2d r[D][U];
+#pragma unroll
+    for (int g = 0; g < D - 1; g++)
+#pragma unroll
+        for (int u = 0; u < U; u++) r[g][u] = *reinterpret_cast<const v2d *>(base + (size_t)(g * U + u) * ld);
+    v2d e[NB];
+#pragma unroll
+    for (int s = 0; s < NB; s++) e[s] = *reinterpret_cast<const v2d *>(E + (size_t)s * ld + j);
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        if (g + D - 1 < NG) {
+#pragma unroll
+            for (int u = 0; u < U; u++) r[(g + D - 1) % D][u] = *reinterpret_cast<const v2d *>(base + (size_t)((g + D - 1) * U + u) * ld);
+        }
+#pragma unroll
+        for (int s = 0; s < NB; s++)
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const double k = K[(size_t)(i0 + g * U + u) * 32 + s];
+                const double p0 = k * e[s].x, p1 = k * e[s].y;
+                r[g % D][u].x = r[g % D][u].x + p0; r[g % D][u].y = r[g % D][u].y + p1;
+            }
+#pragma unroll
+        for (int u = 0; u < U; u++) *reinterpret_cast<v2d *>(base + (size_t)(g * U + u) * ld) = r[g % D][u];
+    }
+}
+
+// the k_s of a row pair in groups of G stages through two sets of scalar registers: the loads of group g + 1 are requested
+// before the arithmetic of group g (the compiler, left alone, requests a group where its registers were last used and
+// waits for it on the spot)
+template <int ROWS, int NB, int G> __global__ __launch_bounds__(256)
+void k_pipe(double * __restrict__ tab, int m, int W, int ld, const double * __restrict__ E, const double * __restrict__ K, int rev)
+{
+    constexpr int U = 2, NG = NB / G;
+    int bx, by; tile_of(rev, bx, by);
+    const int j = bx * 512 + threadIdx.x * 2, i0 = by * ROWS;
+    if (j >= W) return;
+    v2d e[NB];
+#pragma unroll
+    for (int s = 0; s < NB; s++) e[s] = *reinterpret_cast<const v2d *>(E + (size_t)s * ld + j);
+    double * base = tab + (size_t)i0 * ld + j;
+    v2d a[U], b[U];
+    auto load = [&](v2d (&d)[U], const double * p) {
+#pragma unroll
+        for (int u = 0; u < U; u++) d[u] = *reinterpret_cast<const v2d *>(p + (size_t)u * ld);
+    };
+    double kq[2][U][G];
+    auto kload = [&](int set, int row0, int g) {
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int q = 0; q < G; q++) kq[set][u][q] = K[(size_t)(row0 + u) * 32 + g * G + q];
+    };
+    // group 0 of (row0) is in set 0 on entry; leaves group 0 of (next_row0) in set 0
+    auto apply = [&](v2d (&d)[U], double * p, int row0, int next_row0) {
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            // scalar loads return out of order: the only wait there is is "all of them". Asking for group g's registers HERE
+            // puts that wait in front of the requests of group g + 1, which then have the arithmetic of group g to arrive in
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int q = 0; q < G; q += 4)
+                    asm volatile("" :: "s"(kq[g & 1][u][q]), "s"(kq[g & 1][u][q + 1]), "s"(kq[g & 1][u][q + 2]), "s"(kq[g & 1][u][q + 3]));
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 1 < NG) kload((g + 1) & 1, row0, g + 1); else kload((g + 1) & 1, next_row0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < G; q++)
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const double k = kq[g & 1][u][q];
+                    const double p0 = k * e[g * G + q].x, p1 = k * e[g * G + q].y;
+                    d[u].x = d[u].x + p0; d[u].y = d[u].y + p1;
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) *reinterpret_cast<v2d *>(p + (size_t)u * ld) = d[u];
+    };
+    static_assert(NG % 2 == 0, "an even number of groups: a row pair starts and ends in set 0");
+    load(a, base);
+    kload(0, i0, 0);
+#pragma unroll 1
+    for (int i = i0; i < i0 + ROWS; i += 2 * U) {
+        load(b, base + (size_t)U * ld);
+        apply(a, base, i, i + U);
+        if (i + 2 * U < i0 + ROWS) load(a, base + (size_t)2 * U * ld);
+        apply(b, base + (size_t)U * ld, i + U, i + 2 * U < m ? i + 2 * U : i);
+        base += (size_t)2 * U * ld;
+    }
+}
+
+typedef void (*kern_t)(double *, int, int, int, const double *, const double *, int);
+int main(int argc, char ** argv)
+{
+    const char * only = argc > 1 ? argv[1] : nullptr;            // run the variants whose name contains this
     const int m = 4096, W = 8192, ld = 8192;
     double *tab, *E, *K;
     CK(hipMalloc(&tab, (size_t)m * ld * 8)); CK(hipMalloc(&E, (size_t)32 * ld * 8)); CK(hipMalloc(&K, (size_t)m * 32 * 8));
@@ -144,6 +302,25 @@ int main()
     struct V { const char * name; kern_t f; int rows, cols, nb; } vs[] = {
         {"pair   NB=24 <16,2> (the product's)", k_pair<16, 2, 24, 1>, 16, 512, 24},
         {"pair   NB=32 <16,2>", k_pair<16, 2, 32, 1>, 16, 512, 32},
+        {"ring   NB=32 U=2 D=2 (unrolled product)", k_ring<16, 2, 32, 2>, 16, 512, 32},
+        {"ring   NB=32 U=2 D=3", k_ring<16, 2, 32, 3>, 16, 512, 32},
+        {"ring   NB=32 U=2 D=4", k_ring<16, 2, 32, 4>, 16, 512, 32},
+        {"ring   NB=32 U=1 D=4", k_ring<16, 1, 32, 4>, 16, 512, 32},
+        {"ring   NB=32 U=1 D=6", k_ring<16, 1, 32, 6>, 16, 512, 32},
+        {"ring   NB=32 U=2 D=3 32 rows", k_ring<32, 2, 32, 3>, 32, 512, 32},
+        {"ring   NB=24 U=2 D=3", k_ring<16, 2, 24, 3>, 16, 512, 24},
+        {"ring   NB=24 U=2 D=4", k_ring<16, 2, 24, 4>, 16, 512, 24},
+        {"ring   NB=24 U=1 D=3", k_ring<16, 1, 24, 3>, 16, 512, 24},
+        {"pipe   NB=32 groups of 8", k_pipe<16, 32, 8>, 16, 512, 32},
+        {"pipe   NB=32 groups of 4", k_pipe<16, 32, 4>, 16, 512, 32},
+        {"pipe   NB=24 groups of 4", k_pipe<16, 24, 4>, 16, 512, 24},
+        {"pairk  NB=24 scalar loads", k_pairk<16, 2, 24, 0>, 16, 512, 24},
+        {"pairk  NB=24 no k loads (ceiling)", k_pairk<16, 2, 24, 1>, 16, 512, 24},
+        {"pairk  NB=24 k from LDS", k_pairk<16, 2, 24, 2>, 16, 512, 24},
+        {"pairk  NB=32 scalar loads", k_pairk<16, 2, 32, 0>, 16, 512, 32},
+        {"pairk  NB=32 no k loads (ceiling)", k_pairk<16, 2, 32, 1>, 16, 512, 32},
+        {"pairk  NB=32 k from LDS", k_pairk<16, 2, 32, 2>, 16, 512, 32},
+        {"pairk  NB=32 k from LDS, 32 rows", k_pairk<32, 2, 32, 2>, 32, 512, 32},
         {"pair   NB=32 <16,2> 3 waves", k_pair<16, 2, 32, 3>, 16, 512, 32},
         {"pair   NB=32 <16,1>", k_pair<16, 1, 32, 1>, 16, 512, 32},
         {"pair   NB=28 <16,2>", k_pair<16, 2, 28, 1>, 16, 512, 28},
@@ -158,12 +335,24 @@ int main()
     };
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const double bytes = 2.0 * m * W * 8;
+    // the clocks take their time to come up from idle: the first variants of a run were measured 20 % slower than the SAME
+    // code later in the list (identical ISA and descriptor: `pair NB=32 <16,2>` 132 us second in the list, 110 us twelfth)
+    // -- half a second of the first variant before anything is timed
+    {
+        hipEventRecord(e0, 0);
+        float ms = 0.f; int flip = 0;
+        while (ms < 500.f) {
+            for (int w = 0; w < 50; w++) hipLaunchKernelGGL(vs[0].f, dim3((W + vs[0].cols - 1) / vs[0].cols, m / vs[0].rows), dim3(256), 0, 0, tab, m, W, ld, E, K, (flip ^= 1));
+            hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+        }
+    }
     for (auto & v : vs) {
+        if (only && !strstr(v.name, only)) continue;
         dim3 g((W + v.cols - 1) / v.cols, m / v.rows);
         int flip = 0;
         for (int w = 0; w < 6; w++) hipLaunchKernelGGL(v.f, g, dim3(256), 0, 0, tab, m, W, ld, E, K, (flip ^= 1));
         CK(hipDeviceSynchronize());
-        const int reps = 30;
+        const int reps = 100;
         CK(hipEventRecord(e0, 0));
         for (int w = 0; w < reps; w++) hipLaunchKernelGGL(v.f, g, dim3(256), 0, 0, tab, m, W, ld, E, K, (flip ^= 1));
         CK(hipEventRecord(e1, 0));

@@ -632,27 +632,57 @@ void k_blk_sweep_full(double * __restrict__ tab, int m, int W, int ld, const dou
 #pragma unroll
         for (int u = 0; u < U; u++) d[u] = *reinterpret_cast<const double2 *>(p + (size_t)u * ld);
     };
-    auto apply = [&](double2 (&d)[U], double * p, int row0) {
+    // The rows' k_s = -a_i,nv (wave-uniform: scalar loads) in groups of G stages through TWO sets of scalar registers: the
+    // group g + 1 is requested before the arithmetic of group g. Left alone the compiler keeps one set -- a group is
+    // requested where its registers were last used and waited for on the spot, 150 cycles per 256 of arithmetic at 32 stages
+    // -- and scalar loads return out of order, so the only wait there is is "all of them": the empty asm below asks for
+    // group g's registers and so puts that wait IN FRONT of the requests of group g + 1 (everything is the compiler's own
+    // load and wait; nothing is in flight that it does not know of). tools/lab/sweep_lab3.hip `pipe`: 108 -> 96 us at 32
+    // stages, 85.3 -> 84.4 at 24.
+    constexpr int G = (NB % 16 == 0 && U <= 2) ? 8 : 4, NG = NB / G;      // (2 sets x U rows x G stages x 2 scalar registers: 64 of ~100)
+    static_assert(NB % G == 0 && NG % 2 == 0, "an even number of groups: a row group starts and ends in set 0");
+    double kq[2][U][G];
+    auto kload = [&](int set, int row0, int g) {
 #pragma unroll
-        for (int s = 0; s < NB; s++) {
+        for (int u = 0; u < U; u++)
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const double k = K[(size_t)(row0 + u) * BLK_MAX + s];
-                const double p0 = k * e[s].x, p1 = k * e[s].y;
-                d[u].x = d[u].x + p0; d[u].y = d[u].y + p1;
+            for (int q = 0; q < G; q++) kq[set][u][q] = K[(size_t)(row0 + u) * BLK_MAX + g * G + q];
+    };
+    // group 0 of the rows row0 .. is in set 0 on entry; leaves group 0 of the rows next_row0 .. in set 0
+    auto apply = [&](double2 (&d)[U], double * p, int row0, int next_row0) {
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int q = 0; q < G; q += 4)
+                    asm volatile("" :: "s"(kq[g & 1][u][q]), "s"(kq[g & 1][u][q + 1]), "s"(kq[g & 1][u][q + 2]), "s"(kq[g & 1][u][q + 3]));
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 1 < NG) kload((g + 1) & 1, row0, g + 1); else kload((g + 1) & 1, next_row0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < G; q++) {
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const double k = kq[g & 1][u][q];
+                    const double p0 = k * e[g * G + q].x, p1 = k * e[g * G + q].y;
+                    d[u].x = d[u].x + p0; d[u].y = d[u].y + p1;
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int u = 0; u < U; u++) *reinterpret_cast<double2 *>(p + (size_t)u * ld) = d[u];
     };
     double * base = tab + (size_t)i0 * ld + j;
     if (full) {
+        kload(0, i0, 0);
 #pragma unroll 1
         for (int i = i0; i < i0 + ROWS; i += 2 * U) {
             load(b, base + (size_t)U * ld);
-            apply(a, base, i);
+            apply(a, base, i, i + U);
             if (i + 2 * U < i0 + ROWS) load(a, base + (size_t)2 * U * ld);
-            apply(b, base + (size_t)U * ld, i + U);
+            apply(b, base + (size_t)U * ld, i + U, i + 2 * U < i0 + ROWS ? i + 2 * U : i0);     // (the last one: any rows of this block -- nobody reads them)
             base += (size_t)2 * U * ld;
         }
     } else {                                                  // the short last row block

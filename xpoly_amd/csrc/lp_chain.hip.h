@@ -450,14 +450,16 @@ __device__ unsigned long long g_ch_ts[4][BLK_MAX][8];            // [worker clas
 // (tools/lab/gather_lab.hip: the same gather 0.16 us from the L1 at a stride of 64 KiB + 128 B). A stage whose column is in
 // the line held now reads nothing of the tableau. The host asks for it where the stride is such a one and the XCD still
 // seats every worker with the larger LDS block (ch_lds_bytes); other strides leave the lines to the L1.
-enum { CH_LINE_BYTES = 16 * 64 * 8 };
-inline int ch_hist_slots(int B, bool line) { return line ? (B + 3) / 4 * 4 : BLK_MAX; }
-inline size_t ch_lds_bytes(int B, bool line)
+// LINE is the number of columns held: 16 (the whole 128-byte line) where the XCD seats every worker with 8 KB more, else 8
+// (half of it, 4 KB: a batch of 32 stages has 16 KB of history, and 193 workers of 24 KB are one more than 32 compute units
+// of 160 KB hold), else 0.
+inline int ch_hist_slots(int B, int line) { return line ? (B + 3) / 4 * 4 : BLK_MAX; }
+inline size_t ch_lds_bytes(int B, int line)
 {
-    const size_t plain = (size_t)BLK_MAX * 64 * 8, with_line = (size_t)ch_hist_slots(B, true) * 64 * 8 + CH_LINE_BYTES;
+    const size_t plain = (size_t)BLK_MAX * 64 * 8, with_line = (size_t)ch_hist_slots(B, line) * 64 * 8 + (size_t)line * 64 * 8;
     return line ? (with_line > plain ? with_line : plain) : plain;
 }
-template <bool LOCAL, bool LINE>
+template <bool LOCAL, int LINE>
 __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int t0, int B, int npick, int nprep, int nparts0, int force_abort, int fold_next)
 {
     extern __shared__ __attribute__((aligned(16))) double ch_hist[];     // [BLK_MAX][64]: this worker's history, stage-major
@@ -641,13 +643,14 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
             // divergent `if` makes the compiler wait for it where the branch joins -- before the loads behind it are issued;
             // round 4's stage paid two dependent round trips here and in the prep role's round, found in the ISA)
             double x0_mem = 0.0;
-            double2 lnew[8];
-            const bool line_miss = LINE && (first >> 4) != line_group;       // (wave-uniform)
+            constexpr int LN = LINE ? LINE : 16;
+            double2 lnew[LN / 2];
+            const bool line_miss = LINE && first / LN != line_group;         // (wave-uniform)
             if (!LINE) x0_mem = tab[(size_t)ic * ld + first];
             else if (line_miss) {
-                const double2 * lp2 = (const double2 *)&tab[(size_t)ic * ld + (size_t)(first >> 4) * 16];     // ld is a multiple of 16
+                const double2 * lp2 = (const double2 *)&tab[(size_t)ic * ld + (size_t)(first / LN) * LN];      // ld is a multiple of 16
 #pragma unroll
-                for (int q = 0; q < 8; q++) lnew[q] = lp2[q];
+                for (int q = 0; q < LN / 2; q++) lnew[q] = lp2[q];
             }
             const uint32_t pw_word = ch_ld(&v.ppt[(size_t)first * v.pw + (bi >> 5)]);
             const int cc = ch_ld(&v.colcnt[bi]);
@@ -673,10 +676,10 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
             if (lane + 1 < t) ev = ev_mem;                  // (t <= 32: the lanes of the fresh granules are beyond t - 2)
             if (LINE && line_miss) {
 #pragma unroll
-                for (int q = 0; q < 8; q++) { lcache[64 * (2 * q)] = lnew[q].x; lcache[64 * (2 * q + 1)] = lnew[q].y; }
-                line_group = first >> 4;
+                for (int q = 0; q < LN / 2; q++) { lcache[64 * (2 * q)] = lnew[q].x; lcache[64 * (2 * q + 1)] = lnew[q].y; }
+                line_group = first / LN;
             }
-            const double x0 = LINE ? lcache[64 * (first & 15)] : x0_mem;
+            const double x0 = LINE ? lcache[64 * (first % LN)] : x0_mem;
             const double ec_new = ch_readlane_f64(ev, 32), eb_new = ch_readlane_f64(ev, 34);
             const unsigned long long cnv_bits = __builtin_bit_cast(unsigned long long, ch_readlane_f64(ev, 33));
             if (lane == t - 1) ev = ec_new;                 // lane s of ev now holds e_s[first] for every s < t

@@ -154,13 +154,17 @@ template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> &
             // 4 KiB -- the L1 then keeps next to nothing of a column -- and one XCD still seats every worker with the larger
             // LDS block; XPG_CHAIN_LINE=0|1 forces it off / on for A/B runs
             static const int line_env = [] { const char * s = getenv("XPG_CHAIN_LINE"); return s ? atoi(s) : -1; }();
-            const bool line_fits = (size_t)workers * ch_lds_bytes(B, true) <= (size_t)(cus / 8) * 160 * 1024 &&
-                                   (size_t)workers <= (size_t)(cus / 8) * ((size_t)160 * 1024 / ch_lds_bytes(B, true));
-            const bool line = local && line_fits && (line_env == 1 || (line_env != 0 && v.ld % 512 == 0));
+            auto line_fits = [&](int cols) {
+                return (size_t)workers * ch_lds_bytes(B, cols) <= (size_t)(cus / 8) * 160 * 1024 &&
+                       (size_t)workers <= (size_t)(cus / 8) * ((size_t)160 * 1024 / ch_lds_bytes(B, cols));
+            };
+            const bool want_line = local && (line_env == 1 || (line_env != 0 && v.ld % 512 == 0));
+            const int line = !want_line ? 0 : line_fits(16) ? 16 : line_fits(8) ? 8 : 0;
             const size_t lds = ch_lds_bytes(B, line);
-            if (local && line) hipLaunchKernelGGL((k_blk_chain<true, true>), dim3(8 * workers), dim3(64), lds, ctx->stream, v, batch, t0, B, cpick, cprep, nparts0, fa, fn);
-            else if (local) hipLaunchKernelGGL((k_blk_chain<true, false>), dim3(8 * workers), dim3(64), lds, ctx->stream, v, batch, t0, B, cpick, cprep, nparts0, fa, fn);
-            else hipLaunchKernelGGL((k_blk_chain<false, false>), dim3(workers), dim3(64), lds, ctx->stream, v, batch, t0, B, cpick, cprep, nparts0, fa, fn);
+            if (local && line == 16) hipLaunchKernelGGL((k_blk_chain<true, 16>), dim3(8 * workers), dim3(64), lds, ctx->stream, v, batch, t0, B, cpick, cprep, nparts0, fa, fn);
+            else if (local && line == 8) hipLaunchKernelGGL((k_blk_chain<true, 8>), dim3(8 * workers), dim3(64), lds, ctx->stream, v, batch, t0, B, cpick, cprep, nparts0, fa, fn);
+            else if (local) hipLaunchKernelGGL((k_blk_chain<true, 0>), dim3(8 * workers), dim3(64), lds, ctx->stream, v, batch, t0, B, cpick, cprep, nparts0, fa, fn);
+            else hipLaunchKernelGGL((k_blk_chain<false, 0>), dim3(workers), dim3(64), lds, ctx->stream, v, batch, t0, B, cpick, cprep, nparts0, fa, fn);
             break;
         }
         hipLaunchKernelGGL(k_blk_pick, dim3(npick), dim3(tp), 0, ctx->stream, v, batch, t, (int)gprep.x);

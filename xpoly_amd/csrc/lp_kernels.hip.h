@@ -105,11 +105,12 @@ struct LoopState {
     } blk;
 };
 enum { BLK_MAX = 32,           // the most pivots a batch stages (XPG_BLOCK up to this)
-       BLK_DEFAULT = 24,       // the default batch length: the pass applying 24 staged pivots holds 24 register pairs of e_s at four
-                               // waves per SIMD and stays memory-bound (83 us at 4096 x 8192 = 0.81 of the HBM peak, 134 us at
-                               // 4096 x 12289); with 32 it is bound by fp64 issue as much (110 / 172 us, three waves), with 16 the
-                               // pass is at the copy ceiling (78 / 126 us) but paid per 16 pivots: 111.3 k / 108.5 k / 97.6 k
-                               // pivots/s at 4096 x 8192 with 24 / 32 / 16, 88.2 k / 87.8 k / 74.7 k at 4096 x 12289
+       BLK_DEFAULT = 32,       // the default batch length. Rounds 4-5 ran 24: the pass applying 32 staged pivots (32 register pairs of
+                               // e_s, three waves per SIMD) took 110 / 172 us at 4096 x 8192 / 4096 x 12289 against 83 / 134 us with 24 --
+                               // it waited for the rows' scalar k_s in front of every eight stages. With those requested a group ahead
+                               // (k_blk_sweep_full) it takes 93.5 / 156 us: 134.4 k / 128.7 k / 107.2 k pivots/s at 4096 x 8192 with
+                               // 32 / 24 / 16, 104.2 k / 97.3 k / 79.5 k at 4096 x 12289 (profiles/round5_block_length_ab.txt); 32 is
+                               // ahead from 512 x 1024 up (tools/lab/probe_nap_sizes.py)
        BLK_REC_WORDS = 16,
        BLK_PICK_WGS = 64,      // pick workgroups (= records) of the launch-per-stage path: one lane of a wave combines each
        BLK_REC_MAX = 256,      // records of the chain kernel: one per pick worker
