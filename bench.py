@@ -858,7 +858,7 @@ def leg_cfg2b(ctx, xpoly_amd, gen, m=4096, n=8192):
     if launches:
         avg = sweep_ms / 1e3 / launches
         out["roofline"] = dict(
-            bound="hbm", kernel="k_blk_sweep_full<%s,%d> on the 403 MB tableau (1.57 x the 256 MiB Infinity Cache)" % ("16,2" if BLOCK in (24, 32) else "16,4", BLOCK),
+            bound="hbm", kernel="k_blk_sweep_full<%s,%d> on the 403 MB tableau (1.57 x the 256 MiB Infinity Cache)" % ("32,2" if BLOCK == 32 else "16,2" if BLOCK == 24 else "16,4", BLOCK),
             achieved=round(bytes_per_launch / avg / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
             frac=round(bytes_per_launch / avg / 1e9 / HBM_PEAK_GBS, 4), avg_launch_us=round(avg * 1e6, 2),
             launches_sampled=launches,

@@ -18,14 +18,14 @@ ts = np.zeros((4, cap.value, 8), dtype=np.uint64)
 assert lib().xpg_lp_debug_chain_ts(lp._h, ts.ctypes.data_as(C.c_void_p), None, cap.value) == 0
 t = ts.astype(np.int64)
 B = cap.value
-nb = int(__import__("os").environ.get("XPG_BLOCK", "24"))
+nb = int(__import__("os").environ.get("XPG_BLOCK", "32"))
 base = t[0, 1, 0]
-pick_names = [(0, "top"), (1, "partials seen"), (2, "gather in"), (5, "replayed"), (6, "ratio+key"), (7, "wave min"), (3, "record out"), (4, "records seen")]
+pick_names = [(0, "top"), (1, "partials seen"), (2, "gather in"), (5, "replayed"), (6, "ratio+key"), (7, "wave min"), (3, "record out")]   # (the pick role no longer polls the records: the commit granule names the row)
 prep_names = [(0, "top"), (4, "records seen"), (1, "row+payload in"), (2, "replayed"), (5, "scaled"), (3, "obj+pricing"), (6, "partial out")]
 for wc, nm in enumerate(["pick worker 0", "last pick worker", "first prep worker", "last prep worker"]):
     names = pick_names if wc < 2 else prep_names
     print(nm)
-    for st in (1, 2, 8, 9, 14, 15, nb - 2, nb - 1):
+    for st in (1, 2, 8, 9, 16, 17, nb - 2, nb - 1):
         row = [((t[wc, st, p] - base) * 0.01 if t[wc, st, p] else float("nan")) for p, _ in names]
         print("  stage %2d: " % st + "  ".join("%s %7.2f" % (n[:14], x) for (_, n), x in zip(names, row)))
     # mean segment lengths over the stages 2 .. nb-1 (us)

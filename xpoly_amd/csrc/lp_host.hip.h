@@ -191,7 +191,15 @@ template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> &
     // per pass at 4096 x 8192 / 4096 x 12289 = 3.4 / 5.2 us per pivot against 4.9 / 7.9 with 16, tools/lab/sweep_lab2.hip) and
     // 16 (XPG_BLOCK=16); every other length -- the tail of an iteration budget -- goes through the switch kernel
     const bool full32 = B == 32 && rows_env != 1, full16 = B == 16 && rows_env != 1, full24 = B == 24 && rows_env != 1;
-    if (full32) { if (rows_env == 322) XPG_BLK_FULL(32, 2, 32); else if (rows_env == 164) XPG_BLK_FULL(16, 4, 32); else XPG_BLK_FULL(16, 2, 32); }
+    // 32 stages: 16 rows per workgroup where the tableau is of the Infinity Cache's size (4096 x 8192: 93.9 us against 95.5
+    // with 32 rows), 32 rows -- the e_s read from the L2 half as often -- where it is beyond it (4096 x 12289, 403 MB: 150.0
+    // against 156.1 us, 105.7 k against 103.9 k pivots/s); XPG_BLK_ROWS = 162 / 322 / 164 force a form for A/B runs
+    const bool beyond_mall = (size_t)v.m * v.ld * sizeof(double) > ((size_t)320 << 20);
+    if (full32) {
+        if (rows_env == 322 || (rows_env == 32 && beyond_mall)) XPG_BLK_FULL(32, 2, 32);
+        else if (rows_env == 164) XPG_BLK_FULL(16, 4, 32);
+        else XPG_BLK_FULL(16, 2, 32);
+    }
     else if (full24) { if (rows_env == 164) XPG_BLK_FULL(16, 4, 24); else XPG_BLK_FULL(16, 2, 24); }
     else if (full16) { if (rows_env == 324) XPG_BLK_FULL(32, 4, 16); else if (rows_env == 162) XPG_BLK_FULL(16, 2, 16); else XPG_BLK_FULL(16, 4, 16); }
     else if (B <= 8) XPG_BLK_LAUNCH(32, 8, 8);
