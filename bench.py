@@ -445,7 +445,8 @@ def main():
                        "tableau 1.57 x the MALL is the `cfg2b.roofline` object of this line; a plain in-place copy with the same "
                        "tiling runs at 0.86 / 0.79 of the peak at the two sizes (profiles/round3_sweep_lab.txt). At 32 stages the pass is "
                        "bound by fp64 issue next to memory: 2 x 33.5 M x 32 non-fused operations in 93.5 us are 0.62 of the 37.2 T "
-                       "lane-operations/s the device issues of v_mul_f64 / v_add_f64 (tools/lab/valu_f64_lab.hip). With XPG_BLOCK=24 "
+                       "lane-operations/s the device issues of v_mul_f64 / v_add_f64 alone (tools/lab/valu_f64_lab.hip) and 0.74 of the 31 T/s "
+                       "at the 1.9-1.97 GHz it holds UNDER this pass (s_memtime inside it, tools/lab/sweep_lab3.hip). With XPG_BLOCK=24 "
                        "the pass is at 0.81 of the HBM peak (81 us) and with 16 at the copy ceiling (78 us, 0.86), but those bytes "
                        "are paid per 24 / 16 pivots: 128.7 k / 107.2 k pivots/s against 134.4 k with 32 "
                        "(profiles/round5_block_length_ab.txt, DESIGN section 4.2c)" % (BLOCK, BLOCK),

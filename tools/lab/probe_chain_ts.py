@@ -36,3 +36,6 @@ for wc, nm in enumerate(["pick worker 0", "last pick worker", "first prep worker
     print("  mean segments (stages 2..%d): " % (nb - 1) + " | ".join(seg))
 print("stage-to-stage (pick worker 0 top):", np.diff(t[0, 1:nb, 0]) * 0.01)
 print("mean stage: %.3f us" % (np.diff(t[0, 1:nb, 0]).mean() * 0.01))
+# the shader clock during the launch: s_memtime ticks per 100 MHz tick between the tops of consecutive stages (pick worker 0)
+dc = np.diff(t[0, 1:nb, 4]).astype(float); dw = np.diff(t[0, 1:nb, 0]).astype(float)
+print("shader clock during the chain launch: %.0f MHz (min %.0f, max %.0f over the stages)" % ((dc.sum() / dw.sum()) * 100.0, (dc / dw).min() * 100.0, (dc / dw).max() * 100.0))

@@ -215,6 +215,7 @@ void k_ring(double * __restrict__ tab, int m, int W, int ld, const double * __re
     }
 }
 
+__device__ unsigned long long g_clk[4];                    // one workgroup's (s_memtime, 100 MHz wall clock) at its start and end
 // the k_s of a row pair in groups of G stages through two sets of scalar registers: the loads of group g + 1 are requested
 // before the arithmetic of group g (the compiler, left alone, requests a group where its registers were last used and
 // waits for it on the spot)
@@ -225,6 +226,8 @@ void k_pipe(double * __restrict__ tab, int m, int W, int ld, const double * __re
     int bx, by; tile_of(rev, bx, by);
     const int j = bx * 512 + threadIdx.x * 2, i0 = by * ROWS;
     if (j >= W) return;
+    const bool probe = blockIdx.x == 7 && blockIdx.y == gridDim.y / 2 && threadIdx.x == 0;
+    if (probe) { g_clk[0] = __builtin_readcyclecounter(); g_clk[1] = wall_clock64(); }
     v2d e[NB];
 #pragma unroll
     for (int s = 0; s < NB; s++) e[s] = *reinterpret_cast<const v2d *>(E + (size_t)s * ld + j);
@@ -279,6 +282,64 @@ void k_pipe(double * __restrict__ tab, int m, int W, int ld, const double * __re
         apply(b, base + (size_t)U * ld, i + U, i + 2 * U < m ? i + 2 * U : i);
         base += (size_t)2 * U * ld;
     }
+    if (probe) { g_clk[2] = __builtin_readcyclecounter(); g_clk[3] = wall_clock64(); }
+}
+
+// `pipe` with ONE column per thread: half the e registers (more waves per SIMD), U rows share a group of scalar k_s
+template <int ROWS, int U, int NB, int G> __global__ __launch_bounds__(256)
+void k_pipe1(double * __restrict__ tab, int m, int W, int ld, const double * __restrict__ E, const double * __restrict__ K, int rev)
+{
+    constexpr int NG = NB / G;
+    int bx, by; tile_of(rev, bx, by);
+    const int j = bx * 256 + threadIdx.x, i0 = by * ROWS;
+    if (j >= W) return;
+    double e[NB];
+#pragma unroll
+    for (int s = 0; s < NB; s++) e[s] = E[(size_t)s * ld + j];
+    double * base = tab + (size_t)i0 * ld + j;
+    double a[U], b[U];
+    auto load = [&](double (&d)[U], const double * p) {
+#pragma unroll
+        for (int u = 0; u < U; u++) d[u] = p[(size_t)u * ld];
+    };
+    double kq[2][U][G];
+    auto kload = [&](int set, int row0, int g) {
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int q = 0; q < G; q++) kq[set][u][q] = K[(size_t)(row0 + u) * 32 + g * G + q];
+    };
+    auto apply = [&](double (&d)[U], double * p, int row0, int next_row0) {
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int q = 0; q < G; q += 4)
+                    asm volatile("" :: "s"(kq[g & 1][u][q]), "s"(kq[g & 1][u][q + 1]), "s"(kq[g & 1][u][q + 2]), "s"(kq[g & 1][u][q + 3]));
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 1 < NG) kload((g + 1) & 1, row0, g + 1); else kload((g + 1) & 1, next_row0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < G; q++)
+#pragma unroll
+                for (int u = 0; u < U; u++) { const double p0 = kq[g & 1][u][q] * e[g * G + q]; d[u] = d[u] + p0; }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) p[(size_t)u * ld] = d[u];
+    };
+    static_assert(NG % 2 == 0, "an even number of groups");
+    load(a, base);
+    kload(0, i0, 0);
+#pragma unroll 1
+    for (int i = i0; i < i0 + ROWS; i += 2 * U) {
+        load(b, base + (size_t)U * ld);
+        apply(a, base, i, i + U);
+        if (i + 2 * U < i0 + ROWS) load(a, base + (size_t)2 * U * ld);
+        apply(b, base + (size_t)U * ld, i + U, i + 2 * U < m ? i + 2 * U : i);
+        base += (size_t)2 * U * ld;
+    }
 }
 
 typedef void (*kern_t)(double *, int, int, int, const double *, const double *, int);
@@ -312,6 +373,11 @@ int main(int argc, char ** argv)
         {"ring   NB=24 U=2 D=4", k_ring<16, 2, 24, 4>, 16, 512, 24},
         {"ring   NB=24 U=1 D=3", k_ring<16, 1, 24, 3>, 16, 512, 24},
         {"pipe   NB=32 groups of 8", k_pipe<16, 32, 8>, 16, 512, 32},
+        {"pipe   NB=32 groups of 8, 32 rows", k_pipe<32, 32, 8>, 32, 512, 32},
+        {"pipe1  NB=32 U=4 G=4 (one column)", k_pipe1<16, 4, 32, 4>, 16, 256, 32},
+        {"pipe1  NB=32 U=4 G=4 32 rows", k_pipe1<32, 4, 32, 4>, 32, 256, 32},
+        {"pipe1  NB=32 U=2 G=8", k_pipe1<16, 2, 32, 8>, 16, 256, 32},
+        {"pipe1  NB=32 U=8 G=2... (U=8 G=4 = 128 sgprs) skip", k_pipe1<32, 2, 32, 8>, 32, 256, 32},
         {"pipe   NB=32 groups of 4", k_pipe<16, 32, 4>, 16, 512, 32},
         {"pipe   NB=24 groups of 4", k_pipe<16, 24, 4>, 16, 512, 24},
         {"pairk  NB=24 scalar loads", k_pairk<16, 2, 24, 0>, 16, 512, 24},
@@ -360,6 +426,10 @@ int main(int argc, char ** argv)
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         const double us = ms * 1000.0 / reps;
         hipFuncAttributes fa; CK(hipFuncGetAttributes(&fa, (const void *)v.f));
+        if (strstr(v.name, "pipe   ")) {
+            unsigned long long c[4]; CK(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_clk), sizeof c));
+            printf("    (one workgroup of the last launch: %.2f us from its first to its last instruction at %.0f MHz)\n", (c[3] - c[1]) * 0.01, (double)(c[2] - c[0]) / (double)(c[3] - c[1]) * 100.0);
+        }
         printf("  %-38s %8.2f us/launch  frac %.3f   per pivot %5.2f us   %3d VGPRs %4zu B scratch\n", v.name, us, bytes / us / 1e6 / 8.0, us / v.nb, fa.numRegs, (size_t)fa.localSizeBytes);
     }
     return 0;
