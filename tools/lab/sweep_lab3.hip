@@ -342,6 +342,144 @@ void k_pipe1(double * __restrict__ tab, int m, int W, int ld, const double * __r
     }
 }
 
+// `pipe` as a RESIDENT workgroup: one workgroup per (column strip, chunk of rows), as many as the device seats at once; the 32
+// e_s pairs are loaded once per workgroup instead of once per 16 rows (as many load instructions as the rows themselves), and no
+// workgroup is dispatched behind another. gridDim.x = strips, gridDim.y = chunks; rows of chunk c: [c * rpc, (c + 1) * rpc)
+template <int NB, int G> __global__ __launch_bounds__(256)
+void k_resident(double * __restrict__ tab, int m, int W, int ld, const double * __restrict__ E, const double * __restrict__ K, int rev)
+{
+    constexpr int U = 2, NG = NB / G;
+    const int bx = blockIdx.x, c = blockIdx.y;
+    const int rpc = ((m + (int)gridDim.y - 1) / (int)gridDim.y + 3) / 4 * 4;          // rows per chunk, a multiple of 2 U
+    const int j = bx * 512 + threadIdx.x * 2;
+    int i0 = c * rpc, iend = min(i0 + rpc, m);
+    if (j >= W || i0 >= iend) return;
+    v2d e[NB];
+#pragma unroll
+    for (int s = 0; s < NB; s++) e[s] = *reinterpret_cast<const v2d *>(E + (size_t)s * ld + j);
+    // alternate passes walk the chunk in opposite directions (what the Infinity Cache still holds of it is read first)
+    const long long step = rev ? -(long long)ld : (long long)ld;
+    const int dir = rev ? -1 : 1;
+    int i = rev ? iend - 1 : i0;                            // first row; rows i, i + dir, ...
+    const int nrows = iend - i0;                            // a multiple of 4 except in the last chunk (m a multiple of 4 here)
+    double * base = tab + (size_t)i * ld + j;
+    v2d a[U], b[U];
+    auto load = [&](v2d (&d)[U], const double * p) {
+#pragma unroll
+        for (int u = 0; u < U; u++) d[u] = *reinterpret_cast<const v2d *>(p + u * step);
+    };
+    double kq[2][U][G];
+    auto kload = [&](int set, int row0, int g) {
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int q = 0; q < G; q++) kq[set][u][q] = K[(size_t)(row0 + u * dir) * 32 + g * G + q];
+    };
+    auto apply = [&](v2d (&d)[U], double * p, int row0, int next_row0) {
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int q = 0; q < G; q += 4)
+                    asm volatile("" :: "s"(kq[g & 1][u][q]), "s"(kq[g & 1][u][q + 1]), "s"(kq[g & 1][u][q + 2]), "s"(kq[g & 1][u][q + 3]));
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 1 < NG) kload((g + 1) & 1, row0, g + 1); else kload((g + 1) & 1, next_row0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < G; q++)
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const double k = kq[g & 1][u][q];
+                    const double p0 = k * e[g * G + q].x, p1 = k * e[g * G + q].y;
+                    d[u].x = d[u].x + p0; d[u].y = d[u].y + p1;
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) *reinterpret_cast<v2d *>(p + u * step) = d[u];
+    };
+    load(a, base);
+    kload(0, i, 0);
+#pragma unroll 1
+    for (int n = 0; n < nrows; n += 2 * U) {
+        load(b, base + U * step);
+        apply(a, base, i, i + U * dir);
+        const bool more = n + 2 * U < nrows;
+        if (more) load(a, base + 2 * U * step);
+        apply(b, base + U * step, i + U * dir, more ? i + 2 * U * dir : i);
+        base += 2 * U * step; i += 2 * U * dir;
+    }
+}
+
+// `resident` with THREE row groups in flight (the rows two groups ahead are requested before a group's arithmetic)
+template <int NB, int G> __global__ __launch_bounds__(256)
+void k_resident3(double * __restrict__ tab, int m, int W, int ld, const double * __restrict__ E, const double * __restrict__ K, int rev)
+{
+    constexpr int U = 2, NG = NB / G;
+    const int bx = blockIdx.x, c = blockIdx.y;
+    const int rpc = ((m + (int)gridDim.y - 1) / (int)gridDim.y + 3) / 4 * 4;
+    const int j = bx * 512 + threadIdx.x * 2;
+    const int i0 = c * rpc, iend = min(i0 + rpc, m);
+    if (j >= W || i0 >= iend) return;
+    v2d e[NB];
+#pragma unroll
+    for (int s = 0; s < NB; s++) e[s] = *reinterpret_cast<const v2d *>(E + (size_t)s * ld + j);
+    const int ngroups = (iend - i0) / U;
+    double * base = tab + (size_t)i0 * ld + j;
+    v2d a[U], b[U], c3[U];
+    auto load = [&](v2d (&d)[U], int g) {
+#pragma unroll
+        for (int u = 0; u < U; u++) d[u] = *reinterpret_cast<const v2d *>(base + (size_t)(g * U + u) * ld);
+    };
+    double kq[2][U][G];
+    auto kload = [&](int set, int row0, int g) {
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int q = 0; q < G; q++) kq[set][u][q] = K[(size_t)(row0 + u) * 32 + g * G + q];
+    };
+    auto apply = [&](v2d (&d)[U], int grp) {
+        const int row0 = i0 + grp * U, next_row0 = grp + 1 < ngroups ? row0 + U : i0;
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int q = 0; q < G; q += 4)
+                    asm volatile("" :: "s"(kq[g & 1][u][q]), "s"(kq[g & 1][u][q + 1]), "s"(kq[g & 1][u][q + 2]), "s"(kq[g & 1][u][q + 3]));
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 1 < NG) kload((g + 1) & 1, row0, g + 1); else kload((g + 1) & 1, next_row0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < G; q++)
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const double k = kq[g & 1][u][q];
+                    const double p0 = k * e[g * G + q].x, p1 = k * e[g * G + q].y;
+                    d[u].x = d[u].x + p0; d[u].y = d[u].y + p1;
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) *reinterpret_cast<v2d *>(base + (size_t)(grp * U + u) * ld) = d[u];
+    };
+    load(a, 0);
+    if (ngroups > 1) load(b, 1);
+    kload(0, i0, 0);
+#pragma unroll 1
+    for (int n = 0; n < ngroups; n += 3) {
+        if (n + 2 < ngroups) load(c3, n + 2);
+        apply(a, n);
+        if (n + 1 >= ngroups) break;
+        if (n + 3 < ngroups) load(a, n + 3);
+        apply(b, n + 1);
+        if (n + 2 >= ngroups) break;
+        if (n + 4 < ngroups) load(b, n + 4);
+        apply(c3, n + 2);
+    }
+}
+
 typedef void (*kern_t)(double *, int, int, int, const double *, const double *, int);
 int main(int argc, char ** argv)
 {
@@ -373,6 +511,14 @@ int main(int argc, char ** argv)
         {"ring   NB=24 U=2 D=4", k_ring<16, 2, 24, 4>, 16, 512, 24},
         {"ring   NB=24 U=1 D=3", k_ring<16, 1, 24, 3>, 16, 512, 24},
         {"pipe   NB=32 groups of 8", k_pipe<16, 32, 8>, 16, 512, 32},
+        {"resident NB=32, 48 chunks (768 wgs)", k_resident<32, 8>, -48, 512, 32},
+        {"resident3 NB=32, 48 chunks (768 wgs)", k_resident3<32, 8>, -48, 512, 32},
+        {"resident3 NB=32, 43 chunks of 96 rows", k_resident3<32, 8>, -43, 512, 32},
+        {"resident3 NB=24, 64 chunks (1024 wgs)", k_resident3<24, 4>, -64, 512, 24},
+        {"resident NB=32, 32 chunks (512 wgs)", k_resident<32, 8>, -32, 512, 32},
+        {"resident NB=32, 64 chunks (1024 wgs)", k_resident<32, 8>, -64, 512, 32},
+        {"resident NB=32, 96 chunks (1536 wgs)", k_resident<32, 8>, -96, 512, 32},
+        {"resident NB=24, 64 chunks (1024 wgs)", k_resident<24, 4>, -64, 512, 24},
         {"pipe   NB=32 groups of 8, 32 rows", k_pipe<32, 32, 8>, 32, 512, 32},
         {"pipe1  NB=32 U=4 G=4 (one column)", k_pipe1<16, 4, 32, 4>, 16, 256, 32},
         {"pipe1  NB=32 U=4 G=4 32 rows", k_pipe1<32, 4, 32, 4>, 32, 256, 32},
@@ -414,7 +560,7 @@ int main(int argc, char ** argv)
     }
     for (auto & v : vs) {
         if (only && !strstr(v.name, only)) continue;
-        dim3 g((W + v.cols - 1) / v.cols, m / v.rows);
+        dim3 g((W + v.cols - 1) / v.cols, v.rows < 0 ? -v.rows : m / v.rows);
         int flip = 0;
         for (int w = 0; w < 6; w++) hipLaunchKernelGGL(v.f, g, dim3(256), 0, 0, tab, m, W, ld, E, K, (flip ^= 1));
         CK(hipDeviceSynchronize());
