@@ -226,7 +226,7 @@ def test_chain_with_and_without_the_column_line_equals_the_pipelined_loop(shape,
     stride is a multiple of 4 KiB (the first three shapes: W = 1024 / 2048 / 1024) the entering column's line in the pick
     workers' LDS -- against the pipelined loop, which shares none of that code: whole solves of LPs that run thousands of
     pivots (rows that pivot several times inside one batch, columns that come back), state compared bit for bit at three
-    iteration limits; with XPG_CHAIN_LINE forced off and on."""
+    iteration limits; with XPG_CHAIN_LINE forced off, on, and on as a half line."""
     import xpoly_amd
     m, n = shape
     leq, tg = gen.hard_lp_f64(m, n)
@@ -240,7 +240,7 @@ def test_chain_with_and_without_the_column_line_equals_the_pipelined_loop(shape,
         lp.close()
     cp.close()
     monkeypatch.setenv("XPG_LOOP", "block")
-    for line in ("0", "1"):
+    for line in ("0", "1", "8"):                         # off, the whole line, the half line (what 4096 x 8192 takes at 32 stages)
         monkeypatch.setenv("XPG_CHAIN_LINE", line)
         cb = xpoly_amd.Context(0)
         for K in (77, 1200, 3000):

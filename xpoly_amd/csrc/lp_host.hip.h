@@ -152,14 +152,14 @@ template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> &
             const int fn = next_folds ? 1 : 0;
             // the entering column's line in the pick workers' LDS (lp_chain.hip.h, LINE): where the row stride is a multiple of
             // 4 KiB -- the L1 then keeps next to nothing of a column -- and one XCD still seats every worker with the larger
-            // LDS block; XPG_CHAIN_LINE=0|1 forces it off / on for A/B runs
+            // LDS block; XPG_CHAIN_LINE=0|1|8 forces it off / on / on as a half line for A/B runs and tests
             static const int line_env = [] { const char * s = getenv("XPG_CHAIN_LINE"); return s ? atoi(s) : -1; }();
             auto line_fits = [&](int cols) {
                 return (size_t)workers * ch_lds_bytes(B, cols) <= (size_t)(cus / 8) * 160 * 1024 &&
                        (size_t)workers <= (size_t)(cus / 8) * ((size_t)160 * 1024 / ch_lds_bytes(B, cols));
             };
-            const bool want_line = local && (line_env == 1 || (line_env != 0 && v.ld % 512 == 0));
-            const int line = !want_line ? 0 : line_fits(16) ? 16 : line_fits(8) ? 8 : 0;
+            const bool want_line = local && (line_env == 1 || line_env == 8 || (line_env != 0 && v.ld % 512 == 0));      // (8: the half line wherever it fits, for tests)
+            const int line = !want_line ? 0 : (line_env != 8 && line_fits(16)) ? 16 : line_fits(8) ? 8 : 0;
             const size_t lds = ch_lds_bytes(B, line);
             if (local && line == 16) hipLaunchKernelGGL((k_blk_chain<true, 16>), dim3(8 * workers), dim3(64), lds, ctx->stream, v, batch, t0, B, cpick, cprep, nparts0, fa, fn);
             else if (local && line == 8) hipLaunchKernelGGL((k_blk_chain<true, 8>), dim3(8 * workers), dim3(64), lds, ctx->stream, v, batch, t0, B, cpick, cprep, nparts0, fa, fn);
