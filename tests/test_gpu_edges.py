@@ -189,10 +189,11 @@ def test_midsize_whole_solve_every_loop(port, monkeypatch):
             assert np.array_equal(out["eq2bv"], want["eq2bv"]), mode
 
 
-@pytest.mark.parametrize("B", [1, 3, 9, 16])
+@pytest.mark.parametrize("B", [1, 3, 9, 16, 24, 32])
 def test_blocked_loop_small_and_rare_branches(ctx, port, B, monkeypatch):
-    """The blocked loop forced onto small LPs (where it is not the default), batch lengths 1, 3 and
-    16: dependence-test-like data drive it through closed batches and the generic pick; random
+    """The blocked loop forced onto small LPs (where it is not the default), batch lengths 1, 3, 9, 16, 24
+    and 32 (the last three have full-batch passes of their own; batches that close with 17 .. 31 pivots staged
+    take the run-time-length pass): dependence-test-like data drive it through closed batches and the generic pick; random
     problems through phase 1. Status, tableau, objective row, basis: bit-identical to the oracle."""
     import xpoly_amd
     monkeypatch.setenv("XPG_LOOP", "block")
