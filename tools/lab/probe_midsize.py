@@ -17,8 +17,9 @@ for k in range(3):
     cases.append(("random %dx%d" % p["leq"].shape, (p["leq"], p["tgtf"])))
 for name, (leq, tg) in cases:
     line = []
-    for mode in ("block", "pipe"):
-        os.environ["XPG_LOOP"] = mode
+    for mode in ("block", "pipe", "auto"):
+        if mode == "auto": os.environ.pop("XPG_LOOP", None)
+        else: os.environ["XPG_LOOP"] = mode
         ctx = xpoly_amd.Context(0)
         best = None
         for rep in range(3):
@@ -31,4 +32,4 @@ for name, (leq, tg) in cases:
             best = dt if best is None else min(best, dt)
         ctx.close()
         line.append("%s: status %d, %d pivots, %.2f ms (%.1f us/pivot)" % (mode, st, piv, best * 1e3, best * 1e6 / max(1, piv)))
-    print("%-16s %s | %s" % (name, line[0], line[1]))
+    print("%-16s %s | %s | %s" % (name, line[0], line[1], line[2].split(",")[-1]))

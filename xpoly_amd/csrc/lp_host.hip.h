@@ -452,13 +452,25 @@ template <class S> struct Lp : LpBase {
     // ~10 us, one iteration ~90 us), and an over-full HIP queue was measured to stall
     // the stream for tens of ms, so at most 2 x 64 iterations are kept in flight:
     // every 64 iterations an event is recorded and the one from two blocks back awaited.
+    // Where the automatic choice takes the blocked loop: by the bytes one sweep moves. With the chain launch (one persistent
+    // launch stages a batch's pivots) it wins from 48 x 64 LPs up -- whole solves of random, hard and dense LPs of 48 x 64 ...
+    // 600 x 500 take 0.83 ... 0.50 of the pipelined loop's time, no single LP more than 0.92; 24 x 40: 1.06
+    // (tools/lab/probe_loop_choice.py) -- so from 64 KB; where the chain cannot run (XPG_CHAIN=0, the opt-in Dantzig pricing, a
+    // solve whose roll calls failed) the launch-per-stage form only pays where the sweep is what costs: 16 MB, rounds 2-4's
+    // line. XPG_BLOCK_FROM_KB overrides both for A/B runs.
+    size_t blocked_from_bytes() const
+    {
+        static const long env_kb = [] { const char * s = getenv("XPG_BLOCK_FROM_KB"); return s ? atol(s) : -1L; }();
+        if (env_kb >= 0) return (size_t)env_kb << 10;
+        const bool chain_usable = ctx->chain && !chain_off && opt_pricing == 0;
+        return chain_usable ? ((size_t)64 << 10) : ((size_t)16 << 20);
+    }
     void queue_iterations(unsigned k)
     {
         unsigned blk = 0;
-        // blocked loop: chosen explicitly, or by default where one sweep moves >= 16 MB (it trades
-        // launches for HBM traffic; on small tableaux the pipelined loop's two launches per pivot win)
+        // blocked loop: chosen explicitly, or by default from blocked_from_bytes() of sweep traffic up
         bool blocked = std::is_same<S, F64>::value &&
-                       (ctx->loop_mode == 3 || (ctx->loop_auto && (size_t)v.m * v.W * 16 >= ((size_t)16 << 20)));
+                       (ctx->loop_mode == 3 || (ctx->loop_auto && (size_t)v.m * v.W * 16 >= blocked_from_bytes()));
         if (blocked && !irregular_known) {                 // once per build: did k_build meet an inf or a NaN? (LoopState::noncanon)
             LoopState hs;
             if (read_state(&hs) == 0) irregular = hs.noncanon != 0;
