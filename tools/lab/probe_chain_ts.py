@@ -1,4 +1,4 @@
-"""GPU diagnostic (stamped build): raw timeline of one chain launch at 4096 x 8192 -- where the ~7 us of a
+"""GPU diagnostic (stamped build): raw timeline of one chain launch at 4096 x 8192 (XPG_TS_M / XPG_TS_N / XPG_TS_KIND=dense: another LP) -- where the ~7 us of a
 stage go. Worker classes: 0 = worker 0, 1 = last picker (63), 2 = first prep-only worker (64), 3 = last prepper."""
 import ctypes as C
 
@@ -9,7 +9,10 @@ from tools import gen
 from xpoly_amd._capi import lib
 
 ctx = xpoly_amd.Context(0)
-leq, tg = gen.hard_lp_f64(4096, 4095)
+import os
+M_, N_ = int(os.environ.get("XPG_TS_M", "4096")), int(os.environ.get("XPG_TS_N", "4095"))
+leq, tg = (gen.dense_lp_f64 if os.environ.get("XPG_TS_KIND") == "dense" else gen.hard_lp_f64)(M_, N_)
+os.environ.setdefault("XPG_LOOP", "block")
 lp = xpoly_amd.DeviceLP(ctx, xpoly_amd.F64, leq, tg)
 lp.begin(); lp.iterate(1600)
 cap = C.c_int(0)
@@ -38,4 +41,4 @@ print("stage-to-stage (pick worker 0 top):", np.diff(t[0, 1:nb, 0]) * 0.01)
 print("mean stage: %.3f us" % (np.diff(t[0, 1:nb, 0]).mean() * 0.01))
 # the shader clock during the launch: s_memtime ticks per 100 MHz tick between the tops of consecutive stages (pick worker 0)
 dc = np.diff(t[0, 1:nb, 4]).astype(float); dw = np.diff(t[0, 1:nb, 0]).astype(float)
-print("shader clock during the chain launch: %.0f MHz (min %.0f, max %.0f over the stages)" % ((dc.sum() / dw.sum()) * 100.0, (dc / dw).min() * 100.0, (dc / dw).max() * 100.0))
+if dc.sum() > 0: print("shader clock during the chain launch: %.0f MHz (min %.0f, max %.0f over the stages)" % ((dc.sum() / dw.sum()) * 100.0, (dc / dw).min() * 100.0, (dc / dw).max() * 100.0))
