@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/sweep_pmc
 rm -rf $O; mkdir -p $O
 for c in VALUBusy SALUBusy MemUnitBusy MemUnitStalled WriteUnitStalled SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SMEM SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQC_DCACHE_REQ SQC_DCACHE_MISSES SQ_INSTS_SMEM SQ_INSTS_VALU SQ_WAVES FetchSize WriteSize L2CacheHit; do
-  timeout 120 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- $R/tools/_build/sweep_lab3 "pair   NB" > $O/$c.log 2>&1 || echo "$c: failed" >> $O/summary.txt
+  timeout 120 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- $R/tools/_build/sweep_lab3 "NB=32" > $O/$c.log 2>&1 || echo "$c: failed" >> $O/summary.txt
 done
 cd $R && python3 - <<'PY' >> $O/summary.txt
 import csv, glob, os, collections
