@@ -1105,7 +1105,9 @@ def leg_lineq(ctx, xpoly_amd, gen):
             rec[name + "_systems_per_s"] = round(LINEQ_NB / min(resident(name) for _ in range(3)), 0)
         del d_in, d_work, d_out, d_r, d_k
         # (ii) the host-array entry points: PCIe and the cap-row result slots included
-        for name, fn in (("reduce", lambda: lq.reduce(mats, nv, True)), ("fme_slots", lambda: lq.fme(mats, nv, 0, slots=True)),
+        work = mats.copy()                              # (the in-place form overwrites its argument)
+        for name, fn in (("reduce", lambda: lq.reduce_packed(mats, nv, True, copy=False)),
+                         ("reduce_inplace", lambda: lq.reduce_inplace(work, nv, True)), ("fme_slots", lambda: lq.fme(mats, nv, 0, slots=True)),
                          ("fme", lambda: lq.fme_packed(mats, nv, 0, copy=False)), ("rank", lambda: lq.rank(mats))):
             fn()
             t0 = time.perf_counter(); fn(); dt = time.perf_counter() - t0
@@ -1148,7 +1150,9 @@ def leg_lineq(ctx, xpoly_amd, gen):
                                   status_hist=np.bincount(np.clip(st, 0, 4), minlength=5).tolist()),
                 dtype="int32 num/den", bound="integer issue (gcd loops), not HBM",
                 sample="*_systems_per_s: 16384 systems resident in HBM, best of 3 calls timed to xpg_sync; *_host_arrays_*, "
-                       "rational_lps and dep_is_empty: host arrays in and out (PCIe included), second call timed; fme_host_arrays = "
+                       "rational_lps and dep_is_empty: host arrays in and out (PCIe included), second call timed; reduce_host_arrays = the packed entry "
+                       "point xpg_lineq_reduce_batch_packed_rat32 (survivors written by the device straight into pinned memory, one "
+                       "synchronisation), reduce_inplace_host_arrays = the reference-shaped in-place form on top of it; fme_host_arrays = "
                        "the packed entry point (row offsets + live rows through pinned memory), fme_slots_host_arrays = round 2's "
                        "cap-row slots; *_pcie_bound_* = 63 GB/s / (system bytes up + mean live-row bytes down); "
                        "fme_one_system_call_us = mean of 200 one-system packed calls incl. the ctypes layer")

@@ -400,6 +400,16 @@ int xpg_lineq_fme_batch_packed_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * ma
                                      int rhs_idx, int u, int darkshadow, int cap_rows, xpg_rat32 * outs,
                                      long long outs_cap_rows, const xpg_rat32 ** out_view, long long * row_offsets,
                                      int32_t * out_ok);
+/* Lineq::reduce (src/com/linsys.cpp:359-626) with a PACKED result, the form a host-resident caller of many systems wants
+ * (round 6): mats is read only; row_offsets[nb + 1] (in rows) and the surviving rows of every system, back to back, come
+ * back -- the device writes them straight into pinned memory of the handle, so the call synchronises once.  outs /
+ * outs_cap_rows / out_view as for the packed fme above; out_rows (may be NULL) receives the per-system counts
+ * (= row_offsets[b + 1] - row_offsets[b]); out_ok[b] is Lineq::reduce's bool.  The in-place entry point
+ * xpg_lineq_reduce_batch_rat32 is this call plus a copy of every system's survivors to the front of its slot. */
+int xpg_lineq_reduce_batch_packed_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols, int rhs_idx,
+                                        int is_intersect, xpg_rat32 * outs, long long outs_cap_rows,
+                                        const xpg_rat32 ** out_view, long long * row_offsets, int32_t * out_rows,
+                                        int32_t * out_ok);
 /* Gives the device blocks and pinned staging a handle keeps between host-array calls back to the runtime (they are
  * kept to spare one-system callers four hipMalloc / hipFree pairs per call; at most 1 GiB / 16 blocks). */
 int xpg_trim(xpg_ctx * ctx);

@@ -326,3 +326,9 @@ class Port(_Lib):
         if not os.path.exists(PORT_SO):
             build_port()
         super().__init__(PORT_SO)
+
+    def pivot_count(self):
+        """SIX::pivot calls of this process so far (restatement only; the reference keeps no such counter)."""
+        fn = self.lib.orc_pivot_count
+        fn.restype = C.c_longlong
+        return fn()

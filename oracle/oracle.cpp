@@ -245,6 +245,7 @@ void orc_pivot_rat32(int32_t * tab, int m, int W, int32_t * obj, int rhs_idx, in
 void orc_set_strict(int on) { strict_mode() = on != 0; }
 long long orc_appro_count(void) { return counters().appro_calls; }
 long long orc_reduce_count(void) { return counters().reduce_calls; }
+long long orc_pivot_count(void) { return counters().pivots; }
 
 } // extern "C"
 

@@ -141,6 +141,7 @@ void pivot_cells(S * tab, int m, int W, S * obj, int rhs, int r, int nv)
 template <class S> void pivot(Slack<S> & P, int nv, int bv)
 {
     const int r = P.bv2eq[bv];
+    counters().pivots++;                                                  // telemetry only (tools/gen_golden_end.py)
     pivot_cells(P.eq.a.data(), P.eq.r, P.eq.c, P.obj.data(), P.rhs, r, nv);
     P.nv[nv] = 0; P.nv[bv] = 1; P.bv[nv] = 1; P.bv[bv] = 0;               // :1504-1507
     P.eq2bv[r] = nv; P.bv2eq[nv] = r; P.bv2eq[bv] = -1;                   // :1508-1510

@@ -80,8 +80,8 @@ inline long long gcd_ll(long long x, long long y)
     return y;
 }
 
-struct Counters { long long reduce_calls, appro_calls; };
-inline Counters & counters() { static Counters c = {0, 0}; return c; }
+struct Counters { long long reduce_calls, appro_calls, pivots; };
+inline Counters & counters() { static Counters c = {0, 0, 0}; return c; }
 
 // rational.cpp:163-185
 inline void reduce_ll(long long & n, long long & d)

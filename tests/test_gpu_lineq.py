@@ -431,3 +431,32 @@ def test_fme_packed_results_equal_the_slot_form(lq, ctx):
     assert lib().xpg_trim(ctx._h) == 0
     ok, res = lq.fme(mats[:2], nv, u)                      # the handle works on after a trim
     assert rows_equal(res[1], res_s[1]) or True
+
+
+@pytest.mark.parametrize("nb,rows,nv", [(1, 9, 4), (300, 16, 8), (6000, 16, 8), (2500, 40, 12)])
+def test_reduce_packed_and_in_place_forms_agree_with_oracle(lq, port, nb, rows, nv):
+    """Round 6: xpg_lineq_reduce_batch_packed_rat32 (survivors written by the device straight into the handle's pinned buffer, one
+    synchronisation; input untouched) and the reference-shaped in-place entry point on top of it -- small batches go up
+    through pinned staging, batches beyond 4 MB straight from the caller's pages. Every system against Lineq::reduce
+    (src/com/linsys.cpp:359-626) of the oracle; rows of a slot behind the survivors keep the caller's input."""
+    rng = np.random.default_rng(nb + rows)
+    base = np.stack([gen.random_system(rng, rows, nv) for _ in range(min(nb, 128))])
+    mats = np.ascontiguousarray(np.tile(base, ((nb + len(base) - 1) // len(base), 1, 1, 1))[:nb])
+    keep = mats.copy()
+    for inter in (True, False):
+        ok, off, packed = lq.reduce_packed(mats, nv, inter)
+        assert np.array_equal(mats, keep)
+        ok_v, off_v, view = lq.reduce_packed(mats, nv, inter, copy=False)
+        assert np.array_equal(ok, ok_v) and np.array_equal(off, off_v) and np.array_equal(packed, view)
+        work = mats.copy()
+        ok_i, rows_i = lq.reduce_inplace(work, nv, inter)
+        assert np.array_equal(ok_i, ok) and np.array_equal(rows_i, np.diff(off))
+        for b in range(min(nb, 128)):
+            wok, wres = port.reduce(mats[b], nv, inter)
+            assert ok[b] == wok, (b, inter)
+            if wok:
+                assert rows_equal(packed[off[b]:off[b + 1]], wres), (b, inter)
+        for b in range(nb):
+            r = rows_i[b]
+            assert np.array_equal(work[b, :r], packed[off[b]:off[b + 1]]) and np.array_equal(work[b, r:], keep[b, r:]), b
+            assert np.array_equal(packed[off[b]:off[b + 1]], packed[off[b % len(base)]:off[b % len(base) + 1]])

@@ -294,3 +294,69 @@ def overflow_lp_f64(trial, key=2026):
     leq = np.ascontiguousarray(np.concatenate([A, b[:, None]], axis=1))
     tgtf = np.ascontiguousarray(np.concatenate([c, [0.0]]))
     return leq, tgtf
+
+
+def interval_lp_f64(m, n, seed=1, maxlen=24):
+    """A dense-stored LP whose fp64 arithmetic is EXACT, so that the reference's final feasibility check (row sums compared
+    with a 1e-17 window) can succeed at a size where rounded data never does: consecutive-ones rows (a totally
+    unimodular matrix: every basis inverse is integral), integer right-hand sides, rows and columns rescaled by powers of
+    two (pivots are not all on +-1, every product and quotient is still exact). maximise c.x, A x <= b, x >= 0; the first
+    rows tile the columns so that every variable is bounded. Returns (leq [m, n + 1], tgtf [n + 1])."""
+    rng = np.random.default_rng([2718, seed])
+    A = np.zeros((m, n))
+    tiles = max(1, min(m // 2, n // 8))
+    starts = np.linspace(0, n, tiles + 1).astype(int)
+    r = 0
+    for k in range(tiles):
+        A[r, starts[k]:starts[k + 1]] = 1
+        r += 1
+    while r < m:
+        a = int(rng.integers(0, n - 1))
+        A[r, a:min(n, a + int(rng.integers(2, maxlen + 1)))] = 1
+        r += 1
+    b = rng.integers(1, 40, size=m).astype(np.float64)
+    c = rng.integers(1, 9, size=n).astype(np.float64)
+    rs = 2.0 ** rng.integers(-2, 3, size=m)
+    cs = 2.0 ** rng.integers(-2, 3, size=n)
+    A = A * rs[:, None] * cs[None, :]
+    b = b * rs
+    c = c * cs
+    leq = np.ascontiguousarray(np.concatenate([A, b[:, None]], axis=1))
+    tgtf = np.ascontiguousarray(np.concatenate([c, [0.0]]))
+    return leq, tgtf
+
+
+def lp_block_f64(seed):
+    """One small block of block_lp_f64: 3..10 rows, 3..12 variables, origin feasible; even seeds small integers (exact
+    arithmetic), odd seeds U(0.1, 1) data (rounded arithmetic). Returns (A [m, n], b [m], c [n])."""
+    rng = np.random.default_rng([31337, seed])
+    m = int(rng.integers(3, 11)); n = int(rng.integers(3, 13))
+    if seed % 2 == 0:
+        A = rng.integers(0, 5, size=(m, n)).astype(np.float64)
+        A[:, A.sum(axis=0) == 0] = 1.0                       # every variable bounded
+        b = rng.integers(4, 40, size=m).astype(np.float64)
+        c = rng.integers(1, 7, size=n).astype(np.float64)
+    else:
+        A = 0.1 + 0.9 * rng.random((m, n))
+        b = n * (0.5 + 0.5 * rng.random(m))
+        c = 0.1 + 0.9 * rng.random(n)
+    return A, b, c
+
+
+def block_lp_f64(block_seeds):
+    """A block-diagonal LP stored dense: maximise c.x, A x <= b, x >= 0 with A = diag(A_1 .. A_k), the blocks lp_block_f64(s)
+    for s in block_seeds. The reference's pricing takes the first column with a positive cost, so it solves the blocks one after
+    the other and the whole ends SIX_SUCC exactly when every block does (cells of other blocks are zeros: they add nothing to
+    the row sums of the final feasibility check) -- the way to a LARGE fp64 LP that ends with status 0 and a non-zero optimum
+    (dense random LPs of that size never do). The seeds come from a search with the oracle and are part of the
+    fixture (tools/gen_golden_end.py). Returns (leq [m, n + 1], tgtf [n + 1])."""
+    blocks = [lp_block_f64(int(s)) for s in block_seeds]
+    m = sum(b[0].shape[0] for b in blocks); n = sum(b[0].shape[1] for b in blocks)
+    leq = np.zeros((m, n + 1)); tgtf = np.zeros(n + 1)
+    r = c = 0
+    for A, b, cc in blocks:
+        leq[r:r + A.shape[0], c:c + A.shape[1]] = A
+        leq[r:r + A.shape[0], n] = b
+        tgtf[c:c + A.shape[1]] = cc
+        r += A.shape[0]; c += A.shape[1]
+    return leq, tgtf

@@ -26,22 +26,91 @@ inline int lineq_reduce_batch_dev(xpg_ctx * ctx, int nb, R32 * d_mats, int rows,
     XPG_TRY(hipGetLastError());
     return 0;
 }
+// Pinned host memory of the packed-result entry points: grows, never shrinks, freed with the handle.
+// keep: the first `keep` bytes survive a growth (the chunked pipeline below appends while earlier chunks' rows are in it).
+inline int hpack_reserve(xpg_ctx * ctx, size_t bytes, size_t keep = 0)
+{
+    if (bytes <= ctx->hpack_cap) return 0;
+    const size_t cap = bytes + bytes / 4 + 4096;
+    void * fresh = 0;
+    if (hipHostMalloc(&fresh, cap, hipHostMallocDefault) != hipSuccess) { ctx->err = "hipHostMalloc(packed results)"; return XPG_ERR_ALLOC; }
+    if (ctx->hpack && keep) memcpy(fresh, ctx->hpack, keep < ctx->hpack_cap ? keep : ctx->hpack_cap);
+    if (ctx->hpack) (void)hipHostFree(ctx->hpack);
+    ctx->hpack = fresh; ctx->hpack_cap = cap;
+    return 0;
+}
+
+// Lineq::reduce / removeIdenRow for nb host systems with a PACKED result (round 6): row_offsets[nb + 1] (in rows) and the
+// surviving rows of every system back to back. The systems go up once (small batches through the handle's pinned buffer,
+// large ones straight from the caller's pages), are reduced in place in HBM, and k_pack_rows_out writes the survivors
+// STRAIGHT INTO the handle's pinned host buffer (hipHostMalloc memory is mapped on the device: coalesced 16-byte stores
+// over the link), so the row counts, the verdicts, the offsets and the rows are all there after ONE synchronisation -- no
+// device slots come back, nothing is allocated per call beyond the handle's cached blocks. `out` (may be NULL) receives a
+// copy of the rows, *view (may be NULL) the pinned buffer itself (valid until the handle's next packed call), out_rows
+// (may be NULL) the per-system counts.
+inline int lineq_reduce_batch_packed(xpg_ctx * ctx, int nb, const R32 * mats, int rows, int cols, int rhs, int mode, int is_intersect,
+                                     R32 * out, long long out_cap_rows, const R32 ** view, long long * row_offsets,
+                                     int32_t * out_rows, int32_t * out_ok)
+{
+    if (view) *view = 0;
+    if (!ctx || nb < 0 || !mats || rows <= 0 || cols <= 0 || !row_offsets || (mode == 1 && (rhs < 0 || rhs >= cols || !out_ok)) ||
+        (out && out_cap_rows < 0))
+        return XPG_ERR_SHAPE;
+    if (nb == 0) { row_offsets[0] = 0; return 0; }
+    const size_t bi = (size_t)nb * rows * cols * 8;
+    const size_t meta = (size_t)(nb + 1) * 8 + (size_t)nb * 8;       // offsets, then ok and rows
+    const size_t meta_al = (meta + 255) & ~(size_t)255;
+    const bool small_in = bi <= ((size_t)4 << 20);
+    DevBuf di, dr, dk, doff;
+    XPG_TRY(di.alloc(ctx, bi)); XPG_TRY(dr.alloc(ctx, (size_t)nb * 4)); XPG_TRY(dk.alloc(ctx, (size_t)nb * 4));
+    XPG_TRY(doff.alloc(ctx, (size_t)(nb + 1) * 8));
+    int rc = hpack_reserve(ctx, meta_al + (small_in ? bi : 0) + bi);
+    if (rc) return rc;
+    char * hp = (char *)ctx->hpack;
+    char * hrows_out = hp + meta_al + (small_in ? bi : 0);           // where the survivors land
+    if (small_in) {
+        memcpy(hp + meta_al, mats, bi);
+        XPG_TRY(hipMemcpyAsync(di.p, hp + meta_al, bi, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        XPG_TRY(hipMemcpyAsync(di.p, mats, bi, hipMemcpyHostToDevice, ctx->stream));
+    }
+    rc = lineq_reduce_batch_dev(ctx, nb, (R32 *)di.p, rows, cols, rhs, mode, is_intersect, (int32_t *)dr.p, (int32_t *)dk.p);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_rows_scan, dim3(1), dim3(1024), 0, ctx->stream, nb, (const int *)dr.p, (long long *)doff.p);
+    hipLaunchKernelGGL(k_pack_rows, dim3(nb < 4096 ? nb : 4096), dim3(256), 0, ctx->stream, nb, (const R32 *)di.p, rows, cols,
+                       (const int *)dr.p, (const long long *)doff.p, (R32 *)hrows_out);
+    XPG_TRY(hipGetLastError());
+    long long * h_off = (long long *)hp; int32_t * h_ok = (int32_t *)(hp + (size_t)(nb + 1) * 8); int32_t * h_rows = h_ok + nb;
+    XPG_TRY(hipMemcpyAsync(h_off, doff.p, (size_t)(nb + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    XPG_TRY(hipMemcpyAsync(h_rows, dr.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (mode == 1) XPG_TRY(hipMemcpyAsync(h_ok, dk.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+    XPG_TRY(hipStreamSynchronize(ctx->stream));
+    memcpy(row_offsets, h_off, (size_t)(nb + 1) * 8);
+    if (out_rows) memcpy(out_rows, h_rows, (size_t)nb * 4);
+    if (out_ok && mode == 1) memcpy(out_ok, h_ok, (size_t)nb * 4);
+    const long long total = row_offsets[nb];
+    if (out && out_cap_rows < total) return XPG_ERR_SHAPE;
+    if (out && total > 0) memcpy(out, hrows_out, (size_t)total * cols * 8);
+    if (view && total > 0) *view = (const R32 *)hrows_out;
+    return 0;
+}
+// The in-place form of the reference's signature (Lineq::reduce(m, ...) overwrites m): the packed call above, then the
+// survivors of system b copied to the front of its slot. Rows of a slot behind out_rows[b] keep the caller's input.
 inline int lineq_reduce_batch(xpg_ctx * ctx, int nb, R32 * mats, int rows, int cols, int rhs, int mode,
                               int is_intersect, int32_t * out_rows, int32_t * out_ok)
 {
     if (!ctx || nb < 0 || !mats || rows <= 0 || cols <= 0 || !out_rows || (mode == 1 && (rhs < 0 || rhs >= cols)))
         return XPG_ERR_SHAPE;
     if (nb == 0) return 0;
-    const size_t bytes = (size_t)nb * rows * cols * 8;
-    DevBuf dm, dr, dk;
-    XPG_TRY(dm.alloc(ctx, bytes)); XPG_TRY(dr.alloc(ctx, (size_t)nb * 4)); XPG_TRY(dk.alloc(ctx, (size_t)nb * 4));
-    XPG_TRY(hipMemcpyAsync(dm.p, mats, bytes, hipMemcpyHostToDevice, ctx->stream));
-    const int rc = lineq_reduce_batch_dev(ctx, nb, (R32 *)dm.p, rows, cols, rhs, mode, is_intersect, (int32_t *)dr.p, (int32_t *)dk.p);
+    std::vector<long long> off((size_t)nb + 1);
+    std::vector<int32_t> ok_tmp;
+    if (mode == 1 && !out_ok) { ok_tmp.resize((size_t)nb); out_ok = ok_tmp.data(); }
+    const R32 * view = 0;
+    const int rc = lineq_reduce_batch_packed(ctx, nb, mats, rows, cols, rhs, mode, is_intersect, (R32 *)0, 0, &view, off.data(), out_rows, out_ok);
     if (rc) return rc;
-    XPG_TRY(hipMemcpyAsync(mats, dm.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    XPG_TRY(hipMemcpyAsync(out_rows, dr.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (out_ok) XPG_TRY(hipMemcpyAsync(out_ok, dk.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
-    XPG_TRY(hipStreamSynchronize(ctx->stream));
+    const size_t rowb = (size_t)cols * 8, slot = (size_t)rows * rowb;
+    for (int b = 0; b < nb; b++)
+        if (out_rows[b] > 0) memcpy((char *)mats + (size_t)b * slot, (const char *)view + (size_t)off[(size_t)b] * rowb, (size_t)out_rows[b] * rowb);
     return 0;
 }
 
@@ -102,20 +171,6 @@ inline int lineq_fme_batch(xpg_ctx * ctx, int nb, const R32 * mats, int rows, in
     XPG_TRY(hipMemcpyAsync(out_rows, dr.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
     XPG_TRY(hipMemcpyAsync(out_ok, dk.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
     XPG_TRY(hipStreamSynchronize(ctx->stream));
-    return 0;
-}
-
-// Pinned host memory of the packed-result entry points: grows, never shrinks, freed with the handle.
-// keep: the first `keep` bytes survive a growth (the chunked pipeline below appends while earlier chunks' rows are in it).
-inline int hpack_reserve(xpg_ctx * ctx, size_t bytes, size_t keep = 0)
-{
-    if (bytes <= ctx->hpack_cap) return 0;
-    const size_t cap = bytes + bytes / 4 + 4096;
-    void * fresh = 0;
-    if (hipHostMalloc(&fresh, cap, hipHostMallocDefault) != hipSuccess) { ctx->err = "hipHostMalloc(packed results)"; return XPG_ERR_ALLOC; }
-    if (ctx->hpack && keep) memcpy(fresh, ctx->hpack, keep < ctx->hpack_cap ? keep : ctx->hpack_cap);
-    if (ctx->hpack) (void)hipHostFree(ctx->hpack);
-    ctx->hpack = fresh; ctx->hpack_cap = cap;
     return 0;
 }
 

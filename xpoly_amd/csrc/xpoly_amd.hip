@@ -1229,6 +1229,15 @@ int xpg_lineq_reduce_batch_rat32(xpg_ctx * ctx, int nb, xpg_rat32 * mats, int ro
                                  int is_intersect, int32_t * out_rows, int32_t * out_ok)
 {
     XPG_BIND(ctx); return lineq_reduce_batch(ctx, nb, (R32 *)mats, rows, cols, rhs_idx, 1, is_intersect, out_rows, out_ok); }
+int xpg_lineq_reduce_batch_packed_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols, int rhs_idx,
+                                        int is_intersect, xpg_rat32 * outs, long long outs_cap_rows,
+                                        const xpg_rat32 ** out_view, long long * row_offsets, int32_t * out_rows,
+                                        int32_t * out_ok)
+{
+    XPG_BIND(ctx);
+    return lineq_reduce_batch_packed(ctx, nb, (const R32 *)mats, rows, cols, rhs_idx, 1, is_intersect, (R32 *)outs, outs_cap_rows,
+                                     (const R32 **)out_view, row_offsets, out_rows, out_ok);
+}
 int xpg_lineq_remove_iden_batch_rat32(xpg_ctx * ctx, int nb, xpg_rat32 * mats, int rows, int cols,
                                       int32_t * out_rows)
 {

@@ -28,14 +28,42 @@ class Lineq:
         self.ctx = ctx
 
     def reduce(self, mats, rhs_idx, is_intersect=True):
-        """Lineq::reduce (linsys.cpp:359-626). Returns (ok[nb], [system b's surviving rows])."""
-        a = _stack(mats).copy()
+        """Lineq::reduce (linsys.cpp:359-626). Returns (ok[nb], [system b's surviving rows]) -- through the packed entry
+        point; the rows are slices of one array."""
+        ok, off, packed = self.reduce_packed(mats, rhs_idx, is_intersect)
+        return ok, [packed[off[b]: off[b + 1]] for b in range(len(ok))]
+
+    def reduce_packed(self, mats, rhs_idx, is_intersect=True, copy=True):
+        """xpg_lineq_reduce_batch_packed_rat32: (ok[nb], row_offsets[nb + 1], rows[row_offsets[nb], cols, 2]); the input is
+        not modified. copy=False returns the rows as a view of the handle's pinned buffer (valid until the handle's next
+        packed call): what a C++ caller reads its results from."""
+        a = _stack(mats)
+        nb, rows, cols = a.shape[:3]
+        off = np.zeros(nb + 1, dtype=np.int64); ok = np.zeros(nb, dtype=np.int32)
+        view = C.c_void_p()
+        self.ctx.check(lib().xpg_lineq_reduce_batch_packed_rat32(
+            self.ctx._h, C.c_int(nb), vp(a), C.c_int(rows), C.c_int(cols), C.c_int(rhs_idx), C.c_int(int(is_intersect)),
+            None, C.c_longlong(0), C.byref(view), vp(off), None, vp(ok)), "xpg_lineq_reduce_batch_packed_rat32")
+        total = int(off[nb])
+        if not copy and total:
+            buf = (C.c_int32 * (total * cols * 2)).from_address(view.value)
+            return ok, off, np.frombuffer(buf, dtype=np.int32).reshape(total, cols, 2)
+        packed = np.empty((total, cols, 2), dtype=np.int32)
+        if total:
+            C.memmove(packed.ctypes.data, view.value, packed.nbytes)
+        return ok, off, packed
+
+    def reduce_inplace(self, mats, rhs_idx, is_intersect=True):
+        """xpg_lineq_reduce_batch_rat32, the in-place form of the reference's signature: `mats` [nb, rows, cols, 2] (int32,
+        contiguous) is overwritten -- system b's surviving rows at the front of its slot. Returns (ok[nb], out_rows[nb])."""
+        a = mats
+        assert isinstance(a, np.ndarray) and a.dtype == np.int32 and a.ndim == 4 and a.flags.c_contiguous
         nb, rows, cols = a.shape[:3]
         out_rows = np.zeros(nb, dtype=np.int32); ok = np.zeros(nb, dtype=np.int32)
         self.ctx.check(lib().xpg_lineq_reduce_batch_rat32(self.ctx._h, C.c_int(nb), vp(a), C.c_int(rows), C.c_int(cols),
                                                           C.c_int(rhs_idx), C.c_int(int(is_intersect)), vp(out_rows), vp(ok)),
                        "xpg_lineq_reduce_batch_rat32")
-        return ok, [a[b, : out_rows[b]].copy() for b in range(nb)]
+        return ok, out_rows
 
     def move2var(self, mats, rhs_idx, first_sym, last_sym):
         """Lineq::move2var (linsys.cpp:1177-1200): constant symbols become variables in front of the constant."""
