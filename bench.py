@@ -54,7 +54,7 @@ PMC_SUMMARY = os.path.join(ROOT, "profiles", "round5_pmc_hbm_traffic_4096x8192.j
 PMC_SUMMARY_2B = os.path.join(ROOT, "profiles", "round5_pmc_hbm_traffic_4096x12289.json")
 PMC_BATCH = os.path.join(ROOT, "profiles", "round5_pmc_batch_issue.json")
 PMC_RATIONAL = os.path.join(ROOT, "profiles", "round4_pmc_rational_issue.json")
-LEGS = ("pivots", "batched", "sharded", "cfg2b", "six_e2e", "rational", "mip", "lineq")
+LEGS = ("pivots", "batched", "sharded", "cfg2b", "shapes", "six_e2e", "one_call", "rational", "mip", "lineq")
 LINEQ_NB = 16384                           # systems per row-elimination launch (the dependence tests' shapes)
 
 
@@ -655,8 +655,12 @@ def main():
     if world == 1 and not stub:
         if "cfg2b" in legs:
             out["cfg2b"] = leg_cfg2b(ctx, xpoly_amd, gen)
+        if "shapes" in legs:
+            out["shapes"] = leg_shapes(ctx, xpoly_amd, gen)
         if "six_e2e" in legs:
             out["six_e2e"] = leg_six_e2e(ctx, xpoly_amd, gen, with_reference=not a.no_cpu_baseline and not a.no_ref_baseline)
+        if "one_call" in legs:
+            out["one_call"] = leg_one_call(ctx, xpoly_amd, gen, with_reference=not a.no_cpu_baseline and not a.no_ref_baseline)
         if "rational" in legs:
             out["rational"] = leg_rational(ctx, xpoly_amd, gen)
         if "mip" in legs:
@@ -870,6 +874,76 @@ def leg_cfg2b(ctx, xpoly_amd, gen, m=4096, n=8192):
     return out
 
 
+SHAPES = (("tall", 16384, 2048), ("wide", 1024, 20480), ("square", 8192, 8192), ("odd_width", 4096, 4094), ("small", 2048, 2047))
+SHAPE_K_CHECK, SHAPE_K_TIMED = 256, 512
+
+
+def leg_shapes(ctx, xpoly_amd, gen):
+    """Is the headline a tuning to the 4096 x 8192 stride? gen.hard_lp_f64(m, n) at other LP shapes -- tall (16384 x 2048:
+    tableau 16384 x 18433, 2.4 GB), wide (1024 x 20480: tableau 1024 x 21505 -- the reference's own range ends where (n + m)^2 x 8 B wraps 2^32: its vc matrix; n + m >= 23 171 corrupts its heap), square (8192 x 8192: tableau 8192 x 16385), a
+    tableau of odd width (4096 x 8191) and a small one (2048 x 4096) -- through the same automatic loop choice. Per shape:
+    the state after 256 pivots is checked against the REAL reference (tests/golden/g13_shapes.json) before anything is
+    timed; then (t[K = 768] - t[K = 256]) / 512 pivots, HIP events on the full-batch passes, the chain's share from the
+    difference, and which loop / chain / pass instance ran (xpg_lp_loop_info)."""
+    RUNNING = xpoly_amd.six.XPG_RUNNING
+    gold = golden("g13_shapes.json")
+    rows = []
+    for name, m, n in SHAPES:
+        leq, tgtf = gen.hard_lp_f64(m, n)
+        lp = xpoly_amd.DeviceLP(ctx, xpoly_amd.F64, leq, tgtf)
+        del leq
+        W = n + m + 1
+        lp.begin()
+        st = lp.iterate(SHAPE_K_CHECK)
+        rec = dict(shape=name, lp=[m, n], tableau=[m, W], tableau_mb=round(m * W * 8 / 1e6, 1))
+        if st != RUNNING:
+            rec["ended_early_status"] = int(st)
+            rows.append(rec); lp.close(); continue
+        g = gold.get(name)
+        if g:                                           # the verified state: whole tableau, objective row, basis at K = 256
+            got = lp.read()
+            bad = [k for k, ok in (("tableau", checksum(got["tab"]) == g["tab"]), ("objective row", checksum(got["tgtf"]) == g["tgtf"]),
+                                   ("basis", checksum(got["eq2bv"].astype(np.int32)) == g["eq2bv"])) if not ok]
+            del got
+            if bad:
+                sys.exit("bench.py self-check FAILED: shape %s after 256 pivots, %s differ(s) from tests/golden/g13_shapes.json" % (name, ", ".join(bad)))
+            rec["self_check"] = "state after 256 pivots = the real reference's (tests/golden/g13_shapes.json): bit-identical"
+        else:
+            rec["self_check"] = None
+        info = lp.loop_info()
+        pers, launches, sweep_ms = [], 0, 0.0
+        for rep in range(3):
+            lp.begin()
+            assert lp.iterate(SHAPE_K_CHECK) == RUNNING
+            if rep == 2:
+                ctx.profile_begin(32, 1)
+            t1 = time.perf_counter()
+            st = lp.iterate(SHAPE_K_TIMED)
+            t2 = time.perf_counter()
+            if rep == 2:
+                launches, sweep_ms = ctx.profile_end()
+            if rep and st == RUNNING:
+                pers.append((t2 - t1) / SHAPE_K_TIMED)
+        lp.close()
+        if not pers:
+            rec["ended_early_status"] = int(st)
+            rows.append(rec); continue
+        per = min(pers)
+        rec.update(pivots_per_s=round(1.0 / per, 1), us_per_pivot=round(per * 1e6, 3), loop=info)
+        alg = 2 * m * W * 8
+        if launches and info["loop"] == "blocked":
+            avg = sweep_ms / 1e3 / launches
+            ppl = info["pivots_per_pass"]
+            rec["pass"] = dict(kernel="k_blk_sweep_full<%d,2,%d>" % (info["sweep_rows"], ppl), avg_launch_us=round(avg * 1e6, 2), launches_sampled=launches,
+                               algorithmic_bytes_per_launch=alg, achieved_gbs=round(alg / avg / 1e9, 1), frac_of_hbm_peak=round(alg / avg / 1e9 / HBM_PEAK_GBS, 4))
+            rec["chain_us_per_stage"] = round((per * 1e6 * ppl - avg * 1e6) / ppl, 3)
+            rec["loop_effective_frac"] = round(alg / ppl / per / 1e9 / HBM_PEAK_GBS, 4)
+        rows.append(rec)
+    return dict(metric="simplex pivots/sec at LP shapes other than the headline's", unit="pivots/s", shapes=rows,
+                sample="per shape: (t[K=768] - t[K=256]) / 512 on gen.hard_lp_f64(m, n), better of two passes after a warm-up pass; "
+                       "pass = HIP events on the full-batch sweep launches of the last pass; chain_us_per_stage = (time per batch - pass) / pivots per pass")
+
+
 def leg_six_e2e(ctx, xpoly_amd, gen, m=4096, n=8192, max_iter=1280, with_reference=True):
     """What a caller of SIX::maxm / minm waits at BASELINE configs[1]: ONE xpg_six_maxm_f64 / xpg_six_minm_f64 call with host
     arrays in (leq 4096 x 8193, vc 8192 x 8193, tgtf) and status / v / sol out, max_iter = 1280 -- split into host reshaping,
@@ -922,6 +996,109 @@ def leg_six_e2e(ctx, xpoly_amd, gen, m=4096, n=8192, max_iter=1280, with_referen
                                            "stage 1 and ONE pivot (oracle/_ref, the real reference); baseline only")
     out["note"] = ("overhead = the call's wall time minus the device's stage 1 + pivot loop; the target is <= 1.3 x the raw pageable "
                    "host-to-device copy of leq (the bytes that must cross the link once)")
+    return out
+
+
+def leg_one_call(ctx, xpoly_amd, gen, with_reference=True):
+    """The reference's OWN call pattern: one tiny problem per call (Lineq::has_solution -> MIP / SIX::maxm,
+    src/com/linsys.cpp:860-904; 43 us per 14 x 6 rational LP on one core). Latency of ONE call through
+    the C ABI (ctypes: prebuilt argument objects, the raw foreign call timed) and through the C++ adapter classes of
+    include/xpoly_amd/*.hpp on the reference's RMat objects (oracle/_ref/dropin_demo --one-call, which also times the real
+    reference's classes on the same objects on one host core) -- and the batch size at which one batched call on the GPU
+    overtakes a loop of reference calls. A drop-in swap of the class WITHOUT batching is a slow-down for such problems: a
+    kernel launch plus a synchronisation costs more than the reference's whole solve; INTEGRATION.md section 5 has the table."""
+    import ctypes as C
+    from xpoly_amd._capi import lib, vp
+    from xpoly_amd.six import as_kind, empty_kind, RAT
+    L = lib()
+    rows_out = []
+
+    def timed(fn, budget_s=0.25, min_reps=5):
+        fn()
+        n, t0 = 0, time.perf_counter()
+        t1 = t0
+        while n < min_reps or t1 - t0 < budget_s:
+            fn(); n += 1; t1 = time.perf_counter()
+        return (t1 - t0) / n * 1e6
+
+    refl = None
+    if with_reference:
+        from oracle.checker import Ref
+        if Ref.available():
+            refl = Ref()
+    # ---- SIX<RMat,Rational>::maxm, 14 x 6 and 28 x 12 (integer data, x >= 0)
+    for m, nv in ((14, 6), (28, 12)):
+        leq, tg = gen.int_lp_rat(m, nv, seed=gen.XS_SEED + m)
+        vc = gen.to_rat(gen.vc_nonneg(nv, False))
+        v = empty_kind((1,), RAT); sol = empty_kind((nv + 1,), RAT)
+        args = (ctx._h, vp(tg), vp(vc), C.c_int(nv), None, C.c_int(0), vp(leq), C.c_int(m), C.c_int(nv + 1), C.c_uint(0xFFFFFFFF), vp(v), vp(sol))
+        st = L.xpg_six_maxm_rat32(*args)
+        rec = dict(call="SIX<RMat,Rational>::maxm", shape="%dx%d" % (m, nv), status=int(st), c_abi_us=round(timed(lambda: L.xpg_six_maxm_rat32(*args)), 1))
+        # the batch entry point on nb copies: where does one GPU call overtake nb reference calls?
+        per_lp = {}
+        for nb in (1, 16, 256, 4096):
+            bl = np.ascontiguousarray(np.broadcast_to(leq, (nb,) + leq.shape)); bt = np.ascontiguousarray(np.broadcast_to(tg, (nb,) + tg.shape))
+            per_lp[nb] = round(timed(lambda: ctx.six_batch(RAT, True, bt, bl), 0.15, 3) / nb, 3)
+        rec["batched_us_per_lp"] = per_lp
+        if refl is not None:
+            want = refl.six_solve(RAT, True, tg, vc, None, leq)
+            assert want[0] == st and want[1].tolist() == v[0].tolist(), "one_call: result differs from the reference"
+            rec["reference_us"] = round(timed(lambda: refl.six_solve(RAT, True, tg, vc, None, leq)), 1)
+            rec["break_even_batch"] = next((nb for nb in sorted(per_lp) if per_lp[nb] < rec["reference_us"]), None)
+        rows_out.append(rec)
+    # ---- Lineq::has_solution(integer, unique) on a 12 x 5 dependence polyhedron
+    rng = np.random.default_rng(5)
+    sysm = gen.random_system(rng, 12, 4); sysm[..., 1] = 1
+    vc = gen.to_rat(gen.vc_nonneg(4, False))
+    a = as_kind(sysm, RAT, 2)
+    hargs = (ctx._h, vp(a), C.c_int(12), None, C.c_int(0), vp(vc), C.c_int(4), C.c_int(5), C.c_int(4), C.c_int(1), C.c_int(1))
+    r = L.xpg_has_solution_rat32(*hargs)
+    rec = dict(call="Lineq::has_solution(int, unique)", shape="12x5", status=int(r), c_abi_us=round(timed(lambda: L.xpg_has_solution_rat32(*hargs)), 1))
+    from xpoly_amd.six import dep_is_empty_batch
+    per = {}
+    for nb in (1, 16, 256, 4096):
+        stack = np.ascontiguousarray(np.broadcast_to(a, (nb,) + a.shape))
+        per[nb] = round(timed(lambda: dep_is_empty_batch(ctx, stack), 0.15, 3) / nb, 3)
+    rec["batched_us_per_polyhedron (dep_is_empty: reduce + has_solution)"] = per
+    if refl is not None:
+        rec["reference_us"] = round(timed(lambda: refl.has_solution(sysm, None, vc, 4, True, True)), 1)
+        rec["break_even_batch"] = next((nb for nb in sorted(per) if per[nb] < rec["reference_us"]), None)
+    rows_out.append(rec)
+    # ---- MIP<RMat,Rational>::maxm(is_bin), 24-variable knapsack with two capacity rows
+    kl, kt = gen.knapsack_batch_rat(1, 24)
+    kvc = gen.to_rat(gen.vc_nonneg(24, False))
+    v = empty_kind((1,), RAT); sol = empty_kind((25,), RAT)
+    k_tg, k_leq = np.ascontiguousarray(kt[0]), np.ascontiguousarray(kl[0])
+    margs = (ctx._h, vp(k_tg), vp(kvc), C.c_int(24), None, C.c_int(0), vp(k_leq), C.c_int(k_leq.shape[0]), C.c_int(25), C.c_int(1), None, vp(v), vp(sol))
+    st = L.xpg_mip_maxm_rat32(*margs)
+    rec = dict(call="MIP<RMat,Rational>::maxm(is_bin)", shape="26x25", status=int(st), c_abi_us=round(timed(lambda: L.xpg_mip_maxm_rat32(*margs), 0.5, 3), 1))
+    per = {}
+    for nb in (1, 16, 256):
+        bl, bt = gen.knapsack_batch_rat(nb, 24)
+        per[nb] = round(timed(lambda: xpoly_amd.six.mip_batch(ctx, True, True, bt, bl), 0.3, 2) / nb, 3)
+    rec["batched_us_per_mip"] = per
+    if refl is not None:
+        want = refl.mip_solve(RAT, True, True, kt[0], kvc, None, kl[0])
+        assert want[0] == st and want[1].tolist() == v[0].tolist(), "one_call: MIP result differs from the reference"
+        rec["reference_us"] = round(timed(lambda: refl.mip_solve(RAT, True, True, kt[0], kvc, None, kl[0]), 0.5, 2), 1)
+        rec["break_even_batch"] = next((nb for nb in sorted(per) if per[nb] < rec["reference_us"]), None)
+    rows_out.append(rec)
+    out = dict(metric="latency of ONE call at the reference's own call pattern", unit="us", calls=rows_out,
+               sample="mean over >= 0.25 s of back-to-back calls after a warm-up call; c_abi_us = the foreign call alone (ctypes, argument objects "
+                      "prebuilt); reference_us = the real reference (oracle/_ref via ref_driver.cpp) on ONE host core, incl. loading its matrices; "
+                      "batched_* = one batch call on nb problems / nb; break_even_batch = the smallest measured nb whose per-problem time beats the reference")
+    demo = os.path.join(ROOT, "oracle", "_ref", "dropin_demo")
+    if with_reference and os.path.exists(demo):
+        r = subprocess.run([demo, "--one-call"], capture_output=True, text=True, timeout=300)
+        if r.returncode == 0:
+            try:
+                out["cxx_adapter"] = dict(json.loads(r.stdout.strip().splitlines()[-1]),
+                                          note="oracle/_ref/dropin_demo --one-call: xcom::SIX / MIP / Lineq (the real reference, one core) and xpoly_amd::SIX / MIP / "
+                                               "Lineq (include/xpoly_amd/*.hpp -> C ABI -> GPU) on the SAME RMat objects, object construction included; us per call")
+            except ValueError:
+                out["cxx_adapter"] = dict(error=r.stdout[-300:])
+        else:
+            out["cxx_adapter"] = dict(error=(r.stderr or r.stdout)[-300:])
     return out
 
 

@@ -137,6 +137,20 @@ int  xpg_lp_counters(xpg_lp * lp, unsigned * sweeps_full, unsigned * sweeps_part
 int  xpg_lp_chain_aborts(xpg_lp * lp, unsigned * aborts, int * chain_off, unsigned * runs);
 /* ... and how many of the launches that passed did their batch's first stage themselves (no pick / prep launches for it). */
 int  xpg_lp_chain_folds(xpg_lp * lp, unsigned * folds);
+/* Which loop and which kernel instances the handle runs the LP in its current shape with (evidence for bench.py's `shapes`
+ * leg; no reference counterpart).  out[0..n-1], n <= 10: loop (0 pipelined, 1 serial, 3 blocked), pivots per blocked pass,
+ * chain form (0 launch-per-stage kernels, 1 one persistent launch on one XCD, 2 the same spread over the chip), columns of
+ * the entering column's line kept in LDS (0 / 8 / 16), rows per workgroup of the pass (16 / 32), leading dimension, chain
+ * workers, pick workers, prep workers, LDS bytes per chain worker. */
+int  xpg_lp_loop_info(xpg_lp * lp, int32_t * out, int n);
+/* Test view: SIX::normalize (src/com/lpsol.h:1290-1394, convertEq2Ineq :1197-1278) made both ways for one input -- the cells
+ * the HBM route makes on the device (out_dev_cells) and the cells the LDS route makes on the host (out_host_cells), each
+ * [rows][n + 1] (kind 0: double, 1: xpg_rat32; cap_cells = room of each buffer in cells).  out_info[0..6] = rows, n,
+ * substitutions made, equalities kept as pairs, free variables, the device form's return code, the host form's
+ * (XPG_ERR_REF_UNDEFINED where the reference reads past an equality's row, lpsol.h:1232). */
+int  xpg_test_normalize(xpg_ctx * ctx, int kind, const void * tgtf, const void * vc, int vc_rows, const void * eq, int eq_rows,
+                        const void * leq, int leq_rows, int cols, void * out_dev_cells, void * out_host_cells, long long cap_cells,
+                        int32_t * out_info);
 /* Launch geometry, host-side views for tests (no device needed).  xpg_test_sweep_tile: the blocked sweep's workgroup ->
  * tile map for a tableau of `strips` 512-column strips and `rowblocks` row blocks: lid < 0 returns the grid size, else
  * 1 / 0 = workgroup lid has / has no tile, written to (*bx, *by).  xpg_test_pick_ld: the leading dimension a device
@@ -196,7 +210,8 @@ int xpg_six_minm_rat32(xpg_ctx * ctx, const xpg_rat32 * tgtf, const xpg_rat32 * 
  * out_ms[0..7] = total, host reshaping (SIX::normalize, lpsol.h:1290-1394: nothing but the vc diagonal when there are
  * no equalities and no free variables), handle creation incl. the upload of the system, the dual built on the device
  * (minm: upload + transpose; lpsol.h:1602-1629), stage 1 + pivot loop on the device, read-back, release, and the route
- * taken (1 = the LDS-resident batch kernel, 2 = the HBM-resident loop).  Evidence for bench.py; no reference counterpart. */
+ * taken (1 = the LDS-resident batch kernel, 2 = the HBM-resident loop); out_ms[8] = the pivots the HBM-resident route's last
+ * pivot loop made (SIX::solveSlackForm's cnt, lpsol.h:1187).  Evidence for bench.py and the tests; no reference counterpart. */
 int xpg_six_last_profile(double * out_ms, int n);
 
 /* ---- batches of independent small LPs (the dependence-test workload) ------------------
@@ -320,6 +335,17 @@ int xpg_dep_is_empty_batch_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, 
 int xpg_dep_is_empty_batch_ex_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols,
                                     int rhs_idx, const xpg_rat32 * vc, int32_t * out_empty,
                                     long long * out_nodes);
+/* The same with a choice of what happens to a parametrised polyhedron (rhs_idx < cols - 1) that Lineq::reduce does not decide.
+ *   XPG_DEP_PARITY           what the reference does: undefined (XPG_ERR_REF_UNDEFINED in out_empty).  Built with
+ *                            -fsanitize=address the reference heap-overflows there: MIP::verify -> Matrix::is_colequ, from
+ *                            src/com/linsys.cpp:864 -- vc is sized for rhs_idx variables, the system has rhs_idx + symbols.
+ *   XPG_DEP_SYMBOLS_AS_VARS  OPT-IN, NOT PARITY: the evident intent of src/eng/poly.cpp:530-573 -- after move2var the symbols
+ *                            are variables of unknown sign, so has_solution(int, unique) is asked about the widened system:
+ *                            rhs_idx = cols - 1, vc widened by all-zero (= free) rows and columns for the symbols.  Checked
+ *                            against the oracle's move2var + reduce + has_solution on that widened system. */
+enum { XPG_DEP_PARITY = 0, XPG_DEP_SYMBOLS_AS_VARS = 1 };
+int xpg_dep_is_empty_batch_mode_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols, int rhs_idx,
+                                      const xpg_rat32 * vc, int mode, int32_t * out_empty, long long * out_nodes);
 /* Multi-device forms of the two batches above (sharding and devices[] as xpg_six_batch_*_multi;
  * out_nodes receives the sum over the shards). */
 int xpg_mip_batch_rat32_multi(int ndev, const int * devices, int nb, int is_max, int is_bin,

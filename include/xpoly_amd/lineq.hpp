@@ -243,5 +243,118 @@ inline int dep_is_empty_all(const std::vector<RMatT *> & polys, std::vector<int3
                                                empty.data(), (long long *)0);
 }
 
+// Many eliminations in ONE call: Lineq::fme(u[k], results[k]) (linsys.cpp:656-774) on systems of whatever shapes, the constant
+// in column rhs_idx[k] (empty vector: the last column of each). The reference's hot callers eliminate level by level --
+// loop-bound generation (src/eng/ldtran.cpp:178-193: for i = rhs_idx - 1 .. 1: fme(i)) and scanning (src/eng/poly.cpp:4803-4821) --
+// one small system per call; collected over the statements of a SCoP a level becomes one launch. ok[k] is fme's bool.
+// Returns 0 or a negative XPG_ERR_* code.
+template <class RMatT>
+inline int fme_all(const std::vector<RMatT *> & systems, const std::vector<int32_t> & u, const std::vector<int32_t> & rhs_idx,
+                   std::vector<RMatT> & results, std::vector<int32_t> & ok, bool darkshadow = false, xpg_ctx * c = 0)
+{
+    const int nb = (int)systems.size();
+    if ((int)u.size() != nb || (!rhs_idx.empty() && (int)rhs_idx.size() != nb)) return XPG_ERR_SHAPE;
+    results.resize((size_t)nb); ok.assign((size_t)nb, 0);
+    // empty systems stay empty (linsys.cpp:661-664) and do not travel
+    std::vector<int> live;
+    for (int b = 0; b < nb; b++) { if (systems[(size_t)b]->size() == 0) { results[(size_t)b].clean(); ok[(size_t)b] = 1; } else live.push_back(b); }
+    const int nl = (int)live.size();
+    if (nl == 0) return 0;
+    std::vector<int32_t> rows((size_t)nl), cols((size_t)nl), uu((size_t)nl), rr((size_t)nl), orows((size_t)nl), ook((size_t)nl);
+    std::vector<long long> off((size_t)nl + 1, 0), ooff((size_t)nl + 1, 0);
+    for (int k = 0; k < nl; k++) {
+        const RMatT & m = *systems[(size_t)live[(size_t)k]];
+        rows[(size_t)k] = (int32_t)m.get_row_size(); cols[(size_t)k] = (int32_t)m.get_col_size();
+        uu[(size_t)k] = u[(size_t)live[(size_t)k]];
+        rr[(size_t)k] = rhs_idx.empty() ? cols[(size_t)k] - 1 : rhs_idx[(size_t)live[(size_t)k]];
+        off[(size_t)k + 1] = off[(size_t)k] + (long long)rows[(size_t)k] * cols[(size_t)k];
+    }
+    std::vector<xpg_rat32> flat((size_t)off[(size_t)nl]);
+    for (int k = 0; k < nl; k++)
+        std::memcpy((void *)(flat.data() + off[(size_t)k]), (const void *)systems[(size_t)live[(size_t)k]]->get_matrix(),
+                    sizeof(xpg_rat32) * (size_t)rows[(size_t)k] * cols[(size_t)k]);
+    xpg_ctx * h = c ? c : detail::shared_context();
+    // a buffer for the worst case of every result while that is small (one call), else a sizing call first
+    long long capc = 0;
+    for (int k = 0; k < nl; k++) capc += ((long long)rows[(size_t)k] * rows[(size_t)k] / 4 + rows[(size_t)k]) * cols[(size_t)k];
+    std::vector<xpg_rat32> outs;
+    int rc;
+    if (capc * (long long)sizeof(xpg_rat32) <= (64ll << 20)) {
+        outs.resize((size_t)(capc > 0 ? capc : 1));
+        rc = xpg_lineq_fme_batch_ragged_rat32(h, nl, flat.data(), rows.data(), cols.data(), off.data(), rr.data(), uu.data(), darkshadow ? 1 : 0,
+                                              outs.data(), capc, ooff.data(), orows.data(), ook.data());
+    } else {
+        rc = xpg_lineq_fme_batch_ragged_rat32(h, nl, flat.data(), rows.data(), cols.data(), off.data(), rr.data(), uu.data(), darkshadow ? 1 : 0,
+                                              (xpg_rat32 *)0, 0, ooff.data(), orows.data(), ook.data());
+        if (rc == XPG_ERR_SHAPE && ooff[(size_t)nl] > 0) {
+            outs.resize((size_t)ooff[(size_t)nl]);
+            rc = xpg_lineq_fme_batch_ragged_rat32(h, nl, flat.data(), rows.data(), cols.data(), off.data(), rr.data(), uu.data(), darkshadow ? 1 : 0,
+                                                  outs.data(), ooff[(size_t)nl], ooff.data(), orows.data(), ook.data());
+        }
+    }
+    if (rc != 0) return rc;
+    for (int k = 0; k < nl; k++) {
+        RMatT & res = results[(size_t)live[(size_t)k]];
+        res.reinit(orows[(size_t)k], cols[(size_t)k]);
+        if (orows[(size_t)k] * cols[(size_t)k])
+            std::memcpy((void *)res.get_matrix(), (const void *)(outs.data() + ooff[(size_t)k]), sizeof(xpg_rat32) * (size_t)orows[(size_t)k] * cols[(size_t)k]);
+        ok[(size_t)live[(size_t)k]] = ook[(size_t)k];
+    }
+    return 0;
+}
+
+// Lineq::calcBound (linsys.cpp:1047-1078) for many systems: limits[k][j] receives the bounds of variable j of *systems[k]
+// alone (the constant in column rhs_idx[k]); ok[k] is calcBound's bool. Systems of one shape go up together -- one call per
+// shape class (SCoPs have a handful), every elimination chain of a class on the device at once. Returns 0 or XPG_ERR_*.
+template <class RMatT>
+inline int calc_bound_all(const std::vector<RMatT *> & systems, const std::vector<int32_t> & rhs_idx,
+                          std::vector<std::vector<RMatT> > & limits, std::vector<int32_t> & ok, xpg_ctx * c = 0)
+{
+    const int nb = (int)systems.size();
+    if ((int)rhs_idx.size() != nb) return XPG_ERR_SHAPE;
+    limits.assign((size_t)nb, std::vector<RMatT>());
+    ok.assign((size_t)nb, 0);
+    xpg_ctx * h = c ? c : detail::shared_context();
+    std::vector<char> done((size_t)nb, 0);
+    for (int b0 = 0; b0 < nb; b0++) {
+        if (done[(size_t)b0]) continue;
+        const int rows = (int)systems[(size_t)b0]->get_row_size(), cols = (int)systems[(size_t)b0]->get_col_size(), nv = rhs_idx[(size_t)b0];
+        std::vector<int> cls;
+        for (int b = b0; b < nb; b++)
+            if (!done[(size_t)b] && (int)systems[(size_t)b]->get_row_size() == rows && (int)systems[(size_t)b]->get_col_size() == cols && rhs_idx[(size_t)b] == nv) {
+                cls.push_back(b); done[(size_t)b] = 1;
+            }
+        if (rows == 0 || cols == 0 || nv < 1 || nv >= cols) return XPG_ERR_SHAPE;
+        const int nc = (int)cls.size();
+        std::vector<xpg_rat32> flat((size_t)nc * rows * cols);
+        for (int k = 0; k < nc; k++)
+            std::memcpy((void *)(flat.data() + (size_t)k * rows * cols), (const void *)systems[(size_t)cls[(size_t)k]]->get_matrix(), sizeof(xpg_rat32) * (size_t)rows * cols);
+        int cap = 4 * rows + 16;
+        for (int attempt = 0; attempt < 3; attempt++) {
+            std::vector<long long> off((size_t)nc * nv + 1, 0);
+            std::vector<int32_t> kok((size_t)nc, 0);
+            const xpg_rat32 * view = 0;
+            const int rc = xpg_lineq_calc_bound_batch_packed_rat32(h, nc, flat.data(), rows, cols, nv, cap, (xpg_rat32 *)0, 0, &view, off.data(), kok.data());
+            if (rc != 0) return rc;
+            int need = 0;
+            for (int k = 0; k < nc; k++) if (kok[(size_t)k] < 0 && -kok[(size_t)k] > need) need = -kok[(size_t)k];
+            if (need) { cap = need; continue; }                     // a step needed more rows than cap: once more with that many
+            for (int k = 0; k < nc; k++) {
+                const int b = cls[(size_t)k];
+                ok[(size_t)b] = kok[(size_t)k];
+                limits[(size_t)b].resize((size_t)nv);
+                for (int j = 0; j < nv; j++) {
+                    const long long lo = off[(size_t)k * nv + j], hi = off[(size_t)k * nv + j + 1];
+                    RMatT & m = limits[(size_t)b][(size_t)j];
+                    m.reinit((unsigned)(hi - lo), (unsigned)cols);
+                    if (hi > lo) std::memcpy((void *)m.get_matrix(), (const void *)(view + (size_t)lo * cols), sizeof(xpg_rat32) * (size_t)(hi - lo) * cols);
+                }
+            }
+            break;
+        }
+    }
+    return 0;
+}
+
 } // namespace xpoly_amd
 #endif

@@ -12,6 +12,7 @@
 #include <stdint.h>
 #include <signal.h>
 #include <unistd.h>
+#include <vector>
 
 #include "ltype.h"
 #include "comf.h"
@@ -85,9 +86,92 @@ template <class Mat, class T> static int compare_one(Mat & tgtf, Mat & vc, Mat &
     return bad;
 }
 
-int main()
+// ---- --one-call: the reference's own call pattern -- ONE tiny problem per call -- timed on one host core with the reference's
+// classes and with the adapter classes (include/xpoly_amd/*.hpp -> C ABI -> GPU) on the same objects. bench.py leg `one_call`.
+#include <time.h>
+static double now_us() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
+template <class F> static double time_us(F && f, double budget_us = 3e5, int min_reps = 5)
+{
+    f();                                                              // warm (first launch of a kernel, caches)
+    int reps = 0;
+    const double t0 = now_us();
+    double t1 = t0;
+    while (reps < min_reps || t1 - t0 < budget_us) { f(); reps++; t1 = now_us(); if (reps >= 20000) break; }
+    return (t1 - t0) / reps;
+}
+static void fill_lp(RMat & leq, RMat & tgtf, RMat & vc, int m, int nv)
+{
+    leq.reinit(m, nv + 1); tgtf.reinit(1, nv + 1); vc.reinit(nv, nv + 1);
+    for (int i = 0; i < m; i++) { for (int j = 0; j < nv; j++) leq.setr(i, j, irand(1, 9), 1); leq.setr(i, nv, nv * irand(3, 5), 1); }
+    for (int j = 0; j < nv; j++) { tgtf.setr(0, j, irand(1, 9), 1); vc.setr(j, j, -1, 1); }
+}
+static int one_call()
+{
+    printf("{\"cases\": [");
+    const char * sep = "";
+    for (int sz = 0; sz < 2; sz++) {                                  // SIX<RMat,Rational>::maxm, dense integer data (14 x 6, 28 x 12)
+        const int m = sz ? 28 : 14, nv = sz ? 12 : 6;
+        RMat leq, tgtf, vc, eq;
+        fill_lp(leq, tgtf, vc, m, nv);
+        Rational v1, v2; RMat s1, s2;
+        UINT a = 0, b = 0;
+        const double tr = time_us([&] { xcom::SIX<RMat, Rational> six; a = six.maxm(v1, s1, tgtf, vc, eq, leq); });
+        const double tg = time_us([&] { xpoly_amd::SIX<RMat, Rational> six; b = six.maxm(v2, s2, tgtf, vc, eq, leq); });
+        const int same = a == b && memcmp(&v1, &v2, sizeof(Rational)) == 0;
+        printf("%s{\"call\": \"SIX<RMat,Rational>::maxm\", \"shape\": \"%dx%d\", \"status\": %u, \"reference_us\": %.2f, \"adapter_us\": %.2f, \"same_result\": %s}",
+               sep, m, nv, a, tr, tg, same ? "true" : "false");
+        sep = ", ";
+    }
+    {   // Lineq::has_solution(integer, unique) on a dependence-polyhedron-like system (12 rows, 4 variables)
+        const int rows = 12, nv = 4;
+        RMat sys(rows, nv + 1), vc(nv, nv + 1), eq;
+        for (int i = 0; i < rows; i++) for (int j = 0; j <= nv; j++) sys.setr(i, j, j < nv ? irand(-3, 3) : irand(0, 9), 1);
+        for (int j = 0; j < nv; j++) vc.setr(j, j, -1, 1);
+        bool ha = false, hb = false;
+        xcom::Lineq ref(NULL); xpoly_amd::Lineq<RMat> gpu(NULL);
+        const double tr = time_us([&] { RMat v = vc; ha = ref.has_solution(sys, eq, v, nv, true, true); });
+        const double tg = time_us([&] { RMat v = vc; hb = gpu.has_solution(sys, eq, v, nv, true, true); });
+        printf("%s{\"call\": \"Lineq::has_solution(int, unique)\", \"shape\": \"%dx%d\", \"status\": %d, \"reference_us\": %.2f, \"adapter_us\": %.2f, \"same_result\": %s}",
+               sep, rows, nv + 1, (int)ha, tr, tg, ha == hb ? "true" : "false");
+    }
+    {   // MIP<RMat,Rational>::maxm, 0-1 knapsack of 24 variables with two capacity rows (bench.py leg `mip`)
+        const int nv = 24, m = 2;
+        RMat leq(m + nv, nv + 1), tgtf(1, nv + 1), vc(nv, nv + 1), eq;
+        for (int i = 0; i < m; i++) { int sum = 0; for (int j = 0; j < nv; j++) { const int x = irand(1, 9); sum += x; leq.setr(i, j, x, 1); } leq.setr(i, nv, sum / 2, 1); }
+        for (int j = 0; j < nv; j++) { leq.setr(m + j, j, 1, 1); leq.setr(m + j, nv, 1, 1); tgtf.setr(0, j, irand(1, 9), 1); vc.setr(j, j, -1, 1); }
+        Rational v1, v2; RMat s1, s2;
+        UINT a = 0, b = 0;
+        const double tr = time_us([&] { xcom::MIP<RMat, Rational> mip; a = mip.maxm(v1, s1, tgtf, vc, eq, leq, true, NULL); }, 1e6, 2);
+        const double tg = time_us([&] { xpoly_amd::MIP<RMat, Rational> mip; b = mip.maxm(v2, s2, tgtf, vc, eq, leq, true, NULL); }, 1e6, 2);
+        const int same = a == b && memcmp(&v1, &v2, sizeof(Rational)) == 0;
+        printf(", {\"call\": \"MIP<RMat,Rational>::maxm(is_bin)\", \"shape\": \"%dx%d\", \"status\": %u, \"reference_us\": %.2f, \"adapter_us\": %.2f, \"same_result\": %s}",
+               m + nv, nv + 1, a, tr, tg, same ? "true" : "false");
+    }
+    for (int sz = 0; sz < 2; sz++) {                                  // Lineq::reduce and Lineq::fme on ONE system
+        const int rows = sz ? 40 : 16, nv = sz ? 12 : 8;
+        RMat sys(rows, nv + 1);
+        for (int i = 0; i < rows; i++) for (int j = 0; j <= nv; j++) sys.setr(i, j, j < nv ? (irand(0, 9) < 7 ? irand(-3, 3) : 0) : irand(-5, 8), 1);
+        bool ra = false, rb = false;
+        xcom::Lineq ref(NULL); xpoly_amd::Lineq<RMat> gpu(NULL);
+        const double tr = time_us([&] { RMat w = sys; ra = ref.reduce(w, nv, true); });
+        const double tg = time_us([&] { RMat w = sys; rb = gpu.reduce(w, nv, true); });
+        printf(", {\"call\": \"Lineq::reduce\", \"shape\": \"%dx%d\", \"status\": %d, \"reference_us\": %.2f, \"adapter_us\": %.2f, \"same_result\": %s}",
+               rows, nv + 1, (int)ra, tr, tg, ra == rb ? "true" : "false");
+        RMat f1, f2;
+        bool fa = false, fb = false;
+        const double tr2 = time_us([&] { xcom::Lineq r2(&sys, nv); fa = r2.fme(0, f1, false); });
+        const double tg2 = time_us([&] { xpoly_amd::Lineq<RMat> g2(&sys, nv); fb = g2.fme(0, f2, false); });
+        printf(", {\"call\": \"Lineq::fme\", \"shape\": \"%dx%d\", \"status\": %d, \"reference_us\": %.2f, \"adapter_us\": %.2f, \"same_result\": %s}",
+               rows, nv + 1, (int)fa, tr2, tg2, (fa == fb && same_cells(f1, f2)) ? "true" : "false");
+    }
+    printf("]}\n");
+    return 0;
+}
+
+int main(int argc, char ** argv)
 {
     signal(SIGFPE, on_fpe);
+    if (argc > 1 && !strcmp(argv[1], "--one-call")) return one_call();
     int bad = 0, n = 0, undefined = 0;
     {   // src/example/example.cpp:54-93
         FloatMat leq(2, 3), tgtf(1, 3), vc(2, 3), eq;
@@ -309,6 +393,49 @@ int main()
             bool c1 = r.is_consistent(), c2 = g.is_consistent();
             mis = c1 != c2 || !same_cells(sys1, sys2);
             if (mis) printf("MISMATCH is_consistent on system %d: reference %d, xpoly_amd %d\n", it, (int)c1, (int)c2);
+        }
+        bad += mis; n++;
+    }
+    // ---- the collectors for the other hot callers (src/eng/ldtran.cpp:178-193, src/eng/poly.cpp:4803-4821): many systems of mixed
+    // shapes, one elimination level / one calcBound per call, against the reference's Lineq called system by system
+    {
+        const int NS = 36;
+        std::vector<RMat> sys((size_t)NS);
+        std::vector<RMat *> ptr;
+        std::vector<int32_t> u, rhs;
+        for (int k = 0; k < NS; k++) {
+            const int rows = 3 + (k % 3) * 3, nv = 2 + (k % 2);                       // 3 x 3, 6 x 4, 9 x 3, ... (six shape classes)
+            sys[(size_t)k].reinit(rows, nv + 1);
+            for (int i = 0; i < rows; i++) for (int j = 0; j <= nv; j++) sys[(size_t)k].setr(i, j, j < nv ? irand(-3, 3) : irand(-4, 9), 1);
+            ptr.push_back(&sys[(size_t)k]); u.push_back(irand(0, nv - 1)); rhs.push_back(nv);
+        }
+        std::vector<RMat> res; std::vector<int32_t> ok;
+        g_where = "fme_all"; g_case = 0;
+        int rc = xpoly_amd::fme_all(ptr, u, rhs, res, ok);
+        int mis = rc != 0;
+        for (int k = 0; !mis && k < NS; k++) {
+            RMat f1; xcom::Lineq r(&sys[(size_t)k], rhs[(size_t)k]);
+            g_case = k;
+            const bool fa = r.fme((UINT)u[(size_t)k], f1, false);
+            mis = fa != (ok[(size_t)k] != 0) || !same_cells(f1, res[(size_t)k]);
+            if (mis) printf("MISMATCH fme_all on system %d (reference %d, collector %d)\n", k, (int)fa, (int)ok[(size_t)k]);
+        }
+        bad += mis; n++;
+        std::vector<std::vector<RMat> > lim; std::vector<int32_t> cok;
+        g_where = "calc_bound_all";
+        rc = xpoly_amd::calc_bound_all(ptr, rhs, lim, cok);
+        mis = rc != 0;
+        for (int k = 0; !mis && k < NS; k++) {
+            RMat a1[4]; List<RMat*> l1;
+            for (int j = 0; j < rhs[(size_t)k]; j++) l1.append_tail(&a1[j]);
+            g_case = k;
+            xcom::Lineq r(&sys[(size_t)k], rhs[(size_t)k]);
+            const bool ca = r.calcBound(l1);
+            mis = ca != (cok[(size_t)k] > 0);
+            for (int j = 0; !mis && ca && j < rhs[(size_t)k]; j++)
+                mis = a1[j].get_row_size() != lim[(size_t)k][(size_t)j].get_row_size() ||
+                      (a1[j].size() && memcmp(a1[j].get_matrix(), lim[(size_t)k][(size_t)j].get_matrix(), sizeof(Rational) * a1[j].size()) != 0);
+            if (mis) printf("MISMATCH calc_bound_all on system %d (reference %d, collector %d)\n", k, (int)ca, (int)cok[(size_t)k]);
         }
         bad += mis; n++;
     }

@@ -18,8 +18,8 @@ ROOT = os.path.dirname(HERE)
 
 
 def run_worker(**env_over):
-    env = dict(os.environ)
-    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    from conftest import hooks_env
+    env = hooks_env()                                    # (the forced slices / loop forms are hook-only switches: the -DXPG_TEST_HOOKS build)
     for k in ("XPG_BATCH_SLICE", "XPG_BATCH_SLICE_FORCE"):
         env.pop(k, None)
     env.update(env_over)

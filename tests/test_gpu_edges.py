@@ -6,6 +6,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
+from conftest import needs_hooks
+
 from tools import gen
 
 pytestmark = pytest.mark.gpu
@@ -123,6 +125,7 @@ def test_full_size_tableau_properties(ctx, port):
     assert np.array_equal(eq2bv, want["eq2bv"])
 
 
+@needs_hooks
 def test_full_size_loops_against_each_other_and_oracle(port, monkeypatch):
     """4096 x 8192 fp64 under full load: the three device loops -- blocked (16 pivots staged per
     sweep, the default at this size), pipelined (pick workgroups inside the sweep launch) and the
@@ -222,6 +225,7 @@ def test_blocked_loop_small_and_rare_branches(ctx, port, B, monkeypatch):
 
 
 @pytest.mark.parametrize("shape", [(511, 512), (1023, 1024), (640, 383), (300, 723)])
+@needs_hooks
 def test_chain_with_and_without_the_column_line_equals_the_pipelined_loop(shape, monkeypatch):
     """Round 5's chain -- replays from registers with -0.0 for the steps that do not count, one-round gathers, and where the row
     stride is a multiple of 4 KiB (the first three shapes: W = 1024 / 2048 / 1024) the entering column's line in the pick
@@ -274,6 +278,7 @@ def test_batch_sizes_ragged_and_single(ctx, port):
                 assert status[b] == want[0] and np.array_equal(v[b], want[1])
 
 
+@needs_hooks
 def test_wide_tableau_keeps_the_chain(port, monkeypatch):
     """W >= 16 384 (here 1024 x 17 025: 267 prep workers, 268 partial slots -- two polling rounds per pick) used to drop
     silently to the launch-per-stage kernels; the chain now runs there too, and its results are the serial loop's and
@@ -301,6 +306,37 @@ def test_wide_tableau_keeps_the_chain(port, monkeypatch):
     want = port.two_stage(F64, leq, tg, K)
     assert np.array_equal(a["tab"].view(np.uint64), want["tab"].view(np.uint64))
     assert np.array_equal(a["eq2bv"], want["eq2bv"])
+
+
+def test_tableau_wider_than_the_partial_slots_of_one_wave_per_64_columns(port, monkeypatch):
+    """Round 6 (found by bench.py's `shapes` leg): a tableau of W > 32 640 columns -- 96 x 33 097 here -- has more 64-column prep
+    workgroups than the 510 look-ahead partial slots; the blocked loop ran over them (a GPU memory fault at 1024 x 33 793).
+    Its prep workgroups now take 256 columns each there (launch-per-stage form; the chain's hand-off areas end at 32 640).
+    Forced and automatic loop choice against the pipelined loop and the oracle, bit for bit. (The reference itself has no
+    defined behaviour at this width: its vc matrix of (n + m)^2 cells overflows a 32-bit byte count from n + m = 23 171.)"""
+    import xpoly_amd
+    m, n, K = 96, 33000, 70
+    leq, tg = gen.hard_lp_f64(m, n)
+    want = port.two_stage(F64, leq, tg, K)
+    for mode in ("block", "pipe", None):
+        if mode is None:
+            monkeypatch.delenv("XPG_LOOP", raising=False)
+        else:
+            monkeypatch.setenv("XPG_LOOP", mode)
+        c = xpoly_amd.Context(0)
+        lp = xpoly_amd.DeviceLP(c, F64, leq, tg)
+        lp.begin()
+        info = lp.loop_info()
+        if mode == "block":
+            assert info["loop"] == "blocked" and info["chain"] == "launch per stage", info
+        for k in (33, K - 33):
+            assert lp.iterate(k) == xpoly_amd.six.XPG_RUNNING
+        got = lp.read()
+        assert lp.pivots_done() == K
+        for k in ("tab", "tgtf"):
+            assert np.array_equal(got[k].view(np.uint64), want[k].view(np.uint64)), (mode, k)
+        assert np.array_equal(got["eq2bv"], want["eq2bv"]), mode
+        lp.close(); c.close()
 
 
 def test_fp64_loop_on_tableaux_with_inf_and_nan_cells(ctx, port):

@@ -21,8 +21,8 @@ RAT = 1
 
 
 def run_worker(**env_over):
-    env = dict(os.environ)
-    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    from conftest import hooks_env
+    env = hooks_env()                                    # (the forced slices / loop forms are hook-only switches: the -DXPG_TEST_HOOKS build)
     for k in ("XPG_R32_LOOP", "XPG_R32_GENERIC_EVERY"):
         env.pop(k, None)
     env.update(env_over)

@@ -15,6 +15,8 @@ import zlib
 import numpy as np
 import pytest
 
+from conftest import needs_hooks
+
 from tools import gen
 
 pytestmark = pytest.mark.gpu
@@ -137,6 +139,7 @@ def test_bench_lp_through_the_whole_timed_range_against_the_reference(ctx):
     lp.close()
 
 
+@needs_hooks
 def test_chain_roll_call_abort_falls_back_bit_exactly(monkeypatch):
     """ADVICE / VERDICT round 2 item 8: the persistent chain launch needs all its workers resident at once. A launch whose
     roll call fails (here forced on every 3rd batch by the test hook) leaves without touching the state: the batch
@@ -161,6 +164,7 @@ def test_chain_roll_call_abort_falls_back_bit_exactly(monkeypatch):
     lp.close(); c.close()
 
 
+@needs_hooks
 def test_chain_placement_check_failure_switches_to_the_spread_form(monkeypatch):
     """Round 4: the chain's workers are the workgroups with blockIdx % 8 == 0, which the dispatcher puts on ONE XCD -- an
     observation, not a contract, so the roll call checks it (a counter per XCD id). The test hook makes every second
@@ -183,6 +187,7 @@ def test_chain_placement_check_failure_switches_to_the_spread_form(monkeypatch):
     lp.close(); c.close()
 
 
+@needs_hooks
 def test_chain_folds_stage_zero_and_the_unfolded_loop_agree(monkeypatch):
     """Round 4: in the steady state a batch is [chain launch incl. stage 0, sweep]; XPG_CHAIN_FOLD=0 keeps stage 0 as
     launches of its own. Same state either way (= the reference's at K = 1024), and the folded run really folded."""
@@ -326,7 +331,8 @@ def test_cfg4_rational_serial_loop_against_the_reference():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     rec = [r for r in GOLD["g4_large"] if r["K"] == 16][0]
-    env = dict(os.environ, XPG_R32_LOOP="serial")
+    from conftest import hooks_env
+    env = hooks_env(XPG_R32_LOOP="serial")               # (the serial loop exists in the -DXPG_TEST_HOOKS build only)
     r = subprocess.run([sys.executable, "-c", SERIAL_R32_SCRIPT, root], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])

@@ -7,6 +7,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import needs_hooks
+
 from tools import gen
 
 pytestmark = pytest.mark.gpu
@@ -139,12 +141,12 @@ def test_entry_points_bind_their_own_device_and_restore_the_callers(ctx, port):
 def test_sweep_counters_and_tail_batches(monkeypatch):
     """xpg_lp_counters: 100 iterations of the blocked loop are 3 full sweeps (32 pivots each, the default) and one of 4
     pivots (the tail of the budget is enqueued at its own length); 64 more are two full ones and no tail. The
-    same with batches of 16 (XPG_BLOCK), where 64 is a whole number of batches. The tableau is the serial loop's
+    same with batches of 16 (XPG_BLOCK), where 64 is a whole number of batches. The tableau is the pipelined loop's
     either way."""
     import xpoly_amd
     leq, tg = gen.hard_lp_f64(96, 120)
     out = {}
-    for mode in ("block", "block16", "serial"):
+    for mode in ("block", "block16", "pipe"):
         monkeypatch.setenv("XPG_LOOP", mode[:5])
         if mode == "block16":
             monkeypatch.setenv("XPG_BLOCK", "16")
@@ -154,17 +156,17 @@ def test_sweep_counters_and_tail_batches(monkeypatch):
         lp = xpoly_amd.DeviceLP(c, F64, leq, tg)
         lp.begin()
         assert lp.iterate(100) == xpoly_amd.six.XPG_RUNNING
-        if mode != "serial":
+        if mode != "pipe":
             assert lp.counters() == ((3, 1) if mode == "block" else (6, 1))
         assert lp.iterate(64) == xpoly_amd.six.XPG_RUNNING
-        if mode != "serial":
+        if mode != "pipe":
             assert lp.counters() == ((5, 1) if mode == "block" else (10, 1))
         out[mode] = lp.read()
         assert lp.pivots_done() == 164
         lp.close(); c.close()
     for mode in ("block", "block16"):
-        assert np.array_equal(bits(out[mode]["tab"]), bits(out["serial"]["tab"]))
-        assert np.array_equal(bits(out[mode]["tgtf"]), bits(out["serial"]["tgtf"]))
+        assert np.array_equal(bits(out[mode]["tab"]), bits(out["pipe"]["tab"]))
+        assert np.array_equal(bits(out[mode]["tgtf"]), bits(out["pipe"]["tgtf"]))
 
 
 def test_bench_two_ranks_real_solver_on_one_gpu():

@@ -326,11 +326,13 @@ def interval_lp_f64(m, n, seed=1, maxlen=24):
     return leq, tgtf
 
 
-def lp_block_f64(seed):
-    """One small block of block_lp_f64: 3..10 rows, 3..12 variables, origin feasible; even seeds small integers (exact
-    arithmetic), odd seeds U(0.1, 1) data (rounded arithmetic). Returns (A [m, n], b [m], c [n])."""
+def lp_block_f64(seed, wide=False):
+    """One small block of block_lp_f64: 3..10 rows, 3..12 variables (wide: 8..27), origin feasible; even seeds small
+    integers (exact arithmetic), odd seeds U(0.1, 1) data (rounded arithmetic). Returns (A [m, n], b [m], c [n])."""
     rng = np.random.default_rng([31337, seed])
     m = int(rng.integers(3, 11)); n = int(rng.integers(3, 13))
+    if wide:
+        n = int(rng.integers(8, 28))
     if seed % 2 == 0:
         A = rng.integers(0, 5, size=(m, n)).astype(np.float64)
         A[:, A.sum(axis=0) == 0] = 1.0                       # every variable bounded
@@ -343,14 +345,17 @@ def lp_block_f64(seed):
     return A, b, c
 
 
-def block_lp_f64(block_seeds):
+def block_lp_f64(block_seeds, wide=False):
     """A block-diagonal LP stored dense: maximise c.x, A x <= b, x >= 0 with A = diag(A_1 .. A_k), the blocks lp_block_f64(s)
     for s in block_seeds. The reference's pricing takes the first column with a positive cost, so it solves the blocks one after
     the other and the whole ends SIX_SUCC exactly when every block does (cells of other blocks are zeros: they add nothing to
     the row sums of the final feasibility check) -- the way to a LARGE fp64 LP that ends with status 0 and a non-zero optimum
     (dense random LPs of that size never do). The seeds come from a search with the oracle and are part of the
     fixture (tools/gen_golden_end.py). Returns (leq [m, n + 1], tgtf [n + 1])."""
-    blocks = [lp_block_f64(int(s)) for s in block_seeds]
+    return _assemble_blocks([lp_block_f64(int(s), wide) for s in block_seeds])
+
+
+def _assemble_blocks(blocks):
     m = sum(b[0].shape[0] for b in blocks); n = sum(b[0].shape[1] for b in blocks)
     leq = np.zeros((m, n + 1)); tgtf = np.zeros(n + 1)
     r = c = 0
@@ -360,3 +365,16 @@ def block_lp_f64(block_seeds):
         tgtf[c:c + A.shape[1]] = cc
         r += A.shape[0]; c += A.shape[1]
     return leq, tgtf
+
+
+def cover_block_f64(seed):
+    """The dual of lp_block_f64(seed) as a covering block: minimise b.x, A^T x >= c, x >= 0, written in the reference's
+    form -A^T x <= -c. Returns (A [n, m], b [n], c [m]) of that form."""
+    A, b, c = lp_block_f64(seed)
+    return -A.T.copy(), -c, b
+
+
+def cover_lp_f64(block_seeds):
+    """Block-diagonal covering LP for SIX::minm (minimise c.x, A x >= b, x >= 0, every right-hand side negative in the
+    a.x <= b form: the origin is infeasible for the primal, SIX::minm solves the dual): the blocks cover_block_f64(s)."""
+    return _assemble_blocks([cover_block_f64(int(s)) for s in block_seeds])

@@ -58,9 +58,44 @@ def main_cfg2b():
     print("written", OUT)
 
 
+SHAPES = {"tall": (16384, 2048), "wide": (1024, 20480), "square": (8192, 8192), "odd_width": (4096, 4094), "small": (2048, 2047)}
+SHAPES_OUT = os.path.join(ROOT, "tests", "golden", "g13_shapes.json")
+
+
+def main_shape(name, K=256):
+    """bench.py's `shapes` leg (VERDICT round 5, item 2): gen.hard_lp_f64(m, n) at LP shapes other than the headline's -- tall,
+    wide, square, a tableau of odd width, a small one -- after K = 256 pivots of the real reference's TwoStageMethod, so that the
+    pivots/s reported there are of verified states. tests/golden/g13_shapes.json."""
+    import fcntl
+    ref, port = Ref(), Port()
+    m, n = SHAPES[name]
+    leq, tgtf = gen.hard_lp_f64(m, n)
+    t0 = time.time()
+    p = port.two_stage(F64, leq, tgtf, K)
+    t1 = time.time()
+    prec = record(p, K, m, n)
+    del p
+    print(name, (m, n), "restatement %.1f s" % (t1 - t0), flush=True)
+    r = ref.two_stage(F64, leq, tgtf, K)
+    t2 = time.time()
+    rec = record(r, K, m, n)
+    del r
+    print(name, "reference %.1f s" % (t2 - t1), "agree" if prec == rec else "DIFFER", flush=True)
+    assert prec == rec, (prec, rec)
+    rec["reference_seconds"] = round(t2 - t1, 1)
+    with open(SHAPES_OUT + ".lock", "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        out = json.load(open(SHAPES_OUT)) if os.path.exists(SHAPES_OUT) else {}
+        out[name] = rec
+        json.dump(out, open(SHAPES_OUT, "w"), indent=1)
+    print("written", name, SHAPES_OUT)
+
+
 def main():
     if sys.argv[1:] == ["cfg2b"]:
         return main_cfg2b()
+    if len(sys.argv) > 1 and sys.argv[1] == "shape":
+        return main_shape(sys.argv[2])
     ks = [int(x) for x in sys.argv[1:]] or [1024, 2048, 3840]
     ref, port = Ref(), Port()
     leq, tgtf = gen.hard_lp_f64(M, N)

@@ -29,7 +29,7 @@ SYMBOLS = [
     "xpg_dep_is_empty_batch_rat32_multi", "xpg_dep_is_empty_batch_ex_rat32", "xpg_lineq_move2var_batch_rat32", "xpg_mip_warm_f64", "xpg_mip_warm_batch_f64", "xpg_six_last_profile", "xpg_lineq_calc_bound_batch_packed_rat32",
     "xpg_lineq_fme_batch_packed_rat32", "xpg_trim", "xpg_lp_chain_aborts", "xpg_test_sweep_tile", "xpg_test_pick_ld", "xpg_test_canon_ops_rat32", "xpg_test_any_ops_rat32",
     "xpg_six_batch_f64_ragged", "xpg_six_batch_rat32_ragged", "xpg_dep_is_empty_batch_ragged_rat32",
-    "xpg_lineq_reduce_batch_ragged_rat32", "xpg_lineq_fme_batch_ragged_rat32", "xpg_lineq_reduce_batch_packed_rat32",
+    "xpg_lineq_reduce_batch_ragged_rat32", "xpg_lineq_fme_batch_ragged_rat32", "xpg_lineq_reduce_batch_packed_rat32", "xpg_lp_loop_info", "xpg_test_normalize", "xpg_dep_is_empty_batch_mode_rat32",
 ]
 
 _lib = None

@@ -18,6 +18,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "xpoly_amd.hip")
 OUT = os.path.join(HERE, "libxpoly_amd.so")
 OBJ = os.path.join(HERE, "csrc", "_obj")
+# the same sources with -DXPG_TEST_HOOKS: fault injection, forced routes, debug prints and the lab's A/B knobs are compiled
+# in (scalar.hip.h xpg_hook). Loaded only by the tests that need a hook (tests/conftest.py needs_hooks) and by tools/lab.
+HOOKS_OUT = os.path.join(HERE, "libxpoly_amd_hooks.so")
+HOOKS_OBJ = os.path.join(HERE, "csrc", "_obj", "hooks")
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17"]
 PARTS = 4
 # headers each part includes (directly or not): a part is recompiled when one of them, or xpoly_amd.hip, is newer than
@@ -37,11 +41,26 @@ def sources():
     return [os.path.join(d, f) for f in sorted(os.listdir(d)) if os.path.isfile(os.path.join(d, f))] + [inc]
 
 
-def stale():
-    if not os.path.exists(OUT):
+def stale(out=OUT):
+    if not os.path.exists(out):
         return True
-    t = os.path.getmtime(OUT)
+    t = os.path.getmtime(out)
     return any(os.path.getmtime(s) > t for s in sources())
+
+
+def build_hooks(force=False):
+    """xpoly_amd/libxpoly_amd_hooks.so (-DXPG_TEST_HOOKS)."""
+    if not force and not stale(HOOKS_OUT):
+        return HOOKS_OUT
+    return build(force=force, extra=["-DXPG_TEST_HOOKS"], out=HOOKS_OUT, obj=HOOKS_OBJ)
+
+
+def build_all(force=False):
+    """The product library and the test-hooks variant, compiled side by side."""
+    with ThreadPoolExecutor(max_workers=2) as ex:
+        a = ex.submit(build, force)
+        b = ex.submit(build_hooks, force)
+        return a.result(), b.result()
 
 
 def build(force=False, extra=(), out=None, obj=None):
@@ -86,4 +105,9 @@ def build(force=False, extra=(), out=None, obj=None):
 if __name__ == "__main__":
     import sys
     # `python -m xpoly_amd.build` recompiles the parts whose sources changed; `--force` all four
-    print(build(force="--force" in sys.argv[1:]))
+    if "--hooks" in sys.argv[1:]:
+        print(build_hooks(force="--force" in sys.argv[1:]))
+    elif "--product" in sys.argv[1:]:
+        print(build(force="--force" in sys.argv[1:]))
+    else:
+        print(*build_all(force="--force" in sys.argv[1:]))

@@ -1265,33 +1265,33 @@ int batch_dev(xpg_ctx * ctx, int is_max, int nb, const S * tgtf, const S * leq, 
     const int R = is_max ? m : n, V = is_max ? n : m;
     size_t lds = small_lds_bytes<S>(R, V);
     if (lds > 160 * 1024) return XPG_ERR_UNSUPPORTED;     // one LP must fit one CU's LDS
-    if (const char * pad = getenv("XPG_BATCH_LDS_KB")) {  // A/B aid: request more LDS per LP = fewer LPs per CU (occupancy scaling curve)
+    if (const char * pad = xpg_hook("XPG_BATCH_LDS_KB")) {  // A/B aid: request more LDS per LP = fewer LPs per CU (occupancy scaling curve)
         const size_t want = (size_t)atoi(pad) * 1024;
         if (want > lds && want <= 160 * 1024) lds = want;
     }
     // measured on MI355X (32x64 LPs): 64 / 128 / 256 threads -> 61k / 91k / 118k LPs/s
     const int cells = R * (V + R + 2);
     int threads = cells >= 2048 ? 256 : (cells >= 1024 ? 128 : 64);
-    if (const char * c = getenv("XPG_BATCH_COUNT_CLOSES")) { if (c[0] == '1') raw_sol |= 2; }   // profiling aid
-    if (const char * t = getenv("XPG_BATCH_THREADS")) { const int v = atoi(t); if (v >= 64 && v <= 256 && v % 64 == 0) threads = v; }
+    if (const char * c = xpg_hook("XPG_BATCH_COUNT_CLOSES")) { if (c[0] == '1') raw_sol |= 2; }   // profiling aid
+    if (const char * t = xpg_hook("XPG_BATCH_THREADS")) { const int v = atoi(t); if (v >= 64 && v <= 256 && v % 64 == 0) threads = v; }
     const int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
     // One workgroup per LP up to 64 per CU-slot: the hardware's dispatcher then balances LPs of very different
     // lengths (the dependence-test family mixes phase-1 failures of a few dozen pivots with runs of thousands)
     // better than a fixed grid-stride assignment does.
     int grid = 256 * (per_cu > 16 ? 16 : per_cu) * 64;
-    if (const char * g = getenv("XPG_BATCH_GRID_X")) { const int v = atoi(g); if (v >= 1) grid = 256 * (per_cu > 16 ? 16 : per_cu) * v; }
+    if (const char * g = xpg_hook("XPG_BATCH_GRID_X")) { const int v = atoi(g); if (v >= 1) grid = 256 * (per_cu > 16 ? 16 : per_cu) * v; }
     if (grid > nb) grid = nb;
-    static const int waves_env = [] { const char * e = getenv("XPG_BATCH_WAVES"); return e ? atoi(e) : 0; }();   // A/B: 4 or 5
+    static const int waves_env = [] { const char * e = xpg_hook("XPG_BATCH_WAVES"); return e ? atoi(e) : 0; }();   // A/B: 4 or 5
     const bool five = (per_cu >= 5 && waves_env != 4) || waves_env == 5;
     // Time slices (k_batch): where the pivot loop can hand an LP back (sm_solve's `overlapped` shapes) and the launch holds
     // more LPs than the chip seats at once, so that LPs wait for slots at all. XPG_BATCH_SLICE=0 turns them off, =n sets
     // the slice (iterations of the LP's own solve per turn; 8192 dense LPs: 416.6 k LPs/s at 256, 418.4 k at 384-512, 414.6 k
     // at 768, 408.5 k at 1024, 313.5 k unsliced).
-    static const unsigned slice_env = [] { const char * e = getenv("XPG_BATCH_SLICE"); return e ? (unsigned)atoi(e) : 512u; }();
+    static const unsigned slice_env = [] { const char * e = xpg_env("XPG_BATCH_SLICE"); return e ? (unsigned)atoi(e) : 512u; }();
     BatchSlices Q;
     Q.slice = SM_NO_SLICE; Q.slice1 = SM_NO_SLICE; Q.nmain = grid; Q.ckpt = nullptr; Q.stride = 0; Q.queue = nullptr; Q.qmask = 0; Q.ctl = nullptr;
     const int seats = ctx->num_cus * (five ? (per_cu < 5 ? per_cu : 5) : (per_cu < 4 ? per_cu : 4));
-    static const bool slice_force = [] { const char * e = getenv("XPG_BATCH_SLICE_FORCE"); return e && e[0] == '1'; }();   // tests: also when every LP has a seat
+    static const bool slice_force = [] { const char * e = xpg_hook("XPG_BATCH_SLICE_FORCE"); return e && e[0] == '1'; }();   // tests: also when every LP has a seat
     if (slice_env != 0u && threads >= 128 && R <= 64 && R + V <= 127 && (nb > seats + seats / 4 || slice_force) && grid == nb) {
         const size_t stride = (CK_HEADER + lds + 255) & ~(size_t)255;
         size_t qcap = 1; while (qcap < (size_t)2 * nb) qcap <<= 1;
@@ -1305,7 +1305,7 @@ int batch_dev(xpg_ctx * ctx, int is_max, int nb, const S * tgtf, const S * leq, 
                 unsigned char * base = (unsigned char *)ctx->slice_buf;
                 // stage 1's solve in longer turns (8192 dependence-test LPs: 112 k LPs/s at 512, 124.7 k at 1024, 124.2 k at 2048, 122 k
                 // at 4096, 121 k unsliced; XPG_BATCH_SLICE_STAGE1=n, 0: not sliced; a forced test slice applies to both)
-                static const unsigned slice1_env = [] { const char * e = getenv("XPG_BATCH_SLICE_STAGE1"); return e ? (unsigned)atoi(e) : 1536u; }();
+                static const unsigned slice1_env = [] { const char * e = xpg_hook("XPG_BATCH_SLICE_STAGE1"); return e ? (unsigned)atoi(e) : 1536u; }();
                 Q.slice = slice_env; Q.slice1 = slice1_env == 0u ? SM_NO_SLICE : (slice_force ? slice_env : slice1_env); Q.ckpt = base; Q.stride = stride; Q.queue = (unsigned long long *)(base + stride * nb);
                 Q.qmask = (unsigned)(qcap - 1); Q.ctl = (unsigned *)(base + stride * nb + qcap * 8);
                 XPG_HIP(ctx, hipMemsetAsync(Q.queue, 0, qcap * 8 + 256, ctx->stream));

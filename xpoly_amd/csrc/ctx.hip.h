@@ -96,11 +96,11 @@ inline hipError_t lds_limit(const void * fn, int device, size_t bytes)
 // ldscan, profiles/round3_sweep_lab.txt: k * (32 KiB + 128 B) -- 8224, 12336, 16448 elements -- and 32 KiB - 128 B).
 inline int pick_ld(int W)
 {
-    static const int align = [] { const char * s = getenv("XPG_LD_ALIGN"); const int a = s ? atoi(s) : 64; return a >= 16 && a % 16 == 0 ? a : 64; }();
+    static const int align = [] { const char * s = xpg_hook("XPG_LD_ALIGN"); const int a = s ? atoi(s) : 64; return a >= 16 && a % 16 == 0 ? a : 64; }();
     int ld = W % 16 == 0 ? W : round_up(W, align);
     if (ld % 4112 == 0 || (ld + 16) % 4096 == 0) ld += 16;
     // A/B aid: XPG_LD_PAD=n (a multiple of 16 elements) widens every row by n
-    static const int pad = [] { const char * s = getenv("XPG_LD_PAD"); const int a = s ? atoi(s) : 0; return a > 0 && a % 16 == 0 ? a : 0; }();
+    static const int pad = [] { const char * s = xpg_hook("XPG_LD_PAD"); const int a = s ? atoi(s) : 0; return a > 0 && a % 16 == 0 ? a : 0; }();
     return ld + pad;
 }
 
@@ -162,7 +162,7 @@ inline LineqGeom lineq_geom(int nb, int width, size_t sys_lds)
 {
     LineqGeom q;
     q.L = width <= 16 ? 16 : (width <= 32 ? 32 : 64);
-    if (const char * e = getenv("XPG_LINEQ_LANES")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) q.L = v > q.L ? v : q.L; }
+    if (const char * e = xpg_hook("XPG_LINEQ_LANES")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) q.L = v > q.L ? v : q.L; }
     sys_lds = (sys_lds + 15) & ~(size_t)15;
     while (q.L < 64 && sys_lds * (size_t)(64 / q.L) > 64 * 1024) q.L *= 2;
     q.G = 64 / q.L;

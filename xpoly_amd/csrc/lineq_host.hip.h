@@ -124,7 +124,7 @@ inline int lineq_reduce_batch(xpg_ctx * ctx, int nb, R32 * mats, int rows, int c
 struct FmeLds { int cap_lds; size_t lds; };
 inline FmeLds fme_lds(int cap, int cap_in, int cols)
 {
-    static const int full_kb = [] { const char * e = getenv("XPG_FME_FULL_KB"); return e ? atoi(e) : 12; }();   // A/B knob
+    static const int full_kb = [] { const char * e = xpg_hook("XPG_FME_FULL_KB"); return e ? atoi(e) : 12; }();   // A/B knob
     const int capx = cap > cap_in ? cap : cap_in;
     const size_t scratch = lineq_lds_bytes(capx, cols) - (size_t)capx * cols * 8 + 16;
     const size_t tmp = (size_t)cap_in * cols * 8;
@@ -310,7 +310,7 @@ inline int lineq_fme_batch_packed(xpg_ctx * ctx, int nb, const R32 * mats, int r
     // the input in the caller's pageable memory the runtime stages every upload itself and the two directions do not overlap --
     // 16 384 systems of 40 x 13: 2.25 M systems/s on one stream, 1.78 / 1.71 / 2.20 M with 4 / 8 / 16 chunks; 60 x 20: 0.757 M
     // against 0.621 / 0.592 / 0.811 M (tools/lab/run_fme_chunks_ab.sh).
-    static const int chunks_env = [] { const char * e = getenv("XPG_FME_CHUNKS"); return e ? atoi(e) : 0; }();
+    static const int chunks_env = [] { const char * e = xpg_hook("XPG_FME_CHUNKS"); return e ? atoi(e) : 0; }();
     if ((out || view) && nb >= 2048 && bi + bo / 3 >= ((size_t)96 << 20) && chunks_env > 1) {
         int nch = chunks_env;
         if (nch > 16) nch = 16;
@@ -320,7 +320,7 @@ inline int lineq_fme_batch_packed(xpg_ctx * ctx, int nb, const R32 * mats, int r
     DevBuf di, dout, dr, dk, doff, dpk;
     XPG_TRY(di.alloc(ctx, bi)); XPG_TRY(dout.alloc(ctx, bo)); XPG_TRY(dr.alloc(ctx, (size_t)nb * 4)); XPG_TRY(dk.alloc(ctx, (size_t)nb * 4));
     XPG_TRY(doff.alloc(ctx, (size_t)(nb + 1) * 8));
-    static const bool dbg = getenv("XPG_LINEQ_DEBUG") != 0;
+    static const bool dbg = xpg_hook("XPG_LINEQ_DEBUG") != 0;
     const auto T0 = std::chrono::steady_clock::now();
     auto lap = [&](const char * what) { if (dbg) { (void)hipStreamSynchronize(ctx->stream); fprintf(stderr, "  fme_packed %-10s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count()); } };
     const bool small_in = bi <= ((size_t)4 << 20), small_out = bo <= ((size_t)512 << 10);

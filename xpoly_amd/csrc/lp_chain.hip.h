@@ -435,7 +435,8 @@ __device__ unsigned long long g_ch_ts[4][BLK_MAX][8];            // [worker clas
 // 16, 2 x 1 89.1 / 69.6, 1 x 2 86.8 / 69.3, 2 x 2 85.2 / 61.5, 2 x 4 75.3 / 61.4 -- the arithmetic of ONE wave is what a
 // stage is made of, so it is split over more waves, not fewer.
 // nparts0: how many partials the stage before t0 left (a launch of its own: one per 64 columns, like the chain's).
-// force_abort: test hook (XPG_CHAIN_TEST_ABORT=k makes every k-th chain launch fail its roll call, -k its placement check).
+// force_abort: test hook, compiled under -DXPG_TEST_HOOKS only (XPG_CHAIN_TEST_ABORT=k makes every k-th chain launch fail its
+// roll call, -k its placement check); the product build ignores the argument.
 // LOCAL: the workers are the workgroups with blockIdx % 8 == 0 of a grid of 8 x workers -- workgroups are dealt round-robin
 // over the 8 XCDs, so these all land on ONE XCD, whose L2 then is the point of coherence of every hand-off: plain stores,
 // sc1 (L1-bypassing) loads, an L2 round trip per hop instead of a fabric one. The placement is an observation, not a
@@ -486,7 +487,9 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
         const unsigned long long t_in = wall_clock64();
         bool go = false, misplaced = false;
         for (;;) {
-            if (force_abort) { misplaced = force_abort == 2; break; }
+#ifdef XPG_TEST_HOOKS
+            if (force_abort) { misplaced = force_abort == 2; break; }     // fault injection: compiled into the hooks build only
+#endif
             // lanes 0..7 read one XCD's counter each
             const unsigned mine = ch_ld(&st->blk.ch_arrive[lane & 7]);
             unsigned sum = 0, top = 0;

@@ -107,6 +107,60 @@ template <> inline void launch_fused<R32>(xpg_ctx * ctx, const LpView<R32> & v, 
 }
 template <> inline void launch_side_home<R32>(xpg_ctx * ctx, const LpView<R32> & v)
 { hipLaunchKernelGGL(k_side_home, dim3(v.m, (v.W + 255) / 256), dim3(256), 0, ctx->stream, v); }
+// What a batch of the blocked loop launches for an fp64 tableau of a given shape -- decided in ONE place: launch_blk_batch
+// launches it, Lp::blocked_from_bytes asks whether the chain can run at all (the automatic loop choice), xpg_lp_loop_info
+// reports it (bench.py's `shapes` leg).
+// workgroup sizes of pick and prep: 64 = one wave per workgroup, no LDS round in the reductions
+// (measured at 4096 x 8192: 58.7 k pivots/s with a 64-thread pick against 55.7 k with 256; prep +0.8 %)
+inline int blk_tpb_pick() { static const int t = [] { const char * s = xpg_hook("XPG_BLK_TPB_PICK"); return s && atoi(s) == 256 ? 256 : 64; }(); return t; }
+inline int blk_tpb_prep() { static const int t = [] { const char * s = xpg_hook("XPG_BLK_TPB_PREP"); return s && atoi(s) == 256 ? 256 : 64; }(); return t; }
+// Stages 1 .. B-1 in one persistent launch: one one-wave worker per 64 rows / 64 columns, all resident at once -- they
+// poll each other's records. The launch checks that itself (roll call, lp_chain.hip.h) and falls back when the device
+// cannot seat them all, so the shape limits here are only those of the hand-off areas: 256 records (m <= 16 384), 511
+// partial slots (W <= 32 640), and at most eight workers per CU. Taller or wider tableaux, and the opt-in Dantzig pricing,
+// take the launch-per-stage path.
+// shapes the blocked loop's hand-off areas can hold at all (launch-per-stage form: 510 partial slots of up to 256 columns)
+inline bool blk_shape_ok(int W) { return (W + 255) / 256 <= 510; }
+inline bool chain_shape_ok(const xpg_ctx * ctx, int m, int W)
+{
+    const int cpick = (m + 63) / 64, cprep = (W + 63) / 64;
+    const int cus = ctx->num_cus > 0 ? ctx->num_cus : 1;
+    return cpick <= BLK_REC_MAX && cprep <= 510 && cpick + cprep + 1 <= 8 * cus &&
+           blk_tpb_prep() == 64;                   // stage 0's prep leaves one look-ahead partial per 64 columns, as the chain's workers do
+}
+struct BlkPlan {
+    bool chain;            // a batch's stages in one persistent launch (else pick / prep kernels per stage)
+    bool local;            // ... every worker on one XCD, hand-offs through that XCD's L2 (else the spread form, sc1 stores)
+    int line;              // ... the entering column's line in the pick workers' LDS: 0 / 8 / 16 elements
+    int cpick, cprep, workers;
+    size_t lds;
+    int sweep_rows;        // rows per workgroup of the full-batch pass (16 / 32)
+};
+inline BlkPlan blk_plan(const xpg_ctx * ctx, int m, int W, int ld, int B, bool ref_pricing, bool chain_off, bool chain_spread, bool fold)
+{
+    BlkPlan p;
+    p.cpick = (m + 63) / 64; p.cprep = (W + 63) / 64; p.workers = p.cpick + p.cprep + 1;
+    const int cus = ctx->num_cus > 0 ? ctx->num_cus : 1;
+    p.chain = ctx->chain && !chain_off && ref_pricing && (B > 1 || fold) && chain_shape_ok(ctx, m, W);
+    // every worker on one XCD, hand-offs through that XCD's L2 (lp_chain.hip.h) -- where one XCD seats them all: a
+    // worker is one wave with 16 KB of LDS, an XCD has cus / 8 CUs of 160 KB; XPG_CHAIN_XCD=0, or a launch whose
+    // placement check failed, selects the spread form with sc1 stores
+    p.local = p.chain && ctx->chain_local && !chain_spread && p.workers <= (cus / 8) * 9;
+    // the entering column's line in the pick workers' LDS (lp_chain.hip.h, LINE): where the row stride is a multiple of
+    // 4 KiB -- the L1 then keeps next to nothing of a column -- and one XCD still seats every worker with the larger
+    // LDS block; XPG_CHAIN_LINE=0|1|8 forces it off / on / on as a half line for A/B runs and tests
+    static const int line_env = [] { const char * s = xpg_hook("XPG_CHAIN_LINE"); return s ? atoi(s) : -1; }();
+    auto line_fits = [&](int cols) {
+        return (size_t)p.workers * ch_lds_bytes(B, cols) <= (size_t)(cus / 8) * 160 * 1024 &&
+               (size_t)p.workers <= (size_t)(cus / 8) * ((size_t)160 * 1024 / ch_lds_bytes(B, cols));
+    };
+    const bool want_line = p.local && (line_env == 1 || line_env == 8 || (line_env != 0 && ld % 512 == 0));      // (8: the half line wherever it fits, for tests)
+    p.line = !want_line ? 0 : (line_env != 8 && line_fits(16)) ? 16 : line_fits(8) ? 8 : 0;
+    p.lds = ch_lds_bytes(B, p.line);
+    // 32 stages: 16 rows per workgroup where the tableau is of the Infinity Cache's size, 32 rows beyond it (see the launch)
+    p.sweep_rows = (size_t)m * ld * sizeof(double) > ((size_t)320 << 20) ? 32 : 16;
+    return p;
+}
 // One batch of the blocked loop: B x (pick, prep) -- the generic pick once after pick(0) -- and a sweep.
 // fold: this batch's stage 0 is the chain launch's (t0 = 0) -- no pick / generic pick / prep launches. Speculative: the chain
 // launch of the batch before admits it by a ticket once it has committed all its stages; without the ticket this batch's
@@ -117,50 +171,28 @@ template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> &
                                               bool chain_spread, bool fold, bool next_folds)
 {
     const int strips = (v.W + 511) / 512;
-    // workgroup sizes of pick and prep: 64 = one wave per workgroup, no LDS round in the reductions
-    // (measured at 4096 x 8192: 58.7 k pivots/s with a 64-thread pick against 55.7 k with 256; prep +0.8 %)
-    static const int tpb_pick = [] { const char * s = getenv("XPG_BLK_TPB_PICK"); return s && atoi(s) == 256 ? 256 : 64; }();
-    static const int tpb_prep = [] { const char * s = getenv("XPG_BLK_TPB_PREP"); return s && atoi(s) == 256 ? 256 : 64; }();
-    const int tq = tpb_prep, tp = tpb_pick;
+    // prep workgroups leave one look-ahead partial each and there are 510 partial slots (BLK_PART_MAX): one wave per 64 columns
+    // up to W = 32 640, four beyond (W <= 130 560; wider tableaux do not take the blocked loop, blk_shape_ok). Round 6: a
+    // 1024 x 33793 tableau ran 529 one-wave prep workgroups over the 520 slots -- a memory fault.
+    const int tq = (v.W + blk_tpb_prep() - 1) / blk_tpb_prep() <= 510 ? blk_tpb_prep() : 256, tp = blk_tpb_pick();
     const int want_pick = (v.m + tp - 1) / tp;
     const int npick = want_pick < BLK_PICK_WGS ? want_pick : BLK_PICK_WGS;
     const dim3 gprep((v.W + tq - 1) / tq);
-    // Stages 1 .. B-1 in one persistent launch: one one-wave worker per 64 rows / 64 columns, all resident at once -- they
-    // poll each other's records. The launch checks that itself (roll call, lp_chain.hip.h) and falls back when the device
-    // cannot seat them all, so the shape limits here are only those of the hand-off areas: 256 records, 511 partial slots
-    // (W <= 32 640), and at most four workers per CU. Taller or wider tableaux, and the opt-in Dantzig pricing, take the
-    // launch-per-stage path.
-    const int cpick = (v.m + 63) / 64, cprep = (v.W + 63) / 64;
-    const int workers = cpick + cprep + 1;
-    const int cus = ctx->num_cus > 0 ? ctx->num_cus : 1;
-    const bool chain = ctx->chain && !chain_off && ref_pricing && (B > 1 || fold) &&
-                       cpick <= BLK_REC_MAX && cprep <= 510 && workers <= 8 * cus &&
-                       tpb_prep == 64;             // stage 0's prep leaves one look-ahead partial per 64 columns, as the chain's workers do
+    const BlkPlan pl = blk_plan(ctx, v.m, v.W, v.ld, B, ref_pricing, chain_off, chain_spread, fold);
+    const int cpick = pl.cpick, cprep = pl.cprep, workers = pl.workers;
     for (int t = 0; t < B; t++) {
-        if (chain && (t == 1 || fold)) {
+        if (pl.chain && (t == 1 || fold)) {
             const int t0 = fold ? 0 : 1;
             const int test_abort = ctx->chain_test_abort;
-            // every worker on one XCD, hand-offs through that XCD's L2 (lp_chain.hip.h) -- where one XCD seats them all: a
-            // worker is one wave with 16 KB of LDS, an XCD has cus / 8 CUs of 160 KB; XPG_CHAIN_XCD=0, or a launch whose
-            // placement check failed, selects the spread form with sc1 stores
-            const bool local = ctx->chain_local && !chain_spread && workers <= (cus / 8) * 9;
+            const bool local = pl.local;
             // test hooks: k > 0 -- every k-th launch fails its roll call; k < 0 -- every |k|-th ONE-XCD launch "finds" its
             // workers on several XCDs (the spread form has no placement to check)
             const int fa = test_abort > 0 ? (batch % test_abort == test_abort - 1 ? 1 : 0)
                                           : (test_abort < 0 && local && batch % -test_abort == -test_abort - 1 ? 2 : 0);
             const int nparts0 = (int)gprep.x;
             const int fn = next_folds ? 1 : 0;
-            // the entering column's line in the pick workers' LDS (lp_chain.hip.h, LINE): where the row stride is a multiple of
-            // 4 KiB -- the L1 then keeps next to nothing of a column -- and one XCD still seats every worker with the larger
-            // LDS block; XPG_CHAIN_LINE=0|1|8 forces it off / on / on as a half line for A/B runs and tests
-            static const int line_env = [] { const char * s = getenv("XPG_CHAIN_LINE"); return s ? atoi(s) : -1; }();
-            auto line_fits = [&](int cols) {
-                return (size_t)workers * ch_lds_bytes(B, cols) <= (size_t)(cus / 8) * 160 * 1024 &&
-                       (size_t)workers <= (size_t)(cus / 8) * ((size_t)160 * 1024 / ch_lds_bytes(B, cols));
-            };
-            const bool want_line = local && (line_env == 1 || line_env == 8 || (line_env != 0 && v.ld % 512 == 0));      // (8: the half line wherever it fits, for tests)
-            const int line = !want_line ? 0 : (line_env != 8 && line_fits(16)) ? 16 : line_fits(8) ? 8 : 0;
-            const size_t lds = ch_lds_bytes(B, line);
+            const int line = pl.line;
+            const size_t lds = pl.lds;
             if (local && line == 16) hipLaunchKernelGGL((k_blk_chain<true, 16>), dim3(8 * workers), dim3(64), lds, ctx->stream, v, batch, t0, B, cpick, cprep, nparts0, fa, fn);
             else if (local && line == 8) hipLaunchKernelGGL((k_blk_chain<true, 8>), dim3(8 * workers), dim3(64), lds, ctx->stream, v, batch, t0, B, cpick, cprep, nparts0, fa, fn);
             else if (local) hipLaunchKernelGGL((k_blk_chain<true, 0>), dim3(8 * workers), dim3(64), lds, ctx->stream, v, batch, t0, B, cpick, cprep, nparts0, fa, fn);
@@ -175,9 +207,9 @@ template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> &
     // of an xpg_lp_iterate budget -- moves the same bytes for fewer pivots and runs a different kernel)
     const bool timed = B == ctx->block_len && ctx->prof_n < ctx->prof_cap && (ctx->prof_seen++ % ctx->prof_stride) == 0;
     hipEvent_t e0 = timed ? ctx->ev0[ctx->prof_n] : nullptr, e1 = timed ? ctx->ev1[ctx->prof_n] : nullptr;
-    static const int rows_env = [] { const char * s = getenv("XPG_BLK_ROWS"); return s ? atoi(s) : 32; }();
+    static const int rows_env = [] { const char * s = xpg_hook("XPG_BLK_ROWS"); return s ? atoi(s) : 32; }();
     // alternate passes walk the row blocks in opposite directions (Infinity Cache reuse across passes); XPG_SERPENTINE=0 for A/B runs
-    static const int serpentine = [] { const char * s = getenv("XPG_SERPENTINE"); return s ? atoi(s) : 1; }();
+    static const int serpentine = [] { const char * s = xpg_hook("XPG_SERPENTINE"); return s ? atoi(s) : 1; }();
 #define XPG_BLK_LAUNCH(ROWS_, UNR_, CAP_)                                                                                 \
     hipExtLaunchKernelGGL((k_blk_sweep<ROWS_, UNR_, CAP_>), dim3(strips, (v.m + ROWS_ - 1) / ROWS_), dim3(256), 0,        \
                           ctx->stream, e0, e1, 0, (double *)v.tab, v.m, v.W, v.ld, (const double *)v.blkE,                \
@@ -194,7 +226,7 @@ template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> &
     // 32 stages: 16 rows per workgroup where the tableau is of the Infinity Cache's size (4096 x 8192: 93.9 us against 95.5
     // with 32 rows), 32 rows -- the e_s read from the L2 half as often -- where it is beyond it (4096 x 12289, 403 MB: 150.0
     // against 156.1 us, 105.7 k against 103.9 k pivots/s); XPG_BLK_ROWS = 162 / 322 / 164 force a form for A/B runs
-    const bool beyond_mall = (size_t)v.m * v.ld * sizeof(double) > ((size_t)320 << 20);
+    const bool beyond_mall = pl.sweep_rows == 32;
     if (full32) {
         if (rows_env == 322 || (rows_env == 32 && beyond_mall)) XPG_BLK_FULL(32, 2, 32);
         else if (rows_env == 164) XPG_BLK_FULL(16, 4, 32);
@@ -218,7 +250,7 @@ template <> inline void launch_blk_batch<F64>(xpg_ctx * ctx, const LpView<F64> &
 template <> inline void launch_update<R32>(xpg_ctx * ctx, const LpView<R32> & v, int guarded)
 {
     const bool timed = prof_open(ctx);
-    static const int rows = [] { const char * s = getenv("XPG_R32_ROWS"); return s ? atoi(s) : 1; }();   // A/B knob: 8 / 4 / 2 / 1 rows per thread measured 15.6 / 16.5 / 16.8 / 17.2 k pivots/s at 1024 x 2048
+    static const int rows = [] { const char * s = xpg_hook("XPG_R32_ROWS"); return s ? atoi(s) : 1; }();   // A/B knob: 8 / 4 / 2 / 1 rows per thread measured 15.6 / 16.5 / 16.8 / 17.2 k pivots/s at 1024 x 2048
     if (rows <= 1) hipLaunchKernelGGL((k_update_r32<1>), dim3(v.m, (v.W + 255) / 256), dim3(256), 0, ctx->stream, v, guarded);
     else if (rows == 2) hipLaunchKernelGGL((k_update_r32<2>), dim3((v.m + 1) / 2, (v.W + 255) / 256), dim3(256), 0, ctx->stream, v, guarded);
     else if (rows == 4) hipLaunchKernelGGL((k_update_r32<4>), dim3((v.m + 3) / 4, (v.W + 255) / 256), dim3(256), 0, ctx->stream, v, guarded);
@@ -460,16 +492,28 @@ template <class S> struct Lp : LpBase {
     // line. XPG_BLOCK_FROM_KB overrides both for A/B runs.
     size_t blocked_from_bytes() const
     {
-        static const long env_kb = [] { const char * s = getenv("XPG_BLOCK_FROM_KB"); return s ? atol(s) : -1L; }();
+        static const long env_kb = [] { const char * s = xpg_env("XPG_BLOCK_FROM_KB"); return s ? atol(s) : -1L; }();
         if (env_kb >= 0) return (size_t)env_kb << 10;
-        const bool chain_usable = ctx->chain && !chain_off && opt_pricing == 0;
+        const bool chain_usable = ctx->chain && !chain_off && opt_pricing == 0 && chain_shape_ok(ctx, v.m, v.W);   // (the same test launch_blk_batch applies)
         return chain_usable ? ((size_t)64 << 10) : ((size_t)16 << 20);
+    }
+    // xpg_lp_loop_info: what queue_iterations / launch_blk_batch would run for the LP as it stands
+    void loop_info(int32_t * o)
+    {
+        const bool blocked = std::is_same<S, F64>::value && !irregular && blk_shape_ok(v.W) &&
+                             (ctx->loop_mode == 3 || (ctx->loop_auto && (size_t)v.m * v.W * 16 >= blocked_from_bytes()));
+        o[0] = blocked ? 3 : ctx->loop_mode == 1 ? 1 : 0;
+        o[5] = v.ld;
+        if (!blocked) return;
+        const BlkPlan pl = blk_plan(ctx, v.m, v.W, v.ld, ctx->block_len, opt_pricing == 0, chain_off, chain_spread, true);
+        o[1] = ctx->block_len; o[2] = !pl.chain ? 0 : pl.local ? 1 : 2; o[3] = pl.line; o[4] = ctx->block_len == 32 ? pl.sweep_rows : 16;
+        o[6] = pl.workers; o[7] = pl.cpick; o[8] = pl.cprep; o[9] = (int32_t)pl.lds;
     }
     void queue_iterations(unsigned k)
     {
         unsigned blk = 0;
         // blocked loop: chosen explicitly, or by default from blocked_from_bytes() of sweep traffic up
-        bool blocked = std::is_same<S, F64>::value &&
+        bool blocked = std::is_same<S, F64>::value && blk_shape_ok(v.W) &&
                        (ctx->loop_mode == 3 || (ctx->loop_auto && (size_t)v.m * v.W * 16 >= blocked_from_bytes()));
         if (blocked && !irregular_known) {                 // once per build: did k_build meet an inf or a NaN? (LoopState::noncanon)
             LoopState hs;
@@ -479,17 +523,18 @@ template <class S> struct Lp : LpBase {
         if (blocked && irregular) blocked = false;          // NaN ratios need the generic pick's scan order: the pipelined loop has it
         blocked_now = blocked;
         if (blocked) { queue_blocked(k); return; }
-        // (the rational scalar: XPG_R32_LOOP=serial keeps the three-launch loop, =pipe the two-launch one, for A/B runs)
-        static const bool r32_serial = [] { const char * s = getenv("XPG_R32_LOOP"); return s && !strcmp(s, "serial"); }();
-        static const bool r32_pipe = [] { const char * s = getenv("XPG_R32_LOOP"); return s && !strcmp(s, "pipe"); }();
-        static const unsigned generic_every = [] { const char * s = getenv("XPG_R32_GENERIC_EVERY"); const int n = s ? atoi(s) : 0; return (unsigned)(n > 0 ? n : 16); }();
+        // (the rational scalar: XPG_R32_LOOP=pipe forces the two-launch loop, =fused the one-launch loop; =serial, the three-launch
+        // loop -- neither a default nor a fallback -- exists in the -DXPG_TEST_HOOKS build only)
+        static const bool r32_serial = [] { const char * s = xpg_hook("XPG_R32_LOOP"); return s && !strcmp(s, "serial"); }();
+        static const bool r32_pipe = [] { const char * s = xpg_env("XPG_R32_LOOP"); return s && !strcmp(s, "pipe"); }();
+        static const unsigned generic_every = [] { const char * s = xpg_hook("XPG_R32_GENERIC_EVERY"); const int n = s ? atoi(s) : 0; return (unsigned)(n > 0 ? n : 16); }();
         const bool pipelined = ctx->loop_mode != 1 && (std::is_same<S, F64>::value || !r32_serial);
         // The fused loop where it pays: its sweep copies the columns the in-place sweep skips (ping-pong tableau) and its
         // launch lasts as long as the pick -> staging chain inside it. Measured against the two-launch loop
         // (tools/lab/probe_rat_sizes.py, us per pivot fused / two-launch): 256 x 512 21.4 / 19.9, 384 x 785 21.0 / 21.0,
         // 512 x 1213 17.0 / 18.0, 768 x 1769 16.7 / 20.9, 1024 x 2048 19.7 / 24.7, 1280 x 2281 27.0 / 30.3, 1536 x 2637
         // 32.0 / 31.8, 2048 x 3549 51.5 / 46.4. XPG_R32_LOOP=fused / pipe force one or the other.
-        static const bool r32_fused = [] { const char * s = getenv("XPG_R32_LOOP"); return s && !strcmp(s, "fused"); }();
+        static const bool r32_fused = [] { const char * s = xpg_env("XPG_R32_LOOP"); return s && !strcmp(s, "fused"); }();
         const size_t cells = (size_t)v.m * (size_t)v.W;
         const bool fused_pays = r32_fused || (cells >= 350000u && cells <= 5000000u);
         if (pipelined && !std::is_same<S, F64>::value && !r32_pipe && fused_pays && k > 0 && fused_buffers()) {

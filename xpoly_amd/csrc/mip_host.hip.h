@@ -223,7 +223,7 @@ public:
     MipPool()
     {
         unsigned nt = 1;                                    // the calling thread alone unless XPG_HOST_THREADS says otherwise (see above)
-        if (const char * e = getenv("XPG_HOST_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) nt = (unsigned)v; }
+        if (const char * e = xpg_env("XPG_HOST_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) nt = (unsigned)v; }
         for (unsigned w = 1; w < nt; w++) th_.emplace_back([this, w] { worker((int)w); });
     }
     ~MipPool()
@@ -264,7 +264,7 @@ template <class S> int run_mip_tasks(xpg_ctx * ctx, int kind, std::vector<MipTas
     struct Key { int is_max, rows, cols; bool operator<(const Key & o) const
         { return is_max != o.is_max ? is_max < o.is_max : (rows != o.rows ? rows < o.rows : cols < o.cols); } };
     const std::vector<S> none;
-    static const bool dbg = getenv("XPG_MIP_DEBUG") != 0;
+    static const bool dbg = xpg_hook("XPG_MIP_DEBUG") != 0;
     int rounds = 0, launches = 0; double t_prep = 0, t_gpu = 0, t_feed = 0;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (;;) {
@@ -326,7 +326,7 @@ template <class S> int run_mip_tasks(xpg_ctx * ctx, int kind, std::vector<MipTas
         for (size_t q = 0; q < large.size(); q++) {
             MipTask<S> & T = tasks[large[q]];
             std::vector<S> y;
-            const int st = solve_large(ctx, kind, T.is_max, T.F, 10000u, y);
+            const int st = solve_large(ctx, kind, T.is_max, T.F, (const S *)0, (const S *)0, 10000u, y);
             T.on_lp(st, y);
         }
     }
@@ -349,7 +349,7 @@ int mip_solve(xpg_ctx * ctx, int kind, bool is_max, bool is_bin, const S * tgtf,
         return XPG_ERR_SHAPE;
     // x >= 0 (vc = -I) with inequalities and / or equalities at the root, with or without a rational_indicator, is what
     // the device tree walk takes; free or otherwise bounded variables stay with the host controller
-    static const bool on_device = [] { const char * e = getenv("XPG_MIP_DEVICE"); return !(e && e[0] == '0'); }();
+    static const bool on_device = [] { const char * e = xpg_env("XPG_MIP_DEVICE"); return !(e && e[0] == '0'); }();
     if (on_device && mip_device_fits<S>(leq_rows, cols, is_bin, eq_rows)) {
         bool plain = true;
         for (int i = 0; i < vc_rows && plain; i++)
@@ -408,7 +408,7 @@ template <class S> inline MipGeom mip_geom(const xpg_ctx * ctx, int nb, int rmax
     // more trees than the chip holds at that width: one wave per tree, more trees in flight (8192 knapsacks of 24
     // variables: 64 / 128 / 256 threads 623 k / 425 k / 318 k MIPs/s; at 1024, where the deepest tree decides, 163 / 171 / 170 k)
     if (nb >= 8 * cus) g.threads = 64;
-    if (const char * t = getenv("XPG_BATCH_THREADS")) { const int v = atoi(t); if (v >= 64 && v <= 256 && v % 64 == 0) g.threads = v; }
+    if (const char * t = xpg_hook("XPG_BATCH_THREADS")) { const int v = atoi(t); if (v >= 64 && v <= 256 && v % 64 == 0) g.threads = v; }
     const int per_cu = (int)((160 * 1024) / g.lds) > 0 ? (int)((160 * 1024) / g.lds) : 1;
     g.grid = cus * (per_cu > 8 ? 8 : per_cu) * 4;
     if (g.grid > nb) g.grid = nb;
@@ -443,7 +443,7 @@ int mip_batch_device(xpg_ctx * ctx, int nb, bool is_max, bool is_bin, const S * 
     // Speculative ceiling children (mip_kernels.hip.h, SP_*): for batches that leave the chip under-filled -- one tree per
     // walking workgroup, the batch lasts as long as its deepest tree -- helper workgroups behind the walkers solve the node
     // LPs the walks will need next. Not with root equalities (the helper builds plain nodes only). XPG_MIP_SPEC=0: off.
-    static const int spec_env = [] { const char * e = getenv("XPG_MIP_SPEC"); return e ? atoi(e) : 1; }();
+    static const int spec_env = [] { const char * e = xpg_hook("XPG_MIP_SPEC"); return e ? atoi(e) : 1; }();
     const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
     const bool spec = spec_env != 0 && eq_rows == 0 && grid == nb && nb <= 8 * cus;
     const int nhelp = spec ? (spec_env > 1 ? spec_env : cus) : 0;        // (256 / 512 / 2048 helpers measured alike: 3.72 / 3.77 / 3.86 ms for 1024 knapsacks, 4.41 without)
@@ -462,7 +462,7 @@ int mip_batch_device(xpg_ctx * ctx, int nb, bool is_max, bool is_bin, const S * 
                        allow_rational ? (const uint8_t *)dal.p : (const uint8_t *)0, eq_rows > 0 ? (const S *)de.p : (const S *)0, eq_rows,
                        grid, spec ? (int *)dq.p : (int *)0);
     XPG_TRY(hipGetLastError());
-    if (spec && getenv("XPG_MIP_DEBUG")) {
+    if (spec && xpg_hook("XPG_MIP_DEBUG")) {
         int hq[4] = {0, 0, 0, 0};
         XPG_TRY(hipMemcpyAsync(hq, dq.p, sizeof(hq), hipMemcpyDeviceToHost, ctx->stream));
         XPG_TRY(hipStreamSynchronize(ctx->stream));
@@ -486,7 +486,7 @@ int mip_batch(xpg_ctx * ctx, int kind, int nb, bool is_max, bool is_bin, const S
     if (!ctx || nb < 0 || !tgtf || !leq || leq_rows <= 0 || cols < 2 || !out_status || !out_v) return XPG_ERR_SHAPE;
     if (nb == 0) return 0;
     // the whole tree walk on the device where the node LPs fit (XPG_MIP_DEVICE=0: the host controller, for A/B runs)
-    static const bool on_device = [] { const char * e = getenv("XPG_MIP_DEVICE"); return !(e && e[0] == '0'); }();
+    static const bool on_device = [] { const char * e = xpg_env("XPG_MIP_DEVICE"); return !(e && e[0] == '0'); }();
     if (on_device) {
         const int rc = mip_batch_device<S>(ctx, nb, is_max, is_bin, tgtf, leq, leq_rows, cols, out_status, out_v, out_sol, out_nodes, (const uint8_t *)0, (const S *)0, 0);
         if (rc != XPG_ERR_UNSUPPORTED) return rc;
@@ -524,7 +524,7 @@ int mip_batch_eq(xpg_ctx * ctx, int kind, int nb, bool is_max, bool is_bin, cons
     if (!ctx || nb < 0 || !tgtf || eq_rows <= 0 || !eqs || leq_rows < 0 || (leq_rows > 0 && !leq) || cols < 2 || !out_status || !out_v)
         return XPG_ERR_SHAPE;
     if (nb == 0) return 0;
-    static const bool on_device = [] { const char * e = getenv("XPG_MIP_DEVICE"); return !(e && e[0] == '0'); }();
+    static const bool on_device = [] { const char * e = xpg_env("XPG_MIP_DEVICE"); return !(e && e[0] == '0'); }();
     if (on_device && mip_device_fits<S>(leq_rows, cols, is_bin, eq_rows)) {
         const int rc = mip_batch_device<S>(ctx, nb, is_max, is_bin, tgtf, leq, leq_rows, cols, out_status, out_v, out_sol, out_nodes,
                                            (const uint8_t *)0, eqs, eq_rows);
@@ -598,15 +598,18 @@ inline int has_solution(xpg_ctx * ctx, const R32 * leq, int leq_rows, const R32 
 // variables while the matrix has grown by the symbols, which SIX::verify (lpsol.h:1526-1552, "No yet support const
 // term with multi-columns") only ASSERTs in debug builds -- those systems get XPG_ERR_REF_UNDEFINED, the ones
 // reduce decides get their answer.
+// symbols_as_vars (opt-in, NOT parity: XPG_DEP_SYMBOLS_AS_VARS): the evident intent of poly.cpp:530-573 for a parametrised
+// polyhedron -- after move2var the constant symbols ARE variables (free ones: nothing is known of their sign), so has_solution
+// is asked about the widened system, rhs_idx = the last column, vc widened by all-zero rows / columns for the symbols.
 inline int dep_is_empty_batch(xpg_ctx * ctx, int nb, const R32 * mats, int rows, int cols, int rhs_idx, const R32 * vc_in,
-                              int32_t * out_empty, long * out_nodes)
+                              int32_t * out_empty, long * out_nodes, int symbols_as_vars = 0)
 {
     if (!ctx || nb < 0 || !mats || rows <= 0 || cols < 2 || !out_empty || rhs_idx < 1 || rhs_idx > cols - 1) return XPG_ERR_SHAPE;
     if (nb == 0) return 0;
     const int last = cols - 1, nsym = last - rhs_idx;
     // No constant symbols and the default x >= 0: the whole test stays on the device -- reduce, the feasibility
     // objectives, the integer maxm walk, the minm walk of what that left open -- and only the verdicts come back.
-    static const bool on_dev = [] { const char * e = getenv("XPG_MIP_DEVICE"); return !(e && e[0] == '0'); }();
+    static const bool on_dev = [] { const char * e = xpg_env("XPG_MIP_DEVICE"); return !(e && e[0] == '0'); }();
     if (on_dev && nsym == 0 && !vc_in && mip_device_fits<R32>(rows, cols, false) &&
         lineq_lds_bytes(rows, cols) <= 160 * 1024 && rows <= 32767) {
         const int n = cols - 1, rmax = rows + n, depth = n + 2;
@@ -657,15 +660,22 @@ inline int dep_is_empty_batch(xpg_ctx * ctx, int nb, const R32 * mats, int rows,
     std::vector<int32_t> kept(nb), ok(nb);
     int rc = xpg_lineq_reduce_batch_rat32(ctx, nb, (xpg_rat32 *)work.data(), rows, cols, last, 1, kept.data(), ok.data());
     if (rc) return rc;
-    const int nv = rhs_idx;
+    const bool widen = nsym > 0 && symbols_as_vars != 0;
+    const int nv = widen ? last : rhs_idx;
     std::vector<R32> vc((size_t)nv * (nv + 1), R32(0, 1));
-    if (vc_in) vc.assign(vc_in, vc_in + (size_t)nv * (nv + 1));
-    else for (int i = 0; i < nv; i++) vc[(size_t)i * (nv + 1) + i] = R32(-1, 1);
+    if (vc_in && !widen) vc.assign(vc_in, vc_in + (size_t)nv * (nv + 1));
+    else if (vc_in) {                                // the caller's [rhs_idx][rhs_idx + 1] block; the symbols' rows and columns stay zero (free)
+        for (int i = 0; i < rhs_idx; i++) {
+            for (int j = 0; j < rhs_idx; j++) vc[(size_t)i * (nv + 1) + j] = vc_in[(size_t)i * (rhs_idx + 1) + j];
+            vc[(size_t)i * (nv + 1) + nv] = vc_in[(size_t)i * (rhs_idx + 1) + rhs_idx];
+        }
+    }
+    else for (int i = 0; i < rhs_idx; i++) vc[(size_t)i * (nv + 1) + i] = R32(-1, 1);
     std::vector<int> open;                       // systems still undecided
     for (int b = 0; b < nb; b++) {
         if (!ok[b]) out_empty[b] = 1;            // inconsistent bounds: empty (poly.cpp:550-552)
         else if (kept[b] == 0) out_empty[b] = 0; // only redundant constraints: conservatively non-empty (:553-557)
-        else if (nsym > 0) out_empty[b] = XPG_ERR_REF_UNDEFINED;
+        else if (nsym > 0 && !widen) out_empty[b] = XPG_ERR_REF_UNDEFINED;
         else { out_empty[b] = 1; open.push_back(b); }
     }
     long nodes = 0;

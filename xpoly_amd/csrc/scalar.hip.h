@@ -18,6 +18,22 @@
 
 #define XPG_HD __host__ __device__ __forceinline__
 
+// Environment switches (host side). xpg_env: the switches the product documents -- always read.
+// xpg_hook: test hooks (fault injection, forced routes, debug prints) and the lab's A/B knobs -- they exist only in the
+// -DXPG_TEST_HOOKS build (xpoly_amd/libxpoly_amd_hooks.so: the tests that need one load it, tools/lab runs on it); the
+// product library does not look at them.
+#include <stdlib.h>
+inline const char * xpg_env(const char * name) { return getenv(name); }
+inline const char * xpg_hook(const char * name)
+{
+#ifdef XPG_TEST_HOOKS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 // diagnostic builds (-DXPG_TRACE): every committed pivot of workgroup 0 is printed (entering, leaving, row)
 #if defined(XPG_TRACE) && defined(__HIP_DEVICE_COMPILE__)
 #define XPG_TRACE_PIVOT(tag_, e_, l_, r_) do { if (blockIdx.x == 0 && blockIdx.y == 0) printf("%s: enter %d leave %d row %d\n", tag_, (int)(e_), (int)(l_), (int)(r_)); } while (0)

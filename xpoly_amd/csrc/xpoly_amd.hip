@@ -91,26 +91,30 @@ int xpg_create(xpg_ctx ** out, int device)
     c->rowbuf = c->colbuf = 0; c->st = 0; c->row_cap = c->col_cap = 0;
     c->stage = 0; c->stage_cap = 0;
     c->hstage = 0; c->hstage_cap = 0;
-    const char * var = getenv("XPG_UPDATE_VARIANT");
+    const char * var = xpg_hook("XPG_UPDATE_VARIANT");
     c->update_variant = var ? atoi(var) : 0;
-    const char * lm = getenv("XPG_LOOP");              // "serial": the three-launch loop, for A/B runs
-    const char * zz = getenv("XPG_ZIGZAG");
+    // XPG_LOOP: "block" / "pipe" force the blocked / the pipelined loop whatever the size (unset: chosen by size). The
+    // three-launch "serial" loop and the "split" form of the pipelined one (neither a default nor a fallback: kept for the
+    // lab's A/B runs and the tests that compare the loops with each other) are selectable in the -DXPG_TEST_HOOKS build only.
+    const char * lm = xpg_env("XPG_LOOP");
+    if (lm && lm[0] == 's' && !xpg_hook("XPG_LOOP")) lm = nullptr;
+    const char * zz = xpg_hook("XPG_ZIGZAG");
     c->zigzag = zz ? atoi(zz) : 0;                      // measured slower (79.7 vs 77.8 us per sweep): off
     c->loop_mode = (lm && lm[0] == 's' && lm[1] == 'e') ? 1 : ((lm && lm[0] == 's' && lm[1] == 'p') ? 2 : 0);
     if (lm && lm[0] == 'b') c->loop_mode = 3;          // "block": B pivots per sweep (lp_blocked.hip.h)
     if (lm && lm[0] == 'p') c->loop_mode = 0;          // "pipe": always the pipelined loop
-    const char * ch = getenv("XPG_CHAIN");               // "0": launch-per-stage chain, for A/B runs
+    const char * ch = xpg_env("XPG_CHAIN");               // "0": launch-per-stage chain, for A/B runs
     c->chain = ch ? atoi(ch) : 1;
-    const char * cx = getenv("XPG_CHAIN_XCD");
+    const char * cx = xpg_hook("XPG_CHAIN_XCD");
     c->chain_local = cx ? (atoi(cx) != 0 ? 1 : 0) : 1;
-    const char * cf = getenv("XPG_CHAIN_FOLD");
+    const char * cf = xpg_hook("XPG_CHAIN_FOLD");
     c->chain_fold = cf ? (atoi(cf) != 0 ? 1 : 0) : 1;
-    const char * cta = getenv("XPG_CHAIN_TEST_ABORT");
+    const char * cta = xpg_hook("XPG_CHAIN_TEST_ABORT");
     c->chain_test_abort = cta ? atoi(cta) : 0;
     c->num_cus = 0;
     if (hipDeviceGetAttribute(&c->num_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) c->num_cus = 0;
     c->loop_auto = lm ? 0 : 1;                         // unset: blocked loop for large fp64 tableaux, else pipelined
-    const char * bl = getenv("XPG_BLOCK");
+    const char * bl = xpg_env("XPG_BLOCK");
     c->block_len = bl ? atoi(bl) : BLK_DEFAULT;
     if (c->block_len < 1) c->block_len = 1;
     if (c->block_len > BLK_MAX) c->block_len = BLK_MAX;
@@ -500,6 +504,16 @@ int xpg_lp_chain_aborts(xpg_lp * lp, unsigned * aborts, int * chain_off, unsigne
     return 0;
 }
 
+int xpg_lp_loop_info(xpg_lp * lp, int32_t * out, int n)
+{
+    if (!lp || !lp->impl || !out || n < 0) return XPG_ERR_SHAPE;
+    int32_t f[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (lp->impl->kind == 0) ((Lp<F64> *)lp->impl)->loop_info(f);
+    else ((Lp<R32> *)lp->impl)->loop_info(f);
+    for (int k = 0; k < n && k < 10; k++) out[k] = f[k];
+    return 0;
+}
+
 #ifdef XPG_STAMPS
 // diagnostic builds only (not declared in the header): the phase tick sums of the blocked loop
 int xpg_lp_debug(xpg_lp * lp, unsigned long long * out8)
@@ -665,9 +679,21 @@ int xpg_six_last_profile(double * out_ms, int n)
 {
     if (!out_ms || n < 0) return XPG_ERR_SHAPE;
     const SixProfile & p = six_profile();
-    const double f[9] = { p.total_ms, p.reshape_ms, p.create_ms, p.dual_ms, p.solve_ms, p.read_ms, p.destroy_ms, (double)p.route, 0.0 };
+    const double f[9] = { p.total_ms, p.reshape_ms, p.create_ms, p.dual_ms, p.solve_ms, p.read_ms, p.destroy_ms, (double)p.route, (double)p.pivots };
     for (int k = 0; k < n && k < 9; k++) out_ms[k] = f[k];
     return 0;
+}
+int xpg_test_normalize(xpg_ctx * ctx, int kind, const void * tgtf, const void * vc, int vc_rows, const void * eq, int eq_rows,
+                       const void * leq, int leq_rows, int cols, void * out_dev_cells, void * out_host_cells, long long cap_cells,
+                       int32_t * out_info)
+{
+    XPG_BIND(ctx);
+    if (!ctx || !out_dev_cells || !out_host_cells || !out_info || (kind != 0 && kind != 1)) return XPG_ERR_SHAPE;
+    if (kind == 0)
+        return test_normalize<F64>(ctx, (const F64 *)tgtf, (const F64 *)vc, vc_rows, (const F64 *)eq, eq_rows, (const F64 *)leq, leq_rows, cols,
+                                   (F64 *)out_dev_cells, (F64 *)out_host_cells, cap_cells, out_info);
+    return test_normalize<R32>(ctx, (const R32 *)tgtf, (const R32 *)vc, vc_rows, (const R32 *)eq, eq_rows, (const R32 *)leq, leq_rows, cols,
+                               (R32 *)out_dev_cells, (R32 *)out_host_cells, cap_cells, out_info);
 }
 int xpg_six_maxm_f64(xpg_ctx * ctx, const double * tgtf, const double * vc, int vc_rows,
                      const double * eq, int eq_rows, const double * leq, int leq_rows, int cols,
@@ -840,7 +866,7 @@ namespace {
 struct RaggedClass { int rows, cols; std::vector<int> idx; size_t work; };
 inline int ragged_lanes()
 {
-    static const int n = [] { const char * e = getenv("XPG_RAGGED_LANES"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 32 ? 32 : v); }();
+    static const int n = [] { const char * e = xpg_env("XPG_RAGGED_LANES"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 32 ? 32 : v); }();
     return n;
 }
 // fn(lane_ctx, class) for every shape class; the first error wins.
@@ -1191,6 +1217,16 @@ int xpg_dep_is_empty_batch_ex_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mat
     XPG_BIND(ctx);
     long n = 0;
     int rc = dep_is_empty_batch(ctx, nb, (const R32 *)mats, rows, cols, rhs_idx, (const R32 *)vc, out_empty, &n);
+    if (out_nodes) *out_nodes = n;
+    return rc;
+}
+int xpg_dep_is_empty_batch_mode_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols, int rhs_idx,
+                                      const xpg_rat32 * vc, int mode, int32_t * out_empty, long long * out_nodes)
+{
+    XPG_BIND(ctx);
+    if (mode != XPG_DEP_PARITY && mode != XPG_DEP_SYMBOLS_AS_VARS) return XPG_ERR_SHAPE;
+    long n = 0;
+    int rc = dep_is_empty_batch(ctx, nb, (const R32 *)mats, rows, cols, rhs_idx, (const R32 *)vc, out_empty, &n, mode == XPG_DEP_SYMBOLS_AS_VARS ? 1 : 0);
     if (out_nodes) *out_nodes = n;
     return rc;
 }

@@ -167,7 +167,9 @@ class Lineq:
             self.ctx.check(call(outs, capc), "xpg_lineq_fme_batch_ragged_rat32")
         else:
             rc = call(None, 0)
-            if rc != -3:                                    # XPG_ERR_SHAPE: "too small", offsets filled
+            # XPG_ERR_SHAPE from a sizing call means "too small, offsets filled" -- or malformed input (cols > 255, u out of
+            # range, a bad rhs_idx), refused before any offset is written: told apart by whether anything was filled in
+            if rc != -3 or not (int(ooff[nb]) > 0 or out_rows.any()):
                 self.ctx.check(rc, "xpg_lineq_fme_batch_ragged_rat32 (sizing)")
             need = int(ooff[nb])
             outs = np.zeros((max(need, 1), 2), dtype=np.int32)

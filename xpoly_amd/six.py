@@ -252,6 +252,15 @@ class DeviceLP:
         self.ctx.check(lib().xpg_lp_chain_folds(self._h, C.byref(n)), "xpg_lp_chain_folds")
         return n.value
 
+    def loop_info(self):
+        """xpg_lp_loop_info: which loop and kernel instances run the LP in its current shape."""
+        o = (C.c_int32 * 10)()
+        self.ctx.check(lib().xpg_lp_loop_info(self._h, o, C.c_int(10)), "xpg_lp_loop_info")
+        return dict(loop={0: "pipelined", 1: "serial", 3: "blocked"}.get(o[0], o[0]), pivots_per_pass=o[1],
+                    chain={0: "launch per stage", 1: "one launch, one XCD", 2: "one launch, spread"}[o[2]] if o[0] == 3 else None,
+                    chain_line=o[3], sweep_rows=o[4], ld=o[5], chain_workers=o[6], pick_workers=o[7], prep_workers=o[8],
+                    chain_lds_bytes=o[9])
+
     def shape(self):
         r, w, rhs = C.c_int(), C.c_int(), C.c_int()
         self.ctx.check(lib().xpg_lp_shape(self._h, C.byref(r), C.byref(w), C.byref(rhs)), "xpg_lp_shape")
@@ -327,6 +336,7 @@ def six_last_profile():
     names = ("total_ms", "host_reshape_ms", "create_and_upload_ms", "dual_on_device_ms", "device_solve_ms", "read_back_ms", "release_ms")
     d = {k: round(out[i], 3) for i, k in enumerate(names)}
     d["route"] = {1: "LDS batch kernel", 2: "HBM-resident loop"}.get(int(out[7]), "none")
+    d["pivots"] = int(out[8])                        # HBM-resident route: pivots of the loop that ended the solve
     return d
 
 
@@ -396,6 +406,21 @@ def dep_is_empty_batch(ctx, mats, rhs_idx=None, vc=None):
     ctx.check(lib().xpg_dep_is_empty_batch_ex_rat32(ctx._h, C.c_int(nb), vp(mats), C.c_int(rows), C.c_int(cols),
                                                     C.c_int(rhs_idx), vp(vc_a), vp(out), C.byref(nodes)),
               "xpg_dep_is_empty_batch_ex_rat32")
+    return out, nodes.value
+
+
+def dep_is_empty_batch_symbols_as_vars(ctx, mats, rhs_idx, vc=None):
+    """OPT-IN, NON-PARITY (xpg_dep_is_empty_batch_mode_rat32, XPG_DEP_SYMBOLS_AS_VARS): parametrised dependence polyhedra the
+    reference leaves undefined -- the constant symbols behind column rhs_idx become free variables of the widened system.
+    Returns (empty[nb], nodes)."""
+    mats = as_kind(mats, RAT, 3)
+    nb, rows, cols = mats.shape[0], mats.shape[1], mats.shape[2]
+    vc_a = None if vc is None else as_kind(vc, RAT, 2)
+    out = np.zeros(nb, dtype=np.int32)
+    nodes = C.c_longlong()
+    ctx.check(lib().xpg_dep_is_empty_batch_mode_rat32(ctx._h, C.c_int(nb), vp(mats), C.c_int(rows), C.c_int(cols), C.c_int(rhs_idx),
+                                                      vp(vc_a), C.c_int(1), vp(out), C.byref(nodes)),
+              "xpg_dep_is_empty_batch_mode_rat32")
     return out, nodes.value
 
 
