@@ -50,8 +50,8 @@ PCIE_GBS = 63.0                            # MI355X_MICROARCH.md: host link PCIe
 BATCH_PER_GPU = 8192                       # 65 536 LPs over 8 GPUs (BASELINE.json configs[2])
 BATCH_M, BATCH_COLS = 32, 64
 PREWARM_SECONDS = 0.5
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "round5_pmc_hbm_traffic_4096x8192.json")
-PMC_SUMMARY_2B = os.path.join(ROOT, "profiles", "round5_pmc_hbm_traffic_4096x12289.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "round6_pmc_hbm_traffic_4096x8192.json")
+PMC_SUMMARY_2B = os.path.join(ROOT, "profiles", "round6_pmc_hbm_traffic_4096x12289.json")
 PMC_BATCH = os.path.join(ROOT, "profiles", "round5_pmc_batch_issue.json")
 PMC_RATIONAL = os.path.join(ROOT, "profiles", "round4_pmc_rational_issue.json")
 LEGS = ("pivots", "batched", "sharded", "cfg2b", "shapes", "six_e2e", "one_call", "rational", "mip", "lineq")
@@ -93,20 +93,20 @@ def cpu_baseline_pivots(budget_s=10.0):
 
 def cpu_reference_pivots(leq, tgtf):
     """The REAL reference (oracle/_ref/libxpoly_ref.so, if it travelled): SIX::TwoStageMethod with
-    set_param(0, K) for K = 1 and K = 3 on the same LP; per-pivot time by differencing."""
+    set_param(0, K) for K = 1 and K = 9 on the same LP; per-pivot time by differencing."""
     from oracle.checker import F64, Ref
     if not Ref.available():
         return None
     ref = Ref()
     ts = {}
-    for K in (1, 3):
+    for K in (1, 9):                                     # eight pivots of signal (two gave a 2 x spread between runs: 14.7 ... 28.9 pivots/s)
         t0 = time.perf_counter()
         ref.two_stage(F64, leq, tgtf, K)
         ts[K] = time.perf_counter() - t0
-    per = (ts[3] - ts[1]) / 2.0
+    per = (ts[9] - ts[1]) / 8.0
     return dict(value=round(1.0 / per, 4) if per > 0 else None, unit="pivots/s", cores=1, kind="reference",
                 sample="xcom::SIX<FloatMat,Float>::TwoStageMethod on the bench LP (m=4096,n=4095), "
-                       "(t[K=3]-t[K=1])/2 = %.3f s/pivot; set-up %.1f s per call" % (per, ts[1] - per))
+                       "(t[K=9]-t[K=1])/8 = %.3f s/pivot; set-up %.1f s per call" % (per, ts[1] - per))
 
 
 _POOL_STATE = {}
@@ -868,7 +868,7 @@ def leg_cfg2b(ctx, xpoly_amd, gen, m=4096, n=8192):
             frac=round(bytes_per_launch / avg / 1e9 / HBM_PEAK_GBS, 4), avg_launch_us=round(avg * 1e6, 2),
             launches_sampled=launches,
             traffic=(round(json.load(open(PMC_SUMMARY_2B))["traffic_bytes_per_launch"]) if os.path.exists(PMC_SUMMARY_2B) else None),
-            traffic_source="profiles/round5_pmc_hbm_traffic_4096x12289.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of this leg; not collected in this run)",
+            traffic_source="profiles/round6_pmc_hbm_traffic_4096x12289.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of this leg; not collected in this run)",
             note="HIP events on the sweep launches of the timed pass; a plain in-place copy of this tableau with the same "
                  "tiling runs at 0.79 of the peak (tools/lab/sweep_lab2.hip, profiles/round3_sweep_lab.txt)")
     return out

@@ -124,6 +124,7 @@ int  xpg_lp_two_stage(xpg_lp * lp, unsigned max_iter);
 int  xpg_lp_begin(xpg_lp * lp);
 int  xpg_lp_iterate(xpg_lp * lp, unsigned pivots);
 #define XPG_RUNNING (-1000)
+/* Pivots the handle has made over its LIFETIME (every solve on it, phase 1's included): difference two reads for one solve. */
 int  xpg_lp_pivots_done(xpg_lp * lp, unsigned * out);
 /* Blocked loop bookkeeping since xpg_lp_begin / xpg_lp_two_stage: sweeps that applied a full batch of
  * staged pivots (32 by default, XPG_BLOCK = 1 .. 32: the batch's stages, the first included, are chosen and

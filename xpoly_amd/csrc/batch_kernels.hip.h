@@ -1339,44 +1339,6 @@ inline int batch_stuck_check(xpg_ctx * ctx, const int32_t * st, int nb)
     return 0;
 }
 
-// Host-array form: staged through a grow-only scratch area the context owns (one hipMalloc per growth instead of
-// five hipMalloc / hipFree pairs per call: the MIP controller makes a call per lock-step round).
-template <class S>
-int batch_host(xpg_ctx * ctx, int is_max, int nb, const S * tgtf, const S * leq, int m, int cols,
-               unsigned max_iter, int32_t * out_status, S * out_v, S * out_sol, int raw_sol = 0)
-{
-    if (!ctx || nb < 0 || m <= 0 || cols < 2) return XPG_ERR_SHAPE;
-    if (nb == 0) return 0;
-    const size_t bl = (size_t)nb * m * cols * 8, bt = (size_t)nb * cols * 8;
-    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t need = up(bl) + 2 * up(bt) + up((size_t)nb * 8) + up((size_t)nb * 4);
-    if (need > ctx->stage_cap) {
-        if (ctx->stage) (void)hipFree(ctx->stage);
-        ctx->stage = 0; ctx->stage_cap = 0;
-        const size_t cap = need + need / 2;
-        if (hipMalloc(&ctx->stage, cap) != hipSuccess) { ctx->err = "hipMalloc(batch staging)"; return XPG_ERR_ALLOC; }
-        ctx->stage_cap = cap;
-    }
-    char * p = (char *)ctx->stage;
-    S * d_leq = (S *)p; p += up(bl);
-    S * d_tgtf = (S *)p; p += up(bt);
-    S * d_sol = (S *)p; p += up(bt);
-    S * d_v = (S *)p; p += up((size_t)nb * 8);
-    int32_t * d_st = (int32_t *)p;
-    int rc = 0;
-    hipError_t e = hipMemcpyAsync(d_leq, leq, bl, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_tgtf, tgtf, bt, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_sol, out_sol, bt, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) rc = batch_dev<S>(ctx, is_max, nb, d_tgtf, d_leq, m, cols, max_iter, d_st, d_v, d_sol, 0, raw_sol);
-    if (e == hipSuccess && rc == 0) e = hipMemcpyAsync(out_status, d_st, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess && rc == 0) e = hipMemcpyAsync(out_v, d_v, (size_t)nb * 8, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess && rc == 0) e = hipMemcpyAsync(out_sol, d_sol, bt, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return XPG_ERR_HIP; }
-    if (rc == 0) rc = batch_stuck_check(ctx, out_status, nb);
-    return rc;
-}
-
 // The same call for a caller that builds its batch itself (the MIP controller, one batch per lock-step round):
 // batch_stage_prepare hands out pinned host arrays laid out like the device staging, the caller fills leq / tgtf,
 // batch_stage_run copies them down in ONE transfer, launches, and brings status / value / solution back in one.
@@ -1433,5 +1395,58 @@ int batch_stage_run(xpg_ctx * ctx, BatchStage<S> & bs, int is_max, unsigned max_
     if (rc == 0) rc = batch_stuck_check(ctx, bs.h_st, bs.nb);
     return rc;
 }
+
+// Host-array form: staged through a grow-only scratch area the context owns (one hipMalloc per growth instead of
+// five hipMalloc / hipFree pairs per call: the MIP controller makes a call per lock-step round).
+template <class S>
+int batch_host(xpg_ctx * ctx, int is_max, int nb, const S * tgtf, const S * leq, int m, int cols,
+               unsigned max_iter, int32_t * out_status, S * out_v, S * out_sol, int raw_sol = 0)
+{
+    if (!ctx || nb < 0 || m <= 0 || cols < 2) return XPG_ERR_SHAPE;
+    if (nb == 0) return 0;
+    const size_t bl = (size_t)nb * m * cols * 8, bt = (size_t)nb * cols * 8;
+    if (bl + bt <= ((size_t)1 << 20)) {
+        // a small batch -- the drop-in adapter's ONE problem per call above all: through the context's pinned staging, one transfer
+        // down, one up (six pageable transfers of a few hundred bytes cost ~200 us per call: bench.py leg one_call, round 6)
+        BatchStage<S> bs;
+        int rc = batch_stage_prepare<S>(ctx, nb, m, cols, bs);
+        if (rc) return rc;
+        memcpy(bs.h_leq, leq, bl); memcpy(bs.h_tgtf, tgtf, bt);
+        rc = batch_stage_run<S>(ctx, bs, is_max, max_iter, raw_sol);
+        if (rc) return rc;
+        memcpy(out_status, bs.h_st, (size_t)nb * 4); memcpy(out_v, bs.h_v, (size_t)nb * 8);
+        for (int b = 0; b < nb; b++)                                  // (out_sol is written on success only, include/xpoly_amd.h)
+            if (bs.h_st[b] == 0) memcpy(out_sol + (size_t)b * cols, bs.h_sol + (size_t)b * cols, (size_t)cols * 8);
+        return 0;
+    }
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t need = up(bl) + 2 * up(bt) + up((size_t)nb * 8) + up((size_t)nb * 4);
+    if (need > ctx->stage_cap) {
+        if (ctx->stage) (void)hipFree(ctx->stage);
+        ctx->stage = 0; ctx->stage_cap = 0;
+        const size_t cap = need + need / 2;
+        if (hipMalloc(&ctx->stage, cap) != hipSuccess) { ctx->err = "hipMalloc(batch staging)"; return XPG_ERR_ALLOC; }
+        ctx->stage_cap = cap;
+    }
+    char * p = (char *)ctx->stage;
+    S * d_leq = (S *)p; p += up(bl);
+    S * d_tgtf = (S *)p; p += up(bt);
+    S * d_sol = (S *)p; p += up(bt);
+    S * d_v = (S *)p; p += up((size_t)nb * 8);
+    int32_t * d_st = (int32_t *)p;
+    int rc = 0;
+    hipError_t e = hipMemcpyAsync(d_leq, leq, bl, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_tgtf, tgtf, bt, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_sol, out_sol, bt, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) rc = batch_dev<S>(ctx, is_max, nb, d_tgtf, d_leq, m, cols, max_iter, d_st, d_v, d_sol, 0, raw_sol);
+    if (e == hipSuccess && rc == 0) e = hipMemcpyAsync(out_status, d_st, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && rc == 0) e = hipMemcpyAsync(out_v, d_v, (size_t)nb * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && rc == 0) e = hipMemcpyAsync(out_sol, d_sol, bt, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return XPG_ERR_HIP; }
+    if (rc == 0) rc = batch_stuck_check(ctx, out_status, nb);
+    return rc;
+}
+
 
 } // namespace xpg

@@ -426,7 +426,7 @@ int solve_large(xpg_ctx * ctx, int kind, bool is_max, const NormalForm<S> & F, c
 }
 
 // Test view of SIX::normalize's two implementations (six_host.hip.h): the cells normalize_device makes in HBM and the cells
-// normalize_cells_host makes (the LDS route's, pinned to the oracle by every small-LP test), for the same input.
+// normalize_cells_host makes (the LDS route's, which every small-LP parity test exercises), for the same input.
 template <class S>
 int test_normalize(xpg_ctx * ctx, const S * tgtf, const S * vc, int vc_rows, const S * eq, int eq_rows, const S * leq, int leq_rows,
                           int cols, S * out_dev, S * out_host, long long cap_cells, int32_t * out_info)

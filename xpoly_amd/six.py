@@ -107,6 +107,10 @@ class Context:
 
     def close(self):
         if self._h:
+            for r in list(getattr(self, "_lps", ())):       # device LPs of this context first: they hold its stream and buffers
+                lp = r()
+                if lp is not None:
+                    lp.close()
             lib().xpg_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -212,6 +216,10 @@ class DeviceLP:
         ctx.check(lib().xpg_lp_create(ctx._h, C.c_int(kind), leq_p, C.c_int(m), C.c_int(cols), tg_p,
                                       vp(vd), vp(vr), C.c_int(int(on_device)), C.byref(self._h)),
                   "xpg_lp_create")
+        import weakref
+        if not hasattr(ctx, "_lps"):
+            ctx._lps = []
+        ctx._lps.append(weakref.ref(self))
 
     def set_options(self, pricing=0, feas_rel_tol=0.0):
         """Opt-in NON-PARITY modes (xpg_lp_set_options): pricing=1 Dantzig's rule, feas_rel_tol>0 a
