@@ -343,7 +343,7 @@ int xpg_dep_is_empty_batch_ex_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mat
  *   XPG_DEP_SYMBOLS_AS_VARS  OPT-IN, NOT PARITY: the evident intent of src/eng/poly.cpp:530-573 -- after move2var the symbols
  *                            are variables of unknown sign, so has_solution(int, unique) is asked about the widened system:
  *                            rhs_idx = cols - 1, vc widened by all-zero (= free) rows and columns for the symbols.  Checked
- *                            against the oracle's move2var + reduce + has_solution on that widened system. */
+ *                            against the CPU restatement's move2var + reduce + has_solution on that widened system. */
 enum { XPG_DEP_PARITY = 0, XPG_DEP_SYMBOLS_AS_VARS = 1 };
 int xpg_dep_is_empty_batch_mode_rat32(xpg_ctx * ctx, int nb, const xpg_rat32 * mats, int rows, int cols, int rhs_idx,
                                       const xpg_rat32 * vc, int mode, int32_t * out_empty, long long * out_nodes);
