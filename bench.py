@@ -996,6 +996,36 @@ def leg_six_e2e(ctx, xpoly_amd, gen, m=4096, n=8192, max_iter=1280, with_referen
                                            "stage 1 and ONE pivot (oracle/_ref, the real reference); baseline only")
     out["note"] = ("overhead = the call's wall time minus the device's stage 1 + pivot loop; the target is <= 1.3 x the raw pageable "
                    "host-to-device copy of leq (the bytes that must cross the link once)")
+    # ---- calls that END (the dense recipe above has no reachable end under the reference: it stops at max_iter): ONE xpg_six_maxm_f64
+    # call, no iteration limit, on the two full-size LPs whose ends are pinned to the real reference (tests/golden/g12_end_states.json)
+    del leq, vc
+    gold = golden("g12_end_states.json")
+    ends = []
+    six.set_param(0, 0xFFFFFFFF)
+    for key, mk in (("succ_big_six_max", lambda: gen.block_lp_f64(gold["succ_big_block_seeds"], wide=True)),
+                    ("bench_six_max", lambda: gen.hard_lp_f64(M, NVARS))):
+        rec = gold.get(key)
+        if rec is None:
+            continue
+        l2, t2 = mk()
+        n2 = l2.shape[1] - 1
+        v2 = np.zeros((n2, n2 + 1)); v2[np.arange(n2), np.arange(n2)] = -1.0
+        t0 = time.perf_counter()
+        st, v, sol = six.maxm(t2, v2, None, l2)
+        dt = (time.perf_counter() - t0) * 1e3
+        pf = six_last_profile()
+        ok = int(st) == rec["status"] and float(v).hex() == rec["v"] and pf["pivots"] == rec["pivots"]
+        if ok and rec["status"] == 0:
+            ok = checksum(sol) == rec["sol"]
+        if not ok:
+            sys.exit("bench.py self-check FAILED: six_e2e natural end %s: status %d v %s pivots %d, the real reference: %d %s %d"
+                     % (key, st, float(v).hex(), pf["pivots"], rec["status"], rec["v"], rec["pivots"]))
+        ends.append(dict(lp=rec["generator"], leq=list(l2.shape), status=int(st), v=float(v), pivots=pf["pivots"], call_ms=round(dt, 2),
+                         device_solve_ms=pf["device_solve_ms"],
+                         check="status, optimum bits, pivot count%s = SIX::maxm of the real reference at its natural end (tests/golden/g12_end_states.json %s)"
+                               % (", solution checksum" if rec["status"] == 0 else "", key)))
+        del l2, v2
+    out["natural_ends"] = ends
     return out
 
 
