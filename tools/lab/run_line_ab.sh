@@ -1,6 +1,7 @@
 # A/B inside one run (boxes differ by a per cent or two): the pick workers' entering-column line in LDS (XPG_CHAIN_LINE) and the
 # column-major copy of the staged rows (XPG_CHAIN_ET), both blocked legs, every setting twice
 cd $GRAFT_REPO_ROOT
+export XPG_SO_PATH=${XPG_SO_PATH:-$GRAFT_REPO_ROOT/xpoly_amd/libxpoly_amd_hooks.so}   # hook-only knobs: the -DXPG_TEST_HOOKS build
 mkdir -p gpurun_out
 for rep in 1 2; do for mode in "0 0" "1 0"; do
   set -- $mode
