@@ -319,3 +319,32 @@ def test_g10_mip_bench_shape_pins_the_oracle(port):
             assert [int(x) for x in np.asarray(sol).reshape(-1)] == want["sol"], b
         seen.add(st)
     assert {0, 2} <= seen
+
+
+def test_end_state_and_shape_fixtures_are_complete_and_reproducible():
+    """tests/golden/g12_end_states.json / g13_shapes.json (tools/gen_golden_end.py, tools/gen_golden_bench.py shape): every record
+    the GPU tests and bench.py read is there, came from the real reference, and the seeded generators rebuild the inputs'
+    shapes (the inputs themselves are not stored)."""
+    import json
+    from tools import gen
+    g12 = json.load(open(os.path.join(GOLD, "g12_end_states.json")))
+    for key, status in (("bench_end", 3), ("bench_six_max", 3), ("succ_two_stage", 0), ("succ_six_max", 0), ("succ_big_six_max", 0),
+                        ("cover_six_min", 0), ("dense_max_256x512", 1), ("dense_min_256x512", 2), ("rational_k64", 4)):
+        assert g12[key]["status"] == status, key
+        assert g12[key]["reference_seconds"] > 0 and g12[key]["pivots"] > 0, key
+    assert g12["bench_end"]["pivots"] == g12["bench_six_max"]["pivots"] == 4165 and g12["bench_end"]["pivots_pinned_by_reference"]
+    assert g12["succ_two_stage"]["pivots_pinned_by_reference"]
+    a, b = float.fromhex(g12["succ_two_stage"]["maxv"]), float.fromhex(g12["succ_six_max"]["v"])
+    assert a != 0.0 and a != b and abs(a - b) <= 1e-12 * abs(a)     # (the tableau's constant and maxm's sum over sol * tgtf round differently: lpsol.h:2026-2030)
+    leq, tg = gen.block_lp_f64(g12["succ_block_seeds"])
+    assert list(leq.shape) == g12["succ_shape"] and leq.shape[0] >= 2048
+    leq, tg = gen.cover_lp_f64(g12["cover_block_seeds"])
+    assert list(leq.shape) == g12["cover_shape"] and leq.shape[0] >= 2048 and (leq[:, -1] < 0).all()
+    leq, tg = gen.block_lp_f64(g12["succ_big_block_seeds"][:40], wide=True)       # (the whole LP is 366 MB: a prefix)
+    assert leq.shape[1] - 1 == sum(gen.lp_block_f64(s, True)[0].shape[1] for s in g12["succ_big_block_seeds"][:40])
+    assert g12["succ_big_shape"][0] >= 4096 and g12["succ_big_shape"][1] - 1 >= 8192
+    g13 = json.load(open(os.path.join(GOLD, "g13_shapes.json")))
+    for name, (m, n) in dict(tall=(16384, 2048), wide=(1024, 20480), square=(8192, 8192), odd_width=(4096, 4094), small=(2048, 2047)).items():
+        r = g13[name]
+        assert r["K"] == 256 and r["status"] == 4 and r["tab_shape"] == [m, n + m + 1], name
+        assert n + m < 23171                                   # the reference's own range: (n + m)^2 * 8 B must not wrap 2^32

@@ -370,7 +370,7 @@ template <bool LOCAL> __device__ __forceinline__ void ch_commit_loop(const LpVie
             // the pick workers do not read the records: the commit granule tells them that the batch ended here
             ch_drain();
             if (lane == 0)
-                ch_store_granule<LOCAL>(ch_part_g0(v, nprep), ((unsigned long long)(unsigned)CH_CLOSE_ROW << 32) | (unsigned)INT_MAX, (unsigned long long)tag);
+                ch_store_granule<LOCAL>(ch_part_g0(v, nprep), (unsigned long long)(unsigned)INT_MAX, ((unsigned long long)(unsigned)CH_CLOSE_ROW << 32) | (unsigned long long)tag);
             return;
         }
         if (lane == 0) {
@@ -406,10 +406,11 @@ template <bool LOCAL> __device__ __forceinline__ void ch_commit_loop(const LpVie
             // carry it, the rest still hold stage 0's and are ignored)
         }
         // the commit is out: the pick role of stage t+1 may read it. The granule is {INT_MAX -- no column, where a partial
-        // holds its first candidate --, the pivot row, tag}: the row is all a pick worker needs of the records of stage t
+        // holds its first candidate --, 0 -- where a partial holds "any c_j > 0": a launch-per-stage look-ahead that met this
+        // slot with a matching tag would OR it in --, tag, the pivot row}: the row is all a pick worker needs of the records of stage t
         ch_drain();
         if (lane == 0)
-            ch_store_granule<LOCAL>(ch_part_g0(v, nprep), ((unsigned long long)(unsigned)g.r << 32) | (unsigned)INT_MAX, (unsigned long long)tag);
+            ch_store_granule<LOCAL>(ch_part_g0(v, nprep), (unsigned long long)(unsigned)INT_MAX, ((unsigned long long)(unsigned)g.r << 32) | (unsigned long long)tag);
         tp += 1; done += 1; budget -= 1;
     }
 }
@@ -619,14 +620,14 @@ __global__ __launch_bounds__(64) void k_blk_chain(LpView<F64> v, int batch, int 
                     if (__all(ok)) break;
                     // the batch ended at stage t-1 (a NaN ratio, an empty first pass: see ch_commit_loop) -- no partials will come
                     if (base == 0 && lo == 0 && (unsigned)__builtin_amdgcn_readfirstlane((int)g0.z) == want_part
-                        && __builtin_amdgcn_readfirstlane((int)g0.y) == CH_CLOSE_ROW) return;
+                        && __builtin_amdgcn_readfirstlane((int)g0.w) == CH_CLOSE_ROW) return;
                     if (++spins > CH_SPIN_LIMIT) { if (lane == 0) ch_st(&st->status, (int)ST_CHAIN_STUCK); return; }
                     __builtin_amdgcn_s_sleep(CH_POLL_NAP);
                 }
                 nf = min(min(nf, (int)g0.x), min(min((int)g1.x, (int)g2.x), (int)g3.x));
                 if (base == 0 && lo == 0) {
                     // the pivot row of stage t-1: its basic variable is the column every pick worker took then (lpsol.h:1508)
-                    r_prev = __builtin_amdgcn_readfirstlane((int)g0.y);
+                    r_prev = __builtin_amdgcn_readfirstlane((int)g0.w);     // (word 3 of the commit granule; word 1 stays 0: a partial's "any c_j > 0")
                     if (r_prev == CH_CLOSE_ROW) return;
                     if (i == r_prev) { bi = first_prev; sstar = t - 1; }
                 }

@@ -124,7 +124,8 @@ enum { BLK_MAX = 32,           // the most pivots a batch stages (XPG_BLOCK up t
 //                        + 2 w               chain record w, g0 {ratio key, row, tag}: polled by every worker
 //                        + 2 x 256 + 8 w     its payload g1 {pivot element, leaving} g2 {pair word, counter, entering | last
 //                                            stage} g3 {c_nv}: fetched of the winner only
-//   blkP (ints):         4 w                 partial w, g0 {lowest eligible column, any c_j > 0, tag, 0}
+//   blkP (ints):         4 w                 partial w, g0 {lowest eligible column, any c_j > 0, tag, 0}; the chain's commit granule, in the
+//                                            slot behind its last prep worker: {INT_MAX, 0, tag, pivot row | CH_CLOSE_ROW}
 //                        4 x 520 + 16 w      its payload g1 {e_t[that column]} g2 {its objective entry} g3 {e_t[rhs]} (the
 //                                            owner of the constant column), then the Dantzig key (2 ints)
 enum { BLK_REC_G0 = BLK_PICK_WGS * BLK_REC_WORDS, BLK_REC_PAY = BLK_REC_G0 + 2 * BLK_REC_MAX, BLK_REC_PAY_WORDS = 8,
