@@ -503,3 +503,38 @@ def test_six_large_route_with_equalities_and_free_variables_normalizes_on_the_de
         else:
             assert np.array_equal(dev, host), (trial, info.tolist())
     print("device normalize == host normalize on 24 mid-size systems (%d refused as undefined by both)" % seen_undefined)
+
+
+@pytest.mark.parametrize("kind", [F64, RAT])
+def test_device_normalize_corner_cases_through_the_whole_call(ctx, port, kind, monkeypatch):
+    """normalize_device's corners through xpg_six_maxm / minm with the HBM route forced: equalities only (no inequality rows: every
+    equality becomes a pair), a single equality that is substituted into every row, free variables without equalities, and all
+    three together -- status, optimum and solution against the oracle (its strict mode: successful solves with a free variable are
+    undefined in the reference and skipped)."""
+    import xpoly_amd
+    from xpoly_amd.six import six_last_profile
+    monkeypatch.setenv("XPG_FORCE_DEVICE_LP", "1")
+    six = xpoly_amd.SIX(ctx, kind)
+    conv = (lambda a: np.asarray(a, dtype=np.float64)) if kind == F64 else (lambda a: gen.to_rat(np.asarray(a, dtype=np.int32)))
+    cases = [
+        # (tgtf, free, eq, leq)
+        ([1, 1, 0], (), [[1, 1, 3]], None),                                               # equalities only
+        ([2, 1, 0, 0], (), [[1, 1, 1, 6]], [[1, 0, 0, 4], [0, 1, 0, 5], [1, 1, 0, 7]]),     # one equality, substituted (x2 is private)
+        ([1, -1, 0], (1,), None, [[1, 0, 3], [0, -1, 2], [1, -1, 4]]),                      # a free variable, no equality
+        ([1, 1, 1, 0], (2,), [[1, 1, 1, 4], [1, 2, 0, 5]], [[1, 0, 0, 3], [0, 1, 0, 3], [0, 0, 1, 9], [1, 1, 1, 8]]),
+    ]
+    compared = 0
+    for tg, free, eq, leq in cases:
+        nv = len(tg) - 1
+        vc = conv(gen.vc_nonneg(nv, False, free=free))
+        for is_max in (True, False):
+            want = port.six_solve(kind, is_max, conv(tg), vc, None if eq is None else conv(eq), None if leq is None else conv(leq))
+            if want[0] == -7:
+                continue
+            got = (six.maxm if is_max else six.minm)(conv(tg), vc, None if eq is None else conv(eq), None if leq is None else conv(leq))
+            assert six_last_profile()["route"] == "HBM-resident loop"
+            assert got[0] == want[0] and same(got[1], want[1]), (tg, is_max, got[0], want[0], got[1], want[1])
+            if want[0] == 0:
+                assert same(got[2], want[2])
+            compared += 1
+    assert compared >= 4
