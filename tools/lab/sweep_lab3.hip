@@ -481,10 +481,74 @@ void k_resident3(double * __restrict__ tab, int m, int W, int ld, const double *
 }
 
 typedef void (*kern_t)(double *, int, int, int, const double *, const double *, int);
+// round 6: more bytes in flight without more registers -- the tableau rows of a workgroup come through an LDS ring filled by
+// LDS-DMA loads (global_load_lds_dwordx4: no VGPR holds a row before it is needed), D row groups of U rows ahead of the arithmetic.
+// At 3 waves per SIMD the register version keeps 24 KB per CU in flight (U = 2: one group ahead); the ring adds D * U KB per wave.
+template <int ROWS, int U, int NB, int D> __global__ __launch_bounds__(256)
+void k_ldsring(double * __restrict__ tab, int m, int W, int ld, const double * __restrict__ E, const double * __restrict__ K, int rev)
+{
+    __shared__ __attribute__((aligned(16))) double ring[D][U][512];
+    int bx, by; tile_of(rev, bx, by);
+    const int j = bx * 512 + threadIdx.x * 2, i0 = by * ROWS;
+    if (j >= W) return;
+    v2d e[NB];
+#pragma unroll
+    for (int s = 0; s < NB; s++) e[s] = *reinterpret_cast<const v2d *>(E + (size_t)s * ld + j);
+    double * base = tab + (size_t)i0 * ld + j;
+    const int wb = (int)(threadIdx.x & ~63u) * 2;                  // this wave's 128 doubles of a ring row
+    constexpr int NG = ROWS / U;
+    auto issue = [&](int slot, const double * p) {
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(p + (size_t)u * ld),
+                                             (void __attribute__((address_space(3))) *)(&ring[slot][u][wb]), 16, 0, 0);
+    };
+#pragma unroll
+    for (int g = 0; g < D && g < NG; g++) issue(g, base + (size_t)g * U * ld);
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        const int slot = g % D;
+        // the group's U loads are the oldest outstanding LDS-DMA loads: everything younger may stay in flight. Stores are counted
+        // by vmcnt as well (U per group behind the loads): (min(D, NG - g) - 1) groups of loads + the stores issued since
+        constexpr int dummy = 0; (void)dummy;
+        const int younger_loads = ((NG - g) < D ? (NG - g) : D) - 1;
+        // stores of the groups g - 1 .. : all issued BEFORE the loads of group g + D - 1?  order of issue per iteration: [wait][read LDS][issue loads g + D][arith][stores g]
+        // outstanding at the wait of group g: loads g .. g + younger, stores of groups <= g - 1 (older than the loads issued in iterations >= g - 1 ... interleaved)
+        // conservative and simple: wait until at most (younger_loads * U) + 0 remain -- stores older than those loads are then complete too
+        if (younger_loads * U == 0) __builtin_amdgcn_s_waitcnt(0x0f70 | 0);         // vmcnt(0)   (gfx9 encoding: vmcnt[3:0] | expcnt | lgkmcnt; high bits 15:14 = vmcnt[5:4])
+        else if (younger_loads * U == 1) __builtin_amdgcn_s_waitcnt(0x0f70 | 1);
+        else if (younger_loads * U == 2) __builtin_amdgcn_s_waitcnt(0x0f70 | 2);
+        else if (younger_loads * U == 3) __builtin_amdgcn_s_waitcnt(0x0f70 | 3);
+        else if (younger_loads * U == 4) __builtin_amdgcn_s_waitcnt(0x0f70 | 4);
+        else if (younger_loads * U == 6) __builtin_amdgcn_s_waitcnt(0x0f70 | 6);
+        else if (younger_loads * U == 8) __builtin_amdgcn_s_waitcnt(0x0f70 | 8);
+        else if (younger_loads * U == 10) __builtin_amdgcn_s_waitcnt(0x0f70 | 10);
+        else if (younger_loads * U == 12) __builtin_amdgcn_s_waitcnt(0x0f70 | 12);
+        else if (younger_loads * U == 14) __builtin_amdgcn_s_waitcnt(0x0f70 | 14);
+        else __builtin_amdgcn_s_waitcnt(0x0f70 | 0);
+        v2d d[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) d[u] = *reinterpret_cast<const v2d *>(&ring[slot][u][threadIdx.x * 2]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (g + D < NG) issue(slot, base + (size_t)(g + D) * U * ld);
+#pragma unroll
+        for (int s = 0; s < NB; s++)
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const double k = K[(size_t)(i0 + g * U + u) * 32 + s];
+                const double p0 = k * e[s].x, p1 = k * e[s].y;
+                d[u].x = d[u].x + p0; d[u].y = d[u].y + p1;
+            }
+#pragma unroll
+        for (int u = 0; u < U; u++) *reinterpret_cast<v2d *>(base + (size_t)(g * U + u) * ld) = d[u];
+    }
+}
+
 int main(int argc, char ** argv)
 {
     const char * only = argc > 1 ? argv[1] : nullptr;            // run the variants whose name contains this
-    const int m = 4096, W = 8192, ld = 8192;
+    const int m = getenv("LAB_M") ? atoi(getenv("LAB_M")) : 4096, W = getenv("LAB_W") ? atoi(getenv("LAB_W")) : 8192, ld = getenv("LAB_LD") ? atoi(getenv("LAB_LD")) : W;
+    printf("tableau %d x %d (ld %d): %.0f MB\n", m, W, ld, (double)m * ld * 8 / 1e6);
     double *tab, *E, *K;
     CK(hipMalloc(&tab, (size_t)m * ld * 8)); CK(hipMalloc(&E, (size_t)32 * ld * 8)); CK(hipMalloc(&K, (size_t)m * 32 * 8));
     {
@@ -501,6 +565,12 @@ int main(int argc, char ** argv)
     struct V { const char * name; kern_t f; int rows, cols, nb; } vs[] = {
         {"pair   NB=24 <16,2> (the product's)", k_pair<16, 2, 24, 1>, 16, 512, 24},
         {"pair   NB=32 <16,2>", k_pair<16, 2, 32, 1>, 16, 512, 32},
+        {"ldsring NB=32 <16,2> D=2", k_ldsring<16, 2, 32, 2>, 16, 512, 32},
+        {"ldsring NB=32 <16,2> D=4", k_ldsring<16, 2, 32, 4>, 16, 512, 32},
+        {"ldsring NB=32 <16,1> D=8", k_ldsring<16, 1, 32, 8>, 16, 512, 32},
+        {"ldsring NB=32 <32,2> D=4", k_ldsring<32, 2, 32, 4>, 32, 512, 32},
+        {"ldsring NB=32 <32,2> D=6", k_ldsring<32, 2, 32, 6>, 32, 512, 32},
+        {"ldsring NB=16 <16,2> D=4", k_ldsring<16, 2, 16, 4>, 16, 512, 16},
         {"ring   NB=32 U=2 D=2 (unrolled product)", k_ring<16, 2, 32, 2>, 16, 512, 32},
         {"ring   NB=32 U=2 D=3", k_ring<16, 2, 32, 3>, 16, 512, 32},
         {"ring   NB=32 U=2 D=4", k_ring<16, 2, 32, 4>, 16, 512, 32},
