@@ -83,7 +83,7 @@ def main_shape(name, K=256):
     print(name, "reference %.1f s" % (t2 - t1), "agree" if prec == rec else "DIFFER", flush=True)
     assert prec == rec, (prec, rec)
     rec["reference_seconds"] = round(t2 - t1, 1)
-    with open(SHAPES_OUT + ".lock", "w") as lk:
+    with open(os.path.join("/tmp", os.path.basename(SHAPES_OUT) + ".lock"), "w") as lk:
         fcntl.flock(lk, fcntl.LOCK_EX)
         out = json.load(open(SHAPES_OUT)) if os.path.exists(SHAPES_OUT) else {}
         out[name] = rec

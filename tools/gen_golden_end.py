@@ -48,7 +48,7 @@ NO_LIMIT = 0xFFFFFFFF
 
 def save(key, rec, **more):
     import fcntl
-    with open(OUT + ".lock", "w") as lk:                 # several cases may be generated side by side
+    with open(os.path.join("/tmp", os.path.basename(OUT) + ".lock"), "w") as lk:                 # several cases may be generated side by side
         fcntl.flock(lk, fcntl.LOCK_EX)
         out = json.load(open(OUT)) if os.path.exists(OUT) else {}
         out[key] = rec
